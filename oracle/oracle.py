@@ -1,0 +1,149 @@
+"""ctypes front-end of the CPU oracle (TEST INFRASTRUCTURE).
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import
+this module.  It wraps oracle/libdctz_oracle.so (built from dctz_oracle.c by
+`make -C oracle`); see dctz_oracle.h for scope and parity status.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "libdctz_oracle.so")
+
+F32, F64 = 0, 1
+EC, QT = 0, 1
+NAIVE, FAST = 0, 1
+BLK = 64
+
+
+class Stats(C.Structure):
+    _fields_ = [("max", C.c_double), ("min", C.c_double), ("sum", C.c_double),
+                ("mean", C.c_double), ("sf", C.c_double)]
+
+
+def build():
+    subprocess.check_call(["make", "-s", "-C", _HERE])
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        src_m = max(os.path.getmtime(os.path.join(_HERE, f))
+                    for f in ("dctz_oracle.c", "dctz_oracle_impl.inc", "dctz_oracle.h"))
+        if not os.path.exists(_SO) or os.path.getmtime(_SO) < src_m:
+            build()
+        _lib = C.CDLL(_SO)
+        _lib.orc_psnr_f64.restype = C.c_double
+        _lib.orc_psnr_f32.restype = C.c_double
+    return _lib
+
+
+def _suf(dtype):
+    dtype = np.dtype(dtype)
+    if dtype == np.float64:
+        return "f64"
+    if dtype == np.float32:
+        return "f32"
+    raise TypeError(dtype)
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def stats(x):
+    x = np.ascontiguousarray(x)
+    st = Stats()
+    getattr(lib(), "orc_stats_" + _suf(x.dtype))(_p(x), C.c_size_t(x.size), C.byref(st))
+    return st
+
+
+def dct_fwd(a, impl=FAST):
+    a = np.ascontiguousarray(a)
+    b = np.empty_like(a)
+    getattr(lib(), "orc_dct_fwd_" + _suf(a.dtype))(_p(a), _p(b), C.c_int(a.size), C.c_int(impl))
+    return b
+
+
+def dct_inv(a, impl=FAST):
+    a = np.ascontiguousarray(a)
+    b = np.empty_like(a)
+    getattr(lib(), "orc_dct_inv_" + _suf(a.dtype))(_p(a), _p(b), C.c_int(a.size), C.c_int(impl))
+    return b
+
+
+def dct_tables(n, dtype):
+    dtype = np.dtype(dtype)
+    t = [np.zeros(n, dtype) for _ in range(4)]
+    getattr(lib(), "orc_dct_tables_" + _suf(dtype))(C.c_int(n), *[_p(a) for a in t])
+    return t  # as, ax, ias, iax
+
+
+def gen_bins(eb, dtype):
+    dtype = np.dtype(dtype)
+    bc = np.zeros(255, dtype)
+    if dtype == np.float64:
+        lib().orc_gen_bins_f64(_p(bc), C.c_int(255), C.c_double(eb))
+    else:
+        lib().orc_gen_bins_f32(_p(bc), C.c_int(255), C.c_float(eb))
+    return bc
+
+
+class Compressed:
+    """Pre-zlib streams + header scalars of one dctz_compress call."""
+    __slots__ = ("dtype", "n", "eb", "mode", "sf", "mean", "stats", "bin_index", "dc",
+                 "ac_exact", "cnt", "qtable", "qtable_raw", "coef", "scaled")
+
+
+def compress(x, eb, mode=EC, impl=FAST, want_coef=False):
+    """Runs a2..a9 on a COPY of x; the scaled copy is returned as .scaled."""
+    x = np.array(x, copy=True, order="C")
+    suf = _suf(x.dtype)
+    n = x.size
+    nblk = (n + BLK - 1) // BLK
+    out = Compressed()
+    out.dtype, out.n, out.eb, out.mode = x.dtype, n, float(eb), mode
+    out.bin_index = np.zeros(n, np.uint8)
+    out.dc = np.zeros(nblk, np.float32)
+    ac = np.zeros(max(n, 1), np.float32)
+    out.qtable = np.zeros(BLK, x.dtype)
+    out.qtable_raw = np.zeros(BLK, x.dtype)
+    out.coef = np.zeros(n, x.dtype) if want_coef else None
+    st = Stats()
+    cnt = C.c_uint32(0)
+    rc = getattr(lib(), "orc_compress_" + suf)(
+        _p(x), C.c_size_t(n), C.c_double(eb), C.c_int(mode), C.c_int(impl), C.byref(st),
+        _p(out.bin_index), _p(out.dc), _p(ac), C.byref(cnt), _p(out.qtable),
+        _p(out.qtable_raw), _p(out.coef) if want_coef else None)
+    if rc != 0:
+        raise ValueError("error bound not acceptable (dctz-comp-lib.c:135-138)")
+    out.cnt = cnt.value
+    out.ac_exact = ac[:out.cnt].copy()
+    out.stats = st
+    out.sf, out.mean = st.sf, st.mean
+    out.scaled = x
+    return out
+
+
+def decompress(c, impl=FAST):
+    out = np.zeros(c.n, c.dtype)
+    ac = c.ac_exact if c.ac_exact.size else np.zeros(1, np.float32)
+    getattr(lib(), "orc_decompress_" + _suf(c.dtype))(
+        _p(c.bin_index), _p(c.dc), _p(ac), _p(c.qtable), C.c_size_t(c.n), C.c_double(c.eb),
+        C.c_double(c.sf), C.c_int(c.mode), C.c_int(impl), _p(out))
+    return out
+
+
+def psnr(x, r):
+    x = np.ascontiguousarray(x)
+    r = np.ascontiguousarray(r, dtype=x.dtype)
+    md, rm, rg = C.c_double(), C.c_double(), C.c_double()
+    p = getattr(lib(), "orc_psnr_" + _suf(x.dtype))(
+        _p(x), _p(r), C.c_size_t(x.size), C.byref(md), C.byref(rm), C.byref(rg))
+    return {"psnr": p, "maxdiff": md.value, "rmse": rm.value, "range": rg.value}
