@@ -1,0 +1,104 @@
+// dctz_device.h -- types shared by the kernels (dctz_kernels.hip) and the C-ABI
+// shim (dctz_shim.hip): per-dtype traits, the per-call control block, kernel
+// parameter blocks and the launcher prototypes.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/dctz_hip.h"
+#include "dct64_lane.h"
+
+namespace dctz {
+
+constexpr int TILE_BLKS = 64;             // blocks per tile
+constexpr int TILE_ELEMS = TILE_BLKS * 64;
+constexpr int WG = 256;                   // threads per workgroup (4 wavefronts)
+
+template <typename T> struct Traits;
+template <> struct Traits<double> {
+  using Vec = double2;
+  using Bits = unsigned long long;
+  static constexpr int EPV = 2;           // elements per 16-byte vector
+  static constexpr int PITCH = 64 + 2;    // LDS elements per block (16 B of padding)
+  __host__ __device__ static Vec zero() { return make_double2(0.0, 0.0); }
+  __device__ static void div(Vec& v, double s) { v.x = v.x / s; v.y = v.y / s; }
+  __device__ static void mul(Vec& v, double s) { v.x = v.x * s; v.y = v.y * s; }
+  __device__ static void unpack(const Vec& v, double* e) { e[0] = v.x; e[1] = v.y; }
+  __device__ static Vec pack(const double* e) { return make_double2(e[0], e[1]); }
+  __device__ static double huge() { return 1.79769313486231570815e308; }
+  __device__ static double from_bits(Bits b) { return __longlong_as_double((long long)b); }
+};
+template <> struct Traits<float> {
+  using Vec = float4;
+  using Bits = unsigned int;
+  static constexpr int EPV = 4;
+  static constexpr int PITCH = 64 + 4;
+  __host__ __device__ static Vec zero() { return make_float4(0.f, 0.f, 0.f, 0.f); }
+  __device__ static void div(Vec& v, float s) { v.x = v.x / s; v.y = v.y / s; v.z = v.z / s; v.w = v.w / s; }
+  __device__ static void mul(Vec& v, float s) { v.x = v.x * s; v.y = v.y * s; v.z = v.z * s; v.w = v.w * s; }
+  __device__ static void unpack(const Vec& v, float* e) { e[0] = v.x; e[1] = v.y; e[2] = v.z; e[3] = v.w; }
+  __device__ static Vec pack(const float* e) { return make_float4(e[0], e[1], e[2], e[3]); }
+  __device__ static float huge() { return 3.40282346638528859812e38f; }
+  __device__ static float from_bits(Bits b) { return __uint_as_float(b); }
+};
+
+// Per-call control block in device memory; zeroed by ONE hipMemsetAsync before
+// every call (ticket, look-back total, watchdog flag, QT table accumulators).
+struct Ctl {
+  unsigned ticket;                 // next tile to hand out
+  unsigned cnt_total;              // exceptions emitted / consumed so far
+  unsigned error;                  // 1: look-back watchdog, 2: AC_exact underrun
+  unsigned pad0;
+  unsigned long long qraw[64];     // max |coef| per position, raw bits of T (dctz-comp-lib.c:371-372)
+  unsigned long long q0;           // bits of the last block's DC (qtable[0], :355-360)
+  unsigned long long pad1;
+};
+static_assert(sizeof(Ctl) % 16 == 0, "memset block must be a multiple of 16 bytes");
+
+template <typename T>
+struct FwdParams {
+  const T* x;                      // input
+  uint8_t* bin;                    // bin_index out
+  float* dc;                       // DC out
+  float* ac;                       // AC_exact out
+  T* scaled;                       // optional x/sf out
+  T* coef;                         // optional coefficient tap
+  T* qt_item;                      // QT scratch: flagged coefficients, full precision
+  uint8_t* qt_j;                   // QT scratch: their position j
+  const T* tab;                    // TAB_* block (device)
+  const T* rtab;                   // RTAB_* block (device), remainder block only
+  Ctl* ctl;
+  unsigned long long* desc;        // look-back descriptors, one per tile
+  unsigned nfull;                  // number of full 64-element blocks
+  unsigned ntiles;
+  unsigned last_is_full;           // N % 64 == 0
+  T sf, bin_width, range_min, range_max;
+};
+
+template <typename T>
+struct InvParams {
+  const uint8_t* bin;
+  const float* dc;
+  const float* ac;
+  T* out;
+  const T* tab;
+  const T* rtab;
+  const T* qtab;                   // QT: clamped table (device)
+  Ctl* ctl;
+  unsigned long long* desc;
+  unsigned nfull, ntiles, ac_count;
+  T sf, bin_width, range_min, range_max;
+  double eb;
+};
+
+template <typename T> void launch_stats(const T* x, size_t n, double* part, int nparts, double* out, hipStream_t s);
+template <typename T> void launch_compress(const FwdParams<T>& p, int mode, bool scale, int grid, hipStream_t s);
+template <typename T> void launch_compress_rem(const FwdParams<T>& p, int mode, bool scale, int l, hipStream_t s);
+template <typename T> void launch_qt_finish(const FwdParams<T>& p, double eb, int grid, hipStream_t s);
+template <typename T> void launch_decompress(const InvParams<T>& p, int mode, bool scale, int grid, hipStream_t s);
+template <typename T> void launch_decompress_rem(const InvParams<T>& p, int mode, bool scale, int l, hipStream_t s);
+template <typename T> void launch_dct_blocks(const T* x, T* out, const T* gtab, const T* rtab, size_t n,
+                                             bool inverse, int grid, hipStream_t s);
+
+}  // namespace dctz

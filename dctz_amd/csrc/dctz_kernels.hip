@@ -1,0 +1,781 @@
+// dctz_kernels.hip -- gfx950 (MI355X) kernels of the DCTZ hot path.
+//
+// Work decomposition (all kernels, both directions):
+//   * a TILE is 64 consecutive 64-element blocks (4096 elements, 32 KiB fp64);
+//     one 256-thread workgroup owns a tile at a time and takes tiles from a
+//     global ticket counter (persistent grid, ~4 workgroups per CU);
+//   * the tile is staged in LDS once; HBM is touched with 16-byte-per-lane,
+//     fully coalesced accesses only;
+//   * inside the tile a QUAD of lanes owns a block and runs the 64-point DCT of
+//     dct64_lane.h in registers, exchanging partners with DPP quad_perm moves;
+//   * the ordered stream of "stored exactly" coefficients (AC_exact) is placed
+//     with a single-pass decoupled look-back scan over tiles, so the input is
+//     read exactly once by this kernel.
+//
+// Reference code replaced: see include/dctz_hip.h (per entry point) and the
+// comment on each kernel.  Built with -ffp-contract=off: the arithmetic that
+// the reference does unfused (gcc, baseline x86-64, reference Makefile:2) is
+// unfused here too.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "dct64_lane.h"
+#include "dctz_device.h"
+
+namespace dctz {
+
+// ------------------------------------------------------------------ helpers --
+template <int CTRL>
+__device__ __forceinline__ float dpp(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, false));
+}
+template <int CTRL>
+__device__ __forceinline__ double dpp(double v) {
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xf, 0xf, false);
+  hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xf, 0xf, false);
+  return __hiloint2double(hi, lo);
+}
+// quad_perm control words: lane i reads from lane perm[i] of its quad
+constexpr int QP_XOR1 = 0xB1;     // [1,0,3,2]
+constexpr int QP_XOR2 = 0x4E;     // [2,3,0,1]
+constexpr int QP_MIRROR = 0x1B;   // [3,2,1,0]
+constexpr int QP_0132 = 0xB4;     // [0,1,3,2]
+
+__device__ __forceinline__ unsigned long long to_bits(double v) { return (unsigned long long)__double_as_longlong(v); }
+__device__ __forceinline__ unsigned int to_bits(float v) { return __float_as_uint(v); }
+
+template <typename T>
+__device__ __forceinline__ int tile_idx(int e) { return (e >> 6) * Traits<T>::PITCH + (e & 63); }
+
+// conv_tbl of dctz-comp-lib.c:27-43 as arithmetic (sign-interleave of t-127)
+__device__ __forceinline__ unsigned conv_bin(unsigned t) { return t <= 127u ? 254u - 2u * t : 2u * t - 255u; }
+
+// Pass-1 binning of one coefficient (dctz-comp-lib.c:363-414).  Returns the bin
+// id; *out_of_range tells whether the QT table must see it (:367-373).
+template <typename T>
+__device__ __forceinline__ unsigned bin_of(T item, T range_min, T range_max, T bin_width, bool* out_of_range) {
+  const bool out = (item < range_min) || (item > range_max);
+  const int ti = (int)((item - range_min) / bin_width);   // (t_bin_id) cast: trunc toward 0
+  *out_of_range = out;
+  return out ? 255u : conv_bin((unsigned)ti & 255u);
+}
+
+// ------------------------------------------------- decoupled look-back scan --
+// One 64-bit word per tile: status in the top 2 bits, value in the low 32.
+// Single-word relaxed agent-scope accesses need no fences (the datum IS the flag).
+constexpr unsigned long long ST_AGG = 1ull << 62, ST_PREFIX = 2ull << 62, ST_MASK = 3ull << 62;
+constexpr unsigned SPIN_LIMIT = 1u << 22;
+
+__device__ __forceinline__ unsigned lookback(unsigned long long* desc, unsigned tile, unsigned total,
+                                             unsigned* err) {
+  if (tile == 0) {
+    __hip_atomic_store(&desc[0], ST_PREFIX | total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return 0;
+  }
+  __hip_atomic_store(&desc[tile], ST_AGG | total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  unsigned excl = 0;
+  for (int j = (int)tile - 1; j >= 0; --j) {
+    unsigned long long d = 0;
+    unsigned spins = 0;
+    for (;;) {
+      d = __hip_atomic_load(&desc[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (d & ST_MASK) break;
+      if (++spins >= SPIN_LIMIT) break;          // watchdog: never hang the GPU
+      __builtin_amdgcn_s_sleep(1);
+    }
+    if (!(d & ST_MASK)) { atomicExch(err, 1u); break; }
+    excl += (unsigned)d;
+    if ((d & ST_MASK) == ST_PREFIX) break;
+  }
+  __hip_atomic_store(&desc[tile], ST_PREFIX | (unsigned long long)(excl + total), __ATOMIC_RELAXED,
+                     __HIP_MEMORY_SCOPE_AGENT);
+  return excl;
+}
+
+// Exclusive scan of one count per thread over the 256-thread workgroup, chained
+// over tiles by look-back.  Returns this thread's global offset; every thread
+// must call it (two barriers inside).  sc: 8 words of LDS scratch.
+__device__ __forceinline__ unsigned tile_scan(unsigned cnt, unsigned tile, unsigned ntiles, unsigned* sc,
+                                              unsigned long long* desc, Ctl* ctl) {
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  unsigned incl = cnt;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    unsigned o = __shfl_up(incl, d);
+    if (lane >= d) incl += o;
+  }
+  if (lane == 63) sc[wave] = incl;
+  __syncthreads();
+  if (t == 0) {
+    const unsigned total = sc[0] + sc[1] + sc[2] + sc[3];
+    const unsigned excl = lookback(desc, tile, total, &ctl->error);
+    sc[4] = excl;
+    if (tile == ntiles - 1) ctl->cnt_total = excl + total;
+  }
+  __syncthreads();
+  unsigned off = sc[4] + (incl - cnt);
+  if (wave > 0) off += sc[0];
+  if (wave > 1) off += sc[1];
+  if (wave > 2) off += sc[2];
+  return off;
+}
+
+// --------------------------------------------------------- tile load / store --
+// Global -> LDS, 16 B per lane, optional division by sf (dctz-comp-lib.c:193-216)
+// and optional write-back of the scaled data.
+template <typename T, bool SCALE>
+__device__ __forceinline__ void load_tile(T* tile, const T* __restrict__ x, size_t ebase, unsigned valid,
+                                          T sf, T* scaled) {
+  using Vec = typename Traits<T>::Vec;
+  constexpr int EPV = Traits<T>::EPV, NV = TILE_ELEMS / EPV / WG;
+  const int t = threadIdx.x;
+  const Vec* src = reinterpret_cast<const Vec*>(x + ebase);
+  Vec v[NV];
+#pragma unroll
+  for (int i = 0; i < NV; i++) {
+    const unsigned e = (unsigned)(i * WG + t) * EPV;
+    if (e < valid) v[i] = src[i * WG + t];
+    else v[i] = Traits<T>::zero();
+  }
+#pragma unroll
+  for (int i = 0; i < NV; i++) {
+    const unsigned e = (unsigned)(i * WG + t) * EPV;
+    if (SCALE) {
+      Traits<T>::div(v[i], sf);
+      if (scaled != nullptr && e < valid) reinterpret_cast<Vec*>(scaled + ebase)[i * WG + t] = v[i];
+    }
+    *reinterpret_cast<Vec*>(&tile[tile_idx<T>((int)e)]) = v[i];
+  }
+}
+
+template <typename T, bool SCALE>
+__device__ __forceinline__ void store_tile(const T* tile, T* __restrict__ out, size_t ebase, unsigned valid, T sf) {
+  using Vec = typename Traits<T>::Vec;
+  constexpr int EPV = Traits<T>::EPV, NV = TILE_ELEMS / EPV / WG;
+  const int t = threadIdx.x;
+  Vec* dst = reinterpret_cast<Vec*>(out + ebase);
+#pragma unroll
+  for (int i = 0; i < NV; i++) {
+    const unsigned e = (unsigned)(i * WG + t) * EPV;
+    Vec v = *reinterpret_cast<const Vec*>(&tile[tile_idx<T>((int)e)]);
+    if (SCALE) Traits<T>::mul(v, sf);             // dctz-decomp-lib.c:494-511
+    if (e < valid) dst[i * WG + t] = v;
+  }
+}
+
+// ------------------------------------------------------- in-tile transforms --
+// Forward DCT-II of the 64 blocks of the tile, in place in LDS (dct.c:55-103).
+// Two workgroup barriers inside (after reads, after writes).
+template <typename T>
+__device__ __forceinline__ void tile_dct_fwd(T* tile, const T* tab) {
+  const int t = threadIdx.x, blk = t >> 2, lane = t & 3;
+  T* b = tile + blk * Traits<T>::PITCH;
+  T yr[8], yi[8], pr[8], pi[8], lo[8], hi[8];
+#pragma unroll
+  for (int n1 = 0; n1 < 8; n1++) {
+    yr[n1] = b[pack_pos(4 * n1 + lane, 0)];
+    yi[n1] = b[pack_pos(4 * n1 + lane, 1)];
+  }
+  fwd_stage_lane<T>(yr, yi, lane, tab);
+#pragma unroll
+  for (int k = 0; k < 8; k++) { pr[k] = dpp<QP_XOR2>(yr[k]); pi[k] = dpp<QP_XOR2>(yi[k]); }
+  fwd_cross_a<T>(yr, yi, pr, pi, lane);
+#pragma unroll
+  for (int k = 0; k < 8; k++) { pr[k] = dpp<QP_XOR1>(yr[k]); pi[k] = dpp<QP_XOR1>(yi[k]); }
+  fwd_cross_b<T>(yr, yi, pr, pi, lane);
+  pr[0] = dpp<QP_0132>(yr[0]); pi[0] = dpp<QP_0132>(yi[0]);
+#pragma unroll
+  for (int k = 1; k < 8; k++) { pr[k] = dpp<QP_MIRROR>(yr[8 - k]); pi[k] = dpp<QP_MIRROR>(yi[8 - k]); }
+  fwd_split<T>(yr, yi, pr, pi, lane, tab, lo, hi);
+  __syncthreads();                                 // every lane has read its inputs
+  const int q = lane_q(lane);
+#pragma unroll
+  for (int k1 = 0; k1 < 8; k1++) {
+    b[8 * q + k1] = lo[k1];
+    const int kh = (k1 == 0 && lane == 0) ? 32 : 64 - (8 * q + k1);
+    b[kh] = hi[k1];
+  }
+  __syncthreads();
+}
+
+// Inverse DCT-III of the 64 blocks of the tile, in place in LDS (dct.c:115-205).
+template <typename T>
+__device__ __forceinline__ void tile_dct_inv(T* tile, const T* tab) {
+  const int t = threadIdx.x, blk = t >> 2, lane = t & 3;
+  T* b = tile + blk * Traits<T>::PITCH;
+  const int q = lane_q(lane);
+  T lo[8], hi[8], gr[8], gi[8], pr[8], pi[8], zr[8], zi[8], g32r, g32i;
+#pragma unroll
+  for (int k1 = 0; k1 < 8; k1++) {
+    lo[k1] = b[8 * q + k1];
+    const int kh = (k1 == 0 && lane == 0) ? 32 : 64 - (8 * q + k1);
+    hi[k1] = b[kh];
+  }
+  inv_prepare<T>(lo, hi, lane, tab, gr, gi, g32r, g32i);
+  pr[0] = dpp<QP_0132>(gr[0]); pi[0] = dpp<QP_0132>(gi[0]);
+  if (lane == 0) { pr[0] = g32r; pi[0] = g32i; }
+#pragma unroll
+  for (int k = 1; k < 8; k++) { pr[k] = dpp<QP_MIRROR>(gr[8 - k]); pi[k] = dpp<QP_MIRROR>(gi[8 - k]); }
+  inv_merge<T>(gr, gi, pr, pi, lane, tab, zr, zi);
+#pragma unroll
+  for (int k = 0; k < 8; k++) { pr[k] = dpp<QP_XOR1>(zr[k]); pi[k] = dpp<QP_XOR1>(zi[k]); }
+  inv_cross_a<T>(zr, zi, pr, pi, lane);
+#pragma unroll
+  for (int k = 0; k < 8; k++) { pr[k] = dpp<QP_XOR2>(zr[k]); pi[k] = dpp<QP_XOR2>(zi[k]); }
+  inv_cross_b<T>(zr, zi, pr, pi, lane);
+  inv_stage_lane<T>(zr, zi, lane, tab);
+  __syncthreads();
+#pragma unroll
+  for (int n1 = 0; n1 < 8; n1++) {
+    b[pack_pos(4 * n1 + lane, 0)] = zr[n1];
+    b[pack_pos(4 * n1 + lane, 1)] = zi[n1];
+  }
+  __syncthreads();
+}
+
+template <typename T>
+__device__ __forceinline__ void load_tab(T* tab, const T* __restrict__ gtab) {
+  for (int i = threadIdx.x; i < TAB_SIZE; i += WG) tab[i] = gtab[i];
+}
+
+// QT normalisation of an out-of-range coefficient (dctz-comp-lib.c:488-492 /
+// :514-518); error_bound is a double there, so f32 evaluates product and sum in
+// double and rounds once.
+__device__ __forceinline__ double qt_normalise(double item, double q, double eb, double qf, double rmin, double rmax) {
+  if (item < rmin) return (item / q) * eb * qf + rmin;
+  if (item > rmax) return (item / q) * eb * qf + rmax;
+  return item;
+}
+__device__ __forceinline__ float qt_normalise(float item, float q, double eb, float qf, float rmin, float rmax) {
+  if (item < rmin) return (float)((double)(item / q) * eb * (double)qf + (double)rmin);
+  if (item > rmax) return (float)((double)(item / q) * eb * (double)qf + (double)rmax);
+  return item;
+}
+// QT de-normalisation on decode (dctz-decomp-lib.c:404-409 / :450-454)
+__device__ __forceinline__ double qt_restore(double v, double q, double eb, double qf, double rmin, double rmax) {
+  return (v > 0) ? ((v - rmax) / (eb * qf)) * q : ((v - rmin) / (eb * qf)) * q;
+}
+__device__ __forceinline__ float qt_restore(float v, float q, double eb, float qf, float rmin, float rmax) {
+  return (v > 0) ? (float)(((double)(v - rmax) / (eb * (double)qf)) * (double)q)
+                 : (float)(((double)(v - rmin) / (eb * (double)qf)) * (double)q);
+}
+
+// =============================================================== statistics ==
+// calc_data_stat (util.c:12-44): max|x|, min|x| and sum (x[0] is never added,
+// util.c:22 starts at i = 1).  Tree order: `sum` is NOT the reference's serial
+// order (it is never used by the codec; the host wrapper recomputes it
+// serially for the header).
+template <typename T>
+__global__ __launch_bounds__(WG) void k_stats(const T* __restrict__ x, size_t n, double* __restrict__ part) {
+  using Vec = typename Traits<T>::Vec;
+  constexpr int EPV = Traits<T>::EPV;
+  const size_t nvec = n / EPV;
+  const Vec* src = reinterpret_cast<const Vec*>(x);
+  T mx = T(0), mn = Traits<T>::huge();
+  double sum = 0.0;
+  for (size_t i = (size_t)blockIdx.x * WG + threadIdx.x; i < nvec; i += (size_t)gridDim.x * WG) {
+    const Vec v = src[i];
+    T e[EPV];
+    Traits<T>::unpack(v, e);
+#pragma unroll
+    for (int k = 0; k < EPV; k++) {
+      const T a = fabs(e[k]);
+      mx = a > mx ? a : mx;
+      mn = a < mn ? a : mn;
+      if (i != 0 || k != 0) sum += (double)e[k];
+    }
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0)
+    for (size_t i = nvec * EPV; i < n; i++) {
+      const T a = fabs(x[i]);
+      mx = a > mx ? a : mx;
+      mn = a < mn ? a : mn;
+      if (i != 0) sum += (double)x[i];
+    }
+  double dmx = (double)mx, dmn = (double)mn;
+#pragma unroll
+  for (int d = 32; d > 0; d >>= 1) {
+    dmx = fmax(dmx, __shfl_down(dmx, d));
+    dmn = fmin(dmn, __shfl_down(dmn, d));
+    sum += __shfl_down(sum, d);
+  }
+  __shared__ double s[3][WG / 64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (lane == 0) { s[0][wave] = dmx; s[1][wave] = dmn; s[2][wave] = sum; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int w = 1; w < WG / 64; w++) { dmx = fmax(dmx, s[0][w]); dmn = fmin(dmn, s[1][w]); sum += s[2][w]; }
+    part[3 * blockIdx.x + 0] = dmx;
+    part[3 * blockIdx.x + 1] = dmn;
+    part[3 * blockIdx.x + 2] = sum;
+  }
+}
+
+__global__ __launch_bounds__(WG) void k_stats_final(const double* __restrict__ part, int nparts, double* __restrict__ out) {
+  double dmx = 0.0, dmn = 1.79769313486231570815e308, sum = 0.0;
+  for (int i = threadIdx.x; i < nparts; i += WG) {
+    dmx = fmax(dmx, part[3 * i]); dmn = fmin(dmn, part[3 * i + 1]); sum += part[3 * i + 2];
+  }
+#pragma unroll
+  for (int d = 32; d > 0; d >>= 1) {
+    dmx = fmax(dmx, __shfl_down(dmx, d));
+    dmn = fmin(dmn, __shfl_down(dmn, d));
+    sum += __shfl_down(sum, d);
+  }
+  __shared__ double s[3][WG / 64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (lane == 0) { s[0][wave] = dmx; s[1][wave] = dmn; s[2][wave] = sum; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int w = 1; w < WG / 64; w++) { dmx = fmax(dmx, s[0][w]); dmn = fmin(dmn, s[1][w]); sum += s[2][w]; }
+    out[0] = dmx; out[1] = dmn; out[2] = sum;
+  }
+}
+
+// ================================================================= compress ==
+// Fused: scale (dctz-comp-lib.c:193-216) -> DCT-II per block (:337-340, dct.c:55-103)
+// -> DC (:350-351) -> pass-1 binning (:361-414) -> ordered exception stream
+// (:478-544) [-> QT per-position max (:371-372)], full 64-element blocks only.
+template <typename T, int MODE, bool SCALE>
+__global__ __launch_bounds__(WG) void k_compress(FwdParams<T> p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  using Vec = typename Traits<T>::Vec;
+  using Bits = typename Traits<T>::Bits;
+  constexpr int EPV = Traits<T>::EPV;
+  T* tile = reinterpret_cast<T*>(smem);
+  T* tab = tile + TILE_BLKS * Traits<T>::PITCH;
+  Bits* qmax = reinterpret_cast<Bits*>(tab + TAB_SIZE);
+  unsigned* sc = reinterpret_cast<unsigned*>(qmax + 64);
+  const int t = threadIdx.x;
+  load_tab<T>(tab, p.tab);
+  if (MODE == DCTZHIP_QT && t < 64) qmax[t] = 0;
+
+  for (;;) {
+    __syncthreads();                               // tile + sc[] free for reuse
+    if (t == 0) sc[5] = __hip_atomic_fetch_add(&p.ctl->ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    const unsigned tile_id = sc[5];
+    if (tile_id >= p.ntiles) break;
+    const size_t ebase = (size_t)tile_id * TILE_ELEMS;
+    const unsigned blks_here = min((unsigned)TILE_BLKS, p.nfull - tile_id * TILE_BLKS);
+    const unsigned valid = blks_here * 64u;
+
+    load_tile<T, SCALE>(tile, p.x, ebase, valid, p.sf, p.scaled);
+    __syncthreads();
+    tile_dct_fwd<T>(tile, tab);
+
+    // ---- emit: thread t owns elements [16t, 16t+16) of the tile -------------
+    const int blk = t >> 2, j0 = (t & 3) * 16;
+    const bool active = (unsigned)blk < blks_here;
+    T c[16];
+#pragma unroll
+    for (int i = 0; i < 16 / EPV; i++) {
+      const Vec v = *reinterpret_cast<const Vec*>(&tile[blk * Traits<T>::PITCH + j0 + i * EPV]);
+      Traits<T>::unpack(v, &c[i * EPV]);
+    }
+    unsigned w[4] = {0, 0, 0, 0};
+    unsigned mask = 0;
+#pragma unroll
+    for (int i = 0; i < 16; i++) {
+      bool out;
+      unsigned b = bin_of<T>(c[i], p.range_min, p.range_max, p.bin_width, &out);
+      const int j = j0 + i;
+      if (j == 0) { b = 255u; out = false; }       // :361 DC slot
+      else if (b == 255u) mask |= 1u << i;
+      if (MODE == DCTZHIP_QT && out && active) atomicMax(&qmax[j], to_bits(fabs(c[i])));
+      w[i >> 2] |= b << (8 * (i & 3));
+    }
+    if (!active) mask = 0;
+    if (active) {
+      reinterpret_cast<uint4*>(p.bin + ebase)[t] = make_uint4(w[0], w[1], w[2], w[3]);
+      if (p.coef != nullptr) {
+#pragma unroll
+        for (int i = 0; i < 16 / EPV; i++)
+          reinterpret_cast<Vec*>(p.coef + ebase + (size_t)t * 16)[i] = Traits<T>::pack(&c[i * EPV]);
+      }
+      if (j0 == 0) {
+        const unsigned gblk = tile_id * TILE_BLKS + blk;
+        p.dc[gblk] = (float)c[0];                  // :350-351 USE_TRUNCATE
+        if (p.last_is_full && gblk == p.nfull - 1) p.ctl->q0 = (unsigned long long)to_bits(c[0]);   // :355-360
+      }
+    }
+    unsigned r = tile_scan((unsigned)__popc(mask), tile_id, p.ntiles, sc, p.desc, p.ctl);
+#pragma unroll
+    for (int i = 0; i < 16; i++) {
+      if (mask & (1u << i)) {
+        if (MODE == DCTZHIP_EC) p.ac[r] = (float)c[i];            // :535-537
+        else { p.qt_item[r] = c[i]; p.qt_j[r] = (uint8_t)(j0 + i); }
+        r++;
+      }
+    }
+  }
+  if (MODE == DCTZHIP_QT) {
+    __syncthreads();
+    if (t < 64 && qmax[t] != 0) atomicMax(&p.ctl->qraw[t], (unsigned long long)qmax[t]);
+  }
+}
+
+// The last, short block (length l = N % 64): the reference re-plans a length-l
+// (l even) or 2l (l odd) FFT for it (dctz-comp-lib.c:326-336, dct.c:59-72).
+// One wavefront, definition-order DFT with host-built roots.
+template <typename T, int MODE, bool SCALE>
+__global__ __launch_bounds__(64) void k_compress_rem(FwdParams<T> p, int l) {
+  __shared__ T v[128];
+  const int k = threadIdx.x;
+  const size_t base = (size_t)p.nfull * 64;
+  const T* rt = p.rtab;
+  const int N = (l & 1) ? 2 * l : l;
+  if (k < l) {
+    T a = p.x[base + k];
+    if (SCALE) { a = a / p.sf; if (p.scaled != nullptr) p.scaled[base + k] = a; }
+    if (l & 1) { v[k] = a; v[l + (l - 1 - k)] = a; }               // dct.c:61-64
+    else if (k & 1) v[l - 1 - (k >> 1)] = a;                       // dct.c:75-83
+    else v[k >> 1] = a;
+  }
+  __syncthreads();
+  T coef = T(0);
+  if (k < l) {
+    T sr = T(0), si = T(0);
+    for (int j = 0; j < N; j++) {
+      const int tt = (j * k) % N;
+      sr = sr + v[j] * rt[RTAB_WR + tt];
+      si = si + v[j] * rt[RTAB_WI + tt];
+    }
+    coef = rt[RTAB_AS + k] * sr + rt[RTAB_AX + k] * si;            // dct.c:100-102 (Im V = -si)
+  }
+  bool out = false;
+  unsigned b = bin_of<T>(coef, p.range_min, p.range_max, p.bin_width, &out);
+  bool exc = false;
+  if (k == 0) { b = 255u; out = false; } else exc = (b == 255u);
+  if (k >= l) { exc = false; out = false; }
+  const unsigned long long m = __ballot(exc);
+  const unsigned rank = (unsigned)__popcll(m & ((1ull << k) - 1ull));
+  const unsigned start = p.ctl->cnt_total;
+  if (k < l) {
+    p.bin[base + k] = (uint8_t)b;
+    if (p.coef != nullptr) p.coef[base + k] = coef;
+    if (k == 0) { p.dc[p.nfull] = (float)coef; p.ctl->q0 = (unsigned long long)to_bits(coef); }
+    if (MODE == DCTZHIP_QT && out) atomicMax(&p.ctl->qraw[k], (unsigned long long)to_bits(fabs(coef)));
+    if (exc) {
+      if (MODE == DCTZHIP_EC) p.ac[start + rank] = (float)coef;
+      else { p.qt_item[start + rank] = coef; p.qt_j[start + rank] = (uint8_t)k; }
+    }
+  }
+  __syncthreads();
+  if (k == 0) p.ctl->cnt_total = start + (unsigned)__popcll(m);
+}
+
+// QT pass 2 (dctz-comp-lib.c:450-461 clamp, :478-533 normalise + append).
+template <typename T>
+__global__ __launch_bounds__(WG) void k_qt_finish(FwdParams<T> p, double eb) {
+  using Bits = typename Traits<T>::Bits;
+  __shared__ T q[64];
+  if (threadIdx.x < 64) {
+    T v = Traits<T>::from_bits((Bits)p.ctl->qraw[threadIdx.x]);
+    if (v < T(1)) v = T(1);                                        // :450-461
+    q[threadIdx.x] = v;
+  }
+  __syncthreads();
+  const unsigned cnt = p.ctl->cnt_total;
+  for (unsigned i = blockIdx.x * WG + threadIdx.x; i < cnt; i += gridDim.x * WG) {
+    const T item = p.qt_item[i];
+    const int j = p.qt_j[i];
+    // The in-range else-branch of :502-506 cannot fire for finite data and
+    // stores nothing; every flagged coefficient is appended.
+    p.ac[i] = (float)qt_normalise(item, q[j], eb, T(10), p.range_min, p.range_max);
+  }
+}
+
+// =============================================================== decompress ==
+// Fused: de-quantise (dctz-decomp-lib.c:389-417 / :438-463; gen_bins
+// binning.c:12-50) -> DCT-III per block (:428, dct.c:115-205) -> de-scale (:494-511).
+template <typename T, int MODE, bool SCALE>
+__global__ __launch_bounds__(WG) void k_decompress(InvParams<T> p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  using Vec = typename Traits<T>::Vec;
+  constexpr int EPV = Traits<T>::EPV;
+  T* tile = reinterpret_cast<T*>(smem);
+  T* tab = tile + TILE_BLKS * Traits<T>::PITCH;
+  T* qt = tab + TAB_SIZE;
+  unsigned* sc = reinterpret_cast<unsigned*>(qt + 64);
+  const int t = threadIdx.x;
+  load_tab<T>(tab, p.tab);
+  if (MODE == DCTZHIP_QT && t < 64) qt[t] = p.qtab[t];
+
+  for (;;) {
+    __syncthreads();
+    if (t == 0) sc[5] = __hip_atomic_fetch_add(&p.ctl->ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    const unsigned tile_id = sc[5];
+    if (tile_id >= p.ntiles) break;
+    const size_t ebase = (size_t)tile_id * TILE_ELEMS;
+    const unsigned blks_here = min((unsigned)TILE_BLKS, p.nfull - tile_id * TILE_BLKS);
+    const unsigned valid = blks_here * 64u;
+
+    const int blk = t >> 2, j0 = (t & 3) * 16;
+    const bool active = (unsigned)blk < blks_here;
+    uint4 wv = make_uint4(0, 0, 0, 0);
+    if (active) wv = reinterpret_cast<const uint4*>(p.bin + ebase)[t];
+    const unsigned w[4] = {wv.x, wv.y, wv.z, wv.w};
+    unsigned mask = 0;
+#pragma unroll
+    for (int i = 0; i < 16; i++) {
+      const unsigned b = (w[i >> 2] >> (8 * (i & 3))) & 255u;
+      if (b == 255u && (j0 + i) != 0) mask |= 1u << i;             // :400 / :446
+    }
+    if (!active) mask = 0;
+    unsigned r = tile_scan((unsigned)__popc(mask), tile_id, p.ntiles, sc, p.desc, p.ctl);
+
+    T c[16];
+#pragma unroll
+    for (int i = 0; i < 16; i++) {
+      const unsigned b = (w[i >> 2] >> (8 * (i & 3))) & 255u;
+      const int j = j0 + i;
+      T val;
+      if (j == 0) {
+        val = active ? (T)p.dc[tile_id * TILE_BLKS + blk] : T(0);  // :392 / :438
+      } else if (mask & (1u << i)) {
+        T v = T(0);
+        if (r < p.ac_count) v = (T)p.ac[r]; else atomicExch(&p.ctl->error, 2u);
+        r++;
+        if (MODE == DCTZHIP_QT) v = qt_restore(v, qt[j], p.eb, T(10), p.range_min, p.range_max);
+        val = v;
+      } else {
+        const int ti = (b & 1u) ? (int)(b >> 1) + 1 : -(int)(b >> 1);   // binning.c:20 / :40
+        val = (T)ti * p.bin_width;                                      // :416 / :462
+      }
+      c[i] = val;
+    }
+#pragma unroll
+    for (int i = 0; i < 16 / EPV; i++)
+      *reinterpret_cast<Vec*>(&tile[blk * Traits<T>::PITCH + j0 + i * EPV]) = Traits<T>::pack(&c[i * EPV]);
+    __syncthreads();
+    tile_dct_inv<T>(tile, tab);
+    store_tile<T, SCALE>(tile, p.out, ebase, valid, p.sf);
+  }
+}
+
+// Last, short block on decode (dctz-decomp-lib.c:423-428, dct.c:144-199).
+template <typename T, int MODE, bool SCALE>
+__global__ __launch_bounds__(64) void k_decompress_rem(InvParams<T> p, int l) {
+  __shared__ T a[64];
+  __shared__ T cr[128];
+  __shared__ T ci[128];
+  const int k = threadIdx.x;
+  const size_t base = (size_t)p.nfull * 64;
+  const T* rt = p.rtab;
+  const int N = (l & 1) ? 2 * l : l;
+  unsigned b = 0;
+  if (k < l) b = p.bin[base + k];
+  const bool exc = (k < l) && (k != 0) && (b == 255u);
+  const unsigned long long m = __ballot(exc);
+  const unsigned rank = (unsigned)__popcll(m & ((1ull << k) - 1ull));
+  const unsigned start = p.ctl->cnt_total;
+  cr[k] = T(0); ci[k] = T(0); cr[k + 64] = T(0); ci[k + 64] = T(0);
+  if (k < l) {
+    T val;
+    if (k == 0) val = (T)p.dc[p.nfull];
+    else if (exc) {
+      T v = T(0);
+      if (start + rank < p.ac_count) v = (T)p.ac[start + rank]; else atomicExch(&p.ctl->error, 2u);
+      if (MODE == DCTZHIP_QT) v = qt_restore(v, p.qtab[k], p.eb, T(10), p.range_min, p.range_max);
+      val = v;
+    } else {
+      const int ti = (b & 1u) ? (int)(b >> 1) + 1 : -(int)(b >> 1);
+      val = (T)ti * p.bin_width;
+    }
+    a[k] = val;
+  }
+  __syncthreads();
+  if (k < l) {
+    cr[k] = rt[RTAB_IAS + k] * a[k];                               // dct.c:146-151 / :166-172
+    ci[k] = rt[RTAB_IAX + k] * a[k];
+    if ((l & 1) && k >= 1) {                                       // dct.c:152-153
+      cr[l + k] = rt[RTAB_IAX + k] * a[l - k];
+      ci[l + k] = -(rt[RTAB_IAS + k] * a[l - k]);
+    }
+  }
+  __syncthreads();
+  if (k < l) {
+    const int s = (l & 1) ? k : ((k & 1) ? l - 1 - (k >> 1) : (k >> 1));   // dct.c:189-199
+    T acc = T(0);
+    for (int j = 0; j < N; j++) {
+      const int tt = (s * j) % N;
+      acc = acc + (cr[j] * rt[RTAB_WR + tt] - ci[j] * rt[RTAB_WI + tt]);
+    }
+    T val = (l & 1) ? (acc / (T)l) / T(2) : acc / (T)l;            // dct.c:163 / :185
+    if (SCALE) val = val * p.sf;
+    p.out[base + k] = val;
+  }
+}
+
+// ============================================================ transform only ==
+// Batched dct_fftw / ifft_idct over all full blocks (dct.h:17-27; dct-test.c:81-89,144-152).
+template <typename T, bool INVERSE>
+__global__ __launch_bounds__(WG) void k_dct_blocks(const T* __restrict__ x, T* __restrict__ out, const T* __restrict__ gtab,
+                                                   unsigned nfull, unsigned ntiles) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  T* tile = reinterpret_cast<T*>(smem);
+  T* tab = tile + TILE_BLKS * Traits<T>::PITCH;
+  load_tab<T>(tab, gtab);
+  for (unsigned tile_id = blockIdx.x; tile_id < ntiles; tile_id += gridDim.x) {
+    __syncthreads();
+    const size_t ebase = (size_t)tile_id * TILE_ELEMS;
+    const unsigned valid = min((unsigned)TILE_BLKS, nfull - tile_id * TILE_BLKS) * 64u;
+    load_tile<T, false>(tile, x, ebase, valid, T(1), nullptr);
+    __syncthreads();
+    if (INVERSE) tile_dct_inv<T>(tile, tab); else tile_dct_fwd<T>(tile, tab);
+    store_tile<T, false>(tile, out, ebase, valid, T(1));
+  }
+}
+
+template <typename T, bool INVERSE>
+__global__ __launch_bounds__(64) void k_dct_rem(const T* __restrict__ x, T* __restrict__ out, const T* __restrict__ rt, int l) {
+  __shared__ T v[128];
+  __shared__ T w[128];
+  const int k = threadIdx.x;
+  const int N = (l & 1) ? 2 * l : l;
+  v[k] = T(0); v[k + 64] = T(0); w[k] = T(0); w[k + 64] = T(0);
+  __syncthreads();
+  if (!INVERSE) {
+    if (k < l) {
+      const T a = x[k];
+      if (l & 1) { v[k] = a; v[l + (l - 1 - k)] = a; }
+      else if (k & 1) v[l - 1 - (k >> 1)] = a;
+      else v[k >> 1] = a;
+    }
+    __syncthreads();
+    if (k < l) {
+      T sr = T(0), si = T(0);
+      for (int j = 0; j < N; j++) {
+        const int tt = (j * k) % N;
+        sr = sr + v[j] * rt[RTAB_WR + tt];
+        si = si + v[j] * rt[RTAB_WI + tt];
+      }
+      out[k] = rt[RTAB_AS + k] * sr + rt[RTAB_AX + k] * si;
+    }
+  } else {
+    if (k < l) {
+      v[k] = rt[RTAB_IAS + k] * x[k];
+      w[k] = rt[RTAB_IAX + k] * x[k];
+      if ((l & 1) && k >= 1) {
+        v[l + k] = rt[RTAB_IAX + k] * x[l - k];
+        w[l + k] = -(rt[RTAB_IAS + k] * x[l - k]);
+      }
+    }
+    __syncthreads();
+    if (k < l) {
+      const int s = (l & 1) ? k : ((k & 1) ? l - 1 - (k >> 1) : (k >> 1));
+      T acc = T(0);
+      for (int j = 0; j < N; j++) {
+        const int tt = (s * j) % N;
+        acc = acc + (v[j] * rt[RTAB_WR + tt] - w[j] * rt[RTAB_WI + tt]);
+      }
+      out[k] = (l & 1) ? (acc / (T)l) / T(2) : acc / (T)l;
+    }
+  }
+}
+
+// ================================================================= launchers ==
+template <typename T>
+static size_t fwd_smem() {
+  return sizeof(T) * (TILE_BLKS * Traits<T>::PITCH + TAB_SIZE) + 64 * sizeof(typename Traits<T>::Bits) + 32;
+}
+template <typename T>
+static size_t inv_smem() {
+  return sizeof(T) * (TILE_BLKS * Traits<T>::PITCH + TAB_SIZE + 64) + 32;
+}
+template <typename T>
+static size_t dct_smem() {
+  return sizeof(T) * (TILE_BLKS * Traits<T>::PITCH + TAB_SIZE);
+}
+
+template <typename T>
+void launch_stats(const T* x, size_t n, double* part, int nparts, double* out, hipStream_t s) {
+  hipLaunchKernelGGL(k_stats<T>, dim3(nparts), dim3(WG), 0, s, x, n, part);
+  hipLaunchKernelGGL(k_stats_final, dim3(1), dim3(WG), 0, s, (const double*)part, nparts, out);
+}
+
+template <typename T>
+void launch_compress(const FwdParams<T>& p, int mode, bool scale, int grid, hipStream_t s) {
+  const size_t sm = fwd_smem<T>();
+  if (mode == DCTZHIP_EC) {
+    if (scale) hipLaunchKernelGGL((k_compress<T, DCTZHIP_EC, true>), dim3(grid), dim3(WG), sm, s, p);
+    else hipLaunchKernelGGL((k_compress<T, DCTZHIP_EC, false>), dim3(grid), dim3(WG), sm, s, p);
+  } else {
+    if (scale) hipLaunchKernelGGL((k_compress<T, DCTZHIP_QT, true>), dim3(grid), dim3(WG), sm, s, p);
+    else hipLaunchKernelGGL((k_compress<T, DCTZHIP_QT, false>), dim3(grid), dim3(WG), sm, s, p);
+  }
+}
+
+template <typename T>
+void launch_compress_rem(const FwdParams<T>& p, int mode, bool scale, int l, hipStream_t s) {
+  if (mode == DCTZHIP_EC) {
+    if (scale) hipLaunchKernelGGL((k_compress_rem<T, DCTZHIP_EC, true>), dim3(1), dim3(64), 0, s, p, l);
+    else hipLaunchKernelGGL((k_compress_rem<T, DCTZHIP_EC, false>), dim3(1), dim3(64), 0, s, p, l);
+  } else {
+    if (scale) hipLaunchKernelGGL((k_compress_rem<T, DCTZHIP_QT, true>), dim3(1), dim3(64), 0, s, p, l);
+    else hipLaunchKernelGGL((k_compress_rem<T, DCTZHIP_QT, false>), dim3(1), dim3(64), 0, s, p, l);
+  }
+}
+
+template <typename T>
+void launch_qt_finish(const FwdParams<T>& p, double eb, int grid, hipStream_t s) {
+  hipLaunchKernelGGL(k_qt_finish<T>, dim3(grid), dim3(WG), 0, s, p, eb);
+}
+
+template <typename T>
+void launch_decompress(const InvParams<T>& p, int mode, bool scale, int grid, hipStream_t s) {
+  const size_t sm = inv_smem<T>();
+  if (mode == DCTZHIP_EC) {
+    if (scale) hipLaunchKernelGGL((k_decompress<T, DCTZHIP_EC, true>), dim3(grid), dim3(WG), sm, s, p);
+    else hipLaunchKernelGGL((k_decompress<T, DCTZHIP_EC, false>), dim3(grid), dim3(WG), sm, s, p);
+  } else {
+    if (scale) hipLaunchKernelGGL((k_decompress<T, DCTZHIP_QT, true>), dim3(grid), dim3(WG), sm, s, p);
+    else hipLaunchKernelGGL((k_decompress<T, DCTZHIP_QT, false>), dim3(grid), dim3(WG), sm, s, p);
+  }
+}
+
+template <typename T>
+void launch_decompress_rem(const InvParams<T>& p, int mode, bool scale, int l, hipStream_t s) {
+  if (mode == DCTZHIP_EC) {
+    if (scale) hipLaunchKernelGGL((k_decompress_rem<T, DCTZHIP_EC, true>), dim3(1), dim3(64), 0, s, p, l);
+    else hipLaunchKernelGGL((k_decompress_rem<T, DCTZHIP_EC, false>), dim3(1), dim3(64), 0, s, p, l);
+  } else {
+    if (scale) hipLaunchKernelGGL((k_decompress_rem<T, DCTZHIP_QT, true>), dim3(1), dim3(64), 0, s, p, l);
+    else hipLaunchKernelGGL((k_decompress_rem<T, DCTZHIP_QT, false>), dim3(1), dim3(64), 0, s, p, l);
+  }
+}
+
+template <typename T>
+void launch_dct_blocks(const T* x, T* out, const T* gtab, const T* rtab, size_t n, bool inverse, int grid,
+                       hipStream_t s) {
+  const unsigned nfull = (unsigned)(n / 64), ntiles = (nfull + TILE_BLKS - 1) / TILE_BLKS;
+  const int l = (int)(n % 64);
+  if (nfull) {
+    const int g = (int)min((unsigned)grid, ntiles);
+    if (inverse) hipLaunchKernelGGL((k_dct_blocks<T, true>), dim3(g), dim3(WG), dct_smem<T>(), s, x, out, gtab, nfull, ntiles);
+    else hipLaunchKernelGGL((k_dct_blocks<T, false>), dim3(g), dim3(WG), dct_smem<T>(), s, x, out, gtab, nfull, ntiles);
+  }
+  if (l) {
+    const T* xr = x + (size_t)nfull * 64;
+    T* orr = out + (size_t)nfull * 64;
+    if (inverse) hipLaunchKernelGGL((k_dct_rem<T, true>), dim3(1), dim3(64), 0, s, xr, orr, rtab, l);
+    else hipLaunchKernelGGL((k_dct_rem<T, false>), dim3(1), dim3(64), 0, s, xr, orr, rtab, l);
+  }
+}
+
+// explicit instantiations used by dctz_shim.hip
+#define INST(T)                                                                                         \
+  template void launch_stats<T>(const T*, size_t, double*, int, double*, hipStream_t);                  \
+  template void launch_compress<T>(const FwdParams<T>&, int, bool, int, hipStream_t);                   \
+  template void launch_compress_rem<T>(const FwdParams<T>&, int, bool, int, hipStream_t);               \
+  template void launch_qt_finish<T>(const FwdParams<T>&, double, int, hipStream_t);                     \
+  template void launch_decompress<T>(const InvParams<T>&, int, bool, int, hipStream_t);                 \
+  template void launch_decompress_rem<T>(const InvParams<T>&, int, bool, int, hipStream_t);             \
+  template void launch_dct_blocks<T>(const T*, T*, const T*, const T*, size_t, bool, int, hipStream_t);
+INST(double)
+INST(float)
+
+}  // namespace dctz

@@ -1,0 +1,444 @@
+// dctz_shim.hip -- the C ABI of include/dctz_hip.h over the gfx950 kernels.
+//
+// Host-side responsibilities only: argument checking, scratch management,
+// the libm expressions the reference evaluates on the host (scaling factor
+// util.c:29/43, bin ranges dctz-comp-lib.c:271-281, twiddle tables
+// dct.c:37-47/130-134), kernel sequencing on one HIP stream, and reading back
+// the few scalars the host stage needs (cnt, QT table).  No CPU compute path
+// exists: if HIP is unavailable every call returns DCTZHIP_E_HIP.
+#include <hip/hip_runtime.h>
+
+#include <climits>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+
+#include "dctz_device.h"
+#include "dctz_tables.h"
+
+using namespace dctz;
+
+struct dctzhip_ctx {
+  int device = 0;
+  int num_cu = 256;
+  hipStream_t own_stream = nullptr;
+  hipStream_t stream = nullptr;
+  // constant tables
+  double* tab_f64 = nullptr;
+  float* tab_f32 = nullptr;
+  void* rtab = nullptr;             // RTAB_SIZE doubles (either dtype)
+  int rtab_l = -1, rtab_dtype = -1;
+  void* qtab = nullptr;             // 64 doubles
+  // per-call state
+  Ctl* ctl = nullptr;
+  unsigned long long* desc = nullptr;
+  size_t desc_cap = 0;              // tiles
+  double* part = nullptr;           // stats partials
+  double* stats_out = nullptr;      // 4 doubles
+  void* qt_item = nullptr;
+  uint8_t* qt_j = nullptr;
+  size_t qt_cap = 0;                // bytes of qt_item
+  size_t qtj_cap = 0;
+  // pinned host staging
+  unsigned char* h_pin = nullptr;   // [0,64): stats, [64, 64+sizeof(Ctl)): ctl, then tables
+  // profiling
+  int profiling = 0;
+  hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  dctzhip_timings last = {0, 0, 0, 0};
+  int have_timings = 0;
+  char err[512] = {0};
+};
+
+static char g_create_err[512] = "";
+static constexpr int STATS_GRID_MAX = 2048;
+static constexpr size_t PIN_STATS = 0, PIN_CTL = 64, PIN_TAB = 64 + sizeof(Ctl);
+static constexpr size_t PIN_BYTES = PIN_TAB + sizeof(double) * RTAB_SIZE + sizeof(double) * 64;
+
+static int fail(dctzhip_ctx* c, int code, const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(c ? c->err : g_create_err, 512, fmt, ap);
+  va_end(ap);
+  return code;
+}
+
+#define HIPCHK(c, call)                                                                         \
+  do {                                                                                          \
+    hipError_t e_ = (call);                                                                     \
+    if (e_ != hipSuccess)                                                                       \
+      return fail((c), DCTZHIP_E_HIP, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); \
+  } while (0)
+
+extern "C" const char* dctzhip_version(void) { return "0.1.0"; }
+
+extern "C" const char* dctzhip_last_error(const dctzhip_ctx* ctx) { return ctx ? ctx->err : g_create_err; }
+
+extern "C" int dctzhip_ctx_create(dctzhip_ctx** out, int device) {
+  if (!out) return fail(nullptr, DCTZHIP_E_ARG, "dctzhip_ctx_create: out is NULL");
+  *out = nullptr;
+  int ndev = 0;
+  HIPCHK(nullptr, hipGetDeviceCount(&ndev));
+  if (ndev <= 0) return fail(nullptr, DCTZHIP_E_HIP, "no HIP device visible (this library has no CPU path)");
+  if (device < 0) HIPCHK(nullptr, hipGetDevice(&device));
+  if (device >= ndev) return fail(nullptr, DCTZHIP_E_ARG, "device %d out of range (%d visible)", device, ndev);
+  HIPCHK(nullptr, hipSetDevice(device));
+  dctzhip_ctx* c = new dctzhip_ctx();
+  c->device = device;
+  hipDeviceProp_t prop;
+  HIPCHK(nullptr, hipGetDeviceProperties(&prop, device));
+  c->num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+  HIPCHK(nullptr, hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
+  c->stream = c->own_stream;
+  HIPCHK(nullptr, hipMalloc(&c->tab_f64, sizeof(double) * TAB_SIZE));
+  HIPCHK(nullptr, hipMalloc(&c->tab_f32, sizeof(float) * TAB_SIZE));
+  HIPCHK(nullptr, hipMalloc(&c->rtab, sizeof(double) * RTAB_SIZE));
+  HIPCHK(nullptr, hipMalloc(&c->qtab, sizeof(double) * 64));
+  HIPCHK(nullptr, hipMalloc(&c->ctl, sizeof(Ctl)));
+  HIPCHK(nullptr, hipMalloc(&c->part, sizeof(double) * 3 * STATS_GRID_MAX));
+  HIPCHK(nullptr, hipMalloc(&c->stats_out, sizeof(double) * 4));
+  HIPCHK(nullptr, hipHostMalloc(&c->h_pin, PIN_BYTES, hipHostMallocDefault));
+  {
+    double t64[TAB_SIZE];
+    float t32[TAB_SIZE];
+    fill_tab64<double>(t64);
+    fill_tab64<float>(t32);
+    HIPCHK(nullptr, hipMemcpy(c->tab_f64, t64, sizeof(t64), hipMemcpyHostToDevice));
+    HIPCHK(nullptr, hipMemcpy(c->tab_f32, t32, sizeof(t32), hipMemcpyHostToDevice));
+  }
+  for (int i = 0; i < 6; i++) HIPCHK(nullptr, hipEventCreate(&c->ev[i]));
+  *out = c;
+  return DCTZHIP_OK;
+}
+
+extern "C" void dctzhip_ctx_destroy(dctzhip_ctx* c) {
+  if (!c) return;
+  (void)hipSetDevice(c->device);
+  (void)hipStreamSynchronize(c->stream);
+  void* bufs[] = {c->tab_f64, c->tab_f32, c->rtab, c->qtab, c->ctl, c->desc, c->part, c->stats_out, c->qt_item, c->qt_j};
+  for (void* b : bufs) if (b) (void)hipFree(b);
+  if (c->h_pin) (void)hipHostFree(c->h_pin);
+  for (int i = 0; i < 6; i++) if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
+  if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
+  delete c;
+}
+
+extern "C" int dctzhip_set_stream(dctzhip_ctx* c, void* s) {
+  if (!c) return DCTZHIP_E_ARG;
+  c->stream = s ? (hipStream_t)s : c->own_stream;
+  return DCTZHIP_OK;
+}
+extern "C" void* dctzhip_get_stream(dctzhip_ctx* c) { return c ? (void*)c->stream : nullptr; }
+extern "C" int dctzhip_set_profiling(dctzhip_ctx* c, int on) {
+  if (!c) return DCTZHIP_E_ARG;
+  c->profiling = on ? 1 : 0;
+  return DCTZHIP_OK;
+}
+extern "C" int dctzhip_last_timings(dctzhip_ctx* c, dctzhip_timings* t) {
+  if (!c || !t) return DCTZHIP_E_ARG;
+  if (!c->have_timings) return fail(c, DCTZHIP_E_ARG, "no timings recorded (enable profiling first)");
+  *t = c->last;
+  return DCTZHIP_OK;
+}
+
+extern "C" int dctzhip_malloc(dctzhip_ctx* c, void** dptr, size_t bytes) {
+  if (!c || !dptr) return DCTZHIP_E_ARG;
+  HIPCHK(c, hipSetDevice(c->device));
+  HIPCHK(c, hipMalloc(dptr, bytes ? bytes : 16));
+  return DCTZHIP_OK;
+}
+extern "C" int dctzhip_free(dctzhip_ctx* c, void* dptr) {
+  if (!c) return DCTZHIP_E_ARG;
+  if (dptr) HIPCHK(c, hipFree(dptr));
+  return DCTZHIP_OK;
+}
+extern "C" int dctzhip_memcpy_h2d(dctzhip_ctx* c, void* dst, const void* src, size_t bytes) {
+  if (!c) return DCTZHIP_E_ARG;
+  HIPCHK(c, hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return DCTZHIP_OK;
+}
+extern "C" int dctzhip_memcpy_d2h(dctzhip_ctx* c, void* dst, const void* src, size_t bytes) {
+  if (!c) return DCTZHIP_E_ARG;
+  HIPCHK(c, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return DCTZHIP_OK;
+}
+extern "C" int dctzhip_sync(dctzhip_ctx* c) {
+  if (!c) return DCTZHIP_E_ARG;
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return DCTZHIP_OK;
+}
+
+static size_t elem_size(int dtype) { return dtype == DCTZHIP_F64 ? 8 : 4; }
+
+static int ensure_scratch(dctzhip_ctx* c, size_t n, int dtype, int mode) {
+  const size_t ntiles = (n / 64 + TILE_BLKS - 1) / TILE_BLKS + 1;
+  if (ntiles > c->desc_cap) {
+    if (c->desc) HIPCHK(c, hipFree(c->desc));
+    c->desc = nullptr; c->desc_cap = 0;
+    const size_t cap = (ntiles + 1) & ~(size_t)1;      // even -> bytes are a multiple of 16
+    HIPCHK(c, hipMalloc(&c->desc, cap * sizeof(unsigned long long)));
+    c->desc_cap = cap;
+  }
+  if (mode == DCTZHIP_QT) {
+    const size_t need = n * elem_size(dtype);
+    if (need > c->qt_cap) {
+      if (c->qt_item) HIPCHK(c, hipFree(c->qt_item));
+      c->qt_item = nullptr; c->qt_cap = 0;
+      HIPCHK(c, hipMalloc(&c->qt_item, need));
+      c->qt_cap = need;
+    }
+    if (n > c->qtj_cap) {
+      if (c->qt_j) HIPCHK(c, hipFree(c->qt_j));
+      c->qt_j = nullptr; c->qtj_cap = 0;
+      HIPCHK(c, hipMalloc(&c->qt_j, n));
+      c->qtj_cap = n;
+    }
+  }
+  return DCTZHIP_OK;
+}
+
+extern "C" int dctzhip_reserve(dctzhip_ctx* c, size_t n, int dtype, int mode) {
+  if (!c) return DCTZHIP_E_ARG;
+  HIPCHK(c, hipSetDevice(c->device));
+  return ensure_scratch(c, n, dtype, mode);
+}
+
+static int check_common(dctzhip_ctx* c, size_t n, int dtype, int mode) {
+  if (!c) return DCTZHIP_E_ARG;
+  if (dtype != DCTZHIP_F32 && dtype != DCTZHIP_F64) return fail(c, DCTZHIP_E_ARG, "dtype must be DCTZHIP_F32 or DCTZHIP_F64");
+  if (mode != DCTZHIP_EC && mode != DCTZHIP_QT) return fail(c, DCTZHIP_E_ARG, "mode must be DCTZHIP_EC or DCTZHIP_QT");
+  if (n == 0) return fail(c, DCTZHIP_E_ARG, "n == 0");
+  if (n > (size_t)INT_MAX) return fail(c, DCTZHIP_E_ARG, "n exceeds INT_MAX (dctz.h:126: N is an int); shard the array");
+  return DCTZHIP_OK;
+}
+static bool aligned16(const void* p) { return ((uintptr_t)p & 15u) == 0; }
+
+// remainder-block tables -> device (cached per (l, dtype))
+template <typename T>
+static int upload_rtab(dctzhip_ctx* c, int l) {
+  const int dt = sizeof(T) == 8 ? DCTZHIP_F64 : DCTZHIP_F32;
+  if (c->rtab_l == l && c->rtab_dtype == dt) return DCTZHIP_OK;
+  T* h = reinterpret_cast<T*>(c->h_pin + PIN_TAB);
+  fill_rem_tab<T>(l, h);
+  HIPCHK(c, hipMemcpyAsync(c->rtab, h, sizeof(T) * RTAB_SIZE, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));   // staging buffer is reused
+  c->rtab_l = l; c->rtab_dtype = dt;
+  return DCTZHIP_OK;
+}
+
+template <typename T> static const T* tab_of(dctzhip_ctx* c);
+template <> const double* tab_of<double>(dctzhip_ctx* c) { return c->tab_f64; }
+template <> const float* tab_of<float>(dctzhip_ctx* c) { return c->tab_f32; }
+
+// util.c:29 / util.c:43, with the host libm exactly like the reference
+static double scaling_factor(int dtype, double max_abs) {
+  if (max_abs == 0.0) return 1.0;               // documented deviation: reference divides by 0
+  if (dtype == DCTZHIP_F64) return pow(10, ceil(log10(max_abs)) - 1);
+  return (double)powf(10, ceil(log10f((float)max_abs)) - 1);
+}
+
+static int read_timings(dctzhip_ctx* c, int nev_main_start) {
+  (void)nev_main_start;
+  float a = 0, b = 0, d = 0, tot = 0;
+  HIPCHK(c, hipEventElapsedTime(&a, c->ev[0], c->ev[1]));
+  HIPCHK(c, hipEventElapsedTime(&b, c->ev[2], c->ev[3]));
+  HIPCHK(c, hipEventElapsedTime(&d, c->ev[3], c->ev[4]));
+  tot = a + b + d;
+  c->last.stats_ms = a; c->last.main_ms = b; c->last.tail_ms = d; c->last.total_ms = tot;
+  c->have_timings = 1;
+  return DCTZHIP_OK;
+}
+
+template <typename T>
+static int compress_impl(dctzhip_ctx* c, const T* d_in, size_t n, double eb, int mode, uint8_t* d_bin, float* d_dc,
+                         float* d_ac, T* d_scaled, T* d_coef, dctzhip_cinfo* info) {
+  const int dtype = sizeof(T) == 8 ? DCTZHIP_F64 : DCTZHIP_F32;
+  hipStream_t s = c->stream;
+  const unsigned nfull = (unsigned)(n / 64);
+  const int rem = (int)(n % 64);
+  const unsigned ntiles = (nfull + TILE_BLKS - 1) / TILE_BLKS;
+  const unsigned nblk = nfull + (rem ? 1 : 0);
+
+  HIPCHK(c, hipMemsetAsync(c->ctl, 0, sizeof(Ctl), s));
+  if (ntiles) HIPCHK(c, hipMemsetAsync(c->desc, 0, ((ntiles + 1) & ~1u) * sizeof(unsigned long long), s));
+
+  // ---- calc_data_stat (util.c:12-44) ----------------------------------------
+  const size_t nvec = n / Traits<T>::EPV;
+  int sgrid = (int)((nvec + WG - 1) / WG);
+  if (sgrid < 1) sgrid = 1;
+  if (sgrid > STATS_GRID_MAX) sgrid = STATS_GRID_MAX;
+  if (c->profiling) HIPCHK(c, hipEventRecord(c->ev[0], s));
+  launch_stats<T>(d_in, n, c->part, sgrid, c->stats_out, s);
+  if (c->profiling) HIPCHK(c, hipEventRecord(c->ev[1], s));
+  double* hs = reinterpret_cast<double*>(c->h_pin + PIN_STATS);
+  HIPCHK(c, hipMemcpyAsync(hs, c->stats_out, 3 * sizeof(double), hipMemcpyDeviceToHost, s));
+  HIPCHK(c, hipStreamSynchronize(s));
+  const double max_abs = hs[0], min_abs = hs[1], sum = hs[2];
+  const double sf = scaling_factor(dtype, max_abs);
+
+  // ---- bin ranges, dctz-comp-lib.c:271-281 (computed in double, stored in T) --
+  const int half = DCTZHIP_NBINS / 2;
+  FwdParams<T> p;
+  p.x = d_in; p.bin = d_bin; p.dc = d_dc; p.ac = d_ac; p.scaled = d_scaled; p.coef = d_coef;
+  p.qt_item = reinterpret_cast<T*>(c->qt_item); p.qt_j = c->qt_j;
+  p.tab = tab_of<T>(c); p.rtab = reinterpret_cast<const T*>(c->rtab);
+  p.ctl = c->ctl; p.desc = c->desc;
+  p.nfull = nfull; p.ntiles = ntiles; p.last_is_full = rem ? 0u : 1u;
+  p.sf = (T)sf;
+  p.bin_width = (T)(eb * 2.0 * 1.0);
+  p.range_min = (T)(-(half * 2 + 1) * (eb * 1.0));
+  p.range_max = (T)((half * 2 + 1) * (eb * 1.0));
+  const bool scale = (p.sf != (T)1.0);              // :193 / :208
+  if (!scale && d_scaled && d_scaled != d_in)       // sf == 1: "scaled" data is the input itself
+    HIPCHK(c, hipMemcpyAsync(d_scaled, d_in, n * sizeof(T), hipMemcpyDeviceToDevice, s));
+
+  if (rem) { int rc = upload_rtab<T>(c, rem); if (rc) return rc; }
+
+  if (c->profiling) HIPCHK(c, hipEventRecord(c->ev[2], s));
+  if (ntiles) {
+    const int grid = (int)((unsigned)(c->num_cu * 4) < ntiles ? (unsigned)(c->num_cu * 4) : ntiles);
+    launch_compress<T>(p, mode, scale, grid, s);
+  }
+  if (c->profiling) HIPCHK(c, hipEventRecord(c->ev[3], s));
+  if (rem) launch_compress_rem<T>(p, mode, scale, rem, s);
+  if (mode == DCTZHIP_QT) launch_qt_finish<T>(p, eb, c->num_cu * 4, s);
+  if (c->profiling) HIPCHK(c, hipEventRecord(c->ev[4], s));
+  HIPCHK(c, hipGetLastError());
+
+  Ctl* hc = reinterpret_cast<Ctl*>(c->h_pin + PIN_CTL);
+  HIPCHK(c, hipMemcpyAsync(hc, c->ctl, sizeof(Ctl), hipMemcpyDeviceToHost, s));
+  HIPCHK(c, hipStreamSynchronize(s));
+  if (hc->error) return fail(c, DCTZHIP_E_INTERNAL, "in-kernel watchdog tripped (code %u)", hc->error);
+  if (c->profiling) { int rc = read_timings(c, 2); if (rc) return rc; }
+
+  if (info) {
+    memset(info, 0, sizeof(*info));
+    info->sf = sf;
+    info->mean = (dtype == DCTZHIP_F64) ? sum / (double)(int)n : (double)((float)sum / (float)(int)n);
+    info->max_abs = max_abs; info->min_abs = min_abs;
+    info->cnt = hc->cnt_total; info->nblk = nblk;
+    if (mode == DCTZHIP_QT) {
+      for (int j = 0; j < 64; j++) {
+        double v;
+        if (dtype == DCTZHIP_F64) { unsigned long long b = hc->qraw[j]; memcpy(&v, &b, 8); }
+        else { unsigned int b = (unsigned int)hc->qraw[j]; float f; memcpy(&f, &b, 4); v = f; }
+        info->qtable_raw[j] = v;
+        info->qtable[j] = (j >= 1 && v < 1.0) ? 1.0 : v;          // :450-461
+      }
+      double q0;
+      if (dtype == DCTZHIP_F64) { unsigned long long b = hc->q0; memcpy(&q0, &b, 8); }
+      else { unsigned int b = (unsigned int)hc->q0; float f; memcpy(&f, &b, 4); q0 = f; }
+      info->qtable[0] = info->qtable_raw[0] = q0;                 // :355-360
+    }
+  }
+  return DCTZHIP_OK;
+}
+
+extern "C" int dctzhip_compress(dctzhip_ctx* c, const void* d_in, size_t n, int dtype, double eb, int mode,
+                                void* d_bin, float* d_dc, float* d_ac, void* d_scaled, void* d_coef,
+                                dctzhip_cinfo* info) {
+  int rc = check_common(c, n, dtype, mode);
+  if (rc) return rc;
+  if (!d_in || !d_bin || !d_dc || !d_ac) return fail(c, DCTZHIP_E_ARG, "null device buffer");
+  if (!aligned16(d_in) || !aligned16(d_bin) || !aligned16(d_dc) || !aligned16(d_ac) ||
+      (d_scaled && !aligned16(d_scaled)) || (d_coef && !aligned16(d_coef)))
+    return fail(c, DCTZHIP_E_ARG, "device buffers must be 16-byte aligned");
+  if (eb < 1E-6) return fail(c, DCTZHIP_E_BOUND, "ERROR BOUND is not acceptable");   // dctz-comp-lib.c:135-138
+  HIPCHK(c, hipSetDevice(c->device));
+  rc = ensure_scratch(c, n, dtype, mode);
+  if (rc) return rc;
+  if (dtype == DCTZHIP_F64)
+    return compress_impl<double>(c, (const double*)d_in, n, eb, mode, (uint8_t*)d_bin, d_dc, d_ac, (double*)d_scaled,
+                                 (double*)d_coef, info);
+  return compress_impl<float>(c, (const float*)d_in, n, eb, mode, (uint8_t*)d_bin, d_dc, d_ac, (float*)d_scaled,
+                              (float*)d_coef, info);
+}
+
+template <typename T>
+static int decompress_impl(dctzhip_ctx* c, const uint8_t* d_bin, const float* d_dc, const float* d_ac,
+                           uint32_t ac_count, const void* qtable_host, size_t n, double eb, double sf, int mode,
+                           T* d_out) {
+  hipStream_t s = c->stream;
+  const unsigned nfull = (unsigned)(n / 64);
+  const int rem = (int)(n % 64);
+  const unsigned ntiles = (nfull + TILE_BLKS - 1) / TILE_BLKS;
+  HIPCHK(c, hipMemsetAsync(c->ctl, 0, sizeof(Ctl), s));
+  if (ntiles) HIPCHK(c, hipMemsetAsync(c->desc, 0, ((ntiles + 1) & ~1u) * sizeof(unsigned long long), s));
+  if (mode == DCTZHIP_QT) {
+    T* hq = reinterpret_cast<T*>(c->h_pin + PIN_TAB + sizeof(double) * RTAB_SIZE);
+    memcpy(hq, qtable_host, sizeof(T) * 64);
+    HIPCHK(c, hipMemcpyAsync(c->qtab, hq, sizeof(T) * 64, hipMemcpyHostToDevice, s));
+  }
+  if (rem) { int rc = upload_rtab<T>(c, rem); if (rc) return rc; }
+
+  InvParams<T> p;
+  p.bin = d_bin; p.dc = d_dc; p.ac = d_ac; p.out = d_out;
+  p.tab = tab_of<T>(c); p.rtab = reinterpret_cast<const T*>(c->rtab); p.qtab = reinterpret_cast<const T*>(c->qtab);
+  p.ctl = c->ctl; p.desc = c->desc;
+  p.nfull = nfull; p.ntiles = ntiles; p.ac_count = ac_count;
+  p.sf = (T)sf;
+  // gen_bins / gen_bins_f (binning.c:17 / :37): bin_width = error_bound*2*BRSF in
+  // the data type (gen_bins_f receives error_bound already rounded to float)
+  p.bin_width = (T)((T)eb * 2 * 1.0);
+  p.range_max = (T)(eb * DCTZHIP_NBINS);          // dctz-decomp-lib.c:372-381
+  p.range_min = (T)(-eb * DCTZHIP_NBINS);
+  p.eb = eb;
+  const bool scale = (p.sf != (T)1.0);            // :496 / :505
+
+  if (c->profiling) { HIPCHK(c, hipEventRecord(c->ev[0], s)); HIPCHK(c, hipEventRecord(c->ev[1], s)); HIPCHK(c, hipEventRecord(c->ev[2], s)); }
+  if (ntiles) {
+    const int grid = (int)((unsigned)(c->num_cu * 4) < ntiles ? (unsigned)(c->num_cu * 4) : ntiles);
+    launch_decompress<T>(p, mode, scale, grid, s);
+  }
+  if (c->profiling) HIPCHK(c, hipEventRecord(c->ev[3], s));
+  if (rem) launch_decompress_rem<T>(p, mode, scale, rem, s);
+  if (c->profiling) HIPCHK(c, hipEventRecord(c->ev[4], s));
+  HIPCHK(c, hipGetLastError());
+  Ctl* hc = reinterpret_cast<Ctl*>(c->h_pin + PIN_CTL);
+  HIPCHK(c, hipMemcpyAsync(hc, c->ctl, 16, hipMemcpyDeviceToHost, s));
+  HIPCHK(c, hipStreamSynchronize(s));
+  if (hc->error == 2) return fail(c, DCTZHIP_E_ARG, "bin_index flags more exact coefficients than ac_count provides");
+  if (hc->error) return fail(c, DCTZHIP_E_INTERNAL, "in-kernel watchdog tripped (code %u)", hc->error);
+  if (c->profiling) { int rc = read_timings(c, 2); if (rc) return rc; }
+  return DCTZHIP_OK;
+}
+
+extern "C" int dctzhip_decompress(dctzhip_ctx* c, const void* d_bin, const float* d_dc, const float* d_ac,
+                                  uint32_t ac_count, const void* qtable_host, size_t n, int dtype, double eb, double sf,
+                                  int mode, void* d_out) {
+  int rc = check_common(c, n, dtype, mode);
+  if (rc) return rc;
+  if (!d_bin || !d_dc || !d_out || (ac_count && !d_ac)) return fail(c, DCTZHIP_E_ARG, "null device buffer");
+  if (!aligned16(d_bin) || !aligned16(d_out)) return fail(c, DCTZHIP_E_ARG, "device buffers must be 16-byte aligned");
+  if (mode == DCTZHIP_QT && !qtable_host) return fail(c, DCTZHIP_E_ARG, "QT mode needs the 64-entry table");
+  HIPCHK(c, hipSetDevice(c->device));
+  rc = ensure_scratch(c, n, dtype, DCTZHIP_EC);
+  if (rc) return rc;
+  if (dtype == DCTZHIP_F64)
+    return decompress_impl<double>(c, (const uint8_t*)d_bin, d_dc, d_ac, ac_count, qtable_host, n, eb, sf, mode, (double*)d_out);
+  return decompress_impl<float>(c, (const uint8_t*)d_bin, d_dc, d_ac, ac_count, qtable_host, n, eb, sf, mode, (float*)d_out);
+}
+
+extern "C" int dctzhip_dct_blocks(dctzhip_ctx* c, const void* d_in, void* d_out, size_t n, int dtype, int inverse) {
+  int rc = check_common(c, n, dtype, DCTZHIP_EC);
+  if (rc) return rc;
+  if (!d_in || !d_out) return fail(c, DCTZHIP_E_ARG, "null device buffer");
+  if (!aligned16(d_in) || !aligned16(d_out)) return fail(c, DCTZHIP_E_ARG, "device buffers must be 16-byte aligned");
+  HIPCHK(c, hipSetDevice(c->device));
+  const int rem = (int)(n % 64);
+  if (dtype == DCTZHIP_F64) {
+    if (rem) { rc = upload_rtab<double>(c, rem); if (rc) return rc; }
+    launch_dct_blocks<double>((const double*)d_in, (double*)d_out, c->tab_f64, (const double*)c->rtab, n, inverse != 0,
+                              c->num_cu * 4, c->stream);
+  } else {
+    if (rem) { rc = upload_rtab<float>(c, rem); if (rc) return rc; }
+    launch_dct_blocks<float>((const float*)d_in, (float*)d_out, c->tab_f32, (const float*)c->rtab, n, inverse != 0,
+                             c->num_cu * 4, c->stream);
+  }
+  HIPCHK(c, hipGetLastError());
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return DCTZHIP_OK;
+}

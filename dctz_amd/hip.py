@@ -1,0 +1,179 @@
+"""ctypes binding of lib/libdctzhip.so (include/dctz_hip.h).
+
+torch is used only for device buffers and the stream; every compute call goes
+through the C ABI.  No fallback: a missing library or GPU raises.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+F32, F64 = 0, 1
+EC, QT = 0, 1
+
+
+class DctzHipError(RuntimeError):
+    pass
+
+
+def lib_path():
+    return os.path.join(_HERE, "lib", "libdctzhip.so")
+
+
+class CompressInfo(C.Structure):
+    _fields_ = [("sf", C.c_double), ("mean", C.c_double), ("max_abs", C.c_double),
+                ("min_abs", C.c_double), ("cnt", C.c_uint32), ("nblk", C.c_uint32),
+                ("qtable", C.c_double * 64), ("qtable_raw", C.c_double * 64)]
+
+
+class Timings(C.Structure):
+    _fields_ = [("stats_ms", C.c_float), ("main_ms", C.c_float), ("tail_ms", C.c_float),
+                ("total_ms", C.c_float)]
+
+
+_lib = None
+
+_PROTOS = {
+    "dctzhip_ctx_create": (C.c_int, [C.POINTER(C.c_void_p), C.c_int]),
+    "dctzhip_ctx_destroy": (None, [C.c_void_p]),
+    "dctzhip_last_error": (C.c_char_p, [C.c_void_p]),
+    "dctzhip_reserve": (C.c_int, [C.c_void_p, C.c_size_t, C.c_int, C.c_int]),
+    "dctzhip_set_stream": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "dctzhip_get_stream": (C.c_void_p, [C.c_void_p]),
+    "dctzhip_set_profiling": (C.c_int, [C.c_void_p, C.c_int]),
+    "dctzhip_last_timings": (C.c_int, [C.c_void_p, C.POINTER(Timings)]),
+    "dctzhip_malloc": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.c_size_t]),
+    "dctzhip_free": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "dctzhip_memcpy_h2d": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
+    "dctzhip_memcpy_d2h": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
+    "dctzhip_sync": (C.c_int, [C.c_void_p]),
+    "dctzhip_compress": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_double, C.c_int,
+                                   C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                   C.POINTER(CompressInfo)]),
+    "dctzhip_decompress": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32,
+                                     C.c_void_p, C.c_size_t, C.c_int, C.c_double, C.c_double, C.c_int,
+                                     C.c_void_p]),
+    "dctzhip_dct_blocks": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_int]),
+    "dctzhip_version": (C.c_char_p, []),
+}
+
+
+def load_library():
+    """Loads libdctzhip.so; raises DctzHipError if it has not been built."""
+    global _lib
+    if _lib is None:
+        p = lib_path()
+        if not os.path.exists(p):
+            raise DctzHipError(f"{p} is missing: run `make -C dctz_amd` (or __graft_entry__.build()); "
+                               "there is no CPU fallback")
+        lib = C.CDLL(p)
+        for name, (res, args) in _PROTOS.items():
+            fn = getattr(lib, name)          # AttributeError if the ABI lost a symbol
+            fn.restype, fn.argtypes = res, args
+        _lib = lib
+    return _lib
+
+
+def _dt(torch_dtype):
+    import torch
+    if torch_dtype == torch.float64:
+        return F64
+    if torch_dtype == torch.float32:
+        return F32
+    raise TypeError(f"unsupported dtype {torch_dtype}")
+
+
+class Context:
+    """One dctzhip context on a GPU; kernels run on torch's current stream."""
+
+    def __init__(self, device=0):
+        import torch
+        if not torch.cuda.is_available():
+            raise DctzHipError("no GPU visible: the DCTZ hot path has no CPU fallback")
+        self.lib = load_library()
+        self.torch = torch
+        self.device = torch.device("cuda", device)
+        torch.cuda.set_device(self.device)
+        h = C.c_void_p()
+        rc = self.lib.dctzhip_ctx_create(C.byref(h), device)
+        if rc != 0:
+            raise DctzHipError(f"dctzhip_ctx_create: {self.lib.dctzhip_last_error(None).decode()}")
+        self.h = h
+        self._bind_stream()
+
+    def _bind_stream(self):
+        s = self.torch.cuda.current_stream(self.device).cuda_stream
+        self.lib.dctzhip_set_stream(self.h, C.c_void_p(s))
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.dctzhip_ctx_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc, what):
+        if rc != 0:
+            raise DctzHipError(f"{what} failed ({rc}): {self.lib.dctzhip_last_error(self.h).decode()}")
+
+    def set_profiling(self, on=True):
+        self._check(self.lib.dctzhip_set_profiling(self.h, int(on)), "set_profiling")
+
+    def timings(self):
+        t = Timings()
+        self._check(self.lib.dctzhip_last_timings(self.h, C.byref(t)), "last_timings")
+        return {"stats_ms": t.stats_ms, "main_ms": t.main_ms, "tail_ms": t.tail_ms, "total_ms": t.total_ms}
+
+    def reserve(self, n, dtype, mode):
+        self._check(self.lib.dctzhip_reserve(self.h, n, _dt(dtype), mode), "reserve")
+
+    def alloc_outputs(self, n, dtype=None):
+        t = self.torch
+        nblk = (n + 63) // 64
+        return {"bin_index": t.empty(n, dtype=t.uint8, device=self.device),
+                "dc": t.empty(nblk, dtype=t.float32, device=self.device),
+                "ac_exact": t.empty(n, dtype=t.float32, device=self.device)}
+
+    def compress(self, x, eb, mode=EC, out=None, scaled=None, coef=None):
+        """x: 1-D contiguous CUDA tensor (float32|float64).  Returns (out, info)."""
+        assert x.is_cuda and x.is_contiguous() and x.dim() == 1
+        self._bind_stream()
+        n = x.numel()
+        if out is None:
+            out = self.alloc_outputs(n, x.dtype)
+        info = CompressInfo()
+        rc = self.lib.dctzhip_compress(
+            self.h, x.data_ptr(), n, _dt(x.dtype), float(eb), mode, out["bin_index"].data_ptr(),
+            out["dc"].data_ptr(), out["ac_exact"].data_ptr(),
+            scaled.data_ptr() if scaled is not None else None,
+            coef.data_ptr() if coef is not None else None, C.byref(info))
+        self._check(rc, "dctzhip_compress")
+        return out, info
+
+    def decompress(self, out, cnt, n, dtype, eb, sf, mode=EC, qtable=None, dst=None):
+        t = self.torch
+        self._bind_stream()
+        if dst is None:
+            dst = t.empty(n, dtype=dtype, device=self.device)
+        q = None
+        if mode == QT:
+            q = np.ascontiguousarray(qtable, dtype=np.float64 if dtype == t.float64 else np.float32)
+            assert q.size == 64
+        rc = self.lib.dctzhip_decompress(
+            self.h, out["bin_index"].data_ptr(), out["dc"].data_ptr(), out["ac_exact"].data_ptr(),
+            int(cnt), q.ctypes.data_as(C.c_void_p) if q is not None else None, n, _dt(dtype),
+            float(eb), float(sf), mode, dst.data_ptr())
+        self._check(rc, "dctzhip_decompress")
+        return dst
+
+    def dct_blocks(self, x, inverse=False):
+        self._bind_stream()
+        y = self.torch.empty_like(x)
+        rc = self.lib.dctzhip_dct_blocks(self.h, x.data_ptr(), y.data_ptr(), x.numel(), _dt(x.dtype), int(inverse))
+        self._check(rc, "dctzhip_dct_blocks")
+        return y

@@ -1,0 +1,135 @@
+/*
+ * dctz.h -- public API of the drop-in host library libdctz-{ec,qt}.so.
+ *
+ * Binary- and source-compatible with the reference's dctz.h (types, constants
+ * and prototypes at dctz.h:28-128) and dct.h (dct.h:17-27), so a caller such as
+ * dctz-test.c or the Z-checker glue compiles and links against this library
+ * unchanged.  The block-DCT + binning stages behind dctz_compress() /
+ * dctz_decompress() run on an MI355X through include/dctz_hip.h; the zlib tail
+ * and the container stay on the host.
+ *
+ * Build-time variants, as in the reference Makefile:12-17: USE_TRUNCATE is
+ * always defined (DC / AC_exact stored as float); USE_QTABLE selects the QT
+ * library and adds header.bindex_count.
+ *
+ * Differences from the reference header: fftw3.h is not included (nothing here
+ * needs FFTW), and the never-defined ceili() prototype (dctz.h:122) is omitted.
+ */
+#ifndef _DCTZ_H_
+#define _DCTZ_H_
+
+#include <math.h>
+#include <memory.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <time.h>
+
+#include "zlib.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DCTZ_VERSION "0.2.2"          /* wire-format version we interoperate with */
+#define DCTZ_VERSION_MAJOR 0
+#define DCTZ_VERSION_MINOR 2
+#define DCTZ_VERSION_PATCH 2
+
+#ifndef M_PI
+#define M_PI 3.14159265358979323846   /* dct.h:13-15 */
+#endif
+
+#define BLK_SZ 64                     /* elements per block              (dctz.h:28) */
+#define BRSF 1.0                      /* bin range scaling factor        (dctz.h:29) */
+#define SF_ADJ_AMT 1                  /* scaling factor exponent offset  (dctz.h:30) */
+
+#ifndef MAX
+#define MAX(a, b) ({ __typeof__(a) a_ = (a); __typeof__(b) b_ = (b); a_ > b_ ? a_ : b_; })
+#endif
+#ifndef MIN
+#define MIN(a, b) ({ __typeof__(a) a_ = (a); __typeof__(b) b_ = (b); a_ < b_ ? a_ : b_; })
+#endif
+#define CEIL(a, b) (a + b - 1) / b    /* as in dctz.h:42 (unparenthesised) */
+
+/* element type tag (dctz.h:44-47) */
+typedef enum { FLOAT = 0, DOUBLE } t_datatype;
+
+/* a typed view of a caller-owned buffer (dctz.h:49-59); 32 bytes on LP64 */
+typedef struct {
+  t_datatype datatype;
+  double err_bound;
+  char *var_name;
+  union {
+    float *f;
+    double *d;
+  } buf;
+} t_var;
+
+typedef unsigned char t_bin_id;                 /* dctz.h:63 */
+#define NBITS (sizeof(t_bin_id) << 3)           /* dctz.h:65 */
+#define NBINS ((1 << (NBITS)) - 1)              /* 255; id 255 = "stored exactly" */
+
+/* statistics of one array (dctz.h:68-94) */
+typedef struct {
+  union { double d; float f; } mean;
+  union { double d; float f; } min;
+  union { double d; float f; } max;
+  union { double d; float f; } range;
+  union { double d; float f; } sf;
+} t_bstat;
+
+/* container header, 56 bytes, native endianness (dctz.h:96-119) */
+struct header {
+  t_datatype datatype;
+  unsigned int num_elements;
+  double error_bound;
+  unsigned int tot_AC_exact_count;
+  union { double d; float f; } scaling_factor;
+  union { double d; float f; } mean;
+  unsigned int bindex_sz_compressed;
+  unsigned int DC_sz_compressed;
+  unsigned int AC_exact_sz_compressed;
+#ifdef USE_QTABLE
+  unsigned int bindex_count;
+#endif
+};
+
+/* dctz.h:121-128 */
+void calc_data_stat(t_var *in, t_bstat *bs, int N);
+void gen_bins(double min, double max, double *bin_center, int nbins, double error_bound);
+void gen_bins_f(float min, float max, float *bin_center, int nbins, float error_bound);
+void *compress_thread(void *arg);
+int dctz_compress(t_var *var, int N, size_t *outSize, t_var *var_z, double error_bound);
+int dctz_decompress(t_var *var_z, t_var *var_r);
+double calc_psnr(t_var *var, t_var *var_r, int N, double error_bound);
+
+/* dct.h:17-27 -- per-block transform entry points (driven by dct-test.c) */
+void dct_init(int dn);
+void dct_init_f(int dn);
+void dct_fftw(double *a, double *b, int dn, int nblk);
+void dct_fftw_f(float *a, float *b, int dn, int nblk);
+void ifft_idct(int dn, double *a, double *data);
+void ifft_idct_f(int dn, float *a, float *data);
+void dct_finish(void);
+void dct_finish_f(void);
+void idct_finish(void);
+void idct_finish_f(void);
+
+/* ---- additions (not in the reference) ------------------------------------ */
+/* Whole-array forms of dct_fftw / ifft_idct: every 64-element block of a[0..n)
+ * (last one of length n % 64) in one GPU pass; what dct-test.c:81-89 / 144-152
+ * compute with a loop. */
+void dctz_dct_blocks(double *a, double *b, size_t n, int inverse);
+void dctz_dct_blocks_f(float *a, float *b, size_t n, int inverse);
+/* Stage timers of the last dctz_compress / dctz_decompress call, seconds
+ * (the reference's -DTIME_DEBUG split, dctz-comp-lib.c:762-773). */
+typedef struct {
+  double h2d_s, gpu_s, d2h_s, zlib_s, total_s;
+} dctz_stage_times;
+void dctz_last_stage_times(dctz_stage_times *t);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* _DCTZ_H_ */

@@ -1,0 +1,137 @@
+/*
+ * dctz_hip.h -- C ABI of the MI355X (gfx950) hot path of DCTZ.
+ *
+ * This is the seam a DCTZ maintainer binds to: it sits INSIDE the reference's
+ * dctz_compress() / dctz_decompress() (dctz.h:126-127) and replaces exactly the
+ * serial CPU stages between "input in memory" and "three byte streams ready for
+ * zlib" (and the mirror image on the way back).  Plain C types only; device
+ * buffers are passed as void* device pointers; the library never frees or
+ * reallocates caller memory.  Every entry point returns 0 on success or a
+ * negative DCTZHIP_E_* code; dctzhip_last_error() gives the text.  There is NO
+ * CPU fallback: without a usable HIP device every call fails.
+ *
+ * Each function names the reference code it replaces (file:line under the
+ * upstream tree).
+ */
+#ifndef DCTZ_HIP_H
+#define DCTZ_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DCTZHIP_BLK 64            /* dctz.h:28  BLK_SZ */
+#define DCTZHIP_NBINS 255         /* dctz.h:65-66 (t_bin_id = unsigned char) */
+
+enum { DCTZHIP_F32 = 0, DCTZHIP_F64 = 1 };   /* values of t_datatype, dctz.h:44-47 */
+enum { DCTZHIP_EC = 0, DCTZHIP_QT = 1 };     /* -DUSE_QTABLE off/on, Makefile:12-17 */
+
+enum {
+  DCTZHIP_OK = 0,
+  DCTZHIP_E_ARG = -1,        /* bad argument (null, misaligned, n == 0, n > INT_MAX) */
+  DCTZHIP_E_BOUND = -2,      /* error_bound < 1e-6: dctz-comp-lib.c:135-138 */
+  DCTZHIP_E_HIP = -3,        /* a HIP runtime call failed (no device, OOM, ...) */
+  DCTZHIP_E_INTERNAL = -4    /* in-kernel watchdog tripped (look-back spin bound) */
+};
+
+typedef struct dctzhip_ctx dctzhip_ctx;
+
+/* What the compress stage hands back to the host besides the three streams.
+ * For DCTZHIP_F32 the stats are float values widened exactly to double. */
+typedef struct {
+  double sf;                 /* scaling factor, util.c:29/43 (host libm, same expr) */
+  double mean;               /* sum/N, util.c:28/41 -- DEVICE summation order       */
+  double max_abs, min_abs;   /* util.c:18-25 */
+  uint32_t cnt;              /* tot_AC_exact_count, dctz-comp-lib.c:323,497,537     */
+  uint32_t nblk;             /* CEIL(N, 64), dctz-comp-lib.c:227                    */
+  double qtable[64];         /* QT: clamped table as appended to the stream
+                                (dctz-comp-lib.c:450-461, 815-820); slot 0 = DC of
+                                the last block (:355-360).  EC: zeros.             */
+  double qtable_raw[64];     /* QT: table before clamping (= ./qtable.bin, :443-448) */
+} dctzhip_cinfo;
+
+/* Per-kernel device time of the last compress / decompress call, milliseconds,
+ * measured with HIP events on the context's stream (only when profiling is on). */
+typedef struct {
+  float stats_ms;            /* calc_data_stat kernels          */
+  float main_ms;             /* fused block-DCT + binning (or de-quantise + IDCT) */
+  float tail_ms;             /* remainder block + QT normalise   */
+  float total_ms;            /* first kernel start -> last kernel end */
+} dctzhip_timings;
+
+/* ---- context ------------------------------------------------------------- */
+/* device < 0: use the current HIP device.  The context owns a stream, constant
+ * tables and a scratch arena that grows on demand (dctzhip_reserve pre-sizes it
+ * so that later calls do no allocation).  One context per GPU per thread of
+ * control; a context is not re-entrant (neither is the reference: file-static
+ * FFTW plan, dct.c:18-22). */
+int dctzhip_ctx_create(dctzhip_ctx **out, int device);
+void dctzhip_ctx_destroy(dctzhip_ctx *ctx);
+const char *dctzhip_last_error(const dctzhip_ctx *ctx);   /* ctx may be NULL: last create error */
+int dctzhip_reserve(dctzhip_ctx *ctx, size_t n, int dtype, int mode);
+/* Use a caller-owned hipStream_t (e.g. torch's current stream) instead of the
+ * context's own; NULL restores the context stream. */
+int dctzhip_set_stream(dctzhip_ctx *ctx, void *hip_stream);
+void *dctzhip_get_stream(dctzhip_ctx *ctx);
+int dctzhip_set_profiling(dctzhip_ctx *ctx, int on);
+int dctzhip_last_timings(dctzhip_ctx *ctx, dctzhip_timings *t);
+
+/* ---- device memory helpers (so plain-C hosts need no HIP headers) --------- */
+int dctzhip_malloc(dctzhip_ctx *ctx, void **dptr, size_t bytes);
+int dctzhip_free(dctzhip_ctx *ctx, void *dptr);
+int dctzhip_memcpy_h2d(dctzhip_ctx *ctx, void *dst, const void *src, size_t bytes);
+int dctzhip_memcpy_d2h(dctzhip_ctx *ctx, void *dst, const void *src, size_t bytes);
+int dctzhip_sync(dctzhip_ctx *ctx);
+
+/* ---- compress stage ------------------------------------------------------ */
+/* Replaces dctz-comp-lib.c:186-217 (calc_data_stat + scale, util.c:12-44),
+ * :271-281 (bin ranges), :318-416 (dct_init + per-block dct_fftw + DC + pass-1
+ * binning), :435-476 (QT table) and :478-544 (pass-2 exception compaction).
+ *   d_in        n elements (float|double), device, 16-byte aligned; not modified
+ *   d_bin_index n bytes out (bin ids; 255 = DC slot / stored exactly)
+ *   d_dc        nblk floats out (USE_TRUNCATE)
+ *   d_ac_exact  capacity n floats out; info->cnt of them are valid, block-major,
+ *               j ascending -- byte-identical to the reference's AC_exact[]
+ *   d_scaled    optional: receives x/sf (the reference's in-place scaling of the
+ *               caller's buffer, :193-216); may be NULL, may alias d_in
+ *   d_coef      optional debug tap: the DCT coefficients a_x after pass 1
+ *               (= dct_result.bin under -DDCT_FILE_DEBUG, :422-428); may be NULL
+ * Synchronous with respect to the host on return (info is filled). */
+int dctzhip_compress(dctzhip_ctx *ctx, const void *d_in, size_t n, int dtype,
+                     double error_bound, int mode, void *d_bin_index, float *d_dc,
+                     float *d_ac_exact, void *d_scaled, void *d_coef,
+                     dctzhip_cinfo *info);
+
+/* ---- decompress stage ---------------------------------------------------- */
+/* Replaces dctz-decomp-lib.c:358-361 (gen_bins, binning.c:12-50), :372-386,
+ * :389-483 (de-quantise + ifft_idct per block) and :494-511 (de-scale).
+ *   ac_count     number of valid floats in d_ac_exact (header.tot_AC_exact_count);
+ *                a bin_index that flags more than that fails with DCTZHIP_E_ARG
+ *   qtable_host  QT: the 64 table values in the data type, HOST memory (as read
+ *                from the stream tail, dctz-decomp-lib.c:193-199); EC: NULL
+ *   sf           header scaling factor (scaling_factor.d, or .f widened)
+ *   d_out        n elements out
+ * Synchronous with respect to the host on return. */
+int dctzhip_decompress(dctzhip_ctx *ctx, const void *d_bin_index, const float *d_dc,
+                       const float *d_ac_exact, uint32_t ac_count,
+                       const void *qtable_host, size_t n, int dtype,
+                       double error_bound, double sf, int mode, void *d_out);
+
+/* ---- transform only ------------------------------------------------------ */
+/* Batched drop-in for dct_init + per-block dct_fftw / ifft_idct (+ the
+ * remainder-length re-init), dct.h:17-27 as driven by dct-test.c:81-89, 144-152:
+ * forward (inverse = 0) or inverse (inverse = 1) orthonormal DCT of every
+ * 64-element block of d_in, last block of length n % 64 if non-zero. */
+int dctzhip_dct_blocks(dctzhip_ctx *ctx, const void *d_in, void *d_out, size_t n,
+                       int dtype, int inverse);
+
+/* Library/ABI version, "major.minor.patch". */
+const char *dctzhip_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DCTZ_HIP_H */

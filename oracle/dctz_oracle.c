@@ -3,6 +3,7 @@
  * see dctz_oracle.h for scope, parity status and the FFTW note).
  * Build: make -C oracle   (gcc -O2 -ffp-contract=off, no -ffast-math, no -mfma)
  */
+#define _GNU_SOURCE /* sincos(), sincosf() */
 #include "dctz_oracle.h"
 
 #include <math.h>

@@ -1,0 +1,154 @@
+"""Parity of the HIP path (through the C ABI) against the CPU oracle.
+
+Bar: bit-exact on every stream -- bin_index (u8), DC and AC_exact (f32 bits),
+cnt, sf, the QT table -- and on the reconstructed array (the kernels evaluate
+the oracle's pinned expression tree, unfused)."""
+import numpy as np
+import pytest
+
+from oracle import oracle as O
+from tests import workloads as W
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    import dctz_amd
+    c = dctz_amd.Context(0)
+    yield c
+    c.close()
+
+
+def _dev(ctx, a):
+    import torch
+    return torch.from_numpy(np.ascontiguousarray(a)).to(ctx.device)
+
+
+def _bits(a):
+    return np.ascontiguousarray(a).view(np.uint8)
+
+
+def _same(a, b):
+    return a.shape == b.shape and np.array_equal(_bits(a), _bits(b))
+
+
+SIZES = [1, 2, 31, 63, 64, 65, 127, 128, 1000, 1001, 4096, 4097, 12960, 37024, 64 * 64 * 5 + 40]
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+@pytest.mark.parametrize("n", SIZES)
+def test_dct_blocks_bit_exact(ctx, dtype, n):
+    x = W.ragged(n, dtype)
+    nblk = (n + 63) // 64
+    for inverse in (False, True):
+        y = ctx.dct_blocks(_dev(ctx, x), inverse=inverse).cpu().numpy()
+        ref = np.empty_like(x)
+        for b in range(nblk):
+            sl = slice(64 * b, min(n, 64 * b + 64))
+            ref[sl] = O.dct_inv(x[sl], O.FAST) if inverse else O.dct_fwd(x[sl], O.FAST)
+        bad = np.flatnonzero(y.view(np.uint64 if dtype == np.float64 else np.uint32)
+                             != ref.view(np.uint64 if dtype == np.float64 else np.uint32))
+        assert bad.size == 0, (f"inverse={inverse} n={n}: {bad.size} mismatches, first at {bad[:8]} "
+                               f"(block {bad[0] // 64}, j {bad[0] % 64}) maxdiff={np.abs(y - ref).max()}")
+
+
+def _compress_both(ctx, x, eb, mode):
+    import torch
+    xd = _dev(ctx, x)
+    coef = torch.empty_like(xd)
+    scaled = torch.empty_like(xd)
+    out, info = ctx.compress(xd, eb, mode, scaled=scaled, coef=coef)
+    c = O.compress(x, eb, mode, O.FAST, want_coef=True)
+    return xd, out, info, coef, scaled, c
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+@pytest.mark.parametrize("mode", [O.EC, O.QT])
+@pytest.mark.parametrize("n", SIZES)
+def test_compress_streams_bit_exact(ctx, dtype, mode, n):
+    x = W.ragged(n, dtype, scale=37.0)
+    eb = 1e-3
+    xd, out, info, coef, scaled, c = _compress_both(ctx, x, eb, mode)
+    assert np.array_equal(xd.cpu().numpy(), x), "input must not be modified"
+    assert info.sf == c.sf and info.nblk == (n + 63) // 64
+    assert _same(scaled.cpu().numpy(), c.scaled)
+    if mode == O.EC:   # (QT: the oracle's a_x holds the normalised values after pass 2)
+        assert _same(coef.cpu().numpy(), c.coef)
+    assert np.array_equal(out["bin_index"].cpu().numpy(), c.bin_index)
+    assert _same(out["dc"].cpu().numpy(), c.dc)
+    assert info.cnt == c.cnt
+    assert _same(out["ac_exact"][:c.cnt].cpu().numpy(), c.ac_exact)
+    if mode == O.QT:
+        assert _same(np.array(info.qtable[:], dtype=dtype), c.qtable)
+        assert _same(np.array(info.qtable_raw[:], dtype=dtype), c.qtable_raw)
+    # mean: device summation order differs from util.c's serial loop
+    assert abs(info.mean - c.mean) <= 1e-5 * max(1.0, abs(c.mean))
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+@pytest.mark.parametrize("mode", [O.EC, O.QT])
+@pytest.mark.parametrize("n", SIZES)
+def test_decompress_bit_exact(ctx, dtype, mode, n):
+    import torch
+    x = W.ragged(n, dtype, scale=37.0)
+    eb = 1e-3
+    c = O.compress(x, eb, mode, O.FAST)
+    ref = O.decompress(c, O.FAST)
+    out = {"bin_index": _dev(ctx, c.bin_index), "dc": _dev(ctx, c.dc),
+           "ac_exact": _dev(ctx, c.ac_exact if c.cnt else np.zeros(4, np.float32))}
+    tdt = torch.float64 if dtype == np.float64 else torch.float32
+    r = ctx.decompress(out, c.cnt, n, tdt, eb, c.sf, mode, qtable=c.qtable).cpu().numpy()
+    assert _same(r, ref), f"maxdiff={np.abs(r - ref).max()}"
+
+
+@pytest.mark.parametrize("eb", [1e-3, 1e-4, 1e-5, 1e-6])
+def test_c1_known_answer_on_gpu(ctx, eb):
+    """Config 1 (2^20 uniform doubles): at eb = 1e-3 the survey's recorded outputs
+    of the reference (cnt, PSNR, max|err|) must come out of the HIP path."""
+    import json, os, torch
+    x = W.c1()
+    xd = _dev(ctx, x)
+    out, info = ctx.compress(xd, eb, O.EC)
+    c = O.compress(x, eb, O.EC, O.FAST)
+    assert info.sf == c.sf and info.cnt == c.cnt
+    assert np.array_equal(out["bin_index"].cpu().numpy(), c.bin_index)
+    assert _same(out["ac_exact"][:c.cnt].cpu().numpy(), c.ac_exact)
+    r = ctx.decompress(out, info.cnt, x.size, torch.float64, eb, info.sf, O.EC).cpu().numpy()
+    assert _same(r, O.decompress(c, O.FAST))
+    if eb == 1e-3:
+        ka = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "survey_known_answers.json")))["C1_ec"]
+        p = O.psnr((x / info.sf) * info.sf, r)
+        assert info.cnt == ka["cnt"] and info.sf == ka["sf"]
+        assert abs(p["psnr"] - ka["psnr"]) / ka["psnr"] < 1e-6
+        assert abs(p["maxdiff"] - ka["maxerr"]) / ka["maxerr"] < 1e-6
+
+
+def test_c2_fp32_field(ctx):
+    import torch
+    f = W.c2()
+    for mode in (O.EC, O.QT):
+        out, info = ctx.compress(_dev(ctx, f), 1e-4, mode)
+        c = O.compress(f, 1e-4, mode, O.FAST)
+        assert info.sf == c.sf and info.cnt == c.cnt
+        assert np.array_equal(out["bin_index"].cpu().numpy(), c.bin_index)
+        assert _same(out["dc"].cpu().numpy(), c.dc)
+        assert _same(out["ac_exact"][:c.cnt].cpu().numpy(), c.ac_exact)
+        r = ctx.decompress(out, info.cnt, f.size, torch.float32, 1e-4, info.sf, mode,
+                           qtable=np.array(info.qtable[:])).cpu().numpy()
+        assert _same(r, O.decompress(c, O.FAST))
+        assert round(O.psnr(f, r)["psnr"], 2) == 93.63     # survey known answer (C2-like)
+
+
+def test_error_paths(ctx):
+    import dctz_amd, torch
+    x = torch.ones(128, dtype=torch.float64, device=ctx.device)
+    with pytest.raises(dctz_amd.DctzHipError, match="ERROR BOUND"):
+        ctx.compress(x, 1e-7)                            # dctz-comp-lib.c:135-138
+    out, info = ctx.compress(torch.zeros(100, dtype=torch.float64, device=ctx.device), 1e-3)
+    assert info.sf == 1.0 and info.cnt == 0              # documented deviation (sf = 1)
+    # a bin_index that flags more exceptions than the stream carries is refused
+    c = O.compress(W.ragged(1000, np.float64, scale=37.0), 1e-3)
+    outs = {"bin_index": _dev(ctx, c.bin_index), "dc": _dev(ctx, c.dc), "ac_exact": _dev(ctx, c.ac_exact)}
+    with pytest.raises(dctz_amd.DctzHipError):
+        ctx.decompress(outs, max(c.cnt - 1, 0), 1000, torch.float64, 1e-3, c.sf)
