@@ -93,6 +93,8 @@ struct InvParams {
 };
 
 template <typename T> void launch_stats(const T* x, size_t n, double* part, int nparts, double* out, hipStream_t s);
+template <typename T> void launch_serial_sum(const T* x, size_t n, double* out, hipStream_t s);
+template <typename T> void launch_scale(T* x, size_t n, T sf, int grid, hipStream_t s);
 template <typename T> void launch_compress(const FwdParams<T>& p, int mode, bool scale, int grid, hipStream_t s);
 template <typename T> void launch_compress_rem(const FwdParams<T>& p, int mode, bool scale, int l, hipStream_t s);
 template <typename T> void launch_qt_finish(const FwdParams<T>& p, double eb, int grid, hipStream_t s);

@@ -333,6 +333,48 @@ __global__ __launch_bounds__(WG) void k_stats_final(const double* __restrict__ p
   }
 }
 
+// Serial-order sum for the header's `mean` (util.c:18-28 / :31-41): the reference
+// adds x[1..N-1] one after the other in the data type, and a tree reduction
+// cannot reproduce those roundings.  One wavefront: all lanes stage a chunk in
+// LDS with coalesced loads, lane 0 adds it up in index order.  Slow by design
+// (one dependent add per element) and OFF the critical path: the host wrapper
+// runs it on a side stream underneath the zlib tail.
+template <typename T>
+__global__ __launch_bounds__(64) void k_serial_sum(const T* __restrict__ x, size_t n, double* __restrict__ out) {
+  constexpr int CH = 4096;
+  __shared__ T buf[CH];
+  const int lane = threadIdx.x;
+  T sum = T(0);
+  for (size_t base = 0; base < n; base += CH) {
+    const size_t m = (n - base < (size_t)CH) ? n - base : (size_t)CH;
+    for (size_t i = lane; i < m; i += 64) buf[i] = x[base + i];
+    __syncthreads();
+    if (lane == 0) {
+      size_t i = (base == 0) ? 1 : 0;          // util.c:22: the loop starts at i = 1
+      for (; i < m; i++) sum += buf[i];
+    }
+    __syncthreads();
+  }
+  if (lane == 0) out[0] = (double)sum;
+}
+
+// x[i] /= sf in place (dctz-comp-lib.c:193-216), for callers that need the
+// reference's in-place side effect on their own buffer.
+template <typename T>
+__global__ __launch_bounds__(WG) void k_scale(T* __restrict__ x, size_t n, T sf) {
+  using Vec = typename Traits<T>::Vec;
+  constexpr int EPV = Traits<T>::EPV;
+  const size_t nvec = n / EPV;
+  Vec* v = reinterpret_cast<Vec*>(x);
+  for (size_t i = (size_t)blockIdx.x * WG + threadIdx.x; i < nvec; i += (size_t)gridDim.x * WG) {
+    Vec a = v[i];
+    Traits<T>::div(a, sf);
+    v[i] = a;
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0)
+    for (size_t i = nvec * EPV; i < n; i++) x[i] = x[i] / sf;
+}
+
 // ================================================================= compress ==
 // Fused: scale (dctz-comp-lib.c:193-216) -> DCT-II per block (:337-340, dct.c:55-103)
 // -> DC (:350-351) -> pass-1 binning (:361-414) -> ordered exception stream
@@ -698,6 +740,16 @@ void launch_stats(const T* x, size_t n, double* part, int nparts, double* out, h
 }
 
 template <typename T>
+void launch_serial_sum(const T* x, size_t n, double* out, hipStream_t s) {
+  hipLaunchKernelGGL(k_serial_sum<T>, dim3(1), dim3(64), 0, s, x, n, out);
+}
+
+template <typename T>
+void launch_scale(T* x, size_t n, T sf, int grid, hipStream_t s) {
+  hipLaunchKernelGGL(k_scale<T>, dim3(grid), dim3(WG), 0, s, x, n, sf);
+}
+
+template <typename T>
 void launch_compress(const FwdParams<T>& p, int mode, bool scale, int grid, hipStream_t s) {
   const size_t sm = fwd_smem<T>();
   if (mode == DCTZHIP_EC) {
@@ -769,6 +821,8 @@ void launch_dct_blocks(const T* x, T* out, const T* gtab, const T* rtab, size_t 
 // explicit instantiations used by dctz_shim.hip
 #define INST(T)                                                                                         \
   template void launch_stats<T>(const T*, size_t, double*, int, double*, hipStream_t);                  \
+  template void launch_serial_sum<T>(const T*, size_t, double*, hipStream_t);                           \
+  template void launch_scale<T>(T*, size_t, T, int, hipStream_t);                                       \
   template void launch_compress<T>(const FwdParams<T>&, int, bool, int, hipStream_t);                   \
   template void launch_compress_rem<T>(const FwdParams<T>&, int, bool, int, hipStream_t);               \
   template void launch_qt_finish<T>(const FwdParams<T>&, double, int, hipStream_t);                     \

@@ -25,6 +25,10 @@ struct dctzhip_ctx {
   int num_cu = 256;
   hipStream_t own_stream = nullptr;
   hipStream_t stream = nullptr;
+  hipStream_t side_stream = nullptr;   // serial-order mean, runs beside the host zlib tail
+  double* serial_out = nullptr;
+  size_t serial_n = 0;
+  int serial_dtype = -1;
   // constant tables
   double* tab_f64 = nullptr;
   float* tab_f32 = nullptr;
@@ -91,6 +95,8 @@ extern "C" int dctzhip_ctx_create(dctzhip_ctx** out, int device) {
   c->num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
   HIPCHK(nullptr, hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
   c->stream = c->own_stream;
+  HIPCHK(nullptr, hipStreamCreateWithFlags(&c->side_stream, hipStreamNonBlocking));
+  HIPCHK(nullptr, hipMalloc(&c->serial_out, 16));
   HIPCHK(nullptr, hipMalloc(&c->tab_f64, sizeof(double) * TAB_SIZE));
   HIPCHK(nullptr, hipMalloc(&c->tab_f32, sizeof(float) * TAB_SIZE));
   HIPCHK(nullptr, hipMalloc(&c->rtab, sizeof(double) * RTAB_SIZE));
@@ -116,7 +122,8 @@ extern "C" void dctzhip_ctx_destroy(dctzhip_ctx* c) {
   if (!c) return;
   (void)hipSetDevice(c->device);
   (void)hipStreamSynchronize(c->stream);
-  void* bufs[] = {c->tab_f64, c->tab_f32, c->rtab, c->qtab, c->ctl, c->desc, c->part, c->stats_out, c->qt_item, c->qt_j};
+  if (c->side_stream) { (void)hipStreamSynchronize(c->side_stream); (void)hipStreamDestroy(c->side_stream); }
+  void* bufs[] = {c->serial_out, c->tab_f64, c->tab_f32, c->rtab, c->qtab, c->ctl, c->desc, c->part, c->stats_out, c->qt_item, c->qt_j};
   for (void* b : bufs) if (b) (void)hipFree(b);
   if (c->h_pin) (void)hipHostFree(c->h_pin);
   for (int i = 0; i < 6; i++) if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
@@ -266,17 +273,20 @@ static int compress_impl(dctzhip_ctx* c, const T* d_in, size_t n, double eb, int
   if (ntiles) HIPCHK(c, hipMemsetAsync(c->desc, 0, ((ntiles + 1) & ~1u) * sizeof(unsigned long long), s));
 
   // ---- calc_data_stat (util.c:12-44) ----------------------------------------
-  const size_t nvec = n / Traits<T>::EPV;
-  int sgrid = (int)((nvec + WG - 1) / WG);
-  if (sgrid < 1) sgrid = 1;
-  if (sgrid > STATS_GRID_MAX) sgrid = STATS_GRID_MAX;
   if (c->profiling) HIPCHK(c, hipEventRecord(c->ev[0], s));
-  launch_stats<T>(d_in, n, c->part, sgrid, c->stats_out, s);
-  if (c->profiling) HIPCHK(c, hipEventRecord(c->ev[1], s));
-  double* hs = reinterpret_cast<double*>(c->h_pin + PIN_STATS);
-  HIPCHK(c, hipMemcpyAsync(hs, c->stats_out, 3 * sizeof(double), hipMemcpyDeviceToHost, s));
-  HIPCHK(c, hipStreamSynchronize(s));
-  const double max_abs = hs[0], min_abs = hs[1], sum = hs[2];
+  double max_abs, min_abs, sum;
+  {
+    const size_t nvec = n / Traits<T>::EPV;
+    int sgrid = (int)((nvec + WG - 1) / WG);
+    if (sgrid < 1) sgrid = 1;
+    if (sgrid > STATS_GRID_MAX) sgrid = STATS_GRID_MAX;
+    launch_stats<T>(d_in, n, c->part, sgrid, c->stats_out, s);
+    if (c->profiling) HIPCHK(c, hipEventRecord(c->ev[1], s));
+    double* hs = reinterpret_cast<double*>(c->h_pin + PIN_STATS);
+    HIPCHK(c, hipMemcpyAsync(hs, c->stats_out, 3 * sizeof(double), hipMemcpyDeviceToHost, s));
+    HIPCHK(c, hipStreamSynchronize(s));
+    max_abs = hs[0]; min_abs = hs[1]; sum = hs[2];
+  }
   const double sf = scaling_factor(dtype, max_abs);
 
   // ---- bin ranges, dctz-comp-lib.c:271-281 (computed in double, stored in T) --
@@ -334,6 +344,76 @@ static int compress_impl(dctzhip_ctx* c, const T* d_in, size_t n, double eb, int
       info->qtable[0] = info->qtable_raw[0] = q0;                 // :355-360
     }
   }
+  return DCTZHIP_OK;
+}
+
+template <typename T>
+static int stats_impl(dctzhip_ctx* c, const T* d_in, size_t n, double* max_abs, double* min_abs, double* sum) {
+  hipStream_t s = c->stream;
+  const size_t nvec = n / Traits<T>::EPV;
+  int sgrid = (int)((nvec + WG - 1) / WG);
+  if (sgrid < 1) sgrid = 1;
+  if (sgrid > STATS_GRID_MAX) sgrid = STATS_GRID_MAX;
+  launch_stats<T>(d_in, n, c->part, sgrid, c->stats_out, s);
+  double* hs = reinterpret_cast<double*>(c->h_pin + PIN_STATS);
+  HIPCHK(c, hipMemcpyAsync(hs, c->stats_out, 3 * sizeof(double), hipMemcpyDeviceToHost, s));
+  HIPCHK(c, hipStreamSynchronize(s));
+  *max_abs = hs[0]; *min_abs = hs[1]; *sum = hs[2];
+  return DCTZHIP_OK;
+}
+
+extern "C" int dctzhip_stats(dctzhip_ctx* c, const void* d_in, size_t n, int dtype, dctzhip_cinfo* info) {
+  int rc = check_common(c, n, dtype, DCTZHIP_EC);
+  if (rc) return rc;
+  if (!d_in || !info || !aligned16(d_in)) return fail(c, DCTZHIP_E_ARG, "bad buffer");
+  HIPCHK(c, hipSetDevice(c->device));
+  double mx, mn, sum;
+  rc = (dtype == DCTZHIP_F64) ? stats_impl<double>(c, (const double*)d_in, n, &mx, &mn, &sum)
+                              : stats_impl<float>(c, (const float*)d_in, n, &mx, &mn, &sum);
+  if (rc) return rc;
+  memset(info, 0, sizeof(*info));
+  info->max_abs = mx; info->min_abs = mn;
+  info->sf = scaling_factor(dtype, mx);
+  info->mean = (dtype == DCTZHIP_F64) ? sum / (double)(int)n : (double)((float)sum / (float)(int)n);
+  info->nblk = (uint32_t)((n + 63) / 64);
+  return DCTZHIP_OK;
+}
+
+extern "C" int dctzhip_serial_mean_begin(dctzhip_ctx* c, const void* d_in, size_t n, int dtype) {
+  int rc = check_common(c, n, dtype, DCTZHIP_EC);
+  if (rc) return rc;
+  if (!d_in) return fail(c, DCTZHIP_E_ARG, "null device buffer");
+  HIPCHK(c, hipSetDevice(c->device));
+  if (dtype == DCTZHIP_F64) launch_serial_sum<double>((const double*)d_in, n, c->serial_out, c->side_stream);
+  else launch_serial_sum<float>((const float*)d_in, n, c->serial_out, c->side_stream);
+  HIPCHK(c, hipGetLastError());
+  c->serial_n = n; c->serial_dtype = dtype;
+  return DCTZHIP_OK;
+}
+
+extern "C" int dctzhip_serial_mean_end(dctzhip_ctx* c, double* mean) {
+  if (!c || !mean) return DCTZHIP_E_ARG;
+  if (c->serial_dtype < 0) return fail(c, DCTZHIP_E_ARG, "dctzhip_serial_mean_begin was not called");
+  double sum = 0.0;
+  HIPCHK(c, hipMemcpyAsync(&sum, c->serial_out, sizeof(double), hipMemcpyDeviceToHost, c->side_stream));
+  HIPCHK(c, hipStreamSynchronize(c->side_stream));
+  // util.c:28 / :41 -- sum / N in the data type (N is an int)
+  *mean = (c->serial_dtype == DCTZHIP_F64) ? sum / (double)(int)c->serial_n
+                                           : (double)((float)sum / (float)(int)c->serial_n);
+  c->serial_dtype = -1;
+  return DCTZHIP_OK;
+}
+
+extern "C" int dctzhip_scale_inplace(dctzhip_ctx* c, void* d_x, size_t n, int dtype, double sf) {
+  int rc = check_common(c, n, dtype, DCTZHIP_EC);
+  if (rc) return rc;
+  if (!d_x || !aligned16(d_x)) return fail(c, DCTZHIP_E_ARG, "bad buffer");
+  HIPCHK(c, hipSetDevice(c->device));
+  if (sf == 1.0) return DCTZHIP_OK;                 // dctz-comp-lib.c:193 / :208
+  if (dtype == DCTZHIP_F64) launch_scale<double>((double*)d_x, n, sf, c->num_cu * 8, c->stream);
+  else launch_scale<float>((float*)d_x, n, (float)sf, c->num_cu * 8, c->stream);
+  HIPCHK(c, hipGetLastError());
+  HIPCHK(c, hipStreamSynchronize(c->stream));
   return DCTZHIP_OK;
 }
 

@@ -105,6 +105,23 @@ int dctzhip_compress(dctzhip_ctx *ctx, const void *d_in, size_t n, int dtype,
                      float *d_ac_exact, void *d_scaled, void *d_coef,
                      dctzhip_cinfo *info);
 
+/* calc_data_stat alone (util.c:12-44): fills sf, mean (device order), max_abs,
+ * min_abs and nblk of *info. */
+int dctzhip_stats(dctzhip_ctx *ctx, const void *d_in, size_t n, int dtype, dctzhip_cinfo *info);
+
+/* The header's `mean` in the reference's SERIAL summation order (util.c:18-28:
+ * sum of x[1..N-1] in the data type, then / N) -- bit-identical to the
+ * reference, which a parallel reduction cannot be.  begin() enqueues a
+ * single-wavefront kernel on a side stream and returns at once; end() waits
+ * for it.  d_in must stay unmodified in between.  (~0.5 s per GiB of fp64: meant
+ * to run underneath the host zlib tail, which is 20x longer.) */
+int dctzhip_serial_mean_begin(dctzhip_ctx *ctx, const void *d_in, size_t n, int dtype);
+int dctzhip_serial_mean_end(dctzhip_ctx *ctx, double *mean);
+
+/* x[i] /= sf in place on the device (dctz-comp-lib.c:193-216), no-op if sf == 1.
+ * Synchronous. */
+int dctzhip_scale_inplace(dctzhip_ctx *ctx, void *d_x, size_t n, int dtype, double sf);
+
 /* ---- decompress stage ---------------------------------------------------- */
 /* Replaces dctz-decomp-lib.c:358-361 (gen_bins, binning.c:12-50), :372-386,
  * :389-483 (de-quantise + ifft_idct per block) and :494-511 (de-scale).

@@ -1,0 +1,146 @@
+"""The drop-in boundary: dctz_compress() / dctz_decompress() of lib/libdctz-{ec,qt}.so
+called exactly the way dctz-test.c calls them (dctz-test.c:130-181, 250), checked
+against the oracle and the survey's known answers."""
+import ctypes as C
+import os
+import struct
+import zlib
+
+import numpy as np
+import pytest
+
+from oracle import oracle as O
+from tests import workloads as W
+
+pytestmark = pytest.mark.gpu
+LIBDIR = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "dctz_amd", "lib")
+
+
+class TVarBuf(C.Union):
+    _fields_ = [("f", C.POINTER(C.c_float)), ("d", C.POINTER(C.c_double))]
+
+
+class TVar(C.Structure):   # dctz.h:49-59
+    _fields_ = [("datatype", C.c_int), ("err_bound", C.c_double), ("var_name", C.c_char_p), ("buf", TVarBuf)]
+
+
+def _lib(mode):
+    os.environ["DCTZ_QUIET"] = "1"
+    lib = C.CDLL(os.path.join(LIBDIR, f"libdctz-{mode}.so"))
+    lib.dctz_compress.restype = C.c_int
+    lib.dctz_compress.argtypes = [C.POINTER(TVar), C.c_int, C.POINTER(C.c_size_t), C.POINTER(TVar), C.c_double]
+    lib.dctz_decompress.restype = C.c_int
+    lib.dctz_decompress.argtypes = [C.POINTER(TVar), C.POINTER(TVar)]
+    lib.calc_psnr.restype = C.c_double
+    return lib
+
+
+def _tvar(arr):
+    v = TVar()
+    v.datatype = 1 if arr.dtype == np.float64 else 0
+    if arr.dtype == np.float64:
+        v.buf.d = arr.ctypes.data_as(C.POINTER(C.c_double))
+    else:
+        v.buf.f = arr.ctypes.data_as(C.POINTER(C.c_float))
+    return v
+
+
+def _parse(z, dtype, qt):
+    # struct header, dctz.h:96-119 (56 bytes, native endianness; offsets SURVEY 8b)
+    dt, n, eb, cnt = struct.unpack_from("<IIdI", z, 0)
+    sf = struct.unpack_from("<d" if dtype == np.float64 else "<f", z, 24)[0]
+    mean = struct.unpack_from("<d" if dtype == np.float64 else "<f", z, 32)[0]
+    s0, s1, s2 = struct.unpack_from("<III", z, 40)
+    off = 56
+    streams = []
+    for sz in (s0, s1, s2):
+        streams.append(zlib.decompress(bytes(z[off:off + sz])))
+        off += sz
+    q = np.frombuffer(bytes(z[off:off + 64 * np.dtype(dtype).itemsize]), dtype=dtype) if qt else None
+    return dict(dt=dt, n=n, eb=eb, cnt=cnt, sf=sf, mean=mean, sizes=(s0, s1, s2), streams=streams, q=q,
+                bindex_count=struct.unpack_from("<I", z, 52)[0] if qt else None)
+
+
+@pytest.mark.parametrize("mode", ["ec", "qt"])
+@pytest.mark.parametrize("case", ["c1", "ragged_f32", "ragged_f64_rem"])
+def test_dropin_compress_decompress(mode, case):
+    lib = _lib(mode)
+    qt = mode == "qt"
+    if case == "c1":
+        x = W.c1(); eb = 1e-3
+    elif case == "ragged_f32":
+        x = W.ragged(64 * 700 + 17, np.float32, scale=37.0); eb = 1e-4
+    else:
+        x = W.ragged(37024, np.float64, scale=410.0); eb = 1e-3
+    n = x.size
+    orig = x.copy()
+    zbuf = np.zeros(n * x.itemsize + 4096, np.uint8)     # dctz-test.c:143: N*type_size bytes
+    rec = np.zeros(n, x.dtype)
+    var, var_z, var_r = _tvar(x), TVar(), _tvar(rec)
+    var_z.datatype = var.datatype
+    var_z.buf.d = zbuf.ctypes.data_as(C.POINTER(C.c_double))
+    out_size = C.c_size_t(0)
+    assert lib.dctz_compress(C.byref(var), n, C.byref(out_size), C.byref(var_z), eb) == 1
+
+    c = O.compress(orig, eb, O.QT if qt else O.EC, O.FAST)
+    h = _parse(zbuf[:out_size.value], x.dtype, qt)
+    assert (h["dt"], h["n"], h["eb"], h["cnt"]) == (var.datatype, n, eb, c.cnt)
+    assert h["sf"] == c.sf
+    assert h["mean"] == x.dtype.type(c.mean)              # serial-order mean: bit-exact
+    assert h["streams"][0] == c.bin_index.tobytes()
+    assert h["streams"][1] == c.dc.tobytes()
+    assert h["streams"][2] == c.ac_exact.tobytes()
+    if qt:
+        assert h["bindex_count"] == n and np.array_equal(h["q"].view(np.uint8), c.qtable.view(np.uint8))
+    assert np.array_equal(x.view(np.uint8), c.scaled.view(np.uint8)), "caller's buffer must hold x/sf"
+    assert out_size.value == 56 + sum(h["sizes"]) + (64 * x.itemsize if qt else 0)
+    if case == "c1" and mode == "ec" and zlib.ZLIB_VERSION.startswith("1.2.11"):
+        assert out_size.value == 3763394                   # survey known answer (zlib 1.2.11)
+
+    assert lib.dctz_decompress(C.byref(var_z), C.byref(var_r)) == 1
+    assert np.array_equal(rec.view(np.uint8), O.decompress(c, O.FAST).view(np.uint8))
+    if case == "c1" and mode == "ec":
+        p = O.psnr((orig / c.sf) * c.sf, rec)
+        assert abs(p["psnr"] - 96.383701092386) < 1e-6 and abs(p["maxdiff"] - 9.232739551845448e-05) < 1e-10
+
+
+def test_dct_h_per_block_api():
+    """dct_init / dct_fftw / ifft_idct / dct_finish as dct-test.c:81-89, 144-152 drives them."""
+    lib = _lib("ec")
+    x = W.ragged(64 * 3 + 40, np.float64)
+    fwd = np.zeros_like(x); back = np.zeros_like(x)
+    lib.dct_init(64)
+    for b in range(4):
+        l = min(64, x.size - 64 * b)
+        if l != 64:
+            lib.dct_finish(); lib.dct_init(l)
+        lib.dct_fftw(x[64 * b:].ctypes.data_as(C.c_void_p), fwd[64 * b:].ctypes.data_as(C.c_void_p), l, 4)
+    lib.dct_finish()
+    for b in range(4):
+        l = min(64, x.size - 64 * b)
+        lib.ifft_idct(l, fwd[64 * b:].ctypes.data_as(C.c_void_p), back[64 * b:].ctypes.data_as(C.c_void_p))
+    lib.idct_finish()
+    ref = np.concatenate([O.dct_fwd(x[64 * b:64 * b + 64], O.FAST) for b in range(4)])
+    assert np.array_equal(fwd.view(np.uint8), ref.view(np.uint8))
+    assert np.abs(back - x).max() < 1e-13
+
+
+def test_calc_data_stat_and_gen_bins():
+    lib = _lib("ec")
+
+    class U(C.Union):
+        _fields_ = [("d", C.c_double), ("f", C.c_float)]
+
+    class BStat(C.Structure):                               # dctz.h:68-94
+        _fields_ = [("mean", U), ("min", U), ("max", U), ("range", U), ("sf", U)]
+    for dtype in (np.float64, np.float32):
+        x = W.ragged(100003, dtype, scale=512.0)
+        bs = BStat()
+        var = _tvar(x)
+        lib.calc_data_stat(C.byref(var), C.byref(bs), x.size)
+        st = O.stats(x)
+        got = (bs.mean.d, bs.min.d, bs.max.d, bs.sf.d) if dtype == np.float64 else (bs.mean.f, bs.min.f, bs.max.f, bs.sf.f)
+        assert got == tuple(dtype(v) for v in (st.mean, st.min, st.max, st.sf))
+    bc = np.zeros(255)
+    lib.gen_bins(C.c_double(0), C.c_double(0), bc.ctypes.data_as(C.c_void_p), 255, C.c_double(1e-3))
+    assert np.array_equal(bc, O.gen_bins(1e-3, np.float64))
