@@ -99,10 +99,8 @@ def main():
         info = step()
     barrier()
     elapsed = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=ctx.device)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    from dctz_amd import shard
+    elapsed = shard.max_over_ranks(elapsed, ctx.device)
     ms_per_step = elapsed * 1e3 / a.steps
 
     # ---- per-kernel durations (HIP events on the launch stream), same K steps --
@@ -141,25 +139,10 @@ def main():
     # ---- optional: the one real exchange step (streams -> rank 0 over RCCL) ----
     gather_ms = None
     if a.gather and dist is not None:
-        cnt_t = torch.tensor([info.cnt], dtype=torch.int64, device=ctx.device)
-        cnts = [torch.zeros_like(cnt_t) for _ in range(world)]
-        dist.all_gather(cnts, cnt_t)
+        from dctz_amd import shard
         barrier()
         g0 = time.perf_counter()
-        ops = []
-        keep = []
-        if rank == 0:
-            for r in range(1, world):
-                bi = torch.empty(n, dtype=torch.uint8, device=ctx.device)
-                dc = torch.empty((n + 63) // 64, dtype=torch.float32, device=ctx.device)
-                ac = torch.empty(int(cnts[r].item()), dtype=torch.float32, device=ctx.device)
-                keep += [bi, dc, ac]
-                ops += [dist.P2POp(dist.irecv, bi, r), dist.P2POp(dist.irecv, dc, r), dist.P2POp(dist.irecv, ac, r)]
-        else:
-            ops += [dist.P2POp(dist.isend, out["bin_index"], 0), dist.P2POp(dist.isend, out["dc"], 0),
-                    dist.P2POp(dist.isend, out["ac_exact"][:info.cnt], 0)]
-        for w in dist.batch_isend_irecv(ops):
-            w.wait()
+        shard.gather_streams(out, info.cnt, dst=0)
         barrier()
         gather_ms = (time.perf_counter() - g0) * 1e3
 

@@ -1,0 +1,49 @@
+"""Runs the PRODUCT's lane arithmetic (dctz_amd/csrc/dct64_lane.h + dctz_tables.h)
+on the CPU by walking the four quad lanes in a loop (tests/emu/emu_dct64.cpp),
+and requires bit-identity with the oracle's pinned fast flow.  This is what lets
+kernel-vs-oracle GPU comparisons be exact rather than tolerance-based."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from oracle import oracle as O
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+SO = os.path.join(HERE, "emu", "emu_dct64.so")
+
+
+@pytest.fixture(scope="module")
+def emu():
+    src = os.path.join(HERE, "emu", "emu_dct64.cpp")
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-ffp-contract=off", "-shared", "-fPIC", "-o", SO, src])
+    return C.CDLL(SO)
+
+
+@pytest.mark.parametrize("dtype,suf", [(np.float64, "f64"), (np.float32, "f32")])
+def test_lane_flow_bit_identical_to_oracle(emu, dtype, suf):
+    rng = np.random.default_rng(11)
+    for i in range(1500):
+        a = (rng.standard_normal(64) * 10 ** rng.uniform(-3, 2)).astype(dtype)
+        if i == 0:
+            a[:] = 0
+        if i == 1:
+            a[:] = 1
+        b = np.empty_like(a)
+        getattr(emu, "emu_fwd_" + suf)(a.ctypes.data_as(C.c_void_p), b.ctypes.data_as(C.c_void_p))
+        assert np.array_equal(b.view(np.uint8), O.dct_fwd(a, O.FAST).view(np.uint8))
+        getattr(emu, "emu_inv_" + suf)(a.ctypes.data_as(C.c_void_p), b.ctypes.data_as(C.c_void_p))
+        assert np.array_equal(b.view(np.uint8), O.dct_inv(a, O.FAST).view(np.uint8))
+
+
+@pytest.mark.parametrize("dtype,suf", [(np.float64, "f64"), (np.float32, "f32")])
+def test_remainder_tables_identical_to_oracle(emu, dtype, suf):
+    """Host tables of the product (explicit sincos) == the oracle's, for every length."""
+    for l in range(1, 64):
+        tab = np.zeros(512, dtype)
+        getattr(emu, "emu_rem_tab_" + suf)(l, tab.ctypes.data_as(C.c_void_p))
+        as_, ax, ias, iax = O.dct_tables(l, dtype)
+        assert np.array_equal(tab[0:l], as_) and np.array_equal(tab[64:64 + l], ax)
+        assert np.array_equal(tab[192:192 + l], iax) and np.array_equal(tab[129:128 + l], ias[1:])
