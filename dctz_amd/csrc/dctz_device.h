@@ -53,6 +53,8 @@ struct Ctl {
   unsigned long long qraw[64];     // max |coef| per position, raw bits of T (dctz-comp-lib.c:371-372)
   unsigned long long q0;           // bits of the last block's DC (qtable[0], :355-360)
   unsigned long long pad1;
+  unsigned gticket[8 * 32];        // per-group tile tickets, one 128-byte line each
+  unsigned long long dbg[8];       // F_STAMP builds: summed phase cycles of thread 0 of every workgroup
 };
 static_assert(sizeof(Ctl) % 16 == 0, "memset block must be a multiple of 16 bytes");
 
@@ -73,6 +75,8 @@ struct FwdParams {
   unsigned nfull;                  // number of full 64-element blocks
   unsigned ntiles;
   unsigned last_is_full;           // N % 64 == 0
+  unsigned fast_sf, fast_bw;       // divisor inside FastDiv's exponent window (host check)
+  unsigned ngroups;                // ticket groups, min(8, grid)
   T sf, bin_width, range_min, range_max;
 };
 
@@ -88,17 +92,19 @@ struct InvParams {
   Ctl* ctl;
   unsigned long long* desc;
   unsigned nfull, ntiles, ac_count;
+  unsigned ngroups;                // ticket groups, min(8, grid)
   T sf, bin_width, range_min, range_max;
   double eb;
 };
 
 template <typename T> void launch_stats(const T* x, size_t n, double* part, int nparts, double* out, hipStream_t s);
+template <typename T> void launch_debug_divide(const T* x, size_t n, T d, int ok, T* fast, T* ref, hipStream_t s);
 template <typename T> void launch_serial_sum(const T* x, size_t n, double* out, hipStream_t s);
 template <typename T> void launch_scale(T* x, size_t n, T sf, int grid, hipStream_t s);
-template <typename T> void launch_compress(const FwdParams<T>& p, int mode, bool scale, int grid, hipStream_t s);
+template <typename T> void launch_compress(const FwdParams<T>& p, int mode, bool scale, int grid, int feat, hipStream_t s);
 template <typename T> void launch_compress_rem(const FwdParams<T>& p, int mode, bool scale, int l, hipStream_t s);
 template <typename T> void launch_qt_finish(const FwdParams<T>& p, double eb, int grid, hipStream_t s);
-template <typename T> void launch_decompress(const InvParams<T>& p, int mode, bool scale, int grid, hipStream_t s);
+template <typename T> void launch_decompress(const InvParams<T>& p, int mode, bool scale, int grid, int feat, hipStream_t s);
 template <typename T> void launch_decompress_rem(const InvParams<T>& p, int mode, bool scale, int l, hipStream_t s);
 template <typename T> void launch_dct_blocks(const T* x, T* out, const T* gtab, const T* rtab, size_t n,
                                              bool inverse, int grid, hipStream_t s);

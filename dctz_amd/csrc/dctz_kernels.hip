@@ -53,13 +53,87 @@ __device__ __forceinline__ unsigned conv_bin(unsigned t) { return t <= 127u ? 25
 
 // Pass-1 binning of one coefficient (dctz-comp-lib.c:363-414).  Returns the bin
 // id; *out_of_range tells whether the QT table must see it (:367-373).
-template <typename T>
-__device__ __forceinline__ unsigned bin_of(T item, T range_min, T range_max, T bin_width, bool* out_of_range) {
+template <typename T, typename DIV>
+__device__ __forceinline__ unsigned bin_of(T item, T range_min, T range_max, const DIV& bw, bool* out_of_range) {
   const bool out = (item < range_min) || (item > range_max);
-  const int ti = (int)((item - range_min) / bin_width);   // (t_bin_id) cast: trunc toward 0
+  // in range: 0 <= item - range_min <= 510 eb, far inside the fast window; the
+  // quotient of an out-of-range item is never used
+  const int ti = (int)bw.div_small(item - range_min);     // (t_bin_id) cast: trunc toward 0
   *out_of_range = out;
   return out ? 255u : conv_bin((unsigned)ti & 255u);
 }
+
+// ----------------------------------------------- division by a kernel constant --
+// x / d with d uniform over the launch (the scaling factor, the bin width).
+// hipcc expands an IEEE division into: v_div_scale x2, v_rcp, two (f64) / one (f32)
+// Newton steps on the reciprocal, q = x*y, r = fma(-d, q, x), fma(r, y, q) [f32:
+// one more residual step], v_div_fmas, v_div_fixup.  Everything up to the
+// reciprocal y depends on d alone, and the scale/fixup steps are the identity
+// while the exponents of x, d and x/d stay away from the overflow / denormal
+// ends.  So: y is computed once per thread with the very same instructions, x is
+// checked against a conservative exponent window, and inside it the remaining
+// 3 (f64) / 5 (f32) operations give bit-for-bit what `x / d` gives.  Outside the
+// window (and for zeros, whose sign v_div_fixup restores) the full division runs.
+// tests/test_gpu_parity.py::test_fast_division_is_exact checks the identity on
+// the GPU against the compiler's own division.
+template <typename T> struct FastDiv;
+template <> struct FastDiv<double> {
+  double d, y;
+  bool ok;                       // host: |d| in [2^-250, 2^250]
+  __device__ __forceinline__ void init(double dd, bool okk) {
+    d = dd; ok = okk;
+    double r = __builtin_amdgcn_rcp(dd);
+    double e = fma(-dd, r, 1.0); r = fma(r, e, r);
+    e = fma(-dd, r, 1.0); y = fma(r, e, r);
+  }
+  __device__ __forceinline__ double core(double x) const {
+    const double q = x * y;
+    const double r = fma(-d, q, x);
+    return fma(r, y, q);
+  }
+  __device__ __forceinline__ double div(double x) const {          // any x
+    const unsigned ex = ((unsigned)__double2hiint(x) >> 20) & 0x7ffu;
+    if (ok && (ex - 523u) <= 1000u) return core(x);                // |x| in [2^-500, 2^501)
+    if (ok && x == 0.0) return x * y;                              // signed zero
+    return x / d;
+  }
+  // x is zero or inside the window by construction (binning: 0 <= x <= 510 eb)
+  __device__ __forceinline__ double div_small(double x) const { return ok ? core(x) : x / d; }
+};
+template <> struct FastDiv<float> {
+  float d, y;
+  bool ok;                       // host: |d| in [2^-30, 2^30]
+  __device__ __forceinline__ void init(float dd, bool okk) {
+    d = dd; ok = okk;
+    const float r = __builtin_amdgcn_rcpf(dd);
+    const float e = fmaf(-dd, r, 1.0f);
+    y = fmaf(e, r, r);
+  }
+  __device__ __forceinline__ float core(float x) const {
+    const float q = x * y;
+    const float r = fmaf(-d, q, x);
+    const float q2 = fmaf(r, y, q);
+    const float r2 = fmaf(-d, q2, x);
+    return fmaf(r2, y, q2);
+  }
+  __device__ __forceinline__ float div(float x) const {
+    const unsigned ex = (__float_as_uint(x) >> 23) & 0xffu;
+    if (ok && (ex - 64u) <= 126u) return core(x);                  // |x| in [2^-63, 2^64)
+    if (ok && x == 0.0f) return x * y;
+    return x / d;
+  }
+  __device__ __forceinline__ float div_small(float x) const { return ok ? core(x) : x / d; }
+};
+
+// diagnostic phase timers (F_STAMP builds only)
+struct Stamps {
+  unsigned long long last, acc[8];
+  __device__ __forceinline__ void start() { for (int i = 0; i < 8; i++) acc[i] = 0; last = clock64(); }
+  __device__ __forceinline__ void mark(int i) { const unsigned long long n = clock64(); acc[i] += n - last; last = n; }
+  __device__ __forceinline__ void flush(Ctl* ctl) {
+    for (int i = 0; i < 8; i++) atomicAdd(&ctl->dbg[i], acc[i]);
+  }
+};
 
 // ------------------------------------------------- decoupled look-back scan --
 // One 64-bit word per tile: status in the top 2 bits, value in the low 32.
@@ -67,29 +141,50 @@ __device__ __forceinline__ unsigned bin_of(T item, T range_min, T range_max, T b
 constexpr unsigned long long ST_AGG = 1ull << 62, ST_PREFIX = 2ull << 62, ST_MASK = 3ull << 62;
 constexpr unsigned SPIN_LIMIT = 1u << 22;
 
+// Called by all 64 lanes of ONE wavefront.  Lane l inspects predecessor
+// tile-1-l (then the next 64 further back, ...): the walk to the nearest tile
+// whose inclusive prefix is known costs one memory round trip per 64 tiles
+// instead of one per tile.  Returns the exclusive prefix (wave-uniform).
 __device__ __forceinline__ unsigned lookback(unsigned long long* desc, unsigned tile, unsigned total,
                                              unsigned* err) {
+  const int lane = threadIdx.x & 63;
   if (tile == 0) {
-    __hip_atomic_store(&desc[0], ST_PREFIX | total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (lane == 0) __hip_atomic_store(&desc[0], ST_PREFIX | total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     return 0;
   }
-  __hip_atomic_store(&desc[tile], ST_AGG | total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  unsigned excl = 0;
-  for (int j = (int)tile - 1; j >= 0; --j) {
-    unsigned long long d = 0;
-    unsigned spins = 0;
-    for (;;) {
-      d = __hip_atomic_load(&desc[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      if (d & ST_MASK) break;
-      if (++spins >= SPIN_LIMIT) break;          // watchdog: never hang the GPU
+  if (lane == 0) __hip_atomic_store(&desc[tile], ST_AGG | total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  unsigned excl = 0, spins = 0;
+  int base = (int)tile;                            // window = tiles [base-64, base-1]
+  for (;;) {
+    const int idx = base - 1 - lane;
+    unsigned long long d = ST_PREFIX;              // before tile 0: prefix 0
+    if (idx >= 0) d = __hip_atomic_load(&desc[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned long long ready = __ballot((d & ST_MASK) != 0);
+    const unsigned long long pref = __ballot((d & ST_MASK) == ST_PREFIX);
+    unsigned long long need = ~0ull;               // lanes whose value we must add
+    if (pref) {
+      const int f = __ffsll((long long)pref) - 1;  // nearest tile with a known prefix
+      need = (f == 63) ? ~0ull : ((2ull << f) - 1ull);
+    }
+    if ((ready & need) == need) {
+      unsigned v = ((need >> lane) & 1ull) ? (unsigned)d : 0u;
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+      excl += v;
+      if (pref) break;
+      base -= 64;
+      spins = 0;
+    } else {
+      if (++spins >= SPIN_LIMIT) {                 // watchdog: never hang the GPU
+        if (lane == 0) atomicExch(err, 1u);
+        break;
+      }
       __builtin_amdgcn_s_sleep(1);
     }
-    if (!(d & ST_MASK)) { atomicExch(err, 1u); break; }
-    excl += (unsigned)d;
-    if ((d & ST_MASK) == ST_PREFIX) break;
   }
-  __hip_atomic_store(&desc[tile], ST_PREFIX | (unsigned long long)(excl + total), __ATOMIC_RELAXED,
-                     __HIP_MEMORY_SCOPE_AGENT);
+  if (lane == 0)
+    __hip_atomic_store(&desc[tile], ST_PREFIX | (unsigned long long)(excl + total), __ATOMIC_RELAXED,
+                       __HIP_MEMORY_SCOPE_AGENT);
   return excl;
 }
 
@@ -97,8 +192,10 @@ __device__ __forceinline__ unsigned lookback(unsigned long long* desc, unsigned 
 // over tiles by look-back.  Returns this thread's global offset; every thread
 // must call it (two barriers inside).  sc: 8 words of LDS scratch.
 __device__ __forceinline__ unsigned tile_scan(unsigned cnt, unsigned tile, unsigned ntiles, unsigned* sc,
-                                              unsigned long long* desc, Ctl* ctl) {
+                                              unsigned long long* desc, Ctl* ctl, bool publish = false,
+                                              unsigned publish_value = 0, Stamps* st = nullptr) {
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  if (publish && t == 0) sc[6] = publish_value;     // visible to the workgroup after the first barrier
   unsigned incl = cnt;
 #pragma unroll
   for (int d = 1; d < 64; d <<= 1) {
@@ -107,11 +204,15 @@ __device__ __forceinline__ unsigned tile_scan(unsigned cnt, unsigned tile, unsig
   }
   if (lane == 63) sc[wave] = incl;
   __syncthreads();
-  if (t == 0) {
+  if (wave == 0) {                                   // wave-uniform branch: all 64 lanes look back
+    if (st && t == 0) st->mark(4);                   // wave scan + first barrier
     const unsigned total = sc[0] + sc[1] + sc[2] + sc[3];
     const unsigned excl = lookback(desc, tile, total, &ctl->error);
-    sc[4] = excl;
-    if (tile == ntiles - 1) ctl->cnt_total = excl + total;
+    if (t == 0) {
+      sc[4] = excl;
+      if (tile == ntiles - 1) ctl->cnt_total = excl + total;
+      if (st) st->mark(5);                           // look-back (incl. drain of this wave's VMEM)
+    }
   }
   __syncthreads();
   unsigned off = sc[4] + (incl - cnt);
@@ -121,7 +222,73 @@ __device__ __forceinline__ unsigned tile_scan(unsigned cnt, unsigned tile, unsig
   return off;
 }
 
+// ------------------------------------------------------------ tile tickets --
+// Tiles are handed out in increasing order so that the look-back of tile j only
+// ever waits for tiles that some running workgroup already owns.  One global
+// counter saturates at ~90 tickets/us on MI355X (MI355X_MICROARCH.md, row
+// "dequeue"), i.e. ~0.37 ms for the 32 Ki tiles of a 1 GiB shard -- more than the
+// whole kernel should take.  F_GROUP therefore splits the counter into `ngroups`
+// (<= 8) counters on separate 128-byte lines: workgroup b serves group
+// b % ngroups, group g owns tiles g, g + ngroups, g + 2 ngroups, ...  Correct for
+// any placement: every group has at least one workgroup (ngroups <= grid), each
+// group hands its tiles out in increasing order, and a workgroup never waits
+// for a higher tile, so the lowest unfinished tile is always owned or claimable.
+enum : int { F_PIPE = 1, F_GROUP = 2, F_STAMP = 4 };   // F_STAMP: diagnostic build, phase timers into Ctl::dbg
+
+template <int FEAT>
+__device__ __forceinline__ unsigned take_ticket(Ctl* ctl, unsigned ngroups) {
+  if (FEAT & F_GROUP) {
+    const unsigned g = blockIdx.x % ngroups;
+    const unsigned k = __hip_atomic_fetch_add(&ctl->gticket[g * 32], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return k * ngroups + g;
+  }
+  return __hip_atomic_fetch_add(&ctl->ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 // --------------------------------------------------------- tile load / store --
+// Split form used by the software-pipelined kernels: issue the 16-byte loads of a
+// tile into registers (they stay in flight across the compute phase of the
+// previous tile), stage them into LDS later.
+template <typename T>
+__device__ __forceinline__ void issue_tile_loads(typename Traits<T>::Vec (&v)[TILE_ELEMS / Traits<T>::EPV / WG],
+                                                 const T* __restrict__ x, unsigned tile_id, unsigned ntiles,
+                                                 unsigned nfull) {
+  using Vec = typename Traits<T>::Vec;
+  constexpr int EPV = Traits<T>::EPV, NV = TILE_ELEMS / EPV / WG;
+  const int t = threadIdx.x;
+  if (tile_id >= ntiles) return;
+  const unsigned valid = min((unsigned)TILE_BLKS, nfull - tile_id * TILE_BLKS) * 64u;
+  const Vec* src = reinterpret_cast<const Vec*>(x + (size_t)tile_id * TILE_ELEMS);
+#pragma unroll
+  for (int i = 0; i < NV; i++) {
+    const unsigned e = (unsigned)(i * WG + t) * EPV;
+    if (e < valid) v[i] = src[i * WG + t];
+    else v[i] = Traits<T>::zero();
+  }
+}
+
+template <typename T, bool SCALE>
+__device__ __forceinline__ void stage_tile(T* tile, typename Traits<T>::Vec (&v)[TILE_ELEMS / Traits<T>::EPV / WG],
+                                           size_t ebase, unsigned valid, const FastDiv<T>& sfd, T* scaled) {
+  using Vec = typename Traits<T>::Vec;
+  constexpr int EPV = Traits<T>::EPV, NV = TILE_ELEMS / EPV / WG;
+  const int t = threadIdx.x;
+#pragma unroll
+  for (int i = 0; i < NV; i++) {
+    const unsigned e = (unsigned)(i * WG + t) * EPV;
+    Vec a = v[i];
+    if (SCALE) {
+      T el[EPV];
+      Traits<T>::unpack(a, el);
+#pragma unroll
+      for (int k = 0; k < EPV; k++) el[k] = sfd.div(el[k]);        // dctz-comp-lib.c:197-199 / :212-214
+      a = Traits<T>::pack(el);
+      if (scaled != nullptr && e < valid) reinterpret_cast<Vec*>(scaled + ebase)[i * WG + t] = a;
+    }
+    *reinterpret_cast<Vec*>(&tile[tile_idx<T>((int)e)]) = a;
+  }
+}
+
 // Global -> LDS, 16 B per lane, optional division by sf (dctz-comp-lib.c:193-216)
 // and optional write-back of the scaled data.
 template <typename T, bool SCALE>
@@ -379,12 +546,70 @@ __global__ __launch_bounds__(WG) void k_scale(T* __restrict__ x, size_t n, T sf)
 // Fused: scale (dctz-comp-lib.c:193-216) -> DCT-II per block (:337-340, dct.c:55-103)
 // -> DC (:350-351) -> pass-1 binning (:361-414) -> ordered exception stream
 // (:478-544) [-> QT per-position max (:371-372)], full 64-element blocks only.
-template <typename T, int MODE, bool SCALE>
+// emit phase of one tile: thread t owns elements [16t, 16t+16)
+template <typename T, int MODE, int FEAT>
+__device__ __forceinline__ void emit_tile(const FwdParams<T>& p, const T* tile, typename Traits<T>::Bits* qmax,
+                                          unsigned* sc, const FastDiv<T>& bwd, unsigned tile_id, unsigned blks_here,
+                                          bool publish, unsigned publish_value, Stamps* st) {
+  using Vec = typename Traits<T>::Vec;
+  constexpr int EPV = Traits<T>::EPV;
+  const int t = threadIdx.x;
+  const size_t ebase = (size_t)tile_id * TILE_ELEMS;
+  const int blk = t >> 2, j0 = (t & 3) * 16;
+  const bool active = (unsigned)blk < blks_here;
+  T c[16];
+#pragma unroll
+  for (int i = 0; i < 16 / EPV; i++) {
+    const Vec cv = *reinterpret_cast<const Vec*>(&tile[blk * Traits<T>::PITCH + j0 + i * EPV]);
+    Traits<T>::unpack(cv, &c[i * EPV]);
+  }
+  unsigned w[4] = {0, 0, 0, 0};
+  unsigned mask = 0;
+#pragma unroll
+  for (int i = 0; i < 16; i++) {
+    bool out;
+    unsigned b = bin_of<T>(c[i], p.range_min, p.range_max, bwd, &out);
+    const int j = j0 + i;
+    if (j == 0) { b = 255u; out = false; }       // :361 DC slot
+    else if (b == 255u) mask |= 1u << i;
+    if (MODE == DCTZHIP_QT && out && active) atomicMax(&qmax[j], to_bits(fabs(c[i])));
+    w[i >> 2] |= b << (8 * (i & 3));
+  }
+  if (!active) mask = 0;
+  if ((FEAT & F_STAMP) && st && t == 0) st->mark(3);   // binning + bin store issue
+  unsigned r = tile_scan((unsigned)__popc(mask), tile_id, p.ntiles, sc, p.desc, p.ctl, publish, publish_value,
+                         (FEAT & F_STAMP) ? st : nullptr);
+  // all global stores of the tile go out AFTER the look-back, so that the polling
+  // wave's vmcnt(0) waits never sit behind its own stores
+  if (active) {
+    reinterpret_cast<uint4*>(p.bin + ebase)[t] = make_uint4(w[0], w[1], w[2], w[3]);
+    if (p.coef != nullptr) {
+#pragma unroll
+      for (int i = 0; i < 16 / EPV; i++)
+        reinterpret_cast<Vec*>(p.coef + ebase + (size_t)t * 16)[i] = Traits<T>::pack(&c[i * EPV]);
+    }
+    if (j0 == 0) {
+      const unsigned gblk = tile_id * TILE_BLKS + blk;
+      p.dc[gblk] = (float)c[0];                  // :350-351 USE_TRUNCATE
+      if (p.last_is_full && gblk == p.nfull - 1) p.ctl->q0 = (unsigned long long)to_bits(c[0]);   // :355-360
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 16; i++) {
+    if (mask & (1u << i)) {
+      if (MODE == DCTZHIP_EC) p.ac[r] = (float)c[i];            // :535-537
+      else { p.qt_item[r] = c[i]; p.qt_j[r] = (uint8_t)(j0 + i); }
+      r++;
+    }
+  }
+}
+
+template <typename T, int MODE, bool SCALE, int FEAT>
 __global__ __launch_bounds__(WG) void k_compress(FwdParams<T> p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   using Vec = typename Traits<T>::Vec;
   using Bits = typename Traits<T>::Bits;
-  constexpr int EPV = Traits<T>::EPV;
+  constexpr int EPV = Traits<T>::EPV, NV = TILE_ELEMS / EPV / WG;
   T* tile = reinterpret_cast<T*>(smem);
   T* tab = tile + TILE_BLKS * Traits<T>::PITCH;
   Bits* qmax = reinterpret_cast<Bits*>(tab + TAB_SIZE);
@@ -392,65 +617,54 @@ __global__ __launch_bounds__(WG) void k_compress(FwdParams<T> p) {
   const int t = threadIdx.x;
   load_tab<T>(tab, p.tab);
   if (MODE == DCTZHIP_QT && t < 64) qmax[t] = 0;
+  FastDiv<T> sfd, bwd;
+  sfd.init(p.sf, p.fast_sf != 0);
+  bwd.init(p.bin_width, p.fast_bw != 0);
 
-  for (;;) {
-    __syncthreads();                               // tile + sc[] free for reuse
-    if (t == 0) sc[5] = __hip_atomic_fetch_add(&p.ctl->ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (FEAT & F_PIPE) {
+    // software pipeline, two tickets ahead: the loads of the next tile are in
+    // flight while this tile computes, and the ticket after that is on its way
+    if (t == 0) { sc[5] = take_ticket<FEAT>(p.ctl, p.ngroups); sc[6] = take_ticket<FEAT>(p.ctl, p.ngroups); }
     __syncthreads();
-    const unsigned tile_id = sc[5];
-    if (tile_id >= p.ntiles) break;
-    const size_t ebase = (size_t)tile_id * TILE_ELEMS;
-    const unsigned blks_here = min((unsigned)TILE_BLKS, p.nfull - tile_id * TILE_BLKS);
-    const unsigned valid = blks_here * 64u;
-
-    load_tile<T, SCALE>(tile, p.x, ebase, valid, p.sf, p.scaled);
-    __syncthreads();
-    tile_dct_fwd<T>(tile, tab);
-
-    // ---- emit: thread t owns elements [16t, 16t+16) of the tile -------------
-    const int blk = t >> 2, j0 = (t & 3) * 16;
-    const bool active = (unsigned)blk < blks_here;
-    T c[16];
-#pragma unroll
-    for (int i = 0; i < 16 / EPV; i++) {
-      const Vec v = *reinterpret_cast<const Vec*>(&tile[blk * Traits<T>::PITCH + j0 + i * EPV]);
-      Traits<T>::unpack(v, &c[i * EPV]);
+    unsigned tile_id = sc[5], next_id = sc[6];
+    Vec v[NV];
+    issue_tile_loads<T>(v, p.x, tile_id, p.ntiles, p.nfull);
+    while (tile_id < p.ntiles) {
+      unsigned tk = 0;
+      if (t == 0) tk = take_ticket<FEAT>(p.ctl, p.ngroups);
+      const size_t ebase = (size_t)tile_id * TILE_ELEMS;
+      const unsigned blks_here = min((unsigned)TILE_BLKS, p.nfull - tile_id * TILE_BLKS);
+      stage_tile<T, SCALE>(tile, v, ebase, blks_here * 64u, sfd, p.scaled);
+      __syncthreads();
+      issue_tile_loads<T>(v, p.x, next_id, p.ntiles, p.nfull);
+      tile_dct_fwd<T>(tile, tab);
+      emit_tile<T, MODE, FEAT>(p, tile, qmax, sc, bwd, tile_id, blks_here, true, tk, nullptr);
+      tile_id = next_id;
+      next_id = sc[6];
     }
-    unsigned w[4] = {0, 0, 0, 0};
-    unsigned mask = 0;
-#pragma unroll
-    for (int i = 0; i < 16; i++) {
-      bool out;
-      unsigned b = bin_of<T>(c[i], p.range_min, p.range_max, p.bin_width, &out);
-      const int j = j0 + i;
-      if (j == 0) { b = 255u; out = false; }       // :361 DC slot
-      else if (b == 255u) mask |= 1u << i;
-      if (MODE == DCTZHIP_QT && out && active) atomicMax(&qmax[j], to_bits(fabs(c[i])));
-      w[i >> 2] |= b << (8 * (i & 3));
+  } else {
+    Stamps st;
+    if (FEAT & F_STAMP) st.start();
+    for (;;) {
+      __syncthreads();                               // tile + sc[] free for reuse
+      if (t == 0) sc[5] = take_ticket<FEAT>(p.ctl, p.ngroups);
+      __syncthreads();
+      if ((FEAT & F_STAMP) && t == 0) st.mark(0);    // ticket (+ drain of own stores)
+      const unsigned tile_id = sc[5];
+      if (tile_id >= p.ntiles) break;
+      const size_t ebase = (size_t)tile_id * TILE_ELEMS;
+      const unsigned blks_here = min((unsigned)TILE_BLKS, p.nfull - tile_id * TILE_BLKS);
+      Vec v[NV];
+      issue_tile_loads<T>(v, p.x, tile_id, p.ntiles, p.nfull);
+      stage_tile<T, SCALE>(tile, v, ebase, blks_here * 64u, sfd, p.scaled);
+      __syncthreads();
+      if ((FEAT & F_STAMP) && t == 0) st.mark(1);    // load + stage
+      tile_dct_fwd<T>(tile, tab);
+      if ((FEAT & F_STAMP) && t == 0) st.mark(2);    // DCT
+      emit_tile<T, MODE, FEAT>(p, tile, qmax, sc, bwd, tile_id, blks_here, false, 0u, &st);
+      if ((FEAT & F_STAMP) && t == 0) st.mark(6);    // AC writes
     }
-    if (!active) mask = 0;
-    if (active) {
-      reinterpret_cast<uint4*>(p.bin + ebase)[t] = make_uint4(w[0], w[1], w[2], w[3]);
-      if (p.coef != nullptr) {
-#pragma unroll
-        for (int i = 0; i < 16 / EPV; i++)
-          reinterpret_cast<Vec*>(p.coef + ebase + (size_t)t * 16)[i] = Traits<T>::pack(&c[i * EPV]);
-      }
-      if (j0 == 0) {
-        const unsigned gblk = tile_id * TILE_BLKS + blk;
-        p.dc[gblk] = (float)c[0];                  // :350-351 USE_TRUNCATE
-        if (p.last_is_full && gblk == p.nfull - 1) p.ctl->q0 = (unsigned long long)to_bits(c[0]);   // :355-360
-      }
-    }
-    unsigned r = tile_scan((unsigned)__popc(mask), tile_id, p.ntiles, sc, p.desc, p.ctl);
-#pragma unroll
-    for (int i = 0; i < 16; i++) {
-      if (mask & (1u << i)) {
-        if (MODE == DCTZHIP_EC) p.ac[r] = (float)c[i];            // :535-537
-        else { p.qt_item[r] = c[i]; p.qt_j[r] = (uint8_t)(j0 + i); }
-        r++;
-      }
-    }
+    if ((FEAT & F_STAMP) && t == 0) st.flush(p.ctl);
   }
   if (MODE == DCTZHIP_QT) {
     __syncthreads();
@@ -468,9 +682,12 @@ __global__ __launch_bounds__(64) void k_compress_rem(FwdParams<T> p, int l) {
   const size_t base = (size_t)p.nfull * 64;
   const T* rt = p.rtab;
   const int N = (l & 1) ? 2 * l : l;
+  FastDiv<T> sfd, bwd;
+  sfd.init(p.sf, p.fast_sf != 0);
+  bwd.init(p.bin_width, p.fast_bw != 0);
   if (k < l) {
     T a = p.x[base + k];
-    if (SCALE) { a = a / p.sf; if (p.scaled != nullptr) p.scaled[base + k] = a; }
+    if (SCALE) { a = sfd.div(a); if (p.scaled != nullptr) p.scaled[base + k] = a; }
     if (l & 1) { v[k] = a; v[l + (l - 1 - k)] = a; }               // dct.c:61-64
     else if (k & 1) v[l - 1 - (k >> 1)] = a;                       // dct.c:75-83
     else v[k >> 1] = a;
@@ -487,7 +704,7 @@ __global__ __launch_bounds__(64) void k_compress_rem(FwdParams<T> p, int l) {
     coef = rt[RTAB_AS + k] * sr + rt[RTAB_AX + k] * si;            // dct.c:100-102 (Im V = -si)
   }
   bool out = false;
-  unsigned b = bin_of<T>(coef, p.range_min, p.range_max, p.bin_width, &out);
+  unsigned b = bin_of<T>(coef, p.range_min, p.range_max, bwd, &out);
   bool exc = false;
   if (k == 0) { b = 255u; out = false; } else exc = (b == 255u);
   if (k >= l) { exc = false; out = false; }
@@ -532,7 +749,12 @@ __global__ __launch_bounds__(WG) void k_qt_finish(FwdParams<T> p, double eb) {
 // =============================================================== decompress ==
 // Fused: de-quantise (dctz-decomp-lib.c:389-417 / :438-463; gen_bins
 // binning.c:12-50) -> DCT-III per block (:428, dct.c:115-205) -> de-scale (:494-511).
-template <typename T, int MODE, bool SCALE>
+// Loop order per tile k: ticket(k) -> load bins(k) -> count + scan + look-back(k)
+// -> store tile k-1 (its IDCT output is still in LDS) -> gather coefficients(k)
+// -> IDCT(k).  The 32 KiB of stores of tile k-1 are issued AFTER the look-back of
+// tile k, so the polling wave never waits behind them, and they drain under the
+// gather + IDCT of tile k.
+template <typename T, int MODE, bool SCALE, int FEAT>
 __global__ __launch_bounds__(WG) void k_decompress(InvParams<T> p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   using Vec = typename Traits<T>::Vec;
@@ -542,23 +764,29 @@ __global__ __launch_bounds__(WG) void k_decompress(InvParams<T> p) {
   T* qt = tab + TAB_SIZE;
   unsigned* sc = reinterpret_cast<unsigned*>(qt + 64);
   const int t = threadIdx.x;
+  const int blk = t >> 2, j0 = (t & 3) * 16;
   load_tab<T>(tab, p.tab);
   if (MODE == DCTZHIP_QT && t < 64) qt[t] = p.qtab[t];
 
+  bool pending = false;                  // tile `prev_id` sits in LDS, not yet stored
+  unsigned prev_id = 0;
+  Stamps st;
+  if (FEAT & F_STAMP) st.start();
   for (;;) {
-    __syncthreads();
-    if (t == 0) sc[5] = __hip_atomic_fetch_add(&p.ctl->ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __syncthreads();
+    if (t == 0) sc[5] = take_ticket<FEAT>(p.ctl, p.ngroups);
+    __syncthreads();                     // also: every lane is done with sc[] of the previous tile
+    if ((FEAT & F_STAMP) && t == 0) st.mark(0);
     const unsigned tile_id = sc[5];
     if (tile_id >= p.ntiles) break;
     const size_t ebase = (size_t)tile_id * TILE_ELEMS;
     const unsigned blks_here = min((unsigned)TILE_BLKS, p.nfull - tile_id * TILE_BLKS);
-    const unsigned valid = blks_here * 64u;
-
-    const int blk = t >> 2, j0 = (t & 3) * 16;
     const bool active = (unsigned)blk < blks_here;
     uint4 wv = make_uint4(0, 0, 0, 0);
-    if (active) wv = reinterpret_cast<const uint4*>(p.bin + ebase)[t];
+    float dcv = 0.f;
+    if (active) {
+      wv = reinterpret_cast<const uint4*>(p.bin + ebase)[t];
+      if (j0 == 0) dcv = p.dc[tile_id * TILE_BLKS + blk];
+    }
     const unsigned w[4] = {wv.x, wv.y, wv.z, wv.w};
     unsigned mask = 0;
 #pragma unroll
@@ -567,7 +795,17 @@ __global__ __launch_bounds__(WG) void k_decompress(InvParams<T> p) {
       if (b == 255u && (j0 + i) != 0) mask |= 1u << i;             // :400 / :446
     }
     if (!active) mask = 0;
-    unsigned r = tile_scan((unsigned)__popc(mask), tile_id, p.ntiles, sc, p.desc, p.ctl);
+    if ((FEAT & F_STAMP) && t == 0) st.mark(1);                    // bins load
+    unsigned r = tile_scan((unsigned)__popc(mask), tile_id, p.ntiles, sc, p.desc, p.ctl, false, 0u,
+                           (FEAT & F_STAMP) ? &st : nullptr);
+    if ((FEAT & F_STAMP) && t == 0) st.mark(2);
+
+    if (pending) {                       // now flush the previous tile (uniform branch)
+      const unsigned pv = min((unsigned)TILE_BLKS, p.nfull - prev_id * TILE_BLKS) * 64u;
+      store_tile<T, SCALE>(tile, p.out, (size_t)prev_id * TILE_ELEMS, pv, p.sf);
+      __syncthreads();                   // LDS tile free for the next coefficients
+    }
+    if ((FEAT & F_STAMP) && t == 0) st.mark(3);                    // store of the previous tile
 
     T c[16];
 #pragma unroll
@@ -576,7 +814,7 @@ __global__ __launch_bounds__(WG) void k_decompress(InvParams<T> p) {
       const int j = j0 + i;
       T val;
       if (j == 0) {
-        val = active ? (T)p.dc[tile_id * TILE_BLKS + blk] : T(0);  // :392 / :438
+        val = (T)dcv;                                              // :392 / :438
       } else if (mask & (1u << i)) {
         T v = T(0);
         if (r < p.ac_count) v = (T)p.ac[r]; else atomicExch(&p.ctl->error, 2u);
@@ -593,9 +831,17 @@ __global__ __launch_bounds__(WG) void k_decompress(InvParams<T> p) {
     for (int i = 0; i < 16 / EPV; i++)
       *reinterpret_cast<Vec*>(&tile[blk * Traits<T>::PITCH + j0 + i * EPV]) = Traits<T>::pack(&c[i * EPV]);
     __syncthreads();
+    if ((FEAT & F_STAMP) && t == 0) st.mark(6);                    // gather + de-quantise
     tile_dct_inv<T>(tile, tab);
-    store_tile<T, SCALE>(tile, p.out, ebase, valid, p.sf);
+    if ((FEAT & F_STAMP) && t == 0) st.mark(7);                    // IDCT
+    pending = true;
+    prev_id = tile_id;
   }
+  if (pending) {
+    const unsigned pv = min((unsigned)TILE_BLKS, p.nfull - prev_id * TILE_BLKS) * 64u;
+    store_tile<T, SCALE>(tile, p.out, (size_t)prev_id * TILE_ELEMS, pv, p.sf);
+  }
+  if ((FEAT & F_STAMP) && t == 0) st.flush(p.ctl);
 }
 
 // Last, short block on decode (dctz-decomp-lib.c:423-428, dct.c:144-199).
@@ -649,6 +895,18 @@ __global__ __launch_bounds__(64) void k_decompress_rem(InvParams<T> p, int l) {
     T val = (l & 1) ? (acc / (T)l) / T(2) : acc / (T)l;            // dct.c:163 / :185
     if (SCALE) val = val * p.sf;
     p.out[base + k] = val;
+  }
+}
+
+// Diagnostics: FastDiv against the compiler's own division, element by element.
+template <typename T>
+__global__ __launch_bounds__(WG) void k_debug_divide(const T* __restrict__ x, size_t n, T d, int ok,
+                                                     T* __restrict__ fast, T* __restrict__ ref) {
+  FastDiv<T> fd;
+  fd.init(d, ok != 0);
+  for (size_t i = (size_t)blockIdx.x * WG + threadIdx.x; i < n; i += (size_t)gridDim.x * WG) {
+    fast[i] = fd.div(x[i]);
+    ref[i] = x[i] / d;
   }
 }
 
@@ -740,6 +998,11 @@ void launch_stats(const T* x, size_t n, double* part, int nparts, double* out, h
 }
 
 template <typename T>
+void launch_debug_divide(const T* x, size_t n, T d, int ok, T* fast, T* ref, hipStream_t s) {
+  hipLaunchKernelGGL(k_debug_divide<T>, dim3(1024), dim3(WG), 0, s, x, n, d, ok, fast, ref);
+}
+
+template <typename T>
 void launch_serial_sum(const T* x, size_t n, double* out, hipStream_t s) {
   hipLaunchKernelGGL(k_serial_sum<T>, dim3(1), dim3(64), 0, s, x, n, out);
 }
@@ -749,15 +1012,25 @@ void launch_scale(T* x, size_t n, T sf, int grid, hipStream_t s) {
   hipLaunchKernelGGL(k_scale<T>, dim3(grid), dim3(WG), 0, s, x, n, sf);
 }
 
-template <typename T>
-void launch_compress(const FwdParams<T>& p, int mode, bool scale, int grid, hipStream_t s) {
+template <typename T, int FEAT>
+static void launch_compress_f(const FwdParams<T>& p, int mode, bool scale, int grid, hipStream_t s) {
   const size_t sm = fwd_smem<T>();
   if (mode == DCTZHIP_EC) {
-    if (scale) hipLaunchKernelGGL((k_compress<T, DCTZHIP_EC, true>), dim3(grid), dim3(WG), sm, s, p);
-    else hipLaunchKernelGGL((k_compress<T, DCTZHIP_EC, false>), dim3(grid), dim3(WG), sm, s, p);
+    if (scale) hipLaunchKernelGGL((k_compress<T, DCTZHIP_EC, true, FEAT>), dim3(grid), dim3(WG), sm, s, p);
+    else hipLaunchKernelGGL((k_compress<T, DCTZHIP_EC, false, FEAT>), dim3(grid), dim3(WG), sm, s, p);
   } else {
-    if (scale) hipLaunchKernelGGL((k_compress<T, DCTZHIP_QT, true>), dim3(grid), dim3(WG), sm, s, p);
-    else hipLaunchKernelGGL((k_compress<T, DCTZHIP_QT, false>), dim3(grid), dim3(WG), sm, s, p);
+    if (scale) hipLaunchKernelGGL((k_compress<T, DCTZHIP_QT, true, FEAT>), dim3(grid), dim3(WG), sm, s, p);
+    else hipLaunchKernelGGL((k_compress<T, DCTZHIP_QT, false, FEAT>), dim3(grid), dim3(WG), sm, s, p);
+  }
+}
+template <typename T>
+void launch_compress(const FwdParams<T>& p, int mode, bool scale, int grid, int feat, hipStream_t s) {
+  if (feat & 4) { launch_compress_f<T, 4>(p, mode, scale, grid, s); return; }
+  switch (feat & 3) {
+    case 0: launch_compress_f<T, 0>(p, mode, scale, grid, s); break;
+    case 1: launch_compress_f<T, 1>(p, mode, scale, grid, s); break;
+    case 2: launch_compress_f<T, 2>(p, mode, scale, grid, s); break;
+    default: launch_compress_f<T, 3>(p, mode, scale, grid, s); break;
   }
 }
 
@@ -777,15 +1050,25 @@ void launch_qt_finish(const FwdParams<T>& p, double eb, int grid, hipStream_t s)
   hipLaunchKernelGGL(k_qt_finish<T>, dim3(grid), dim3(WG), 0, s, p, eb);
 }
 
-template <typename T>
-void launch_decompress(const InvParams<T>& p, int mode, bool scale, int grid, hipStream_t s) {
+template <typename T, int FEAT>
+static void launch_decompress_f(const InvParams<T>& p, int mode, bool scale, int grid, hipStream_t s) {
   const size_t sm = inv_smem<T>();
   if (mode == DCTZHIP_EC) {
-    if (scale) hipLaunchKernelGGL((k_decompress<T, DCTZHIP_EC, true>), dim3(grid), dim3(WG), sm, s, p);
-    else hipLaunchKernelGGL((k_decompress<T, DCTZHIP_EC, false>), dim3(grid), dim3(WG), sm, s, p);
+    if (scale) hipLaunchKernelGGL((k_decompress<T, DCTZHIP_EC, true, FEAT>), dim3(grid), dim3(WG), sm, s, p);
+    else hipLaunchKernelGGL((k_decompress<T, DCTZHIP_EC, false, FEAT>), dim3(grid), dim3(WG), sm, s, p);
   } else {
-    if (scale) hipLaunchKernelGGL((k_decompress<T, DCTZHIP_QT, true>), dim3(grid), dim3(WG), sm, s, p);
-    else hipLaunchKernelGGL((k_decompress<T, DCTZHIP_QT, false>), dim3(grid), dim3(WG), sm, s, p);
+    if (scale) hipLaunchKernelGGL((k_decompress<T, DCTZHIP_QT, true, FEAT>), dim3(grid), dim3(WG), sm, s, p);
+    else hipLaunchKernelGGL((k_decompress<T, DCTZHIP_QT, false, FEAT>), dim3(grid), dim3(WG), sm, s, p);
+  }
+}
+template <typename T>
+void launch_decompress(const InvParams<T>& p, int mode, bool scale, int grid, int feat, hipStream_t s) {
+  if (feat & 4) { launch_decompress_f<T, 4>(p, mode, scale, grid, s); return; }
+  switch (feat & 3) {
+    case 0: launch_decompress_f<T, 0>(p, mode, scale, grid, s); break;
+    case 1: launch_decompress_f<T, 1>(p, mode, scale, grid, s); break;
+    case 2: launch_decompress_f<T, 2>(p, mode, scale, grid, s); break;
+    default: launch_decompress_f<T, 3>(p, mode, scale, grid, s); break;
   }
 }
 
@@ -821,12 +1104,13 @@ void launch_dct_blocks(const T* x, T* out, const T* gtab, const T* rtab, size_t 
 // explicit instantiations used by dctz_shim.hip
 #define INST(T)                                                                                         \
   template void launch_stats<T>(const T*, size_t, double*, int, double*, hipStream_t);                  \
+  template void launch_debug_divide<T>(const T*, size_t, T, int, T*, T*, hipStream_t);                  \
   template void launch_serial_sum<T>(const T*, size_t, double*, hipStream_t);                           \
   template void launch_scale<T>(T*, size_t, T, int, hipStream_t);                                       \
-  template void launch_compress<T>(const FwdParams<T>&, int, bool, int, hipStream_t);                   \
+  template void launch_compress<T>(const FwdParams<T>&, int, bool, int, int, hipStream_t);              \
   template void launch_compress_rem<T>(const FwdParams<T>&, int, bool, int, hipStream_t);               \
   template void launch_qt_finish<T>(const FwdParams<T>&, double, int, hipStream_t);                     \
-  template void launch_decompress<T>(const InvParams<T>&, int, bool, int, hipStream_t);                 \
+  template void launch_decompress<T>(const InvParams<T>&, int, bool, int, int, hipStream_t);            \
   template void launch_decompress_rem<T>(const InvParams<T>&, int, bool, int, hipStream_t);             \
   template void launch_dct_blocks<T>(const T*, T*, const T*, const T*, size_t, bool, int, hipStream_t);
 INST(double)

@@ -48,6 +48,9 @@ struct dctzhip_ctx {
   // pinned host staging
   unsigned char* h_pin = nullptr;   // [0,64): stats, [64, 64+sizeof(Ctl)): ctl, then tables
   // profiling
+  int feat = 3;                     // kernel features: 1 pipeline, 2 grouped tickets (DCTZHIP_FEAT)
+  int fastdiv = 1;                  // hoisted-reciprocal division (DCTZHIP_FASTDIV)
+  int wg_per_cu = 4;                // persistent grid = CUs * this (DCTZHIP_WG_PER_CU)
   int profiling = 0;
   hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
   dctzhip_timings last = {0, 0, 0, 0};
@@ -93,6 +96,9 @@ extern "C" int dctzhip_ctx_create(dctzhip_ctx** out, int device) {
   hipDeviceProp_t prop;
   HIPCHK(nullptr, hipGetDeviceProperties(&prop, device));
   c->num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+  if (const char* e = getenv("DCTZHIP_FEAT")) c->feat = atoi(e) & 7;
+  if (const char* e = getenv("DCTZHIP_FASTDIV")) c->fastdiv = atoi(e) != 0;
+  if (const char* e = getenv("DCTZHIP_WG_PER_CU")) { int v = atoi(e); if (v >= 1 && v <= 8) c->wg_per_cu = v; }
   HIPCHK(nullptr, hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
   c->stream = c->own_stream;
   HIPCHK(nullptr, hipStreamCreateWithFlags(&c->side_stream, hipStreamNonBlocking));
@@ -176,6 +182,14 @@ extern "C" int dctzhip_sync(dctzhip_ctx* c) {
   if (!c) return DCTZHIP_E_ARG;
   HIPCHK(c, hipStreamSynchronize(c->stream));
   return DCTZHIP_OK;
+}
+
+// FastDiv's divisor window (dctz_kernels.hip): |d| in [2^-250, 2^250] (f64) / [2^-30, 2^30] (f32)
+static unsigned divisor_in_window(int dtype, double d) {
+  if (!(d == d) || d == 0.0) return 0;
+  int e = 0;
+  (void)frexp(fabs(d), &e);                      // |d| = m * 2^e, m in [0.5, 1)
+  return (dtype == DCTZHIP_F64) ? (e - 1 >= -250 && e - 1 < 250) : (e - 1 >= -30 && e - 1 < 30);
 }
 
 static size_t elem_size(int dtype) { return dtype == DCTZHIP_F64 ? 8 : 4; }
@@ -296,11 +310,13 @@ static int compress_impl(dctzhip_ctx* c, const T* d_in, size_t n, double eb, int
   p.qt_item = reinterpret_cast<T*>(c->qt_item); p.qt_j = c->qt_j;
   p.tab = tab_of<T>(c); p.rtab = reinterpret_cast<const T*>(c->rtab);
   p.ctl = c->ctl; p.desc = c->desc;
-  p.nfull = nfull; p.ntiles = ntiles; p.last_is_full = rem ? 0u : 1u;
+  p.nfull = nfull; p.ntiles = ntiles; p.last_is_full = rem ? 0u : 1u; p.ngroups = 1;
   p.sf = (T)sf;
   p.bin_width = (T)(eb * 2.0 * 1.0);
   p.range_min = (T)(-(half * 2 + 1) * (eb * 1.0));
   p.range_max = (T)((half * 2 + 1) * (eb * 1.0));
+  p.fast_sf = c->fastdiv ? divisor_in_window(dtype, (double)p.sf) : 0u;
+  p.fast_bw = c->fastdiv ? divisor_in_window(dtype, (double)p.bin_width) : 0u;
   const bool scale = (p.sf != (T)1.0);              // :193 / :208
   if (!scale && d_scaled && d_scaled != d_in)       // sf == 1: "scaled" data is the input itself
     HIPCHK(c, hipMemcpyAsync(d_scaled, d_in, n * sizeof(T), hipMemcpyDeviceToDevice, s));
@@ -309,8 +325,10 @@ static int compress_impl(dctzhip_ctx* c, const T* d_in, size_t n, double eb, int
 
   if (c->profiling) HIPCHK(c, hipEventRecord(c->ev[2], s));
   if (ntiles) {
-    const int grid = (int)((unsigned)(c->num_cu * 4) < ntiles ? (unsigned)(c->num_cu * 4) : ntiles);
-    launch_compress<T>(p, mode, scale, grid, s);
+    const unsigned cap = (unsigned)(c->num_cu * c->wg_per_cu);
+    const int grid = (int)(cap < ntiles ? cap : ntiles);
+    p.ngroups = grid < 8 ? (unsigned)grid : 8u;
+    launch_compress<T>(p, mode, scale, grid, c->feat, s);
   }
   if (c->profiling) HIPCHK(c, hipEventRecord(c->ev[3], s));
   if (rem) launch_compress_rem<T>(p, mode, scale, rem, s);
@@ -323,6 +341,10 @@ static int compress_impl(dctzhip_ctx* c, const T* d_in, size_t n, double eb, int
   HIPCHK(c, hipStreamSynchronize(s));
   if (hc->error) return fail(c, DCTZHIP_E_INTERNAL, "in-kernel watchdog tripped (code %u)", hc->error);
   if (c->profiling) { int rc = read_timings(c, 2); if (rc) return rc; }
+  if (c->feat & 4) {
+    fprintf(stderr, "[dctzhip stamps] compress cycles: ticket %llu load %llu dct %llu bin %llu scan %llu lookback %llu acwrite %llu\n",
+            hc->dbg[0], hc->dbg[1], hc->dbg[2], hc->dbg[3], hc->dbg[4], hc->dbg[5], hc->dbg[6]);
+  }
 
   if (info) {
     memset(info, 0, sizeof(*info));
@@ -404,6 +426,23 @@ extern "C" int dctzhip_serial_mean_end(dctzhip_ctx* c, double* mean) {
   return DCTZHIP_OK;
 }
 
+extern "C" int dctzhip_debug_divide(dctzhip_ctx* c, const void* d_x, size_t n, int dtype, double divisor,
+                                    void* d_fast, void* d_ref) {
+  int rc = check_common(c, n, dtype, DCTZHIP_EC);
+  if (rc) return rc;
+  if (!d_x || !d_fast || !d_ref) return fail(c, DCTZHIP_E_ARG, "null device buffer");
+  HIPCHK(c, hipSetDevice(c->device));
+  if (dtype == DCTZHIP_F64)
+    launch_debug_divide<double>((const double*)d_x, n, divisor, (int)divisor_in_window(dtype, divisor), (double*)d_fast,
+                                (double*)d_ref, c->stream);
+  else
+    launch_debug_divide<float>((const float*)d_x, n, (float)divisor, (int)divisor_in_window(dtype, (double)(float)divisor),
+                               (float*)d_fast, (float*)d_ref, c->stream);
+  HIPCHK(c, hipGetLastError());
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return DCTZHIP_OK;
+}
+
 extern "C" int dctzhip_scale_inplace(dctzhip_ctx* c, void* d_x, size_t n, int dtype, double sf) {
   int rc = check_common(c, n, dtype, DCTZHIP_EC);
   if (rc) return rc;
@@ -458,7 +497,7 @@ static int decompress_impl(dctzhip_ctx* c, const uint8_t* d_bin, const float* d_
   p.bin = d_bin; p.dc = d_dc; p.ac = d_ac; p.out = d_out;
   p.tab = tab_of<T>(c); p.rtab = reinterpret_cast<const T*>(c->rtab); p.qtab = reinterpret_cast<const T*>(c->qtab);
   p.ctl = c->ctl; p.desc = c->desc;
-  p.nfull = nfull; p.ntiles = ntiles; p.ac_count = ac_count;
+  p.nfull = nfull; p.ntiles = ntiles; p.ac_count = ac_count; p.ngroups = 1;
   p.sf = (T)sf;
   // gen_bins / gen_bins_f (binning.c:17 / :37): bin_width = error_bound*2*BRSF in
   // the data type (gen_bins_f receives error_bound already rounded to float)
@@ -470,16 +509,21 @@ static int decompress_impl(dctzhip_ctx* c, const uint8_t* d_bin, const float* d_
 
   if (c->profiling) { HIPCHK(c, hipEventRecord(c->ev[0], s)); HIPCHK(c, hipEventRecord(c->ev[1], s)); HIPCHK(c, hipEventRecord(c->ev[2], s)); }
   if (ntiles) {
-    const int grid = (int)((unsigned)(c->num_cu * 4) < ntiles ? (unsigned)(c->num_cu * 4) : ntiles);
-    launch_decompress<T>(p, mode, scale, grid, s);
+    const unsigned cap = (unsigned)(c->num_cu * c->wg_per_cu);
+    const int grid = (int)(cap < ntiles ? cap : ntiles);
+    p.ngroups = grid < 8 ? (unsigned)grid : 8u;
+    launch_decompress<T>(p, mode, scale, grid, c->feat, s);
   }
   if (c->profiling) HIPCHK(c, hipEventRecord(c->ev[3], s));
   if (rem) launch_decompress_rem<T>(p, mode, scale, rem, s);
   if (c->profiling) HIPCHK(c, hipEventRecord(c->ev[4], s));
   HIPCHK(c, hipGetLastError());
   Ctl* hc = reinterpret_cast<Ctl*>(c->h_pin + PIN_CTL);
-  HIPCHK(c, hipMemcpyAsync(hc, c->ctl, 16, hipMemcpyDeviceToHost, s));
+  HIPCHK(c, hipMemcpyAsync(hc, c->ctl, (c->feat & 4) ? sizeof(Ctl) : 16, hipMemcpyDeviceToHost, s));
   HIPCHK(c, hipStreamSynchronize(s));
+  if (c->feat & 4)
+    fprintf(stderr, "[dctzhip stamps] decompress cycles: ticket %llu binload %llu scan+lookback %llu (scan %llu lookback %llu) store %llu gather %llu idct %llu\n",
+            hc->dbg[0], hc->dbg[1], hc->dbg[2] + hc->dbg[4] + hc->dbg[5], hc->dbg[4], hc->dbg[5], hc->dbg[3], hc->dbg[6], hc->dbg[7]);
   if (hc->error == 2) return fail(c, DCTZHIP_E_ARG, "bin_index flags more exact coefficients than ac_count provides");
   if (hc->error) return fail(c, DCTZHIP_E_INTERNAL, "in-kernel watchdog tripped (code %u)", hc->error);
   if (c->profiling) { int rc = read_timings(c, 2); if (rc) return rc; }

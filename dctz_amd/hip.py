@@ -55,6 +55,12 @@ _PROTOS = {
                                      C.c_void_p, C.c_size_t, C.c_int, C.c_double, C.c_double, C.c_int,
                                      C.c_void_p]),
     "dctzhip_dct_blocks": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_int]),
+    "dctzhip_stats": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.POINTER(CompressInfo)]),
+    "dctzhip_serial_mean_begin": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]),
+    "dctzhip_serial_mean_end": (C.c_int, [C.c_void_p, C.POINTER(C.c_double)]),
+    "dctzhip_scale_inplace": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_double]),
+    "dctzhip_debug_divide": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_double, C.c_void_p,
+                                       C.c_void_p]),
     "dctzhip_version": (C.c_char_p, []),
 }
 
@@ -170,6 +176,14 @@ class Context:
             float(eb), float(sf), mode, dst.data_ptr())
         self._check(rc, "dctzhip_decompress")
         return dst
+
+    def debug_divide(self, x, divisor):
+        self._bind_stream()
+        fast, ref = self.torch.empty_like(x), self.torch.empty_like(x)
+        rc = self.lib.dctzhip_debug_divide(self.h, x.data_ptr(), x.numel(), _dt(x.dtype), float(divisor),
+                                           fast.data_ptr(), ref.data_ptr())
+        self._check(rc, "dctzhip_debug_divide")
+        return fast, ref
 
     def dct_blocks(self, x, inverse=False):
         self._bind_stream()

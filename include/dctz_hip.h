@@ -145,6 +145,12 @@ int dctzhip_decompress(dctzhip_ctx *ctx, const void *d_bin_index, const float *d
 int dctzhip_dct_blocks(dctzhip_ctx *ctx, const void *d_in, void *d_out, size_t n,
                        int dtype, int inverse);
 
+/* Diagnostics: element-wise x / divisor computed (a) by the kernels' hoisted-
+ * reciprocal division and (b) by the compiler's IEEE division; the two outputs
+ * must be bit-identical (tests/test_gpu_parity.py::test_fast_division_is_exact). */
+int dctzhip_debug_divide(dctzhip_ctx *ctx, const void *d_x, size_t n, int dtype,
+                         double divisor, void *d_fast, void *d_ref);
+
 /* Library/ABI version, "major.minor.patch". */
 const char *dctzhip_version(void);
 

@@ -152,3 +152,39 @@ def test_error_paths(ctx):
     outs = {"bin_index": _dev(ctx, c.bin_index), "dc": _dev(ctx, c.dc), "ac_exact": _dev(ctx, c.ac_exact)}
     with pytest.raises(dctz_amd.DctzHipError):
         ctx.decompress(outs, max(c.cnt - 1, 0), 1000, torch.float64, 1e-3, c.sf)
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_fast_division_is_exact(ctx, dtype):
+    """The kernels' hoisted-reciprocal division == the compiler's IEEE division ==
+    numpy's, bit for bit: random magnitudes over the whole exponent range, values
+    straddling the fast-path window, zeros of both signs, denormals, inf, nan, and
+    quotients sitting next to rounding midpoints."""
+    import torch
+    rng = np.random.default_rng(99)
+    info = np.finfo(dtype)
+    divisors = [0.1, 10.0, 100.0, 1e-3, 2e-3, 2e-4, 2e-5, 2e-6, 1e5, 3.0, 0.002 * (1 + 2 ** -20), 1e30 if dtype == np.float64 else 1e9,
+                1e-30 if dtype == np.float64 else 1e-9, 1e300 if dtype == np.float64 else 1e30]
+    m = 1 << 20
+    mant = rng.uniform(1, 2, m)
+    expo = rng.integers(info.minexp - 10, info.maxexp, m)
+    wide = np.ldexp(mant, expo).astype(dtype) * rng.choice([-1.0, 1.0], m).astype(dtype)
+    narrow = (rng.standard_normal(m) * 10 ** rng.uniform(-3, 3, m)).astype(dtype)
+    special = np.array([0.0, -0.0, np.inf, -np.inf, np.nan, info.tiny, -info.tiny, info.max, -info.max,
+                        info.smallest_subnormal, 1.0, -1.0], dtype=dtype)
+    for d in divisors:
+        dd = dtype(d)
+        # x = RN(d * (k + 1/2 ulp-ish)): quotients next to the midpoints between floats
+        k = rng.uniform(1, 2, 1 << 16).astype(dtype)
+        mid = (k + np.spacing(k) / 2).astype(np.float64) * np.float64(dd)
+        near = np.concatenate([np.nextafter(mid.astype(dtype), dtype(np.inf)), mid.astype(dtype),
+                               np.nextafter(mid.astype(dtype), dtype(-np.inf))])
+        x = np.concatenate([wide, narrow, special, near])
+        fast, ref = ctx.debug_divide(_dev(ctx, x), float(dd))
+        fast, ref = fast.cpu().numpy(), ref.cpu().numpy()
+        with np.errstate(all="ignore"):
+            host = (x / dd).astype(dtype)
+        nan = np.isnan(host)
+        assert np.array_equal(np.isnan(fast), nan) and np.array_equal(np.isnan(ref), nan)
+        assert np.array_equal(fast[~nan].view(np.uint8), ref[~nan].view(np.uint8)), f"fast != device '/' for d={d}"
+        assert np.array_equal(ref[~nan].view(np.uint8), host[~nan].view(np.uint8)), f"device '/' != IEEE for d={d}"
