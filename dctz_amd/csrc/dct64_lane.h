@@ -83,9 +83,15 @@ DCTZ_HD void fft8(T (&xr)[8], T (&xi)[8], T r) {
 }
 
 // One cross-lane radix-2 step on one value.  The lower lane of the pair keeps
-// mine + theirs, the upper lane theirs - mine.
+// mine + theirs, the upper lane theirs - mine: theirs + s*mine with s = +1 / -1.
+// The product by +-1 is exact, so the fused form rounds once, exactly like the
+// plain add / subtract (one instruction instead of select + add).
+DCTZ_HD double fma_(double a, double b, double c) { return __builtin_fma(a, b, c); }
+DCTZ_HD float fma_(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
 template <typename T>
-DCTZ_HD T bfly(T mine, T theirs, bool upper) { return theirs + (upper ? -mine : mine); }
+DCTZ_HD T bfly(T mine, T theirs, bool upper) { return fma_(upper ? T(-1) : T(1), mine, theirs); }
+template <typename T>
+DCTZ_HD T bfly_s(T mine, T theirs, T s) { return fma_(s, mine, theirs); }
 
 // ---------------------------------------------------------------- forward ---
 // F1: in-lane radix-8 + 32-point twiddle.  On entry y = packed points
@@ -125,27 +131,28 @@ DCTZ_HD void fwd_cross_b(T (&yr)[8], T (&yi)[8], const T (&pr)[8], const T (&pi)
 // z = own Z[8q+k1]; p[k1] = Z[32 - (8q+k1)] (from the mirror lane for k1 >= 1,
 // from quad_perm [0,1,3,2] for k1 = 0).  Outputs: lo[k1] = b[8q+k1],
 // hi[k1] = b[64-(8q+k1)], except quad lane 0 / k1 = 0 where hi[0] = b[32].
+// One frequency pair: (ar, ai) = own Z[k], (cr, ci) = Z[32-k], k = 8q + k1.
+template <typename T>
+DCTZ_HD void fwd_split_one(int k1, T ar, T ai, T cr, T ci, int lane, const T* tab, T& lo, T& hi) {
+  const int k = 8 * lane_q(lane) + k1;
+  T Er = ar + cr, Ei = ai - ci, Or = ai + ci, Oi = cr - ar;
+  T cw = tab[TAB_CW + k], sw = tab[TAB_SW + k];
+  T P = cw * Or + sw * Oi;
+  T Q = cw * Oi - sw * Or;
+  T Vr = Er + P, Vi = Ei + Q;
+  lo = tab[TAB_HS + k] * Vr - tab[TAB_HX + k] * Vi;
+  if (k1 == 0 && lane == 0) {
+    T Xr = Er - P, Xi = Q - Ei;                       // V[32]
+    hi = tab[TAB_HS + 32] * Xr - tab[TAB_HX + 32] * Xi;
+  } else {
+    hi = tab[TAB_HS + 64 - k] * Vr + tab[TAB_HX + 64 - k] * Vi;   // V[64-k] = conj V[k]
+  }
+}
 template <typename T>
 DCTZ_HD void fwd_split(const T (&zr)[8], const T (&zi)[8], const T (&pr)[8], const T (&pi)[8],
                        int lane, const T* tab, T (&lo)[8], T (&hi)[8]) {
-  const int q = lane_q(lane);
 #pragma unroll
-  for (int k1 = 0; k1 < 8; k1++) {
-    const int k = 8 * q + k1;
-    T ar = zr[k1], ai = zi[k1], cr = pr[k1], ci = pi[k1];
-    T Er = ar + cr, Ei = ai - ci, Or = ai + ci, Oi = cr - ar;
-    T cw = tab[TAB_CW + k], sw = tab[TAB_SW + k];
-    T P = cw * Or + sw * Oi;
-    T Q = cw * Oi - sw * Or;
-    T Vr = Er + P, Vi = Ei + Q;
-    lo[k1] = tab[TAB_HS + k] * Vr - tab[TAB_HX + k] * Vi;
-    if (k1 == 0 && lane == 0) {
-      T Xr = Er - P, Xi = Q - Ei;                     // V[32]
-      hi[0] = tab[TAB_HS + 32] * Xr - tab[TAB_HX + 32] * Xi;
-    } else {
-      hi[k1] = tab[TAB_HS + 64 - k] * Vr + tab[TAB_HX + 64 - k] * Vi;   // V[64-k] = conj V[k]
-    }
-  }
+  for (int k1 = 0; k1 < 8; k1++) fwd_split_one<T>(k1, zr[k1], zi[k1], pr[k1], pi[k1], lane, tab, lo[k1], hi[k1]);
 }
 
 // ---------------------------------------------------------------- inverse ---

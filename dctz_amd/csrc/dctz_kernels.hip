@@ -22,6 +22,12 @@
 #include "dct64_lane.h"
 #include "dctz_device.h"
 
+// minimum waves per SIMD the register allocator must leave room for in the two
+// big kernels (256-thread workgroups: N waves/SIMD <=> N workgroups per CU)
+#ifndef DCTZ_MINWAVES
+#define DCTZ_MINWAVES 3
+#endif
+
 namespace dctz {
 
 // ------------------------------------------------------------------ helpers --
@@ -49,13 +55,20 @@ template <typename T>
 __device__ __forceinline__ int tile_idx(int e) { return (e >> 6) * Traits<T>::PITCH + (e & 63); }
 
 // conv_tbl of dctz-comp-lib.c:27-43 as arithmetic (sign-interleave of t-127)
-__device__ __forceinline__ unsigned conv_bin(unsigned t) { return t <= 127u ? 254u - 2u * t : 2u * t - 255u; }
+// t <= 127 ? 254 - 2t : 2t - 255  ==  zigzag(127 - t): (u << 1) ^ (u >> 31), u = 127 - t
+__device__ __forceinline__ unsigned conv_bin(unsigned t) {
+  const int u = 127 - (int)t;
+  return (unsigned)((u << 1) ^ (u >> 31));
+}
 
 // Pass-1 binning of one coefficient (dctz-comp-lib.c:363-414).  Returns the bin
 // id; *out_of_range tells whether the QT table must see it (:367-373).
 template <typename T, typename DIV>
 __device__ __forceinline__ unsigned bin_of(T item, T range_min, T range_max, const DIV& bw, bool* out_of_range) {
-  const bool out = (item < range_min) || (item > range_max);
+  // range_min == -range_max exactly (both are +-255 eb rounded once), so the
+  // reference's (item < range_min || item > range_max) is one |item| compare
+  (void)range_min;
+  const bool out = fabs(item) > range_max;
   // in range: 0 <= item - range_min <= 510 eb, far inside the fast window; the
   // quotient of an out-of-range item is never used
   const int ti = (int)bw.div_small(item - range_min);     // (t_bin_id) cast: trunc toward 0
@@ -145,20 +158,27 @@ constexpr unsigned SPIN_LIMIT = 1u << 22;
 // tile-1-l (then the next 64 further back, ...): the walk to the nearest tile
 // whose inclusive prefix is known costs one memory round trip per 64 tiles
 // instead of one per tile.  Returns the exclusive prefix (wave-uniform).
+// publish_agg = false: the tile's aggregate is already out (software-pipelined
+// kernels publish it one iteration before they resolve it); have_first: the
+// caller loaded the first window (lane l: desc[tile-1-l]) ahead of time.
 __device__ __forceinline__ unsigned lookback(unsigned long long* desc, unsigned tile, unsigned total,
-                                             unsigned* err) {
+                                             unsigned* err, bool publish_agg = true, bool have_first = false,
+                                             unsigned long long d_first = 0) {
   const int lane = threadIdx.x & 63;
-  if (tile == 0) {
-    if (lane == 0) __hip_atomic_store(&desc[0], ST_PREFIX | total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    return 0;
+  if (publish_agg) {
+    if (tile == 0) {
+      if (lane == 0) __hip_atomic_store(&desc[0], ST_PREFIX | total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      return 0;
+    }
+    if (lane == 0) __hip_atomic_store(&desc[tile], ST_AGG | total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
-  if (lane == 0) __hip_atomic_store(&desc[tile], ST_AGG | total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   unsigned excl = 0, spins = 0;
   int base = (int)tile;                            // window = tiles [base-64, base-1]
   for (;;) {
     const int idx = base - 1 - lane;
     unsigned long long d = ST_PREFIX;              // before tile 0: prefix 0
-    if (idx >= 0) d = __hip_atomic_load(&desc[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (have_first) { d = d_first; have_first = false; }
+    else if (idx >= 0) d = __hip_atomic_load(&desc[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     const unsigned long long ready = __ballot((d & ST_MASK) != 0);
     const unsigned long long pref = __ballot((d & ST_MASK) == ST_PREFIX);
     unsigned long long need = ~0ull;               // lanes whose value we must add
@@ -338,30 +358,40 @@ template <typename T>
 __device__ __forceinline__ void tile_dct_fwd(T* tile, const T* tab) {
   const int t = threadIdx.x, blk = t >> 2, lane = t & 3;
   T* b = tile + blk * Traits<T>::PITCH;
-  T yr[8], yi[8], pr[8], pi[8], lo[8], hi[8];
+  T yr[8], yi[8];
 #pragma unroll
   for (int n1 = 0; n1 < 8; n1++) {
     yr[n1] = b[pack_pos(4 * n1 + lane, 0)];
     yi[n1] = b[pack_pos(4 * n1 + lane, 1)];
   }
-  fwd_stage_lane<T>(yr, yi, lane, tab);
-#pragma unroll
-  for (int k = 0; k < 8; k++) { pr[k] = dpp<QP_XOR2>(yr[k]); pi[k] = dpp<QP_XOR2>(yi[k]); }
-  fwd_cross_a<T>(yr, yi, pr, pi, lane);
-#pragma unroll
-  for (int k = 0; k < 8; k++) { pr[k] = dpp<QP_XOR1>(yr[k]); pi[k] = dpp<QP_XOR1>(yi[k]); }
-  fwd_cross_b<T>(yr, yi, pr, pi, lane);
-  pr[0] = dpp<QP_0132>(yr[0]); pi[0] = dpp<QP_0132>(yi[0]);
-#pragma unroll
-  for (int k = 1; k < 8; k++) { pr[k] = dpp<QP_MIRROR>(yr[8 - k]); pi[k] = dpp<QP_MIRROR>(yi[8 - k]); }
-  fwd_split<T>(yr, yi, pr, pi, lane, tab, lo, hi);
   __syncthreads();                                 // every lane has read its inputs
+  fwd_stage_lane<T>(yr, yi, lane, tab);
+  {
+    const T s = (lane & 2) ? T(-1) : T(1);
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+      const T r = bfly_s(yr[k], dpp<QP_XOR2>(yr[k]), s), i = bfly_s(yi[k], dpp<QP_XOR2>(yi[k]), s);
+      if (lane == 3) { yr[k] = i; yi[k] = -r; }    // times -i
+      else { yr[k] = r; yi[k] = i; }
+    }
+  }
+  {
+    const T s = (lane & 1) ? T(-1) : T(1);
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+      yr[k] = bfly_s(yr[k], dpp<QP_XOR1>(yr[k]), s);
+      yi[k] = bfly_s(yi[k], dpp<QP_XOR1>(yi[k]), s);
+    }
+  }
   const int q = lane_q(lane);
 #pragma unroll
-  for (int k1 = 0; k1 < 8; k1++) {
-    b[8 * q + k1] = lo[k1];
-    const int kh = (k1 == 0 && lane == 0) ? 32 : 64 - (8 * q + k1);
-    b[kh] = hi[k1];
+  for (int k1 = 0; k1 < 8; k1++) {                 // split + twiddle, results straight to LDS
+    T pr, pi, lo, hi;
+    if (k1 == 0) { pr = dpp<QP_0132>(yr[0]); pi = dpp<QP_0132>(yi[0]); }
+    else { pr = dpp<QP_MIRROR>(yr[8 - k1]); pi = dpp<QP_MIRROR>(yi[8 - k1]); }
+    fwd_split_one<T>(k1, yr[k1], yi[k1], pr, pi, lane, tab, lo, hi);
+    b[8 * q + k1] = lo;
+    b[(k1 == 0 && lane == 0) ? 32 : 64 - (8 * q + k1)] = hi;
   }
   __syncthreads();
 }
@@ -372,27 +402,40 @@ __device__ __forceinline__ void tile_dct_inv(T* tile, const T* tab) {
   const int t = threadIdx.x, blk = t >> 2, lane = t & 3;
   T* b = tile + blk * Traits<T>::PITCH;
   const int q = lane_q(lane);
-  T lo[8], hi[8], gr[8], gi[8], pr[8], pi[8], zr[8], zi[8], g32r, g32i;
+  T lo[8], hi[8], gr[8], gi[8], zr[8], zi[8], g32r, g32i;
 #pragma unroll
   for (int k1 = 0; k1 < 8; k1++) {
     lo[k1] = b[8 * q + k1];
-    const int kh = (k1 == 0 && lane == 0) ? 32 : 64 - (8 * q + k1);
-    hi[k1] = b[kh];
+    hi[k1] = b[(k1 == 0 && lane == 0) ? 32 : 64 - (8 * q + k1)];
   }
+  __syncthreads();                                 // every lane has read its inputs
   inv_prepare<T>(lo, hi, lane, tab, gr, gi, g32r, g32i);
-  pr[0] = dpp<QP_0132>(gr[0]); pi[0] = dpp<QP_0132>(gi[0]);
-  if (lane == 0) { pr[0] = g32r; pi[0] = g32i; }
+  {
+    T pr[8], pi[8];
+    pr[0] = dpp<QP_0132>(gr[0]); pi[0] = dpp<QP_0132>(gi[0]);
+    if (lane == 0) { pr[0] = g32r; pi[0] = g32i; }
 #pragma unroll
-  for (int k = 1; k < 8; k++) { pr[k] = dpp<QP_MIRROR>(gr[8 - k]); pi[k] = dpp<QP_MIRROR>(gi[8 - k]); }
-  inv_merge<T>(gr, gi, pr, pi, lane, tab, zr, zi);
+    for (int k = 1; k < 8; k++) { pr[k] = dpp<QP_MIRROR>(gr[8 - k]); pi[k] = dpp<QP_MIRROR>(gi[8 - k]); }
+    inv_merge<T>(gr, gi, pr, pi, lane, tab, zr, zi);
+  }
+  {
+    const T s = (lane & 1) ? T(-1) : T(1);
 #pragma unroll
-  for (int k = 0; k < 8; k++) { pr[k] = dpp<QP_XOR1>(zr[k]); pi[k] = dpp<QP_XOR1>(zi[k]); }
-  inv_cross_a<T>(zr, zi, pr, pi, lane);
+    for (int k = 0; k < 8; k++) {
+      const T r = bfly_s(zr[k], dpp<QP_XOR1>(zr[k]), s), i = bfly_s(zi[k], dpp<QP_XOR1>(zi[k]), s);
+      if (lane == 3) { zr[k] = -i; zi[k] = r; }    // times +i
+      else { zr[k] = r; zi[k] = i; }
+    }
+  }
+  {
+    const T s = (lane & 2) ? T(-1) : T(1);
 #pragma unroll
-  for (int k = 0; k < 8; k++) { pr[k] = dpp<QP_XOR2>(zr[k]); pi[k] = dpp<QP_XOR2>(zi[k]); }
-  inv_cross_b<T>(zr, zi, pr, pi, lane);
+    for (int k = 0; k < 8; k++) {
+      zr[k] = bfly_s(zr[k], dpp<QP_XOR2>(zr[k]), s);
+      zi[k] = bfly_s(zi[k], dpp<QP_XOR2>(zi[k]), s);
+    }
+  }
   inv_stage_lane<T>(zr, zi, lane, tab);
-  __syncthreads();
 #pragma unroll
   for (int n1 = 0; n1 < 8; n1++) {
     b[pack_pos(4 * n1 + lane, 0)] = zr[n1];
@@ -605,7 +648,7 @@ __device__ __forceinline__ void emit_tile(const FwdParams<T>& p, const T* tile, 
 }
 
 template <typename T, int MODE, bool SCALE, int FEAT>
-__global__ __launch_bounds__(WG) void k_compress(FwdParams<T> p) {
+__global__ __launch_bounds__(WG, DCTZ_MINWAVES) void k_compress(FwdParams<T> p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   using Vec = typename Traits<T>::Vec;
   using Bits = typename Traits<T>::Bits;
@@ -621,26 +664,129 @@ __global__ __launch_bounds__(WG) void k_compress(FwdParams<T> p) {
   sfd.init(p.sf, p.fast_sf != 0);
   bwd.init(p.bin_width, p.fast_bw != 0);
 
-  if (FEAT & F_PIPE) {
-    // software pipeline, two tickets ahead: the loads of the next tile are in
-    // flight while this tile computes, and the ticket after that is on its way
+  if constexpr ((FEAT & F_PIPE) != 0 && MODE == DCTZHIP_EC) {
+    // Software pipeline over tiles (EC mode):
+    //  * tickets run two ahead, so the 32 KiB of loads of tile k+1 are in flight
+    //    while tile k is transformed;
+    //  * tile k publishes its exception count as soon as it is known, parks its
+    //    AC_exact values in LDS and moves on; its look-back is resolved one
+    //    iteration later (after the DCT of tile k+1), when the predecessors have
+    //    long published, with the first look-back window fetched ahead as well.
+    // Neither HBM latency nor the look-back round trip sits on the critical path.
+    float* park = reinterpret_cast<float*>(sc + 16);
+    constexpr unsigned NONE = 0xffffffffu;
+    const int lane = t & 63, wave = t >> 6;
+    const int blk = t >> 2, j0 = (t & 3) * 16;
     if (t == 0) { sc[5] = take_ticket<FEAT>(p.ctl, p.ngroups); sc[6] = take_ticket<FEAT>(p.ctl, p.ngroups); }
     __syncthreads();
-    unsigned tile_id = sc[5], next_id = sc[6];
+    unsigned cur = sc[5], nxt = sc[6], prv = NONE, prv_total = 0;
     Vec v[NV];
-    issue_tile_loads<T>(v, p.x, tile_id, p.ntiles, p.nfull);
-    while (tile_id < p.ntiles) {
+    issue_tile_loads<T>(v, p.x, cur, p.ntiles, p.nfull);
+    Stamps st;
+    if (FEAT & F_STAMP) st.start();
+    while (cur < p.ntiles) {
       unsigned tk = 0;
       if (t == 0) tk = take_ticket<FEAT>(p.ctl, p.ngroups);
-      const size_t ebase = (size_t)tile_id * TILE_ELEMS;
-      const unsigned blks_here = min((unsigned)TILE_BLKS, p.nfull - tile_id * TILE_BLKS);
+      const bool have_prv = (prv != NONE);
+      unsigned long long d_first = ST_PREFIX;
+      if (wave == 0 && have_prv) {
+        const int idx = (int)prv - 1 - lane;
+        if (idx >= 0) d_first = __hip_atomic_load(&p.desc[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      const size_t ebase = (size_t)cur * TILE_ELEMS;
+      const unsigned blks_here = min((unsigned)TILE_BLKS, p.nfull - cur * TILE_BLKS);
       stage_tile<T, SCALE>(tile, v, ebase, blks_here * 64u, sfd, p.scaled);
+      __syncthreads();                                                   // A
+      if ((FEAT & F_STAMP) && t == 0) st.mark(0);                        // stage (wait for prefetched loads)
+      issue_tile_loads<T>(v, p.x, nxt, p.ntiles, p.nfull);
+      tile_dct_fwd<T>(tile, tab);                                        // B, C
+      if ((FEAT & F_STAMP) && t == 0) st.mark(1);                        // DCT
+
+      const bool active = (unsigned)blk < blks_here;
+      T c[16];
+#pragma unroll
+      for (int i = 0; i < 16 / EPV; i++) {
+        const Vec cv = *reinterpret_cast<const Vec*>(&tile[blk * Traits<T>::PITCH + j0 + i * EPV]);
+        Traits<T>::unpack(cv, &c[i * EPV]);
+      }
+      unsigned w[4] = {0, 0, 0, 0};
+      unsigned mask = 0;
+#pragma unroll
+      for (int i = 0; i < 16; i++) {
+        bool out;
+        unsigned b = bin_of<T>(c[i], p.range_min, p.range_max, bwd, &out);
+        if (j0 + i == 0) b = 255u;                   // :361 DC slot
+        else if (b == 255u) mask |= 1u << i;
+        w[i >> 2] |= b << (8 * (i & 3));
+      }
+      if (!active) mask = 0;
+      const unsigned cnt = (unsigned)__popc(mask);
+      unsigned incl = cnt;
+#pragma unroll
+      for (int d = 1; d < 64; d <<= 1) {
+        const unsigned o = __shfl_up(incl, d);
+        if (lane >= d) incl += o;
+      }
+      if (lane == 63) sc[wave] = incl;
+      if ((FEAT & F_STAMP) && t == 0) st.mark(2);                        // binning
+      if (t == 0) sc[6] = tk;
+      __syncthreads();                                                   // D
+      if ((FEAT & F_STAMP) && t == 0) st.mark(3);                        // ticket wait + barrier D
+      const unsigned total = sc[0] + sc[1] + sc[2] + sc[3];
+      unsigned local_off = incl - cnt;
+      if (wave > 0) local_off += sc[0];
+      if (wave > 1) local_off += sc[1];
+      if (wave > 2) local_off += sc[2];
+      const unsigned after = sc[6];
+      if (wave == 0) {
+        if (lane == 0)
+          __hip_atomic_store(&p.desc[cur], ST_AGG | (unsigned long long)total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (have_prv) {
+          const unsigned excl = lookback(p.desc, prv, prv_total, &p.ctl->error, false, true, d_first);
+          if (lane == 0) {
+            sc[4] = excl;
+            if (prv == p.ntiles - 1) p.ctl->cnt_total = excl + prv_total;
+          }
+        }
+      }
+      __syncthreads();                                                   // E
+      if ((FEAT & F_STAMP) && t == 0) st.mark(4);                        // resolve look-back of prv
+      if (have_prv) {
+        const unsigned base = sc[4];
+        for (unsigned i = t; i < prv_total; i += WG) p.ac[base + i] = park[i];   // :535-537, coalesced
+      }
+      __syncthreads();                                                   // F: park is free again
+      if ((FEAT & F_STAMP) && t == 0) st.mark(5);                        // copy-out
+      {
+        unsigned r = local_off;
+#pragma unroll
+        for (int i = 0; i < 16; i++)
+          if (mask & (1u << i)) park[r++] = (float)c[i];
+      }
+      if (active) {
+        reinterpret_cast<uint4*>(p.bin + ebase)[t] = make_uint4(w[0], w[1], w[2], w[3]);
+        if (p.coef != nullptr) {
+#pragma unroll
+          for (int i = 0; i < 16 / EPV; i++)
+            reinterpret_cast<Vec*>(p.coef + ebase + (size_t)t * 16)[i] = Traits<T>::pack(&c[i * EPV]);
+        }
+        if (j0 == 0) p.dc[cur * TILE_BLKS + blk] = (float)c[0];           // :350-351 USE_TRUNCATE
+      }
+      prv = cur; prv_total = total; cur = nxt; nxt = after;
+      if ((FEAT & F_STAMP) && t == 0) st.mark(6);                        // park + stores
+    }
+    if ((FEAT & F_STAMP) && t == 0) st.flush(p.ctl);
+    if (prv != NONE) {                                                   // resolve the last tile
+      if (wave == 0) {
+        const unsigned excl = lookback(p.desc, prv, prv_total, &p.ctl->error, false);
+        if (lane == 0) {
+          sc[4] = excl;
+          if (prv == p.ntiles - 1) p.ctl->cnt_total = excl + prv_total;
+        }
+      }
       __syncthreads();
-      issue_tile_loads<T>(v, p.x, next_id, p.ntiles, p.nfull);
-      tile_dct_fwd<T>(tile, tab);
-      emit_tile<T, MODE, FEAT>(p, tile, qmax, sc, bwd, tile_id, blks_here, true, tk, nullptr);
-      tile_id = next_id;
-      next_id = sc[6];
+      const unsigned base = sc[4];
+      for (unsigned i = t; i < prv_total; i += WG) p.ac[base + i] = park[i];
     }
   } else {
     Stamps st;
@@ -755,7 +901,7 @@ __global__ __launch_bounds__(WG) void k_qt_finish(FwdParams<T> p, double eb) {
 // tile k, so the polling wave never waits behind them, and they drain under the
 // gather + IDCT of tile k.
 template <typename T, int MODE, bool SCALE, int FEAT>
-__global__ __launch_bounds__(WG) void k_decompress(InvParams<T> p) {
+__global__ __launch_bounds__(WG, DCTZ_MINWAVES) void k_decompress(InvParams<T> p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   using Vec = typename Traits<T>::Vec;
   constexpr int EPV = Traits<T>::EPV;
@@ -979,8 +1125,9 @@ __global__ __launch_bounds__(64) void k_dct_rem(const T* __restrict__ x, T* __re
 
 // ================================================================= launchers ==
 template <typename T>
-static size_t fwd_smem() {
-  return sizeof(T) * (TILE_BLKS * Traits<T>::PITCH + TAB_SIZE) + 64 * sizeof(typename Traits<T>::Bits) + 32;
+static size_t fwd_smem(bool pipe) {
+  return sizeof(T) * (TILE_BLKS * Traits<T>::PITCH + TAB_SIZE) + 64 * sizeof(typename Traits<T>::Bits) + 64 +
+         (pipe ? TILE_ELEMS * sizeof(float) : 0);       // + AC_exact park of one tile
 }
 template <typename T>
 static size_t inv_smem() {
@@ -1014,7 +1161,7 @@ void launch_scale(T* x, size_t n, T sf, int grid, hipStream_t s) {
 
 template <typename T, int FEAT>
 static void launch_compress_f(const FwdParams<T>& p, int mode, bool scale, int grid, hipStream_t s) {
-  const size_t sm = fwd_smem<T>();
+  const size_t sm = fwd_smem<T>((FEAT & F_PIPE) && mode == DCTZHIP_EC);
   if (mode == DCTZHIP_EC) {
     if (scale) hipLaunchKernelGGL((k_compress<T, DCTZHIP_EC, true, FEAT>), dim3(grid), dim3(WG), sm, s, p);
     else hipLaunchKernelGGL((k_compress<T, DCTZHIP_EC, false, FEAT>), dim3(grid), dim3(WG), sm, s, p);
@@ -1025,6 +1172,7 @@ static void launch_compress_f(const FwdParams<T>& p, int mode, bool scale, int g
 }
 template <typename T>
 void launch_compress(const FwdParams<T>& p, int mode, bool scale, int grid, int feat, hipStream_t s) {
+  if ((feat & 7) == 7) { launch_compress_f<T, 7>(p, mode, scale, grid, s); return; }
   if (feat & 4) { launch_compress_f<T, 4>(p, mode, scale, grid, s); return; }
   switch (feat & 3) {
     case 0: launch_compress_f<T, 0>(p, mode, scale, grid, s); break;

@@ -48,7 +48,8 @@ struct dctzhip_ctx {
   // pinned host staging
   unsigned char* h_pin = nullptr;   // [0,64): stats, [64, 64+sizeof(Ctl)): ctl, then tables
   // profiling
-  int feat = 3;                     // kernel features: 1 pipeline, 2 grouped tickets (DCTZHIP_FEAT)
+  int feat = 0;                     // compress kernel features: 1 pipeline, 2 grouped tickets, 4 stamps (DCTZHIP_FEAT)
+  int feat_d = 2;                   // decompress kernel features (DCTZHIP_FEAT overrides both)
   int fastdiv = 1;                  // hoisted-reciprocal division (DCTZHIP_FASTDIV)
   int wg_per_cu = 4;                // persistent grid = CUs * this (DCTZHIP_WG_PER_CU)
   int profiling = 0;
@@ -96,7 +97,7 @@ extern "C" int dctzhip_ctx_create(dctzhip_ctx** out, int device) {
   hipDeviceProp_t prop;
   HIPCHK(nullptr, hipGetDeviceProperties(&prop, device));
   c->num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-  if (const char* e = getenv("DCTZHIP_FEAT")) c->feat = atoi(e) & 7;
+  if (const char* e = getenv("DCTZHIP_FEAT")) { c->feat = atoi(e) & 7; c->feat_d = c->feat; }
   if (const char* e = getenv("DCTZHIP_FASTDIV")) c->fastdiv = atoi(e) != 0;
   if (const char* e = getenv("DCTZHIP_WG_PER_CU")) { int v = atoi(e); if (v >= 1 && v <= 8) c->wg_per_cu = v; }
   HIPCHK(nullptr, hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
@@ -342,6 +343,10 @@ static int compress_impl(dctzhip_ctx* c, const T* d_in, size_t n, double eb, int
   if (hc->error) return fail(c, DCTZHIP_E_INTERNAL, "in-kernel watchdog tripped (code %u)", hc->error);
   if (c->profiling) { int rc = read_timings(c, 2); if (rc) return rc; }
   if (c->feat & 4) {
+    if ((c->feat & 1) && mode == DCTZHIP_EC)
+      fprintf(stderr, "[dctzhip stamps] compress(pipe) cycles: stage %llu dct %llu bin %llu ticket+D %llu resolve %llu copyout %llu park+stores %llu\n",
+              hc->dbg[0], hc->dbg[1], hc->dbg[2], hc->dbg[3], hc->dbg[4], hc->dbg[5], hc->dbg[6]);
+    else
     fprintf(stderr, "[dctzhip stamps] compress cycles: ticket %llu load %llu dct %llu bin %llu scan %llu lookback %llu acwrite %llu\n",
             hc->dbg[0], hc->dbg[1], hc->dbg[2], hc->dbg[3], hc->dbg[4], hc->dbg[5], hc->dbg[6]);
   }
@@ -512,16 +517,16 @@ static int decompress_impl(dctzhip_ctx* c, const uint8_t* d_bin, const float* d_
     const unsigned cap = (unsigned)(c->num_cu * c->wg_per_cu);
     const int grid = (int)(cap < ntiles ? cap : ntiles);
     p.ngroups = grid < 8 ? (unsigned)grid : 8u;
-    launch_decompress<T>(p, mode, scale, grid, c->feat, s);
+    launch_decompress<T>(p, mode, scale, grid, c->feat_d, s);
   }
   if (c->profiling) HIPCHK(c, hipEventRecord(c->ev[3], s));
   if (rem) launch_decompress_rem<T>(p, mode, scale, rem, s);
   if (c->profiling) HIPCHK(c, hipEventRecord(c->ev[4], s));
   HIPCHK(c, hipGetLastError());
   Ctl* hc = reinterpret_cast<Ctl*>(c->h_pin + PIN_CTL);
-  HIPCHK(c, hipMemcpyAsync(hc, c->ctl, (c->feat & 4) ? sizeof(Ctl) : 16, hipMemcpyDeviceToHost, s));
+  HIPCHK(c, hipMemcpyAsync(hc, c->ctl, (c->feat_d & 4) ? sizeof(Ctl) : 16, hipMemcpyDeviceToHost, s));
   HIPCHK(c, hipStreamSynchronize(s));
-  if (c->feat & 4)
+  if (c->feat_d & 4)
     fprintf(stderr, "[dctzhip stamps] decompress cycles: ticket %llu binload %llu scan+lookback %llu (scan %llu lookback %llu) store %llu gather %llu idct %llu\n",
             hc->dbg[0], hc->dbg[1], hc->dbg[2] + hc->dbg[4] + hc->dbg[5], hc->dbg[4], hc->dbg[5], hc->dbg[3], hc->dbg[6], hc->dbg[7]);
   if (hc->error == 2) return fail(c, DCTZHIP_E_ARG, "bin_index flags more exact coefficients than ac_count provides");
