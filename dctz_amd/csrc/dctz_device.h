@@ -66,6 +66,9 @@ struct FwdParams {
   float* ac;                       // AC_exact out
   T* scaled;                       // optional x/sf out
   T* coef;                         // optional coefficient tap
+  float* ac_tmp;                   // two-level scheme: tile-local AC_exact lists, slot = tile * 4096
+  unsigned* tile_cnt;              // two-level scheme: list lengths (NULL selects the single-pass kernels' rules)
+  const unsigned* tile_off;        // two-level scheme: exclusive prefix of tile_cnt (k_scan_tiles)
   T* qt_item;                      // QT scratch: flagged coefficients, full precision
   uint8_t* qt_j;                   // QT scratch: their position j
   const T* tab;                    // TAB_* block (device)
@@ -89,6 +92,7 @@ struct InvParams {
   const T* tab;
   const T* rtab;
   const T* qtab;                   // QT: clamped table (device)
+  const unsigned* tile_off;        // two-level scheme: exclusive prefix of per-tile flag counts (else NULL)
   Ctl* ctl;
   unsigned long long* desc;
   unsigned nfull, ntiles, ac_count;
@@ -104,6 +108,9 @@ template <typename T> void launch_scale(T* x, size_t n, T sf, int grid, hipStrea
 template <typename T> void launch_compress(const FwdParams<T>& p, int mode, bool scale, int grid, int feat, hipStream_t s);
 template <typename T> void launch_compress_rem(const FwdParams<T>& p, int mode, bool scale, int l, hipStream_t s);
 template <typename T> void launch_qt_finish(const FwdParams<T>& p, double eb, int grid, hipStream_t s);
+template <typename T> void launch_compact_ac(const FwdParams<T>& p, int mode, double eb, unsigned nlists, int grid, hipStream_t s);
+void launch_scan_tiles(const unsigned* cnt, unsigned* off, unsigned n, Ctl* ctl, hipStream_t s);
+void launch_count_tiles(const uint8_t* bin, unsigned nfull, unsigned ntiles, unsigned* tile_cnt, int grid, hipStream_t s);
 template <typename T> void launch_decompress(const InvParams<T>& p, int mode, bool scale, int grid, int feat, hipStream_t s);
 template <typename T> void launch_decompress_rem(const InvParams<T>& p, int mode, bool scale, int l, hipStream_t s);
 template <typename T> void launch_dct_blocks(const T* x, T* out, const T* gtab, const T* rtab, size_t n,

@@ -27,6 +27,14 @@
 #ifndef DCTZ_MINWAVES
 #define DCTZ_MINWAVES 3
 #endif
+// Scheduling fence between the stages of the in-register transform: keeps the
+// compiler from hoisting the next stage's LDS / DPP operands over the current one
+// (which costs tens of VGPRs and, with them, a wave per SIMD).
+#ifndef DCTZ_NO_SCHED_FENCE
+#define SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
+#else
+#define SCHED_FENCE() ((void)0)
+#endif
 
 namespace dctz {
 
@@ -242,6 +250,26 @@ __device__ __forceinline__ unsigned tile_scan(unsigned cnt, unsigned tile, unsig
   return off;
 }
 
+// Intra-tile exclusive scan only (two-level scheme): returns this thread's offset
+// inside the tile's exception list and the tile total.  One barrier.
+__device__ __forceinline__ unsigned tile_scan_local(unsigned cnt, unsigned* sc, unsigned* total) {
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  unsigned incl = cnt;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    unsigned o = __shfl_up(incl, d);
+    if (lane >= d) incl += o;
+  }
+  if (lane == 63) sc[wave] = incl;
+  __syncthreads();
+  unsigned off = incl - cnt;
+  if (wave > 0) off += sc[0];
+  if (wave > 1) off += sc[1];
+  if (wave > 2) off += sc[2];
+  *total = sc[0] + sc[1] + sc[2] + sc[3];
+  return off;
+}
+
 // ------------------------------------------------------------ tile tickets --
 // Tiles are handed out in increasing order so that the look-back of tile j only
 // ever waits for tiles that some running workgroup already owns.  One global
@@ -253,7 +281,11 @@ __device__ __forceinline__ unsigned tile_scan(unsigned cnt, unsigned tile, unsig
 // any placement: every group has at least one workgroup (ngroups <= grid), each
 // group hands its tiles out in increasing order, and a workgroup never waits
 // for a higher tile, so the lowest unfinished tile is always owned or claimable.
-enum : int { F_PIPE = 1, F_GROUP = 2, F_STAMP = 4 };   // F_STAMP: diagnostic build, phase timers into Ctl::dbg
+// F_LOOKBACK: single-pass kernels (tickets + decoupled look-back); default (0) is the
+// two-level scheme: static tiles, tile-local exception lists, tiny scan, compaction.
+// F_GROUP: per-group ticket counters (look-back kernels).  F_STAMP: diagnostic phase
+// timers into Ctl::dbg (look-back kernels).
+enum : int { F_LOOKBACK = 1, F_GROUP = 2, F_STAMP = 4 };
 
 template <int FEAT>
 __device__ __forceinline__ unsigned take_ticket(Ctl* ctl, unsigned ngroups) {
@@ -366,6 +398,7 @@ __device__ __forceinline__ void tile_dct_fwd(T* tile, const T* tab) {
   }
   __syncthreads();                                 // every lane has read its inputs
   fwd_stage_lane<T>(yr, yi, lane, tab);
+  SCHED_FENCE();
   {
     const T s = (lane & 2) ? T(-1) : T(1);
 #pragma unroll
@@ -375,6 +408,7 @@ __device__ __forceinline__ void tile_dct_fwd(T* tile, const T* tab) {
       else { yr[k] = r; yi[k] = i; }
     }
   }
+  SCHED_FENCE();
   {
     const T s = (lane & 1) ? T(-1) : T(1);
 #pragma unroll
@@ -383,6 +417,7 @@ __device__ __forceinline__ void tile_dct_fwd(T* tile, const T* tab) {
       yi[k] = bfly_s(yi[k], dpp<QP_XOR1>(yi[k]), s);
     }
   }
+  SCHED_FENCE();
   const int q = lane_q(lane);
 #pragma unroll
   for (int k1 = 0; k1 < 8; k1++) {                 // split + twiddle, results straight to LDS
@@ -392,6 +427,7 @@ __device__ __forceinline__ void tile_dct_fwd(T* tile, const T* tab) {
     fwd_split_one<T>(k1, yr[k1], yi[k1], pr, pi, lane, tab, lo, hi);
     b[8 * q + k1] = lo;
     b[(k1 == 0 && lane == 0) ? 32 : 64 - (8 * q + k1)] = hi;
+    SCHED_FENCE();
   }
   __syncthreads();
 }
@@ -410,6 +446,7 @@ __device__ __forceinline__ void tile_dct_inv(T* tile, const T* tab) {
   }
   __syncthreads();                                 // every lane has read its inputs
   inv_prepare<T>(lo, hi, lane, tab, gr, gi, g32r, g32i);
+  SCHED_FENCE();
   {
     T pr[8], pi[8];
     pr[0] = dpp<QP_0132>(gr[0]); pi[0] = dpp<QP_0132>(gi[0]);
@@ -418,6 +455,7 @@ __device__ __forceinline__ void tile_dct_inv(T* tile, const T* tab) {
     for (int k = 1; k < 8; k++) { pr[k] = dpp<QP_MIRROR>(gr[8 - k]); pi[k] = dpp<QP_MIRROR>(gi[8 - k]); }
     inv_merge<T>(gr, gi, pr, pi, lane, tab, zr, zi);
   }
+  SCHED_FENCE();
   {
     const T s = (lane & 1) ? T(-1) : T(1);
 #pragma unroll
@@ -427,6 +465,7 @@ __device__ __forceinline__ void tile_dct_inv(T* tile, const T* tab) {
       else { zr[k] = r; zi[k] = i; }
     }
   }
+  SCHED_FENCE();
   {
     const T s = (lane & 2) ? T(-1) : T(1);
 #pragma unroll
@@ -435,7 +474,9 @@ __device__ __forceinline__ void tile_dct_inv(T* tile, const T* tab) {
       zi[k] = bfly_s(zi[k], dpp<QP_XOR2>(zi[k]), s);
     }
   }
+  SCHED_FENCE();
   inv_stage_lane<T>(zr, zi, lane, tab);
+  SCHED_FENCE();
 #pragma unroll
   for (int n1 = 0; n1 < 8; n1++) {
     b[pack_pos(4 * n1 + lane, 0)] = zr[n1];
@@ -620,8 +661,15 @@ __device__ __forceinline__ void emit_tile(const FwdParams<T>& p, const T* tile, 
   }
   if (!active) mask = 0;
   if ((FEAT & F_STAMP) && st && t == 0) st->mark(3);   // binning + bin store issue
-  unsigned r = tile_scan((unsigned)__popc(mask), tile_id, p.ntiles, sc, p.desc, p.ctl, publish, publish_value,
-                         (FEAT & F_STAMP) ? st : nullptr);
+  unsigned r;
+  if (FEAT & F_LOOKBACK) {
+    r = tile_scan((unsigned)__popc(mask), tile_id, p.ntiles, sc, p.desc, p.ctl, publish, publish_value,
+                  (FEAT & F_STAMP) ? st : nullptr);
+  } else {                                           // tile-local list; k_compact_ac places it later
+    unsigned total;
+    r = tile_id * TILE_ELEMS + tile_scan_local((unsigned)__popc(mask), sc, &total);
+    if (t == 0) p.tile_cnt[tile_id] = total;
+  }
   // all global stores of the tile go out AFTER the look-back, so that the polling
   // wave's vmcnt(0) waits never sit behind its own stores
   if (active) {
@@ -637,10 +685,11 @@ __device__ __forceinline__ void emit_tile(const FwdParams<T>& p, const T* tile, 
       if (p.last_is_full && gblk == p.nfull - 1) p.ctl->q0 = (unsigned long long)to_bits(c[0]);   // :355-360
     }
   }
+  float* acdst = (FEAT & F_LOOKBACK) ? p.ac : p.ac_tmp;
 #pragma unroll
   for (int i = 0; i < 16; i++) {
     if (mask & (1u << i)) {
-      if (MODE == DCTZHIP_EC) p.ac[r] = (float)c[i];            // :535-537
+      if (MODE == DCTZHIP_EC) acdst[r] = (float)c[i];           // :535-537
       else { p.qt_item[r] = c[i]; p.qt_j[r] = (uint8_t)(j0 + i); }
       r++;
     }
@@ -664,129 +713,20 @@ __global__ __launch_bounds__(WG, DCTZ_MINWAVES) void k_compress(FwdParams<T> p) 
   sfd.init(p.sf, p.fast_sf != 0);
   bwd.init(p.bin_width, p.fast_bw != 0);
 
-  if constexpr ((FEAT & F_PIPE) != 0 && MODE == DCTZHIP_EC) {
-    // Software pipeline over tiles (EC mode):
-    //  * tickets run two ahead, so the 32 KiB of loads of tile k+1 are in flight
-    //    while tile k is transformed;
-    //  * tile k publishes its exception count as soon as it is known, parks its
-    //    AC_exact values in LDS and moves on; its look-back is resolved one
-    //    iteration later (after the DCT of tile k+1), when the predecessors have
-    //    long published, with the first look-back window fetched ahead as well.
-    // Neither HBM latency nor the look-back round trip sits on the critical path.
-    float* park = reinterpret_cast<float*>(sc + 16);
-    constexpr unsigned NONE = 0xffffffffu;
-    const int lane = t & 63, wave = t >> 6;
-    const int blk = t >> 2, j0 = (t & 3) * 16;
-    if (t == 0) { sc[5] = take_ticket<FEAT>(p.ctl, p.ngroups); sc[6] = take_ticket<FEAT>(p.ctl, p.ngroups); }
-    __syncthreads();
-    unsigned cur = sc[5], nxt = sc[6], prv = NONE, prv_total = 0;
-    Vec v[NV];
-    issue_tile_loads<T>(v, p.x, cur, p.ntiles, p.nfull);
-    Stamps st;
-    if (FEAT & F_STAMP) st.start();
-    while (cur < p.ntiles) {
-      unsigned tk = 0;
-      if (t == 0) tk = take_ticket<FEAT>(p.ctl, p.ngroups);
-      const bool have_prv = (prv != NONE);
-      unsigned long long d_first = ST_PREFIX;
-      if (wave == 0 && have_prv) {
-        const int idx = (int)prv - 1 - lane;
-        if (idx >= 0) d_first = __hip_atomic_load(&p.desc[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      }
-      const size_t ebase = (size_t)cur * TILE_ELEMS;
-      const unsigned blks_here = min((unsigned)TILE_BLKS, p.nfull - cur * TILE_BLKS);
+  if constexpr ((FEAT & F_LOOKBACK) == 0) {
+    // two-level scheme: tiles are assigned statically (no inter-workgroup traffic
+    // at all in this kernel); every tile leaves its exceptions as a tile-local
+    // list + a count, k_scan_tiles / k_compact_ac stitch them into AC_exact[]
+    for (unsigned tile_id = blockIdx.x; tile_id < p.ntiles; tile_id += gridDim.x) {
+      const size_t ebase = (size_t)tile_id * TILE_ELEMS;
+      const unsigned blks_here = min((unsigned)TILE_BLKS, p.nfull - tile_id * TILE_BLKS);
+      Vec v[NV];
+      issue_tile_loads<T>(v, p.x, tile_id, p.ntiles, p.nfull);
+      __syncthreads();                               // previous tile's LDS reads are done
       stage_tile<T, SCALE>(tile, v, ebase, blks_here * 64u, sfd, p.scaled);
-      __syncthreads();                                                   // A
-      if ((FEAT & F_STAMP) && t == 0) st.mark(0);                        // stage (wait for prefetched loads)
-      issue_tile_loads<T>(v, p.x, nxt, p.ntiles, p.nfull);
-      tile_dct_fwd<T>(tile, tab);                                        // B, C
-      if ((FEAT & F_STAMP) && t == 0) st.mark(1);                        // DCT
-
-      const bool active = (unsigned)blk < blks_here;
-      T c[16];
-#pragma unroll
-      for (int i = 0; i < 16 / EPV; i++) {
-        const Vec cv = *reinterpret_cast<const Vec*>(&tile[blk * Traits<T>::PITCH + j0 + i * EPV]);
-        Traits<T>::unpack(cv, &c[i * EPV]);
-      }
-      unsigned w[4] = {0, 0, 0, 0};
-      unsigned mask = 0;
-#pragma unroll
-      for (int i = 0; i < 16; i++) {
-        bool out;
-        unsigned b = bin_of<T>(c[i], p.range_min, p.range_max, bwd, &out);
-        if (j0 + i == 0) b = 255u;                   // :361 DC slot
-        else if (b == 255u) mask |= 1u << i;
-        w[i >> 2] |= b << (8 * (i & 3));
-      }
-      if (!active) mask = 0;
-      const unsigned cnt = (unsigned)__popc(mask);
-      unsigned incl = cnt;
-#pragma unroll
-      for (int d = 1; d < 64; d <<= 1) {
-        const unsigned o = __shfl_up(incl, d);
-        if (lane >= d) incl += o;
-      }
-      if (lane == 63) sc[wave] = incl;
-      if ((FEAT & F_STAMP) && t == 0) st.mark(2);                        // binning
-      if (t == 0) sc[6] = tk;
-      __syncthreads();                                                   // D
-      if ((FEAT & F_STAMP) && t == 0) st.mark(3);                        // ticket wait + barrier D
-      const unsigned total = sc[0] + sc[1] + sc[2] + sc[3];
-      unsigned local_off = incl - cnt;
-      if (wave > 0) local_off += sc[0];
-      if (wave > 1) local_off += sc[1];
-      if (wave > 2) local_off += sc[2];
-      const unsigned after = sc[6];
-      if (wave == 0) {
-        if (lane == 0)
-          __hip_atomic_store(&p.desc[cur], ST_AGG | (unsigned long long)total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (have_prv) {
-          const unsigned excl = lookback(p.desc, prv, prv_total, &p.ctl->error, false, true, d_first);
-          if (lane == 0) {
-            sc[4] = excl;
-            if (prv == p.ntiles - 1) p.ctl->cnt_total = excl + prv_total;
-          }
-        }
-      }
-      __syncthreads();                                                   // E
-      if ((FEAT & F_STAMP) && t == 0) st.mark(4);                        // resolve look-back of prv
-      if (have_prv) {
-        const unsigned base = sc[4];
-        for (unsigned i = t; i < prv_total; i += WG) p.ac[base + i] = park[i];   // :535-537, coalesced
-      }
-      __syncthreads();                                                   // F: park is free again
-      if ((FEAT & F_STAMP) && t == 0) st.mark(5);                        // copy-out
-      {
-        unsigned r = local_off;
-#pragma unroll
-        for (int i = 0; i < 16; i++)
-          if (mask & (1u << i)) park[r++] = (float)c[i];
-      }
-      if (active) {
-        reinterpret_cast<uint4*>(p.bin + ebase)[t] = make_uint4(w[0], w[1], w[2], w[3]);
-        if (p.coef != nullptr) {
-#pragma unroll
-          for (int i = 0; i < 16 / EPV; i++)
-            reinterpret_cast<Vec*>(p.coef + ebase + (size_t)t * 16)[i] = Traits<T>::pack(&c[i * EPV]);
-        }
-        if (j0 == 0) p.dc[cur * TILE_BLKS + blk] = (float)c[0];           // :350-351 USE_TRUNCATE
-      }
-      prv = cur; prv_total = total; cur = nxt; nxt = after;
-      if ((FEAT & F_STAMP) && t == 0) st.mark(6);                        // park + stores
-    }
-    if ((FEAT & F_STAMP) && t == 0) st.flush(p.ctl);
-    if (prv != NONE) {                                                   // resolve the last tile
-      if (wave == 0) {
-        const unsigned excl = lookback(p.desc, prv, prv_total, &p.ctl->error, false);
-        if (lane == 0) {
-          sc[4] = excl;
-          if (prv == p.ntiles - 1) p.ctl->cnt_total = excl + prv_total;
-        }
-      }
       __syncthreads();
-      const unsigned base = sc[4];
-      for (unsigned i = t; i < prv_total; i += WG) p.ac[base + i] = park[i];
+      tile_dct_fwd<T>(tile, tab);
+      emit_tile<T, MODE, FEAT>(p, tile, qmax, sc, bwd, tile_id, blks_here, false, 0u, nullptr);
     }
   } else {
     Stamps st;
@@ -856,22 +796,28 @@ __global__ __launch_bounds__(64) void k_compress_rem(FwdParams<T> p, int l) {
   if (k >= l) { exc = false; out = false; }
   const unsigned long long m = __ballot(exc);
   const unsigned rank = (unsigned)__popcll(m & ((1ull << k) - 1ull));
-  const unsigned start = p.ctl->cnt_total;
+  // single-pass: append after the full blocks; two-level: this block is list #ntiles
+  const unsigned start = p.tile_cnt ? p.ntiles * TILE_ELEMS : p.ctl->cnt_total;
+  float* acdst = p.tile_cnt ? p.ac_tmp : p.ac;
   if (k < l) {
     p.bin[base + k] = (uint8_t)b;
     if (p.coef != nullptr) p.coef[base + k] = coef;
     if (k == 0) { p.dc[p.nfull] = (float)coef; p.ctl->q0 = (unsigned long long)to_bits(coef); }
     if (MODE == DCTZHIP_QT && out) atomicMax(&p.ctl->qraw[k], (unsigned long long)to_bits(fabs(coef)));
     if (exc) {
-      if (MODE == DCTZHIP_EC) p.ac[start + rank] = (float)coef;
+      if (MODE == DCTZHIP_EC) acdst[start + rank] = (float)coef;
       else { p.qt_item[start + rank] = coef; p.qt_j[start + rank] = (uint8_t)k; }
     }
   }
   __syncthreads();
-  if (k == 0) p.ctl->cnt_total = start + (unsigned)__popcll(m);
+  if (k == 0) {
+    if (p.tile_cnt) p.tile_cnt[p.ntiles] = (unsigned)__popcll(m);
+    else p.ctl->cnt_total = start + (unsigned)__popcll(m);
+  }
 }
 
-// QT pass 2 (dctz-comp-lib.c:450-461 clamp, :478-533 normalise + append).
+// QT pass 2 for the single-pass kernels (dctz-comp-lib.c:450-461 clamp, :478-533
+// normalise + append): the flagged coefficients are already in global order.
 template <typename T>
 __global__ __launch_bounds__(WG) void k_qt_finish(FwdParams<T> p, double eb) {
   using Bits = typename Traits<T>::Bits;
@@ -892,9 +838,90 @@ __global__ __launch_bounds__(WG) void k_qt_finish(FwdParams<T> p, double eb) {
   }
 }
 
+// Two-level scheme, step 2: exclusive prefix over the per-tile exception counts
+// (one workgroup; n <= 2^19 entries for the largest legal input).  off[n] = total.
+__global__ __launch_bounds__(1024) void k_scan_tiles(const unsigned* __restrict__ cnt, unsigned* __restrict__ off,
+                                                     unsigned n, Ctl* ctl) {
+  __shared__ unsigned part[1024 / 64];
+  __shared__ unsigned carry_s;
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  if (t == 0) carry_s = 0;
+  __syncthreads();
+  for (unsigned base = 0; base < n; base += 1024) {
+    const unsigned i = base + t;
+    const unsigned v = (i < n) ? cnt[i] : 0u;
+    unsigned incl = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      unsigned o = __shfl_up(incl, d);
+      if (lane >= d) incl += o;
+    }
+    if (lane == 63) part[wave] = incl;
+    __syncthreads();
+    unsigned woff = 0;
+    for (int w = 0; w < wave; w++) woff += part[w];
+    const unsigned carry = carry_s;
+    if (i < n) off[i] = carry + woff + incl - v;
+    __syncthreads();
+    if (t == 1023) carry_s = carry + woff + incl;
+    __syncthreads();
+  }
+  if (t == 0) { off[n] = carry_s; ctl->cnt_total = carry_s; }
+}
+
+// Two-level scheme, step 3: move every tile-local list to its place in AC_exact[]
+// (dctz-comp-lib.c:478-544 order: lists are already block-major, j ascending).
+// QT: clamp the table (:450-461) and normalise on the way (:488-518).
+template <typename T, int MODE>
+__global__ __launch_bounds__(WG) void k_compact_ac(FwdParams<T> p, double eb, unsigned nlists) {
+  using Bits = typename Traits<T>::Bits;
+  __shared__ T q[64];
+  if (MODE == DCTZHIP_QT) {
+    if (threadIdx.x < 64) {
+      T v = Traits<T>::from_bits((Bits)p.ctl->qraw[threadIdx.x]);
+      if (v < T(1)) v = T(1);
+      q[threadIdx.x] = v;
+    }
+    __syncthreads();
+  }
+  for (unsigned l = blockIdx.x; l < nlists; l += gridDim.x) {
+    const unsigned n = p.tile_cnt[l], dst = p.tile_off[l];
+    const size_t src = (size_t)l * TILE_ELEMS;
+    for (unsigned i = threadIdx.x; i < n; i += WG) {
+      if (MODE == DCTZHIP_EC) p.ac[dst + i] = p.ac_tmp[src + i];
+      else p.ac[dst + i] = (float)qt_normalise(p.qt_item[src + i], q[p.qt_j[src + i]], eb, T(10), p.range_min, p.range_max);
+    }
+  }
+}
+
 // =============================================================== decompress ==
 // Fused: de-quantise (dctz-decomp-lib.c:389-417 / :438-463; gen_bins
 // binning.c:12-50) -> DCT-III per block (:428, dct.c:115-205) -> de-scale (:494-511).
+// Two-level scheme, decode side: per-tile count of "stored exactly" flags
+// (bin id 255 at j != 0, dctz-decomp-lib.c:400 / :446), 1 byte per element read.
+__global__ __launch_bounds__(WG) void k_count_tiles(const uint8_t* __restrict__ bin, unsigned nfull, unsigned ntiles,
+                                                    unsigned* __restrict__ tile_cnt) {
+  __shared__ unsigned part[WG / 64];
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  for (unsigned tile_id = blockIdx.x; tile_id < ntiles; tile_id += gridDim.x) {
+    const unsigned blks_here = min((unsigned)TILE_BLKS, nfull - tile_id * TILE_BLKS);
+    unsigned c = 0;
+    if ((unsigned)(t >> 2) < blks_here) {
+      const uint4 wv = reinterpret_cast<const uint4*>(bin + (size_t)tile_id * TILE_ELEMS)[t];
+      const unsigned w[4] = {wv.x, wv.y, wv.z, wv.w};
+#pragma unroll
+      for (int i = 0; i < 16; i++)
+        if (((w[i >> 2] >> (8 * (i & 3))) & 255u) == 255u && ((t & 3) * 16 + i) != 0) c++;
+    }
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) c += __shfl_down(c, d);
+    if (lane == 0) part[wave] = c;
+    __syncthreads();
+    if (t == 0) tile_cnt[tile_id] = part[0] + part[1] + part[2] + part[3];
+    __syncthreads();
+  }
+}
+
 // Loop order per tile k: ticket(k) -> load bins(k) -> count + scan + look-back(k)
 // -> store tile k-1 (its IDCT output is still in LDS) -> gather coefficients(k)
 // -> IDCT(k).  The 32 KiB of stores of tile k-1 are issued AFTER the look-back of
@@ -918,11 +945,19 @@ __global__ __launch_bounds__(WG, DCTZ_MINWAVES) void k_decompress(InvParams<T> p
   unsigned prev_id = 0;
   Stamps st;
   if (FEAT & F_STAMP) st.start();
+  unsigned static_id = blockIdx.x;
   for (;;) {
-    if (t == 0) sc[5] = take_ticket<FEAT>(p.ctl, p.ngroups);
-    __syncthreads();                     // also: every lane is done with sc[] of the previous tile
-    if ((FEAT & F_STAMP) && t == 0) st.mark(0);
-    const unsigned tile_id = sc[5];
+    unsigned tile_id;
+    if (FEAT & F_LOOKBACK) {
+      if (t == 0) sc[5] = take_ticket<FEAT>(p.ctl, p.ngroups);
+      __syncthreads();                   // also: every lane is done with sc[] of the previous tile
+      if ((FEAT & F_STAMP) && t == 0) st.mark(0);
+      tile_id = sc[5];
+    } else {                             // two-level scheme: static tiles, offsets from k_scan_tiles
+      __syncthreads();
+      tile_id = static_id;
+      static_id += gridDim.x;
+    }
     if (tile_id >= p.ntiles) break;
     const size_t ebase = (size_t)tile_id * TILE_ELEMS;
     const unsigned blks_here = min((unsigned)TILE_BLKS, p.nfull - tile_id * TILE_BLKS);
@@ -942,8 +977,14 @@ __global__ __launch_bounds__(WG, DCTZ_MINWAVES) void k_decompress(InvParams<T> p
     }
     if (!active) mask = 0;
     if ((FEAT & F_STAMP) && t == 0) st.mark(1);                    // bins load
-    unsigned r = tile_scan((unsigned)__popc(mask), tile_id, p.ntiles, sc, p.desc, p.ctl, false, 0u,
-                           (FEAT & F_STAMP) ? &st : nullptr);
+    unsigned r;
+    if (FEAT & F_LOOKBACK) {
+      r = tile_scan((unsigned)__popc(mask), tile_id, p.ntiles, sc, p.desc, p.ctl, false, 0u,
+                    (FEAT & F_STAMP) ? &st : nullptr);
+    } else {
+      unsigned total;
+      r = p.tile_off[tile_id] + tile_scan_local((unsigned)__popc(mask), sc, &total);
+    }
     if ((FEAT & F_STAMP) && t == 0) st.mark(2);
 
     if (pending) {                       // now flush the previous tile (uniform branch)
@@ -1005,7 +1046,7 @@ __global__ __launch_bounds__(64) void k_decompress_rem(InvParams<T> p, int l) {
   const bool exc = (k < l) && (k != 0) && (b == 255u);
   const unsigned long long m = __ballot(exc);
   const unsigned rank = (unsigned)__popcll(m & ((1ull << k) - 1ull));
-  const unsigned start = p.ctl->cnt_total;
+  const unsigned start = p.tile_off ? p.tile_off[p.ntiles] : p.ctl->cnt_total;
   cr[k] = T(0); ci[k] = T(0); cr[k + 64] = T(0); ci[k + 64] = T(0);
   if (k < l) {
     T val;
@@ -1161,7 +1202,7 @@ void launch_scale(T* x, size_t n, T sf, int grid, hipStream_t s) {
 
 template <typename T, int FEAT>
 static void launch_compress_f(const FwdParams<T>& p, int mode, bool scale, int grid, hipStream_t s) {
-  const size_t sm = fwd_smem<T>((FEAT & F_PIPE) && mode == DCTZHIP_EC);
+  const size_t sm = fwd_smem<T>(false);
   if (mode == DCTZHIP_EC) {
     if (scale) hipLaunchKernelGGL((k_compress<T, DCTZHIP_EC, true, FEAT>), dim3(grid), dim3(WG), sm, s, p);
     else hipLaunchKernelGGL((k_compress<T, DCTZHIP_EC, false, FEAT>), dim3(grid), dim3(WG), sm, s, p);
@@ -1172,14 +1213,10 @@ static void launch_compress_f(const FwdParams<T>& p, int mode, bool scale, int g
 }
 template <typename T>
 void launch_compress(const FwdParams<T>& p, int mode, bool scale, int grid, int feat, hipStream_t s) {
-  if ((feat & 7) == 7) { launch_compress_f<T, 7>(p, mode, scale, grid, s); return; }
-  if (feat & 4) { launch_compress_f<T, 4>(p, mode, scale, grid, s); return; }
-  switch (feat & 3) {
-    case 0: launch_compress_f<T, 0>(p, mode, scale, grid, s); break;
-    case 1: launch_compress_f<T, 1>(p, mode, scale, grid, s); break;
-    case 2: launch_compress_f<T, 2>(p, mode, scale, grid, s); break;
-    default: launch_compress_f<T, 3>(p, mode, scale, grid, s); break;
-  }
+  if (!(feat & F_LOOKBACK)) { launch_compress_f<T, 0>(p, mode, scale, grid, s); return; }
+  if (feat & F_STAMP) launch_compress_f<T, F_LOOKBACK | F_STAMP>(p, mode, scale, grid, s);
+  else if (feat & F_GROUP) launch_compress_f<T, F_LOOKBACK | F_GROUP>(p, mode, scale, grid, s);
+  else launch_compress_f<T, F_LOOKBACK>(p, mode, scale, grid, s);
 }
 
 template <typename T>
@@ -1198,6 +1235,20 @@ void launch_qt_finish(const FwdParams<T>& p, double eb, int grid, hipStream_t s)
   hipLaunchKernelGGL(k_qt_finish<T>, dim3(grid), dim3(WG), 0, s, p, eb);
 }
 
+void launch_scan_tiles(const unsigned* cnt, unsigned* off, unsigned n, Ctl* ctl, hipStream_t s) {
+  hipLaunchKernelGGL(k_scan_tiles, dim3(1), dim3(1024), 0, s, cnt, off, n, ctl);
+}
+
+void launch_count_tiles(const uint8_t* bin, unsigned nfull, unsigned ntiles, unsigned* tile_cnt, int grid, hipStream_t s) {
+  hipLaunchKernelGGL(k_count_tiles, dim3(grid), dim3(WG), 0, s, bin, nfull, ntiles, tile_cnt);
+}
+
+template <typename T>
+void launch_compact_ac(const FwdParams<T>& p, int mode, double eb, unsigned nlists, int grid, hipStream_t s) {
+  if (mode == DCTZHIP_EC) hipLaunchKernelGGL((k_compact_ac<T, DCTZHIP_EC>), dim3(grid), dim3(WG), 0, s, p, eb, nlists);
+  else hipLaunchKernelGGL((k_compact_ac<T, DCTZHIP_QT>), dim3(grid), dim3(WG), 0, s, p, eb, nlists);
+}
+
 template <typename T, int FEAT>
 static void launch_decompress_f(const InvParams<T>& p, int mode, bool scale, int grid, hipStream_t s) {
   const size_t sm = inv_smem<T>();
@@ -1211,13 +1262,10 @@ static void launch_decompress_f(const InvParams<T>& p, int mode, bool scale, int
 }
 template <typename T>
 void launch_decompress(const InvParams<T>& p, int mode, bool scale, int grid, int feat, hipStream_t s) {
-  if (feat & 4) { launch_decompress_f<T, 4>(p, mode, scale, grid, s); return; }
-  switch (feat & 3) {
-    case 0: launch_decompress_f<T, 0>(p, mode, scale, grid, s); break;
-    case 1: launch_decompress_f<T, 1>(p, mode, scale, grid, s); break;
-    case 2: launch_decompress_f<T, 2>(p, mode, scale, grid, s); break;
-    default: launch_decompress_f<T, 3>(p, mode, scale, grid, s); break;
-  }
+  if (!(feat & F_LOOKBACK)) { launch_decompress_f<T, 0>(p, mode, scale, grid, s); return; }
+  if (feat & F_STAMP) launch_decompress_f<T, F_LOOKBACK | F_STAMP>(p, mode, scale, grid, s);
+  else if (feat & F_GROUP) launch_decompress_f<T, F_LOOKBACK | F_GROUP>(p, mode, scale, grid, s);
+  else launch_decompress_f<T, F_LOOKBACK>(p, mode, scale, grid, s);
 }
 
 template <typename T>
@@ -1258,6 +1306,7 @@ void launch_dct_blocks(const T* x, T* out, const T* gtab, const T* rtab, size_t 
   template void launch_compress<T>(const FwdParams<T>&, int, bool, int, int, hipStream_t);              \
   template void launch_compress_rem<T>(const FwdParams<T>&, int, bool, int, hipStream_t);               \
   template void launch_qt_finish<T>(const FwdParams<T>&, double, int, hipStream_t);                     \
+  template void launch_compact_ac<T>(const FwdParams<T>&, int, double, unsigned, int, hipStream_t);     \
   template void launch_decompress<T>(const InvParams<T>&, int, bool, int, int, hipStream_t);            \
   template void launch_decompress_rem<T>(const InvParams<T>&, int, bool, int, hipStream_t);             \
   template void launch_dct_blocks<T>(const T*, T*, const T*, const T*, size_t, bool, int, hipStream_t);

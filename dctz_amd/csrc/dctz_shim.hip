@@ -41,6 +41,11 @@ struct dctzhip_ctx {
   size_t desc_cap = 0;              // tiles
   double* part = nullptr;           // stats partials
   double* stats_out = nullptr;      // 4 doubles
+  float* ac_tmp = nullptr;          // two-level scheme: tile-local AC_exact lists
+  size_t ac_tmp_cap = 0;            // floats
+  unsigned* tile_cnt = nullptr;     // two-level scheme: per-tile counts / exclusive prefix
+  unsigned* tile_off = nullptr;
+  size_t tile_cap = 0;              // entries
   void* qt_item = nullptr;
   uint8_t* qt_j = nullptr;
   size_t qt_cap = 0;                // bytes of qt_item
@@ -48,10 +53,10 @@ struct dctzhip_ctx {
   // pinned host staging
   unsigned char* h_pin = nullptr;   // [0,64): stats, [64, 64+sizeof(Ctl)): ctl, then tables
   // profiling
-  int feat = 0;                     // compress kernel features: 1 pipeline, 2 grouped tickets, 4 stamps (DCTZHIP_FEAT)
-  int feat_d = 2;                   // decompress kernel features (DCTZHIP_FEAT overrides both)
+  int feat = 0;                     // 0: two-level scheme (default); 1: single-pass look-back kernels,
+  int feat_d = 0;                   //    +2 grouped tickets, +4 phase stamps (DCTZHIP_FEAT sets both)
   int fastdiv = 1;                  // hoisted-reciprocal division (DCTZHIP_FASTDIV)
-  int wg_per_cu = 4;                // persistent grid = CUs * this (DCTZHIP_WG_PER_CU)
+  int wg_per_cu = 3;                // persistent grid = CUs * this = resident workgroups (DCTZHIP_WG_PER_CU)
   int profiling = 0;
   hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
   dctzhip_timings last = {0, 0, 0, 0};
@@ -130,7 +135,7 @@ extern "C" void dctzhip_ctx_destroy(dctzhip_ctx* c) {
   (void)hipSetDevice(c->device);
   (void)hipStreamSynchronize(c->stream);
   if (c->side_stream) { (void)hipStreamSynchronize(c->side_stream); (void)hipStreamDestroy(c->side_stream); }
-  void* bufs[] = {c->serial_out, c->tab_f64, c->tab_f32, c->rtab, c->qtab, c->ctl, c->desc, c->part, c->stats_out, c->qt_item, c->qt_j};
+  void* bufs[] = {c->ac_tmp, c->tile_cnt, c->tile_off, c->serial_out, c->tab_f64, c->tab_f32, c->rtab, c->qtab, c->ctl, c->desc, c->part, c->stats_out, c->qt_item, c->qt_j};
   for (void* b : bufs) if (b) (void)hipFree(b);
   if (c->h_pin) (void)hipHostFree(c->h_pin);
   for (int i = 0; i < 6; i++) if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
@@ -195,29 +200,41 @@ static unsigned divisor_in_window(int dtype, double d) {
 
 static size_t elem_size(int dtype) { return dtype == DCTZHIP_F64 ? 8 : 4; }
 
-static int ensure_scratch(dctzhip_ctx* c, size_t n, int dtype, int mode) {
-  const size_t ntiles = (n / 64 + TILE_BLKS - 1) / TILE_BLKS + 1;
-  if (ntiles > c->desc_cap) {
-    if (c->desc) HIPCHK(c, hipFree(c->desc));
-    c->desc = nullptr; c->desc_cap = 0;
-    const size_t cap = (ntiles + 1) & ~(size_t)1;      // even -> bytes are a multiple of 16
-    HIPCHK(c, hipMalloc(&c->desc, cap * sizeof(unsigned long long)));
-    c->desc_cap = cap;
+template <typename P>
+static int regrow(dctzhip_ctx* c, P** ptr, size_t* cap, size_t need, size_t elem) {
+  if (need <= *cap) return DCTZHIP_OK;
+  if (*ptr) HIPCHK(c, hipFree(*ptr));
+  *ptr = nullptr; *cap = 0;
+  HIPCHK(c, hipMalloc(ptr, need * elem));
+  *cap = need;
+  return DCTZHIP_OK;
+}
+
+// compress = true: scratch of the compress stage (tile-local lists); else decode (counts only)
+static int ensure_scratch(dctzhip_ctx* c, size_t n, int dtype, int mode, bool compress = true) {
+  const size_t ntiles = (n / 64 + TILE_BLKS - 1) / TILE_BLKS;
+  const size_t lists = ntiles + 1;                     // + the remainder block's list
+  int rc;
+  if ((c->feat | c->feat_d) & 1) {                     // single-pass kernels: look-back descriptors
+    size_t cap = (ntiles + 2) & ~(size_t)1;            // even -> bytes are a multiple of 16
+    if ((rc = regrow(c, &c->desc, &c->desc_cap, cap, sizeof(unsigned long long)))) return rc;
   }
+  {
+    size_t cap = c->tile_cap;
+    if ((rc = regrow(c, &c->tile_cnt, &cap, lists + 1, sizeof(unsigned)))) return rc;
+    if ((rc = regrow(c, &c->tile_off, &c->tile_cap, lists + 1, sizeof(unsigned)))) return rc;
+  }
+  if (!compress) return DCTZHIP_OK;
+  const size_t slots = lists * TILE_ELEMS;             // two-level: list l lives at l * 4096
+  const size_t items = (c->feat & 1) ? n : slots;
   if (mode == DCTZHIP_QT) {
-    const size_t need = n * elem_size(dtype);
-    if (need > c->qt_cap) {
-      if (c->qt_item) HIPCHK(c, hipFree(c->qt_item));
-      c->qt_item = nullptr; c->qt_cap = 0;
-      HIPCHK(c, hipMalloc(&c->qt_item, need));
-      c->qt_cap = need;
-    }
-    if (n > c->qtj_cap) {
-      if (c->qt_j) HIPCHK(c, hipFree(c->qt_j));
-      c->qt_j = nullptr; c->qtj_cap = 0;
-      HIPCHK(c, hipMalloc(&c->qt_j, n));
-      c->qtj_cap = n;
-    }
+    size_t cap_b = c->qt_cap;
+    char* qi = (char*)c->qt_item;
+    if ((rc = regrow(c, &qi, &cap_b, items * elem_size(dtype), 1))) return rc;
+    c->qt_item = qi; c->qt_cap = cap_b;
+    if ((rc = regrow(c, &c->qt_j, &c->qtj_cap, items, 1))) return rc;
+  } else if (!(c->feat & 1)) {
+    if ((rc = regrow(c, &c->ac_tmp, &c->ac_tmp_cap, slots, sizeof(float)))) return rc;
   }
   return DCTZHIP_OK;
 }
@@ -284,8 +301,9 @@ static int compress_impl(dctzhip_ctx* c, const T* d_in, size_t n, double eb, int
   const unsigned ntiles = (nfull + TILE_BLKS - 1) / TILE_BLKS;
   const unsigned nblk = nfull + (rem ? 1 : 0);
 
+  const bool two_level = !(c->feat & 1);
   HIPCHK(c, hipMemsetAsync(c->ctl, 0, sizeof(Ctl), s));
-  if (ntiles) HIPCHK(c, hipMemsetAsync(c->desc, 0, ((ntiles + 1) & ~1u) * sizeof(unsigned long long), s));
+  if (ntiles && !two_level) HIPCHK(c, hipMemsetAsync(c->desc, 0, ((ntiles + 1) & ~1u) * sizeof(unsigned long long), s));
 
   // ---- calc_data_stat (util.c:12-44) ----------------------------------------
   if (c->profiling) HIPCHK(c, hipEventRecord(c->ev[0], s));
@@ -309,6 +327,9 @@ static int compress_impl(dctzhip_ctx* c, const T* d_in, size_t n, double eb, int
   FwdParams<T> p;
   p.x = d_in; p.bin = d_bin; p.dc = d_dc; p.ac = d_ac; p.scaled = d_scaled; p.coef = d_coef;
   p.qt_item = reinterpret_cast<T*>(c->qt_item); p.qt_j = c->qt_j;
+  p.ac_tmp = c->ac_tmp;
+  p.tile_cnt = two_level ? c->tile_cnt : nullptr;
+  p.tile_off = two_level ? c->tile_off : nullptr;
   p.tab = tab_of<T>(c); p.rtab = reinterpret_cast<const T*>(c->rtab);
   p.ctl = c->ctl; p.desc = c->desc;
   p.nfull = nfull; p.ntiles = ntiles; p.last_is_full = rem ? 0u : 1u; p.ngroups = 1;
@@ -333,7 +354,13 @@ static int compress_impl(dctzhip_ctx* c, const T* d_in, size_t n, double eb, int
   }
   if (c->profiling) HIPCHK(c, hipEventRecord(c->ev[3], s));
   if (rem) launch_compress_rem<T>(p, mode, scale, rem, s);
-  if (mode == DCTZHIP_QT) launch_qt_finish<T>(p, eb, c->num_cu * 4, s);
+  if (two_level) {                                  // stitch the tile-local lists into AC_exact[]
+    const unsigned nlists = ntiles + (rem ? 1u : 0u);
+    launch_scan_tiles(c->tile_cnt, c->tile_off, nlists, c->ctl, s);
+    launch_compact_ac<T>(p, mode, eb, nlists, c->num_cu * 8, s);
+  } else if (mode == DCTZHIP_QT) {
+    launch_qt_finish<T>(p, eb, c->num_cu * 4, s);
+  }
   if (c->profiling) HIPCHK(c, hipEventRecord(c->ev[4], s));
   HIPCHK(c, hipGetLastError());
 
@@ -489,8 +516,9 @@ static int decompress_impl(dctzhip_ctx* c, const uint8_t* d_bin, const float* d_
   const unsigned nfull = (unsigned)(n / 64);
   const int rem = (int)(n % 64);
   const unsigned ntiles = (nfull + TILE_BLKS - 1) / TILE_BLKS;
+  const bool two_level = !(c->feat_d & 1);
   HIPCHK(c, hipMemsetAsync(c->ctl, 0, sizeof(Ctl), s));
-  if (ntiles) HIPCHK(c, hipMemsetAsync(c->desc, 0, ((ntiles + 1) & ~1u) * sizeof(unsigned long long), s));
+  if (ntiles && !two_level) HIPCHK(c, hipMemsetAsync(c->desc, 0, ((ntiles + 1) & ~1u) * sizeof(unsigned long long), s));
   if (mode == DCTZHIP_QT) {
     T* hq = reinterpret_cast<T*>(c->h_pin + PIN_TAB + sizeof(double) * RTAB_SIZE);
     memcpy(hq, qtable_host, sizeof(T) * 64);
@@ -502,6 +530,7 @@ static int decompress_impl(dctzhip_ctx* c, const uint8_t* d_bin, const float* d_
   p.bin = d_bin; p.dc = d_dc; p.ac = d_ac; p.out = d_out;
   p.tab = tab_of<T>(c); p.rtab = reinterpret_cast<const T*>(c->rtab); p.qtab = reinterpret_cast<const T*>(c->qtab);
   p.ctl = c->ctl; p.desc = c->desc;
+  p.tile_off = two_level ? c->tile_off : nullptr;
   p.nfull = nfull; p.ntiles = ntiles; p.ac_count = ac_count; p.ngroups = 1;
   p.sf = (T)sf;
   // gen_bins / gen_bins_f (binning.c:17 / :37): bin_width = error_bound*2*BRSF in
@@ -512,7 +541,12 @@ static int decompress_impl(dctzhip_ctx* c, const uint8_t* d_bin, const float* d_
   p.eb = eb;
   const bool scale = (p.sf != (T)1.0);            // :496 / :505
 
-  if (c->profiling) { HIPCHK(c, hipEventRecord(c->ev[0], s)); HIPCHK(c, hipEventRecord(c->ev[1], s)); HIPCHK(c, hipEventRecord(c->ev[2], s)); }
+  if (c->profiling) HIPCHK(c, hipEventRecord(c->ev[0], s));
+  if (two_level) {                                  // per-tile flag counts -> exclusive prefix
+    if (ntiles) launch_count_tiles(d_bin, nfull, ntiles, c->tile_cnt, c->num_cu * 8, s);
+    launch_scan_tiles(c->tile_cnt, c->tile_off, ntiles, c->ctl, s);
+  }
+  if (c->profiling) { HIPCHK(c, hipEventRecord(c->ev[1], s)); HIPCHK(c, hipEventRecord(c->ev[2], s)); }
   if (ntiles) {
     const unsigned cap = (unsigned)(c->num_cu * c->wg_per_cu);
     const int grid = (int)(cap < ntiles ? cap : ntiles);
@@ -544,7 +578,7 @@ extern "C" int dctzhip_decompress(dctzhip_ctx* c, const void* d_bin, const float
   if (!aligned16(d_bin) || !aligned16(d_out)) return fail(c, DCTZHIP_E_ARG, "device buffers must be 16-byte aligned");
   if (mode == DCTZHIP_QT && !qtable_host) return fail(c, DCTZHIP_E_ARG, "QT mode needs the 64-entry table");
   HIPCHK(c, hipSetDevice(c->device));
-  rc = ensure_scratch(c, n, dtype, DCTZHIP_EC);
+  rc = ensure_scratch(c, n, dtype, DCTZHIP_EC, false);
   if (rc) return rc;
   if (dtype == DCTZHIP_F64)
     return decompress_impl<double>(c, (const uint8_t*)d_bin, d_dc, d_ac, ac_count, qtable_host, n, eb, sf, mode, (double*)d_out);
