@@ -80,6 +80,7 @@ struct FwdParams {
   unsigned last_is_full;           // N % 64 == 0
   unsigned fast_sf, fast_bw;       // divisor inside FastDiv's exponent window (host check)
   unsigned ngroups;                // ticket groups, min(8, grid)
+  unsigned prefetch;               // two-level kernel: request the next tile before (1) / after (0) the emit phase
   T sf, bin_width, range_min, range_max;
 };
 

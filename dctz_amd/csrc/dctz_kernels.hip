@@ -337,7 +337,9 @@ __device__ __forceinline__ void stage_tile(T* tile, typename Traits<T>::Vec (&v)
       a = Traits<T>::pack(el);
       if (scaled != nullptr && e < valid) reinterpret_cast<Vec*>(scaled + ebase)[i * WG + t] = a;
     }
-    *reinterpret_cast<Vec*>(&tile[tile_idx<T>((int)e)]) = a;
+    // element (i*WG + t)*EPV lives at block i*(WG*EPV/64) + (t*EPV >> 6): one base
+    // address per thread plus a compile-time stride (immediate offsets)
+    *reinterpret_cast<Vec*>(tile + tile_idx<T>(t * EPV) + i * (WG * EPV / 64) * Traits<T>::PITCH) = a;
   }
 }
 
@@ -364,7 +366,7 @@ __device__ __forceinline__ void load_tile(T* tile, const T* __restrict__ x, size
       Traits<T>::div(v[i], sf);
       if (scaled != nullptr && e < valid) reinterpret_cast<Vec*>(scaled + ebase)[i * WG + t] = v[i];
     }
-    *reinterpret_cast<Vec*>(&tile[tile_idx<T>((int)e)]) = v[i];
+    *reinterpret_cast<Vec*>(tile + tile_idx<T>(t * EPV) + i * (WG * EPV / 64) * Traits<T>::PITCH) = v[i];
   }
 }
 
@@ -377,7 +379,7 @@ __device__ __forceinline__ void store_tile(const T* tile, T* __restrict__ out, s
 #pragma unroll
   for (int i = 0; i < NV; i++) {
     const unsigned e = (unsigned)(i * WG + t) * EPV;
-    Vec v = *reinterpret_cast<const Vec*>(&tile[tile_idx<T>((int)e)]);
+    Vec v = *reinterpret_cast<const Vec*>(tile + tile_idx<T>(t * EPV) + i * (WG * EPV / 64) * Traits<T>::PITCH);
     if (SCALE) Traits<T>::mul(v, sf);             // dctz-decomp-lib.c:494-511
     if (e < valid) dst[i * WG + t] = v;
   }
@@ -720,6 +722,8 @@ __global__ __launch_bounds__(WG, DCTZ_MINWAVES) void k_compress(FwdParams<T> p) 
     for (unsigned tile_id = blockIdx.x; tile_id < p.ntiles; tile_id += gridDim.x) {
       const size_t ebase = (size_t)tile_id * TILE_ELEMS;
       const unsigned blks_here = min((unsigned)TILE_BLKS, p.nfull - tile_id * TILE_BLKS);
+      // (carrying the next tile's 32 KiB in registers across the emit phase was
+      // tried: it costs a wave per SIMD or spills, and loses -- DESIGN.md section 6)
       Vec v[NV];
       issue_tile_loads<T>(v, p.x, tile_id, p.ntiles, p.nfull);
       __syncthreads();                               // previous tile's LDS reads are done
@@ -843,30 +847,40 @@ __global__ __launch_bounds__(WG) void k_qt_finish(FwdParams<T> p, double eb) {
 __global__ __launch_bounds__(1024) void k_scan_tiles(const unsigned* __restrict__ cnt, unsigned* __restrict__ off,
                                                      unsigned n, Ctl* ctl) {
   __shared__ unsigned part[1024 / 64];
-  __shared__ unsigned carry_s;
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-  if (t == 0) carry_s = 0;
-  __syncthreads();
-  for (unsigned base = 0; base < n; base += 1024) {
-    const unsigned i = base + t;
-    const unsigned v = (i < n) ? cnt[i] : 0u;
-    unsigned incl = v;
+  const unsigned chunk = (n + 1023u) / 1024u;       // contiguous entries per thread
+  const unsigned lo = min(n, (unsigned)t * chunk), hi = min(n, lo + chunk);
+  constexpr int RC = 32;                            // chunk <= 32 (<= 128 Mi elements): counts stay in registers
+  unsigned vals[RC];
+  unsigned sum = 0;
+  if (chunk <= RC) {
 #pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-      unsigned o = __shfl_up(incl, d);
-      if (lane >= d) incl += o;
-    }
-    if (lane == 63) part[wave] = incl;
-    __syncthreads();
-    unsigned woff = 0;
-    for (int w = 0; w < wave; w++) woff += part[w];
-    const unsigned carry = carry_s;
-    if (i < n) off[i] = carry + woff + incl - v;
-    __syncthreads();
-    if (t == 1023) carry_s = carry + woff + incl;
-    __syncthreads();
+    for (int k = 0; k < RC; k++) vals[k] = (lo + k < hi) ? cnt[lo + k] : 0u;   // independent loads
+#pragma unroll
+    for (int k = 0; k < RC; k++) sum += vals[k];
+  } else {
+    for (unsigned i = lo; i < hi; i++) sum += cnt[i];
   }
-  if (t == 0) { off[n] = carry_s; ctl->cnt_total = carry_s; }
+  unsigned incl = sum;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    unsigned o = __shfl_up(incl, d);
+    if (lane >= d) incl += o;
+  }
+  if (lane == 63) part[wave] = incl;
+  __syncthreads();
+  unsigned run = incl - sum;
+  for (int w = 0; w < wave; w++) run += part[w];
+  if (chunk <= RC) {
+#pragma unroll
+    for (int k = 0; k < RC; k++) {
+      if (lo + k < hi) off[lo + k] = run;
+      run += vals[k];
+    }
+  } else {
+    for (unsigned i = lo; i < hi; i++) { off[i] = run; run += cnt[i]; }
+  }
+  if (t == 1023) { off[n] = run; ctl->cnt_total = run; }
 }
 
 // Two-level scheme, step 3: move every tile-local list to its place in AC_exact[]
@@ -884,10 +898,12 @@ __global__ __launch_bounds__(WG) void k_compact_ac(FwdParams<T> p, double eb, un
     }
     __syncthreads();
   }
-  for (unsigned l = blockIdx.x; l < nlists; l += gridDim.x) {
+  // one wavefront per list: thousands of short, independent copies in flight
+  const unsigned lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
+  for (unsigned l = blockIdx.x * (WG / 64) + wv; l < nlists; l += gridDim.x * (WG / 64)) {
     const unsigned n = p.tile_cnt[l], dst = p.tile_off[l];
     const size_t src = (size_t)l * TILE_ELEMS;
-    for (unsigned i = threadIdx.x; i < n; i += WG) {
+    for (unsigned i = lane; i < n; i += 64) {
       if (MODE == DCTZHIP_EC) p.ac[dst + i] = p.ac_tmp[src + i];
       else p.ac[dst + i] = (float)qt_normalise(p.qt_item[src + i], q[p.qt_j[src + i]], eb, T(10), p.range_min, p.range_max);
     }

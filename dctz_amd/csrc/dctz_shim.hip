@@ -56,6 +56,7 @@ struct dctzhip_ctx {
   int feat = 0;                     // 0: two-level scheme (default); 1: single-pass look-back kernels,
   int feat_d = 0;                   //    +2 grouped tickets, +4 phase stamps (DCTZHIP_FEAT sets both)
   int fastdiv = 1;                  // hoisted-reciprocal division (DCTZHIP_FASTDIV)
+  int prefetch = 1;                 // compress: request tile k+1 before the emit phase of tile k (DCTZHIP_PREFETCH)
   int wg_per_cu = 3;                // persistent grid = CUs * this = resident workgroups (DCTZHIP_WG_PER_CU)
   int profiling = 0;
   hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
@@ -104,6 +105,7 @@ extern "C" int dctzhip_ctx_create(dctzhip_ctx** out, int device) {
   c->num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
   if (const char* e = getenv("DCTZHIP_FEAT")) { c->feat = atoi(e) & 7; c->feat_d = c->feat; }
   if (const char* e = getenv("DCTZHIP_FASTDIV")) c->fastdiv = atoi(e) != 0;
+  if (const char* e = getenv("DCTZHIP_PREFETCH")) c->prefetch = atoi(e) != 0;
   if (const char* e = getenv("DCTZHIP_WG_PER_CU")) { int v = atoi(e); if (v >= 1 && v <= 8) c->wg_per_cu = v; }
   HIPCHK(nullptr, hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
   c->stream = c->own_stream;
@@ -333,6 +335,7 @@ static int compress_impl(dctzhip_ctx* c, const T* d_in, size_t n, double eb, int
   p.tab = tab_of<T>(c); p.rtab = reinterpret_cast<const T*>(c->rtab);
   p.ctl = c->ctl; p.desc = c->desc;
   p.nfull = nfull; p.ntiles = ntiles; p.last_is_full = rem ? 0u : 1u; p.ngroups = 1;
+  p.prefetch = (unsigned)c->prefetch;
   p.sf = (T)sf;
   p.bin_width = (T)(eb * 2.0 * 1.0);
   p.range_min = (T)(-(half * 2 + 1) * (eb * 1.0));
@@ -357,7 +360,7 @@ static int compress_impl(dctzhip_ctx* c, const T* d_in, size_t n, double eb, int
   if (two_level) {                                  // stitch the tile-local lists into AC_exact[]
     const unsigned nlists = ntiles + (rem ? 1u : 0u);
     launch_scan_tiles(c->tile_cnt, c->tile_off, nlists, c->ctl, s);
-    launch_compact_ac<T>(p, mode, eb, nlists, c->num_cu * 8, s);
+    launch_compact_ac<T>(p, mode, eb, nlists, (int)((nlists + 3) / 4 < (unsigned)(c->num_cu * 32) ? (nlists + 3) / 4 : (unsigned)(c->num_cu * 32)), s);
   } else if (mode == DCTZHIP_QT) {
     launch_qt_finish<T>(p, eb, c->num_cu * 4, s);
   }

@@ -37,7 +37,8 @@ def main():
         kv = dict(s.split("=") for s in spec.split(","))
         os.environ["DCTZHIP_FEAT"] = kv.get("feat", "3")
         os.environ["DCTZHIP_FASTDIV"] = kv.get("fd", "1")
-        os.environ["DCTZHIP_WG_PER_CU"] = kv.get("wg", "4")
+        os.environ["DCTZHIP_WG_PER_CU"] = kv.get("wg", "3")
+        os.environ["DCTZHIP_PREFETCH"] = kv.get("pf", "1")
         c = dctz_amd.Context(0)
         c.set_profiling(True)
         c.reserve(n, tdt, mode)
