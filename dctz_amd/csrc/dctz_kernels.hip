@@ -846,41 +846,46 @@ __global__ __launch_bounds__(WG) void k_qt_finish(FwdParams<T> p, double eb) {
 // (one workgroup; n <= 2^19 entries for the largest legal input).  off[n] = total.
 __global__ __launch_bounds__(1024) void k_scan_tiles(const unsigned* __restrict__ cnt, unsigned* __restrict__ off,
                                                      unsigned n, Ctl* ctl) {
+  // Segments of 8192 entries go through LDS so that global accesses are coalesced
+  // (a strided walk through one CU's address path took 34 us for 32 Ki entries);
+  // in LDS thread t owns 8 consecutive entries at pitch 9 (conflict-free).
+  constexpr unsigned SEG = 8192, PER = SEG / 1024;
+  __shared__ unsigned buf[SEG + SEG / PER];
   __shared__ unsigned part[1024 / 64];
-  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-  const unsigned chunk = (n + 1023u) / 1024u;       // contiguous entries per thread
-  const unsigned lo = min(n, (unsigned)t * chunk), hi = min(n, lo + chunk);
-  constexpr int RC = 32;                            // chunk <= 32 (<= 128 Mi elements): counts stay in registers
-  unsigned vals[RC];
-  unsigned sum = 0;
-  if (chunk <= RC) {
+  __shared__ unsigned carry_s;
+  const unsigned t = threadIdx.x, lane = t & 63u, wave = t >> 6;
+  if (t == 0) carry_s = 0;
+  for (unsigned base = 0; base < n; base += SEG) {
+    const unsigned m = min(SEG, n - base);
+    for (unsigned i = t; i < m; i += 1024) buf[i + i / PER] = cnt[base + i];
+    __syncthreads();
+    unsigned vals[PER], sum = 0;
 #pragma unroll
-    for (int k = 0; k < RC; k++) vals[k] = (lo + k < hi) ? cnt[lo + k] : 0u;   // independent loads
+    for (unsigned k = 0; k < PER; k++) {
+      vals[k] = (t * PER + k < m) ? buf[t * (PER + 1) + k] : 0u;
+      sum += vals[k];
+    }
+    unsigned incl = sum;
 #pragma unroll
-    for (int k = 0; k < RC; k++) sum += vals[k];
-  } else {
-    for (unsigned i = lo; i < hi; i++) sum += cnt[i];
-  }
-  unsigned incl = sum;
+    for (int d = 1; d < 64; d <<= 1) {
+      unsigned o = __shfl_up(incl, d);
+      if (lane >= (unsigned)d) incl += o;
+    }
+    if (lane == 63) part[wave] = incl;
+    __syncthreads();
+    unsigned run = carry_s + incl - sum;
+    for (unsigned w = 0; w < wave; w++) run += part[w];
 #pragma unroll
-  for (int d = 1; d < 64; d <<= 1) {
-    unsigned o = __shfl_up(incl, d);
-    if (lane >= d) incl += o;
-  }
-  if (lane == 63) part[wave] = incl;
-  __syncthreads();
-  unsigned run = incl - sum;
-  for (int w = 0; w < wave; w++) run += part[w];
-  if (chunk <= RC) {
-#pragma unroll
-    for (int k = 0; k < RC; k++) {
-      if (lo + k < hi) off[lo + k] = run;
+    for (unsigned k = 0; k < PER; k++) {
+      buf[t * (PER + 1) + k] = run;
       run += vals[k];
     }
-  } else {
-    for (unsigned i = lo; i < hi; i++) { off[i] = run; run += cnt[i]; }
+    __syncthreads();
+    for (unsigned i = t; i < m; i += 1024) off[base + i] = buf[i + i / PER];
+    if (t == 1023) carry_s = run;                   // inclusive total through this segment
+    __syncthreads();
   }
-  if (t == 1023) { off[n] = run; ctl->cnt_total = run; }
+  if (t == 0) { off[n] = carry_s; ctl->cnt_total = carry_s; }
 }
 
 // Two-level scheme, step 3: move every tile-local list to its place in AC_exact[]
