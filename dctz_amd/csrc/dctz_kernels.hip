@@ -527,16 +527,26 @@ __global__ __launch_bounds__(WG) void k_stats(const T* __restrict__ x, size_t n,
   const Vec* src = reinterpret_cast<const Vec*>(x);
   T mx = T(0), mn = Traits<T>::huge();
   double sum = 0.0;
-  for (size_t i = (size_t)blockIdx.x * WG + threadIdx.x; i < nvec; i += (size_t)gridDim.x * WG) {
-    const Vec v = src[i];
-    T e[EPV];
-    Traits<T>::unpack(v, e);
+  constexpr int UN = 4;                            // each workgroup streams 16 KiB contiguous per trip
+  for (size_t i0 = (size_t)blockIdx.x * WG * UN + threadIdx.x; i0 < nvec; i0 += (size_t)gridDim.x * WG * UN) {
+    Vec v[UN];
 #pragma unroll
-    for (int k = 0; k < EPV; k++) {
-      const T a = fabs(e[k]);
-      mx = a > mx ? a : mx;
-      mn = a < mn ? a : mn;
-      if (i != 0 || k != 0) sum += (double)e[k];
+    for (int u = 0; u < UN; u++) {
+      const size_t i = i0 + (size_t)u * WG;
+      v[u] = (i < nvec) ? src[i] : src[i0];        // a repeated vector changes neither max nor min
+    }
+#pragma unroll
+    for (int u = 0; u < UN; u++) {
+      const size_t i = i0 + (size_t)u * WG;
+      T e[EPV];
+      Traits<T>::unpack(v[u], e);
+#pragma unroll
+      for (int k = 0; k < EPV; k++) {
+        const T a = fabs(e[k]);
+        mx = a > mx ? a : mx;
+        mn = a < mn ? a : mn;
+        if (i < nvec && (i != 0 || k != 0)) sum += (double)e[k];
+      }
     }
   }
   if (blockIdx.x == 0 && threadIdx.x == 0)

@@ -56,6 +56,7 @@ struct dctzhip_ctx {
   int feat = 0;                     // 0: two-level scheme (default); 1: single-pass look-back kernels,
   int feat_d = 0;                   //    +2 grouped tickets, +4 phase stamps (DCTZHIP_FEAT sets both)
   int fastdiv = 1;                  // hoisted-reciprocal division (DCTZHIP_FASTDIV)
+  int stats_grid = 2048;            // workgroups of the statistics kernel (DCTZHIP_STATS_GRID, <= 2048)
   int prefetch = 1;                 // compress: request tile k+1 before the emit phase of tile k (DCTZHIP_PREFETCH)
   int wg_per_cu = 3;                // persistent grid = CUs * this = resident workgroups (DCTZHIP_WG_PER_CU)
   int profiling = 0;
@@ -106,6 +107,7 @@ extern "C" int dctzhip_ctx_create(dctzhip_ctx** out, int device) {
   if (const char* e = getenv("DCTZHIP_FEAT")) { c->feat = atoi(e) & 7; c->feat_d = c->feat; }
   if (const char* e = getenv("DCTZHIP_FASTDIV")) c->fastdiv = atoi(e) != 0;
   if (const char* e = getenv("DCTZHIP_PREFETCH")) c->prefetch = atoi(e) != 0;
+  if (const char* e = getenv("DCTZHIP_STATS_GRID")) { int v = atoi(e); if (v >= 1 && v <= STATS_GRID_MAX) c->stats_grid = v; }
   if (const char* e = getenv("DCTZHIP_WG_PER_CU")) { int v = atoi(e); if (v >= 1 && v <= 8) c->wg_per_cu = v; }
   HIPCHK(nullptr, hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
   c->stream = c->own_stream;
@@ -312,9 +314,9 @@ static int compress_impl(dctzhip_ctx* c, const T* d_in, size_t n, double eb, int
   double max_abs, min_abs, sum;
   {
     const size_t nvec = n / Traits<T>::EPV;
-    int sgrid = (int)((nvec + WG - 1) / WG);
+    int sgrid = (int)((nvec + WG * 4 - 1) / (WG * 4));
     if (sgrid < 1) sgrid = 1;
-    if (sgrid > STATS_GRID_MAX) sgrid = STATS_GRID_MAX;
+    if (sgrid > c->stats_grid) sgrid = c->stats_grid;
     launch_stats<T>(d_in, n, c->part, sgrid, c->stats_out, s);
     if (c->profiling) HIPCHK(c, hipEventRecord(c->ev[1], s));
     double* hs = reinterpret_cast<double*>(c->h_pin + PIN_STATS);
@@ -408,9 +410,9 @@ template <typename T>
 static int stats_impl(dctzhip_ctx* c, const T* d_in, size_t n, double* max_abs, double* min_abs, double* sum) {
   hipStream_t s = c->stream;
   const size_t nvec = n / Traits<T>::EPV;
-  int sgrid = (int)((nvec + WG - 1) / WG);
+  int sgrid = (int)((nvec + WG * 4 - 1) / (WG * 4));
   if (sgrid < 1) sgrid = 1;
-  if (sgrid > STATS_GRID_MAX) sgrid = STATS_GRID_MAX;
+  if (sgrid > c->stats_grid) sgrid = c->stats_grid;
   launch_stats<T>(d_in, n, c->part, sgrid, c->stats_out, s);
   double* hs = reinterpret_cast<double*>(c->h_pin + PIN_STATS);
   HIPCHK(c, hipMemcpyAsync(hs, c->stats_out, 3 * sizeof(double), hipMemcpyDeviceToHost, s));
