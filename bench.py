@@ -136,6 +136,18 @@ def main():
     ach_d = bytes_d_main / (acc["d_main"] * 1e-3) / 1e9
     ach_s = bytes_stats / (acc["c_stats"] * 1e-3) / 1e9
 
+    # HBM traffic of the dominant kernel from the PMC pass of the SAME command
+    # (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate runs, gfx950 correction
+    # applied: profiles/r01_pmc_traffic.json says how); null if no matching record
+    traffic = None
+    try:
+        rec_t = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
+        key = f"{a.dtype}_{a.n}_{a.mode}_{a.eb:g}"
+        if key in rec_t.get("k_compress", {}):
+            traffic = rec_t["k_compress"][key]["hbm_bytes_per_launch"]
+    except (OSError, ValueError):
+        pass
+
     # ---- optional: the one real exchange step (streams -> rank 0 over RCCL) ----
     gather_ms = None
     if a.gather and dist is not None:
@@ -178,7 +190,7 @@ def main():
             "pct_hbm_peak_input": 100.0 * (n * es / (ms_per_step * 1e-3) / 1e9) / HBM_PEAK_GBPS,
             "roofline": {"bound": "hbm", "kernel": "k_compress (fused scale+DCT-II+binning+ordered AC_exact)",
                          "achieved": ach_c, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": ach_c / HBM_PEAK_GBPS,
-                         "traffic": None, "algorithmic_bytes_per_launch": bytes_c_main,
+                         "traffic": traffic, "algorithmic_bytes_per_launch": bytes_c_main,
                          "avg_launch_ms": acc["c_main"]},
             "kernels": {"k_stats": {"ms": acc["c_stats"], "GBps": ach_s, "frac": ach_s / HBM_PEAK_GBPS},
                         "k_compress": {"ms": acc["c_main"], "GBps": ach_c, "frac": ach_c / HBM_PEAK_GBPS},

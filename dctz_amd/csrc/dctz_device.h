@@ -11,6 +11,9 @@
 
 namespace dctz {
 
+#ifndef DCTZ_PITCH
+#define DCTZ_PITCH 66      // LDS elements per block (fp64); fp32 uses DCTZ_PITCH + 2 when even
+#endif
 constexpr int TILE_BLKS = 64;             // blocks per tile
 constexpr int TILE_ELEMS = TILE_BLKS * 64;
 constexpr int WG = 256;                   // threads per workgroup (4 wavefronts)
@@ -20,7 +23,7 @@ template <> struct Traits<double> {
   using Vec = double2;
   using Bits = unsigned long long;
   static constexpr int EPV = 2;           // elements per 16-byte vector
-  static constexpr int PITCH = 64 + 2;    // LDS elements per block (16 B of padding)
+  static constexpr int PITCH = DCTZ_PITCH;   // LDS elements per block
   __host__ __device__ static Vec zero() { return make_double2(0.0, 0.0); }
   __device__ static void div(Vec& v, double s) { v.x = v.x / s; v.y = v.y / s; }
   __device__ static void mul(Vec& v, double s) { v.x = v.x * s; v.y = v.y * s; }
@@ -33,7 +36,7 @@ template <> struct Traits<float> {
   using Vec = float4;
   using Bits = unsigned int;
   static constexpr int EPV = 4;
-  static constexpr int PITCH = 64 + 4;
+  static constexpr int PITCH = (DCTZ_PITCH % 2) ? DCTZ_PITCH : DCTZ_PITCH + 2;
   __host__ __device__ static Vec zero() { return make_float4(0.f, 0.f, 0.f, 0.f); }
   __device__ static void div(Vec& v, float s) { v.x = v.x / s; v.y = v.y / s; v.z = v.z / s; v.w = v.w / s; }
   __device__ static void mul(Vec& v, float s) { v.x = v.x * s; v.y = v.y * s; v.z = v.z * s; v.w = v.w * s; }
@@ -80,7 +83,6 @@ struct FwdParams {
   unsigned last_is_full;           // N % 64 == 0
   unsigned fast_sf, fast_bw;       // divisor inside FastDiv's exponent window (host check)
   unsigned ngroups;                // ticket groups, min(8, grid)
-  unsigned prefetch;               // two-level kernel: request the next tile before (1) / after (0) the emit phase
   T sf, bin_width, range_min, range_max;
 };
 

@@ -105,7 +105,10 @@ template <> struct FastDiv<double> {
     d = dd; ok = okk;
     double r = __builtin_amdgcn_rcp(dd);
     double e = fma(-dd, r, 1.0); r = fma(r, e, r);
-    e = fma(-dd, r, 1.0); y = fma(r, e, r);
+    e = fma(-dd, r, 1.0); r = fma(r, e, r);
+    // the divisor is a kernel argument, so y is wave-uniform: keep it in SGPRs
+    y = __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(r)),
+                         __builtin_amdgcn_readfirstlane(__double2loint(r)));
   }
   __device__ __forceinline__ double core(double x) const {
     const double q = x * y;
@@ -128,7 +131,7 @@ template <> struct FastDiv<float> {
     d = dd; ok = okk;
     const float r = __builtin_amdgcn_rcpf(dd);
     const float e = fmaf(-dd, r, 1.0f);
-    y = fmaf(e, r, r);
+    y = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(fmaf(e, r, r))));   // wave-uniform -> SGPR
   }
   __device__ __forceinline__ float core(float x) const {
     const float q = x * y;
@@ -297,6 +300,32 @@ __device__ __forceinline__ unsigned take_ticket(Ctl* ctl, unsigned ngroups) {
   return __hip_atomic_fetch_add(&ctl->ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
+// 16-byte vector <-> LDS.  With an odd pitch (bank-conflict-free quad accesses,
+// see fwd_quad_block) a block base is only element-aligned, so the vector moves
+// as individual elements (the compiler pairs them into ds_*2_b64 / ds_*2_b32).
+template <typename T>
+__device__ __forceinline__ void lds_store_vec(T* p, const typename Traits<T>::Vec& v) {
+  if constexpr ((Traits<T>::PITCH * sizeof(T)) % 16 == 0) {
+    *reinterpret_cast<typename Traits<T>::Vec*>(p) = v;
+  } else {
+    T el[Traits<T>::EPV];
+    Traits<T>::unpack(v, el);
+#pragma unroll
+    for (int k = 0; k < Traits<T>::EPV; k++) p[k] = el[k];
+  }
+}
+template <typename T>
+__device__ __forceinline__ typename Traits<T>::Vec lds_load_vec(const T* p) {
+  if constexpr ((Traits<T>::PITCH * sizeof(T)) % 16 == 0) {
+    return *reinterpret_cast<const typename Traits<T>::Vec*>(p);
+  } else {
+    T el[Traits<T>::EPV];
+#pragma unroll
+    for (int k = 0; k < Traits<T>::EPV; k++) el[k] = p[k];
+    return Traits<T>::pack(el);
+  }
+}
+
 // --------------------------------------------------------- tile load / store --
 // Split form used by the software-pipelined kernels: issue the 16-byte loads of a
 // tile into registers (they stay in flight across the compute phase of the
@@ -339,7 +368,7 @@ __device__ __forceinline__ void stage_tile(T* tile, typename Traits<T>::Vec (&v)
     }
     // element (i*WG + t)*EPV lives at block i*(WG*EPV/64) + (t*EPV >> 6): one base
     // address per thread plus a compile-time stride (immediate offsets)
-    *reinterpret_cast<Vec*>(tile + tile_idx<T>(t * EPV) + i * (WG * EPV / 64) * Traits<T>::PITCH) = a;
+    lds_store_vec<T>(tile + tile_idx<T>(t * EPV) + i * (WG * EPV / 64) * Traits<T>::PITCH, a);
   }
 }
 
@@ -366,7 +395,7 @@ __device__ __forceinline__ void load_tile(T* tile, const T* __restrict__ x, size
       Traits<T>::div(v[i], sf);
       if (scaled != nullptr && e < valid) reinterpret_cast<Vec*>(scaled + ebase)[i * WG + t] = v[i];
     }
-    *reinterpret_cast<Vec*>(tile + tile_idx<T>(t * EPV) + i * (WG * EPV / 64) * Traits<T>::PITCH) = v[i];
+    lds_store_vec<T>(tile + tile_idx<T>(t * EPV) + i * (WG * EPV / 64) * Traits<T>::PITCH, v[i]);
   }
 }
 
@@ -379,7 +408,7 @@ __device__ __forceinline__ void store_tile(const T* tile, T* __restrict__ out, s
 #pragma unroll
   for (int i = 0; i < NV; i++) {
     const unsigned e = (unsigned)(i * WG + t) * EPV;
-    Vec v = *reinterpret_cast<const Vec*>(tile + tile_idx<T>(t * EPV) + i * (WG * EPV / 64) * Traits<T>::PITCH);
+    Vec v = lds_load_vec<T>(tile + tile_idx<T>(t * EPV) + i * (WG * EPV / 64) * Traits<T>::PITCH);
     if (SCALE) Traits<T>::mul(v, sf);             // dctz-decomp-lib.c:494-511
     if (e < valid) dst[i * WG + t] = v;
   }
@@ -388,9 +417,22 @@ __device__ __forceinline__ void store_tile(const T* tile, T* __restrict__ out, s
 // ------------------------------------------------------- in-tile transforms --
 // Forward DCT-II of the 64 blocks of the tile, in place in LDS (dct.c:55-103).
 // Two workgroup barriers inside (after reads, after writes).
+// Quad -> block map of the forward transform.  With an odd pitch a quad's reads
+// hit elements blk + 4*lane + const (mod 32 banks / bank pairs); giving the 8 quads
+// of a half-wave the blocks {0,1,2,3,16,17,18,19} + 4*(h&3) + 32*(h>>2) tiles all
+// 32.  (The inverse reads 8q' + k1, for which consecutive blocks already tile.)
+__device__ __forceinline__ int fwd_quad_block(int quad) {
+#if (DCTZ_PITCH % 2) == 1
+  const int h = quad >> 3, k = quad & 7;
+  return (k & 3) | ((h & 3) << 2) | ((k >> 2) << 4) | ((h >> 2) << 5);
+#else
+  return quad;
+#endif
+}
+
 template <typename T>
 __device__ __forceinline__ void tile_dct_fwd(T* tile, const T* tab) {
-  const int t = threadIdx.x, blk = t >> 2, lane = t & 3;
+  const int t = threadIdx.x, blk = fwd_quad_block(t >> 2), lane = t & 3;
   T* b = tile + blk * Traits<T>::PITCH;
   T yr[8], yi[8];
 #pragma unroll
@@ -656,7 +698,7 @@ __device__ __forceinline__ void emit_tile(const FwdParams<T>& p, const T* tile, 
   T c[16];
 #pragma unroll
   for (int i = 0; i < 16 / EPV; i++) {
-    const Vec cv = *reinterpret_cast<const Vec*>(&tile[blk * Traits<T>::PITCH + j0 + i * EPV]);
+    const Vec cv = lds_load_vec<T>(&tile[blk * Traits<T>::PITCH + j0 + i * EPV]);
     Traits<T>::unpack(cv, &c[i * EPV]);
   }
   unsigned w[4] = {0, 0, 0, 0};
@@ -1047,7 +1089,7 @@ __global__ __launch_bounds__(WG, DCTZ_MINWAVES) void k_decompress(InvParams<T> p
     }
 #pragma unroll
     for (int i = 0; i < 16 / EPV; i++)
-      *reinterpret_cast<Vec*>(&tile[blk * Traits<T>::PITCH + j0 + i * EPV]) = Traits<T>::pack(&c[i * EPV]);
+      lds_store_vec<T>(&tile[blk * Traits<T>::PITCH + j0 + i * EPV], Traits<T>::pack(&c[i * EPV]));
     __syncthreads();
     if ((FEAT & F_STAMP) && t == 0) st.mark(6);                    // gather + de-quantise
     tile_dct_inv<T>(tile, tab);

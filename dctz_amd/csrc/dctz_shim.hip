@@ -57,8 +57,7 @@ struct dctzhip_ctx {
   int feat_d = 0;                   //    +2 grouped tickets, +4 phase stamps (DCTZHIP_FEAT sets both)
   int fastdiv = 1;                  // hoisted-reciprocal division (DCTZHIP_FASTDIV)
   int stats_grid = 2048;            // workgroups of the statistics kernel (DCTZHIP_STATS_GRID, <= 2048)
-  int prefetch = 1;                 // compress: request tile k+1 before the emit phase of tile k (DCTZHIP_PREFETCH)
-  int wg_per_cu = 3;                // persistent grid = CUs * this = resident workgroups (DCTZHIP_WG_PER_CU)
+  int wg_per_cu = 0;                // grid = CUs * this; 0 = resident workgroups per CU: 3 (fp64), 4 (fp32) (DCTZHIP_WG_PER_CU)
   int profiling = 0;
   hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
   dctzhip_timings last = {0, 0, 0, 0};
@@ -106,7 +105,6 @@ extern "C" int dctzhip_ctx_create(dctzhip_ctx** out, int device) {
   c->num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
   if (const char* e = getenv("DCTZHIP_FEAT")) { c->feat = atoi(e) & 7; c->feat_d = c->feat; }
   if (const char* e = getenv("DCTZHIP_FASTDIV")) c->fastdiv = atoi(e) != 0;
-  if (const char* e = getenv("DCTZHIP_PREFETCH")) c->prefetch = atoi(e) != 0;
   if (const char* e = getenv("DCTZHIP_STATS_GRID")) { int v = atoi(e); if (v >= 1 && v <= STATS_GRID_MAX) c->stats_grid = v; }
   if (const char* e = getenv("DCTZHIP_WG_PER_CU")) { int v = atoi(e); if (v >= 1 && v <= 8) c->wg_per_cu = v; }
   HIPCHK(nullptr, hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
@@ -337,7 +335,6 @@ static int compress_impl(dctzhip_ctx* c, const T* d_in, size_t n, double eb, int
   p.tab = tab_of<T>(c); p.rtab = reinterpret_cast<const T*>(c->rtab);
   p.ctl = c->ctl; p.desc = c->desc;
   p.nfull = nfull; p.ntiles = ntiles; p.last_is_full = rem ? 0u : 1u; p.ngroups = 1;
-  p.prefetch = (unsigned)c->prefetch;
   p.sf = (T)sf;
   p.bin_width = (T)(eb * 2.0 * 1.0);
   p.range_min = (T)(-(half * 2 + 1) * (eb * 1.0));
@@ -352,7 +349,7 @@ static int compress_impl(dctzhip_ctx* c, const T* d_in, size_t n, double eb, int
 
   if (c->profiling) HIPCHK(c, hipEventRecord(c->ev[2], s));
   if (ntiles) {
-    const unsigned cap = (unsigned)(c->num_cu * c->wg_per_cu);
+    const unsigned cap = (unsigned)(c->num_cu * (c->wg_per_cu ? c->wg_per_cu : (sizeof(T) == 8 ? 3 : 4)));
     const int grid = (int)(cap < ntiles ? cap : ntiles);
     p.ngroups = grid < 8 ? (unsigned)grid : 8u;
     launch_compress<T>(p, mode, scale, grid, c->feat, s);
@@ -553,7 +550,7 @@ static int decompress_impl(dctzhip_ctx* c, const uint8_t* d_bin, const float* d_
   }
   if (c->profiling) { HIPCHK(c, hipEventRecord(c->ev[1], s)); HIPCHK(c, hipEventRecord(c->ev[2], s)); }
   if (ntiles) {
-    const unsigned cap = (unsigned)(c->num_cu * c->wg_per_cu);
+    const unsigned cap = (unsigned)(c->num_cu * (c->wg_per_cu ? c->wg_per_cu : (sizeof(T) == 8 ? 3 : 4)));
     const int grid = (int)(cap < ntiles ? cap : ntiles);
     p.ngroups = grid < 8 ? (unsigned)grid : 8u;
     launch_decompress<T>(p, mode, scale, grid, c->feat_d, s);

@@ -1,8 +1,8 @@
 #!/usr/bin/env python3
 """A/B of kernel variants in ONE process, interleaved rounds (cdna guide rule 24).
 Variants are selected through the shim's environment knobs at context creation:
-DCTZHIP_FEAT (1 = software pipeline, 2 = grouped tickets), DCTZHIP_FASTDIV,
-DCTZHIP_WG_PER_CU.  Prints median kernel times (HIP events) per variant."""
+DCTZHIP_FEAT (0 = two-level scheme, 1 = single-pass look-back, +2 grouped tickets,
++4 phase stamps), DCTZHIP_FASTDIV, DCTZHIP_WG_PER_CU, DCTZHIP_STATS_GRID.  Prints median kernel times (HIP events) per variant."""
 import argparse
 import json
 import os
@@ -20,7 +20,7 @@ def main():
     ap.add_argument("--dtype", default="f64")
     ap.add_argument("--mode", default="ec")
     ap.add_argument("--eb", type=float, default=1e-3)
-    ap.add_argument("--variants", default="feat=0,fd=0,wg=4;feat=0,fd=1,wg=4;feat=1,fd=1,wg=4;feat=2,fd=1,wg=4;feat=3,fd=1,wg=4;feat=3,fd=1,wg=2;feat=3,fd=1,wg=3")
+    ap.add_argument("--variants", default="feat=0;feat=1;feat=3;feat=0,fd=0")
     a = ap.parse_args()
     import numpy as np
     import torch
@@ -37,8 +37,7 @@ def main():
         kv = dict(s.split("=") for s in spec.split(","))
         os.environ["DCTZHIP_FEAT"] = kv.get("feat", "0")
         os.environ["DCTZHIP_FASTDIV"] = kv.get("fd", "1")
-        os.environ["DCTZHIP_WG_PER_CU"] = kv.get("wg", "3")
-        os.environ["DCTZHIP_PREFETCH"] = kv.get("pf", "1")
+        os.environ["DCTZHIP_WG_PER_CU"] = kv.get("wg", "0")
         os.environ["DCTZHIP_STATS_GRID"] = kv.get("sg", "2048")
         c = dctz_amd.Context(0)
         c.set_profiling(True)
