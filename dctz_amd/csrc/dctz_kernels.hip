@@ -19,6 +19,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <type_traits>
+
 #include "dct64_lane.h"
 #include "dctz_device.h"
 
@@ -115,6 +117,12 @@ template <> struct FastDiv<double> {
     const double r = fma(-d, q, x);
     return fma(r, y, q);
   }
+  __device__ __forceinline__ bool in_window(double x) const {
+    return ((((unsigned)__double2hiint(x) >> 20) & 0x7ffu) - 523u) <= 1000u;
+  }
+  __device__ __forceinline__ double slow(double x) const {         // outside the window
+    return (ok && x == 0.0) ? x * y : x / d;                       // signed zero / full division
+  }
   __device__ __forceinline__ double div(double x) const {          // any x
     const unsigned ex = ((unsigned)__double2hiint(x) >> 20) & 0x7ffu;
     if (ok && (ex - 523u) <= 1000u) return core(x);                // |x| in [2^-500, 2^501)
@@ -140,6 +148,10 @@ template <> struct FastDiv<float> {
     const float r2 = fmaf(-d, q2, x);
     return fmaf(r2, y, q2);
   }
+  __device__ __forceinline__ bool in_window(float x) const {
+    return (((__float_as_uint(x) >> 23) & 0xffu) - 64u) <= 126u;
+  }
+  __device__ __forceinline__ float slow(float x) const { return (ok && x == 0.0f) ? x * y : x / d; }
   __device__ __forceinline__ float div(float x) const {
     const unsigned ex = (__float_as_uint(x) >> 23) & 0xffu;
     if (ok && (ex - 64u) <= 126u) return core(x);                  // |x| in [2^-63, 2^64)
@@ -148,6 +160,14 @@ template <> struct FastDiv<float> {
   }
   __device__ __forceinline__ float div_small(float x) const { return ok ? core(x) : x / d; }
 };
+
+template <typename T>
+__device__ __forceinline__ unsigned bin_from_quotient(T item, T range_max, T q, bool* out_of_range) {
+  const bool out = fabs(item) > range_max;          // == (item < range_min || item > range_max): range_min = -range_max
+  const int ti = (int)q;                            // (t_bin_id) cast: trunc toward 0
+  *out_of_range = out;
+  return out ? 255u : conv_bin((unsigned)ti & 255u);
+}
 
 // diagnostic phase timers (F_STAMP builds only)
 struct Stamps {
@@ -348,9 +368,13 @@ __device__ __forceinline__ void issue_tile_loads(typename Traits<T>::Vec (&v)[TI
   }
 }
 
-template <typename T, bool SCALE>
-__device__ __forceinline__ void stage_tile(T* tile, typename Traits<T>::Vec (&v)[TILE_ELEMS / Traits<T>::EPV / WG],
-                                           size_t ebase, unsigned valid, const FastDiv<T>& sfd, T* scaled) {
+// LEVEL 2: the host saw min|x| and max|x| of the whole array inside FastDiv's
+// window (k_stats), so every element takes the 3-operation path, no test.
+// LEVEL 1: window unknown (zeros, extreme exponents possible): per-element test,
+// exact fallback.  LEVEL 0: divisor outside the window: plain IEEE division.
+template <typename T, bool SCALE, int LEVEL>
+__device__ __forceinline__ void stage_tile_l(T* tile, typename Traits<T>::Vec (&v)[TILE_ELEMS / Traits<T>::EPV / WG],
+                                             size_t ebase, unsigned valid, const FastDiv<T>& sfd, T* scaled) {
   using Vec = typename Traits<T>::Vec;
   constexpr int EPV = Traits<T>::EPV, NV = TILE_ELEMS / EPV / WG;
   const int t = threadIdx.x;
@@ -362,7 +386,8 @@ __device__ __forceinline__ void stage_tile(T* tile, typename Traits<T>::Vec (&v)
       T el[EPV];
       Traits<T>::unpack(a, el);
 #pragma unroll
-      for (int k = 0; k < EPV; k++) el[k] = sfd.div(el[k]);        // dctz-comp-lib.c:197-199 / :212-214
+      for (int k = 0; k < EPV; k++)                                // dctz-comp-lib.c:197-199 / :212-214
+        el[k] = (LEVEL == 2) ? sfd.core(el[k]) : (LEVEL == 1) ? sfd.div(el[k]) : el[k] / sfd.d;
       a = Traits<T>::pack(el);
       if (scaled != nullptr && e < valid) reinterpret_cast<Vec*>(scaled + ebase)[i * WG + t] = a;
     }
@@ -372,8 +397,14 @@ __device__ __forceinline__ void stage_tile(T* tile, typename Traits<T>::Vec (&v)
   }
 }
 
-// Global -> LDS, 16 B per lane, optional division by sf (dctz-comp-lib.c:193-216)
-// and optional write-back of the scaled data.
+template <typename T, bool SCALE>
+__device__ __forceinline__ void stage_tile(T* tile, typename Traits<T>::Vec (&v)[TILE_ELEMS / Traits<T>::EPV / WG],
+                                           size_t ebase, unsigned valid, const FastDiv<T>& sfd, T* scaled, unsigned level) {
+  if (level == 2) stage_tile_l<T, SCALE, 2>(tile, v, ebase, valid, sfd, scaled);
+  else if (level == 1) stage_tile_l<T, SCALE, 1>(tile, v, ebase, valid, sfd, scaled);
+  else stage_tile_l<T, SCALE, 0>(tile, v, ebase, valid, sfd, scaled);
+}
+
 template <typename T, bool SCALE>
 __device__ __forceinline__ void load_tile(T* tile, const T* __restrict__ x, size_t ebase, unsigned valid,
                                           T sf, T* scaled) {
@@ -703,16 +734,21 @@ __device__ __forceinline__ void emit_tile(const FwdParams<T>& p, const T* tile, 
   }
   unsigned w[4] = {0, 0, 0, 0};
   unsigned mask = 0;
+  auto bin_loop = [&](auto fast) {                   // divisor test hoisted: a launch constant
 #pragma unroll
-  for (int i = 0; i < 16; i++) {
-    bool out;
-    unsigned b = bin_of<T>(c[i], p.range_min, p.range_max, bwd, &out);
-    const int j = j0 + i;
-    if (j == 0) { b = 255u; out = false; }       // :361 DC slot
-    else if (b == 255u) mask |= 1u << i;
-    if (MODE == DCTZHIP_QT && out && active) atomicMax(&qmax[j], to_bits(fabs(c[i])));
-    w[i >> 2] |= b << (8 * (i & 3));
-  }
+    for (int i = 0; i < 16; i++) {
+      const T u = c[i] - p.range_min;                // 0 <= u <= 510 eb whenever the bin is used
+      const T q = decltype(fast)::value ? bwd.core(u) : u / bwd.d;
+      bool out;
+      unsigned b = bin_from_quotient<T>(c[i], p.range_max, q, &out);
+      const int j = j0 + i;
+      if (j == 0) { b = 255u; out = false; }       // :361 DC slot
+      else if (b == 255u) mask |= 1u << i;
+      if (MODE == DCTZHIP_QT && out && active) atomicMax(&qmax[j], to_bits(fabs(c[i])));
+      w[i >> 2] |= b << (8 * (i & 3));
+    }
+  };
+  if (bwd.ok) bin_loop(std::true_type{}); else bin_loop(std::false_type{});
   if (!active) mask = 0;
   if ((FEAT & F_STAMP) && st && t == 0) st->mark(3);   // binning + bin store issue
   unsigned r;
@@ -779,7 +815,7 @@ __global__ __launch_bounds__(WG, DCTZ_MINWAVES) void k_compress(FwdParams<T> p) 
       Vec v[NV];
       issue_tile_loads<T>(v, p.x, tile_id, p.ntiles, p.nfull);
       __syncthreads();                               // previous tile's LDS reads are done
-      stage_tile<T, SCALE>(tile, v, ebase, blks_here * 64u, sfd, p.scaled);
+      stage_tile<T, SCALE>(tile, v, ebase, blks_here * 64u, sfd, p.scaled, p.fast_sf);
       __syncthreads();
       tile_dct_fwd<T>(tile, tab);
       emit_tile<T, MODE, FEAT>(p, tile, qmax, sc, bwd, tile_id, blks_here, false, 0u, nullptr);
@@ -798,7 +834,7 @@ __global__ __launch_bounds__(WG, DCTZ_MINWAVES) void k_compress(FwdParams<T> p) 
       const unsigned blks_here = min((unsigned)TILE_BLKS, p.nfull - tile_id * TILE_BLKS);
       Vec v[NV];
       issue_tile_loads<T>(v, p.x, tile_id, p.ntiles, p.nfull);
-      stage_tile<T, SCALE>(tile, v, ebase, blks_here * 64u, sfd, p.scaled);
+      stage_tile<T, SCALE>(tile, v, ebase, blks_here * 64u, sfd, p.scaled, p.fast_sf);
       __syncthreads();
       if ((FEAT & F_STAMP) && t == 0) st.mark(1);    // load + stage
       tile_dct_fwd<T>(tile, tab);

@@ -55,7 +55,7 @@ struct dctzhip_ctx {
   // profiling
   int feat = 0;                     // 0: two-level scheme (default); 1: single-pass look-back kernels,
   int feat_d = 0;                   //    +2 grouped tickets, +4 phase stamps (DCTZHIP_FEAT sets both)
-  int fastdiv = 1;                  // hoisted-reciprocal division (DCTZHIP_FASTDIV)
+  int fastdiv = 2;                  // hoisted-reciprocal division: 0 off, 1 per-tile window test, 2 + skip the test when k_stats proves it (DCTZHIP_FASTDIV)
   int stats_grid = 2048;            // workgroups of the statistics kernel (DCTZHIP_STATS_GRID, <= 2048)
   int wg_per_cu = 0;                // grid = CUs * this; 0 = resident workgroups per CU: 3 (fp64), 4 (fp32) (DCTZHIP_WG_PER_CU)
   int profiling = 0;
@@ -104,7 +104,7 @@ extern "C" int dctzhip_ctx_create(dctzhip_ctx** out, int device) {
   HIPCHK(nullptr, hipGetDeviceProperties(&prop, device));
   c->num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
   if (const char* e = getenv("DCTZHIP_FEAT")) { c->feat = atoi(e) & 7; c->feat_d = c->feat; }
-  if (const char* e = getenv("DCTZHIP_FASTDIV")) c->fastdiv = atoi(e) != 0;
+  if (const char* e = getenv("DCTZHIP_FASTDIV")) c->fastdiv = atoi(e);
   if (const char* e = getenv("DCTZHIP_STATS_GRID")) { int v = atoi(e); if (v >= 1 && v <= STATS_GRID_MAX) c->stats_grid = v; }
   if (const char* e = getenv("DCTZHIP_WG_PER_CU")) { int v = atoi(e); if (v >= 1 && v <= 8) c->wg_per_cu = v; }
   HIPCHK(nullptr, hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
@@ -198,6 +198,14 @@ static unsigned divisor_in_window(int dtype, double d) {
   int e = 0;
   (void)frexp(fabs(d), &e);                      // |d| = m * 2^e, m in [0.5, 1)
   return (dtype == DCTZHIP_F64) ? (e - 1 >= -250 && e - 1 < 250) : (e - 1 >= -30 && e - 1 < 30);
+}
+
+// FastDiv's numerator window: |x| in [2^-500, 2^500] (f64) / [2^-63, 2^63] (f32), zero excluded
+static bool value_in_window(int dtype, double v) {
+  if (!(v == v) || v == 0.0 || std::isinf(v)) return false;
+  int e = 0;
+  (void)frexp(fabs(v), &e);
+  return (dtype == DCTZHIP_F64) ? (e - 1 >= -500 && e - 1 < 500) : (e - 1 >= -63 && e - 1 < 63);
 }
 
 static size_t elem_size(int dtype) { return dtype == DCTZHIP_F64 ? 8 : 4; }
@@ -339,7 +347,9 @@ static int compress_impl(dctzhip_ctx* c, const T* d_in, size_t n, double eb, int
   p.bin_width = (T)(eb * 2.0 * 1.0);
   p.range_min = (T)(-(half * 2 + 1) * (eb * 1.0));
   p.range_max = (T)((half * 2 + 1) * (eb * 1.0));
+  // 2: every element is inside FastDiv's window (k_stats saw min|x| and max|x| there) -> no per-element test
   p.fast_sf = c->fastdiv ? divisor_in_window(dtype, (double)p.sf) : 0u;
+  if (p.fast_sf && c->fastdiv >= 2 && value_in_window(dtype, min_abs) && value_in_window(dtype, max_abs)) p.fast_sf = 2;
   p.fast_bw = c->fastdiv ? divisor_in_window(dtype, (double)p.bin_width) : 0u;
   const bool scale = (p.sf != (T)1.0);              // :193 / :208
   if (!scale && d_scaled && d_scaled != d_in)       // sf == 1: "scaled" data is the input itself
