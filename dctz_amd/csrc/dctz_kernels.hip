@@ -1052,92 +1052,141 @@ __global__ __launch_bounds__(WG, DCTZ_MINWAVES) void k_decompress(InvParams<T> p
 
   bool pending = false;                  // tile `prev_id` sits in LDS, not yet stored
   unsigned prev_id = 0;
-  Stamps st;
-  if (FEAT & F_STAMP) st.start();
-  unsigned static_id = blockIdx.x;
-  for (;;) {
-    unsigned tile_id;
-    if (FEAT & F_LOOKBACK) {
+
+  // this thread's 16 bin ids and (quad lane 0) its block's DC for a given tile
+  auto fetch = [&](unsigned id, uint4& wv, float& dcv) {
+    wv = make_uint4(0, 0, 0, 0);
+    dcv = 0.f;
+    if (id < p.ntiles && (unsigned)blk < min((unsigned)TILE_BLKS, p.nfull - id * TILE_BLKS)) {
+      wv = reinterpret_cast<const uint4*>(p.bin + (size_t)id * TILE_ELEMS)[t];
+      if (j0 == 0) dcv = p.dc[id * TILE_BLKS + blk];
+    }
+  };
+  // coefficient of position j from its bin id / fetched exact value / DC
+  auto dequant = [&](unsigned b, int j, bool exc, float exact, float dcv) -> T {
+    if (j == 0) return (T)dcv;                                     // :392 / :438
+    if (exc) {
+      T v = (T)exact;
+      if (MODE == DCTZHIP_QT) v = qt_restore(v, qt[j], p.eb, T(10), p.range_min, p.range_max);
+      return v;
+    }
+    const int ti = (b & 1u) ? (int)(b >> 1) + 1 : -(int)(b >> 1);  // binning.c:20 / :40
+    return (T)ti * p.bin_width;                                    // :416 / :462
+  };
+
+  if constexpr ((FEAT & F_LOOKBACK) == 0) {
+    // Two-level scheme: static tiles, exception offsets from k_scan_tiles.  Order per
+    // tile k: flags + local scan -> issue the AC_exact gathers of k -> prefetch the
+    // bin ids / DC of tile k+G -> store tile k-G (still in LDS) while the gathers
+    // fly -> coefficients(k) to LDS -> IDCT(k).
+    unsigned tile_id = blockIdx.x;
+    uint4 wv, wv_n;
+    float dcv, dcv_n;
+    fetch(tile_id, wv, dcv);
+    bool underrun = false;
+    while (tile_id < p.ntiles) {
+      const unsigned blks_here = min((unsigned)TILE_BLKS, p.nfull - tile_id * TILE_BLKS);
+      const bool active = (unsigned)blk < blks_here;
+      const unsigned w[4] = {wv.x, wv.y, wv.z, wv.w};
+      unsigned mask = 0;
+#pragma unroll
+      for (int i = 0; i < 16; i++) {
+        const unsigned b = (w[i >> 2] >> (8 * (i & 3))) & 255u;
+        if (b == 255u && (j0 + i) != 0) mask |= 1u << i;           // :400 / :446
+      }
+      if (!active) mask = 0;
+      __syncthreads();                   // sc[] of the previous tile is consumed
+      unsigned total;
+      unsigned r = p.tile_off[tile_id] + tile_scan_local((unsigned)__popc(mask), sc, &total);
+      float av[16];
+#pragma unroll
+      for (int i = 0; i < 16; i++) {     // gathers first, uses later
+        av[i] = 0.f;
+        if (mask & (1u << i)) {
+          if (r < p.ac_count) av[i] = p.ac[r]; else underrun = true;
+          r++;
+        }
+      }
+      const unsigned next_id = tile_id + gridDim.x;
+      fetch(next_id, wv_n, dcv_n);
+      if (pending) {                     // flush the previous tile (uniform branch)
+        const unsigned pv = min((unsigned)TILE_BLKS, p.nfull - prev_id * TILE_BLKS) * 64u;
+        store_tile<T, SCALE>(tile, p.out, (size_t)prev_id * TILE_ELEMS, pv, p.sf);
+        __syncthreads();                 // LDS tile free for the next coefficients
+      }
+      T c[16];
+#pragma unroll
+      for (int i = 0; i < 16; i++)
+        c[i] = dequant((w[i >> 2] >> (8 * (i & 3))) & 255u, j0 + i, (mask >> i) & 1u, av[i], dcv);
+#pragma unroll
+      for (int i = 0; i < 16 / EPV; i++)
+        lds_store_vec<T>(&tile[blk * Traits<T>::PITCH + j0 + i * EPV], Traits<T>::pack(&c[i * EPV]));
+      __syncthreads();
+      tile_dct_inv<T>(tile, tab);
+      pending = true;
+      prev_id = tile_id;
+      tile_id = next_id; wv = wv_n; dcv = dcv_n;
+    }
+    if (underrun) atomicExch(&p.ctl->error, 2u);
+  } else {
+    Stamps st;
+    if (FEAT & F_STAMP) st.start();
+    for (;;) {
       if (t == 0) sc[5] = take_ticket<FEAT>(p.ctl, p.ngroups);
       __syncthreads();                   // also: every lane is done with sc[] of the previous tile
       if ((FEAT & F_STAMP) && t == 0) st.mark(0);
-      tile_id = sc[5];
-    } else {                             // two-level scheme: static tiles, offsets from k_scan_tiles
-      __syncthreads();
-      tile_id = static_id;
-      static_id += gridDim.x;
-    }
-    if (tile_id >= p.ntiles) break;
-    const size_t ebase = (size_t)tile_id * TILE_ELEMS;
-    const unsigned blks_here = min((unsigned)TILE_BLKS, p.nfull - tile_id * TILE_BLKS);
-    const bool active = (unsigned)blk < blks_here;
-    uint4 wv = make_uint4(0, 0, 0, 0);
-    float dcv = 0.f;
-    if (active) {
-      wv = reinterpret_cast<const uint4*>(p.bin + ebase)[t];
-      if (j0 == 0) dcv = p.dc[tile_id * TILE_BLKS + blk];
-    }
-    const unsigned w[4] = {wv.x, wv.y, wv.z, wv.w};
-    unsigned mask = 0;
+      const unsigned tile_id = sc[5];
+      if (tile_id >= p.ntiles) break;
+      const unsigned blks_here = min((unsigned)TILE_BLKS, p.nfull - tile_id * TILE_BLKS);
+      const bool active = (unsigned)blk < blks_here;
+      uint4 wv;
+      float dcv;
+      fetch(tile_id, wv, dcv);
+      const unsigned w[4] = {wv.x, wv.y, wv.z, wv.w};
+      unsigned mask = 0;
 #pragma unroll
-    for (int i = 0; i < 16; i++) {
-      const unsigned b = (w[i >> 2] >> (8 * (i & 3))) & 255u;
-      if (b == 255u && (j0 + i) != 0) mask |= 1u << i;             // :400 / :446
-    }
-    if (!active) mask = 0;
-    if ((FEAT & F_STAMP) && t == 0) st.mark(1);                    // bins load
-    unsigned r;
-    if (FEAT & F_LOOKBACK) {
-      r = tile_scan((unsigned)__popc(mask), tile_id, p.ntiles, sc, p.desc, p.ctl, false, 0u,
-                    (FEAT & F_STAMP) ? &st : nullptr);
-    } else {
-      unsigned total;
-      r = p.tile_off[tile_id] + tile_scan_local((unsigned)__popc(mask), sc, &total);
-    }
-    if ((FEAT & F_STAMP) && t == 0) st.mark(2);
-
-    if (pending) {                       // now flush the previous tile (uniform branch)
-      const unsigned pv = min((unsigned)TILE_BLKS, p.nfull - prev_id * TILE_BLKS) * 64u;
-      store_tile<T, SCALE>(tile, p.out, (size_t)prev_id * TILE_ELEMS, pv, p.sf);
-      __syncthreads();                   // LDS tile free for the next coefficients
-    }
-    if ((FEAT & F_STAMP) && t == 0) st.mark(3);                    // store of the previous tile
-
-    T c[16];
-#pragma unroll
-    for (int i = 0; i < 16; i++) {
-      const unsigned b = (w[i >> 2] >> (8 * (i & 3))) & 255u;
-      const int j = j0 + i;
-      T val;
-      if (j == 0) {
-        val = (T)dcv;                                              // :392 / :438
-      } else if (mask & (1u << i)) {
-        T v = T(0);
-        if (r < p.ac_count) v = (T)p.ac[r]; else atomicExch(&p.ctl->error, 2u);
-        r++;
-        if (MODE == DCTZHIP_QT) v = qt_restore(v, qt[j], p.eb, T(10), p.range_min, p.range_max);
-        val = v;
-      } else {
-        const int ti = (b & 1u) ? (int)(b >> 1) + 1 : -(int)(b >> 1);   // binning.c:20 / :40
-        val = (T)ti * p.bin_width;                                      // :416 / :462
+      for (int i = 0; i < 16; i++) {
+        const unsigned b = (w[i >> 2] >> (8 * (i & 3))) & 255u;
+        if (b == 255u && (j0 + i) != 0) mask |= 1u << i;           // :400 / :446
       }
-      c[i] = val;
-    }
+      if (!active) mask = 0;
+      if ((FEAT & F_STAMP) && t == 0) st.mark(1);                  // bins load
+      unsigned r = tile_scan((unsigned)__popc(mask), tile_id, p.ntiles, sc, p.desc, p.ctl, false, 0u,
+                             (FEAT & F_STAMP) ? &st : nullptr);
+      if ((FEAT & F_STAMP) && t == 0) st.mark(2);
+      if (pending) {                     // now flush the previous tile (uniform branch)
+        const unsigned pv = min((unsigned)TILE_BLKS, p.nfull - prev_id * TILE_BLKS) * 64u;
+        store_tile<T, SCALE>(tile, p.out, (size_t)prev_id * TILE_ELEMS, pv, p.sf);
+        __syncthreads();                 // LDS tile free for the next coefficients
+      }
+      if ((FEAT & F_STAMP) && t == 0) st.mark(3);                  // store of the previous tile
+      T c[16];
 #pragma unroll
-    for (int i = 0; i < 16 / EPV; i++)
-      lds_store_vec<T>(&tile[blk * Traits<T>::PITCH + j0 + i * EPV], Traits<T>::pack(&c[i * EPV]));
-    __syncthreads();
-    if ((FEAT & F_STAMP) && t == 0) st.mark(6);                    // gather + de-quantise
-    tile_dct_inv<T>(tile, tab);
-    if ((FEAT & F_STAMP) && t == 0) st.mark(7);                    // IDCT
-    pending = true;
-    prev_id = tile_id;
+      for (int i = 0; i < 16; i++) {
+        const bool exc = (mask >> i) & 1u;
+        float exact = 0.f;
+        if (exc) {
+          if (r < p.ac_count) exact = p.ac[r]; else atomicExch(&p.ctl->error, 2u);
+          r++;
+        }
+        c[i] = dequant((w[i >> 2] >> (8 * (i & 3))) & 255u, j0 + i, exc, exact, dcv);
+      }
+#pragma unroll
+      for (int i = 0; i < 16 / EPV; i++)
+        lds_store_vec<T>(&tile[blk * Traits<T>::PITCH + j0 + i * EPV], Traits<T>::pack(&c[i * EPV]));
+      __syncthreads();
+      if ((FEAT & F_STAMP) && t == 0) st.mark(6);                  // gather + de-quantise
+      tile_dct_inv<T>(tile, tab);
+      if ((FEAT & F_STAMP) && t == 0) st.mark(7);                  // IDCT
+      pending = true;
+      prev_id = tile_id;
+    }
+    if ((FEAT & F_STAMP) && t == 0) st.flush(p.ctl);
   }
   if (pending) {
     const unsigned pv = min((unsigned)TILE_BLKS, p.nfull - prev_id * TILE_BLKS) * 64u;
     store_tile<T, SCALE>(tile, p.out, (size_t)prev_id * TILE_ELEMS, pv, p.sf);
   }
-  if ((FEAT & F_STAMP) && t == 0) st.flush(p.ctl);
 }
 
 // Last, short block on decode (dctz-decomp-lib.c:423-428, dct.c:144-199).

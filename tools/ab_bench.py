@@ -36,7 +36,7 @@ def main():
     for spec in a.variants.split(";"):
         kv = dict(s.split("=") for s in spec.split(","))
         os.environ["DCTZHIP_FEAT"] = kv.get("feat", "0")
-        os.environ["DCTZHIP_FASTDIV"] = kv.get("fd", "1")
+        os.environ["DCTZHIP_FASTDIV"] = kv.get("fd", "2")
         os.environ["DCTZHIP_WG_PER_CU"] = kv.get("wg", "0")
         os.environ["DCTZHIP_STATS_GRID"] = kv.get("sg", "2048")
         c = dctz_amd.Context(0)
