@@ -1,16 +1,18 @@
 // dctz_kernels.hip -- gfx950 (MI355X) kernels of the DCTZ hot path.
 //
-// Work decomposition (all kernels, both directions):
-//   * a TILE is 64 consecutive 64-element blocks (4096 elements, 32 KiB fp64);
-//     one 256-thread workgroup owns a tile at a time and takes tiles from a
-//     global ticket counter (persistent grid, ~4 workgroups per CU);
-//   * the tile is staged in LDS once; HBM is touched with 16-byte-per-lane,
-//     fully coalesced accesses only;
+// Work decomposition (both directions):
+//   * a TILE is 64 consecutive 64-element blocks (4096 elements, 32 KiB fp64); one
+//     256-thread workgroup owns a tile at a time; the grid is persistent (as many
+//     workgroups as are resident: 3 per CU fp64, 4 fp32) and strides over the tiles;
+//   * the tile is staged in LDS once; HBM is touched with 16-byte-per-lane, fully
+//     coalesced accesses only;
 //   * inside the tile a QUAD of lanes owns a block and runs the 64-point DCT of
 //     dct64_lane.h in registers, exchanging partners with DPP quad_perm moves;
-//   * the ordered stream of "stored exactly" coefficients (AC_exact) is placed
-//     with a single-pass decoupled look-back scan over tiles, so the input is
-//     read exactly once by this kernel.
+//   * the ordered stream of "stored exactly" coefficients (AC_exact) is placed by
+//     the TWO-LEVEL scheme: every tile leaves a tile-local list + a count,
+//     k_scan_tiles turns counts into offsets, k_compact_ac moves the lists; the big
+//     kernels have no inter-workgroup traffic.  A single-pass variant (tickets +
+//     decoupled look-back, FEAT & F_LOOKBACK) is kept and is byte-identical.
 //
 // Reference code replaced: see include/dctz_hip.h (per entry point) and the
 // comment on each kernel.  Built with -ffp-contract=off: the arithmetic that
