@@ -144,3 +144,22 @@ def test_calc_data_stat_and_gen_bins():
     bc = np.zeros(255)
     lib.gen_bins(C.c_double(0), C.c_double(0), bc.ctypes.data_as(C.c_void_p), 255, C.c_double(1e-3))
     assert np.array_equal(bc, O.gen_bins(1e-3, np.float64))
+
+
+@pytest.mark.parametrize("mode", ["ec", "qt"])
+def test_plain_c_caller_links_and_runs(mode, tmp_path):
+    """A C program written against include/dctz.h only (the reference's calling
+    convention) builds with gcc, links the drop-in library and round-trips."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / f"dropin_{mode}")
+    flags = ["-DUSE_TRUNCATE"] + (["-DUSE_QTABLE"] if mode == "qt" else [])
+    subprocess.check_call(["gcc", "-std=gnu99", "-O1", os.path.join(root, "tests", "c", "dropin_roundtrip.c"),
+                           "-I", os.path.join(root, "include"), "-L", LIBDIR, f"-ldctz-{mode}",
+                           f"-Wl,-rpath,{LIBDIR}", "-lm", "-o", exe] + flags)
+    for n, eb, f32 in ((100000, 1e-3, 0), (64 * 777 + 13, 1e-4, 1)):
+        out = subprocess.check_output([exe, str(n), str(eb), str(f32)], env=dict(os.environ, DCTZ_QUIET="1"), text=True)
+        line = [l for l in out.splitlines() if l.startswith("RESULT")][0].split()
+        psnr, maxerr = float(line[4]), float(line[5])
+        assert int(line[1]) == n and float(line[3]) > 1.0
+        assert psnr > 60.0 and maxerr <= 8.5 * eb * 10.0      # sf = 10 for |x| up to ~50
