@@ -14,9 +14,12 @@ namespace dctz {
 #ifndef DCTZ_PITCH
 #define DCTZ_PITCH 66      // LDS elements per block (fp64); fp32 uses DCTZ_PITCH + 2 when even
 #endif
-constexpr int TILE_BLKS = 64;             // blocks per tile
+#ifndef DCTZ_TILE_BLKS
+#define DCTZ_TILE_BLKS 16      // 16 blocks = one wavefront per workgroup: barriers cost nothing, 12 workgroups per CU (fp64)
+#endif
+constexpr int TILE_BLKS = DCTZ_TILE_BLKS; // blocks per tile (one quad of lanes per block)
 constexpr int TILE_ELEMS = TILE_BLKS * 64;
-constexpr int WG = 256;                   // threads per workgroup (4 wavefronts)
+constexpr int WG = TILE_BLKS * 4;         // threads per workgroup
 
 template <typename T> struct Traits;
 template <> struct Traits<double> {
@@ -83,6 +86,7 @@ struct FwdParams {
   unsigned last_is_full;           // N % 64 == 0
   unsigned fast_sf, fast_bw;       // divisor inside FastDiv's exponent window (host check)
   unsigned ngroups;                // ticket groups, min(8, grid)
+  unsigned nlists_main;            // two-level scheme: number of workgroup lists = grid of k_compress
   T sf, bin_width, range_min, range_max;
 };
 
@@ -100,6 +104,7 @@ struct InvParams {
   unsigned long long* desc;
   unsigned nfull, ntiles, ac_count;
   unsigned ngroups;                // ticket groups, min(8, grid)
+  unsigned nlists_main;            // two-level scheme: number of workgroup ranges = grid of k_decompress
   T sf, bin_width, range_min, range_max;
   double eb;
 };

@@ -259,7 +259,9 @@ __device__ __forceinline__ unsigned tile_scan(unsigned cnt, unsigned tile, unsig
   __syncthreads();
   if (wave == 0) {                                   // wave-uniform branch: all 64 lanes look back
     if (st && t == 0) st->mark(4);                   // wave scan + first barrier
-    const unsigned total = sc[0] + sc[1] + sc[2] + sc[3];
+    unsigned total = 0;
+#pragma unroll
+    for (int w = 0; w < WG / 64; w++) total += sc[w];
     const unsigned excl = lookback(desc, tile, total, &ctl->error);
     if (t == 0) {
       sc[4] = excl;
@@ -269,10 +271,21 @@ __device__ __forceinline__ unsigned tile_scan(unsigned cnt, unsigned tile, unsig
   }
   __syncthreads();
   unsigned off = sc[4] + (incl - cnt);
-  if (wave > 0) off += sc[0];
-  if (wave > 1) off += sc[1];
-  if (wave > 2) off += sc[2];
+#pragma unroll
+  for (int w = 0; w < WG / 64 - 1; w++)
+    if (wave > w) off += sc[w];
   return off;
+}
+
+// Two-level scheme: workgroup b of G owns the contiguous tiles [lo, hi) -- the same
+// partition in k_compress / k_compact_ac and in k_count_tiles / k_decompress.
+struct TileRange { unsigned lo, hi; };
+__host__ __device__ __forceinline__ TileRange tile_range(unsigned b, unsigned G, unsigned ntiles) {
+  const unsigned q = ntiles / G, r = ntiles % G;
+  TileRange tr;
+  tr.lo = b * q + (b < r ? b : r);
+  tr.hi = tr.lo + q + (b < r ? 1u : 0u);
+  return tr;
 }
 
 // Intra-tile exclusive scan only (two-level scheme): returns this thread's offset
@@ -287,11 +300,13 @@ __device__ __forceinline__ unsigned tile_scan_local(unsigned cnt, unsigned* sc, 
   }
   if (lane == 63) sc[wave] = incl;
   __syncthreads();
-  unsigned off = incl - cnt;
-  if (wave > 0) off += sc[0];
-  if (wave > 1) off += sc[1];
-  if (wave > 2) off += sc[2];
-  *total = sc[0] + sc[1] + sc[2] + sc[3];
+  unsigned off = incl - cnt, sum = 0;
+#pragma unroll
+  for (int w = 0; w < WG / 64; w++) {
+    if (wave > w) off += sc[w];
+    sum += sc[w];
+  }
+  *total = sum;
   return off;
 }
 
@@ -721,7 +736,8 @@ __global__ __launch_bounds__(WG) void k_scale(T* __restrict__ x, size_t n, T sf)
 template <typename T, int MODE, int FEAT>
 __device__ __forceinline__ void emit_tile(const FwdParams<T>& p, const T* tile, typename Traits<T>::Bits* qmax,
                                           unsigned* sc, const FastDiv<T>& bwd, unsigned tile_id, unsigned blks_here,
-                                          bool publish, unsigned publish_value, Stamps* st) {
+                                          bool publish, unsigned publish_value, Stamps* st, unsigned list_base = 0,
+                                          unsigned* run = nullptr) {
   using Vec = typename Traits<T>::Vec;
   constexpr int EPV = Traits<T>::EPV;
   const int t = threadIdx.x;
@@ -757,10 +773,10 @@ __device__ __forceinline__ void emit_tile(const FwdParams<T>& p, const T* tile, 
   if (FEAT & F_LOOKBACK) {
     r = tile_scan((unsigned)__popc(mask), tile_id, p.ntiles, sc, p.desc, p.ctl, publish, publish_value,
                   (FEAT & F_STAMP) ? st : nullptr);
-  } else {                                           // tile-local list; k_compact_ac places it later
+  } else {                                           // workgroup-local list; k_compact_ac places it later
     unsigned total;
-    r = tile_id * TILE_ELEMS + tile_scan_local((unsigned)__popc(mask), sc, &total);
-    if (t == 0) p.tile_cnt[tile_id] = total;
+    r = list_base + *run + tile_scan_local((unsigned)__popc(mask), sc, &total);
+    *run += total;
   }
   // all global stores of the tile go out AFTER the look-back, so that the polling
   // wave's vmcnt(0) waits never sit behind its own stores
@@ -809,7 +825,10 @@ __global__ __launch_bounds__(WG, DCTZ_MINWAVES) void k_compress(FwdParams<T> p) 
     // two-level scheme: tiles are assigned statically (no inter-workgroup traffic
     // at all in this kernel); every tile leaves its exceptions as a tile-local
     // list + a count, k_scan_tiles / k_compact_ac stitch them into AC_exact[]
-    for (unsigned tile_id = blockIdx.x; tile_id < p.ntiles; tile_id += gridDim.x) {
+    const TileRange tr = tile_range(blockIdx.x, gridDim.x, p.ntiles);
+    const unsigned list_base = tr.lo * TILE_ELEMS;   // this workgroup's exception list lives in its tiles' slots
+    unsigned run = 0;                                // its length so far (uniform over the workgroup)
+    for (unsigned tile_id = tr.lo; tile_id < tr.hi; tile_id++) {
       const size_t ebase = (size_t)tile_id * TILE_ELEMS;
       const unsigned blks_here = min((unsigned)TILE_BLKS, p.nfull - tile_id * TILE_BLKS);
       // (carrying the next tile's 32 KiB in registers across the emit phase was
@@ -820,8 +839,9 @@ __global__ __launch_bounds__(WG, DCTZ_MINWAVES) void k_compress(FwdParams<T> p) 
       stage_tile<T, SCALE>(tile, v, ebase, blks_here * 64u, sfd, p.scaled, p.fast_sf);
       __syncthreads();
       tile_dct_fwd<T>(tile, tab);
-      emit_tile<T, MODE, FEAT>(p, tile, qmax, sc, bwd, tile_id, blks_here, false, 0u, nullptr);
+      emit_tile<T, MODE, FEAT>(p, tile, qmax, sc, bwd, tile_id, blks_here, false, 0u, nullptr, list_base, &run);
     }
+    if (t == 0) p.tile_cnt[blockIdx.x] = run;
   } else {
     Stamps st;
     if (FEAT & F_STAMP) st.start();
@@ -905,7 +925,7 @@ __global__ __launch_bounds__(64) void k_compress_rem(FwdParams<T> p, int l) {
   }
   __syncthreads();
   if (k == 0) {
-    if (p.tile_cnt) p.tile_cnt[p.ntiles] = (unsigned)__popcll(m);
+    if (p.tile_cnt) p.tile_cnt[p.nlists_main] = (unsigned)__popcll(m);
     else p.ctl->cnt_total = start + (unsigned)__popcll(m);
   }
 }
@@ -993,12 +1013,13 @@ __global__ __launch_bounds__(WG) void k_compact_ac(FwdParams<T> p, double eb, un
     }
     __syncthreads();
   }
-  // one wavefront per list: thousands of short, independent copies in flight
-  const unsigned lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
-  for (unsigned l = blockIdx.x * (WG / 64) + wv; l < nlists; l += gridDim.x * (WG / 64)) {
+  // list l < G belongs to workgroup l of k_compress (slots of its tile range); list G is
+  // the remainder block's.  One workgroup per list, 16 bytes per lane where aligned.
+  const unsigned G = p.nlists_main;
+  for (unsigned l = blockIdx.x; l < nlists; l += gridDim.x) {
     const unsigned n = p.tile_cnt[l], dst = p.tile_off[l];
-    const size_t src = (size_t)l * TILE_ELEMS;
-    for (unsigned i = lane; i < n; i += 64) {
+    const size_t src = (size_t)(l < G ? tile_range(l, G, p.ntiles).lo : p.ntiles) * TILE_ELEMS;
+    for (unsigned i = threadIdx.x; i < n; i += WG) {
       if (MODE == DCTZHIP_EC) p.ac[dst + i] = p.ac_tmp[src + i];
       else p.ac[dst + i] = (float)qt_normalise(p.qt_item[src + i], q[p.qt_j[src + i]], eb, T(10), p.range_min, p.range_max);
     }
@@ -1014,9 +1035,10 @@ __global__ __launch_bounds__(WG) void k_count_tiles(const uint8_t* __restrict__ 
                                                     unsigned* __restrict__ tile_cnt) {
   __shared__ unsigned part[WG / 64];
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-  for (unsigned tile_id = blockIdx.x; tile_id < ntiles; tile_id += gridDim.x) {
+  const TileRange tr = tile_range(blockIdx.x, gridDim.x, ntiles);     // the range k_decompress's workgroup b owns
+  unsigned c = 0;
+  for (unsigned tile_id = tr.lo; tile_id < tr.hi; tile_id++) {
     const unsigned blks_here = min((unsigned)TILE_BLKS, nfull - tile_id * TILE_BLKS);
-    unsigned c = 0;
     if ((unsigned)(t >> 2) < blks_here) {
       const uint4 wv = reinterpret_cast<const uint4*>(bin + (size_t)tile_id * TILE_ELEMS)[t];
       const unsigned w[4] = {wv.x, wv.y, wv.z, wv.w};
@@ -1024,12 +1046,16 @@ __global__ __launch_bounds__(WG) void k_count_tiles(const uint8_t* __restrict__ 
       for (int i = 0; i < 16; i++)
         if (((w[i >> 2] >> (8 * (i & 3))) & 255u) == 255u && ((t & 3) * 16 + i) != 0) c++;
     }
+  }
 #pragma unroll
-    for (int d = 32; d > 0; d >>= 1) c += __shfl_down(c, d);
-    if (lane == 0) part[wave] = c;
-    __syncthreads();
-    if (t == 0) tile_cnt[tile_id] = part[0] + part[1] + part[2] + part[3];
-    __syncthreads();
+  for (int d = 32; d > 0; d >>= 1) c += __shfl_down(c, d);
+  if (lane == 0) part[wave] = c;
+  __syncthreads();
+  if (t == 0) {
+    unsigned sum = 0;
+#pragma unroll
+    for (int w = 0; w < WG / 64; w++) sum += part[w];
+    tile_cnt[blockIdx.x] = sum;
   }
 }
 
@@ -1081,12 +1107,14 @@ __global__ __launch_bounds__(WG, DCTZ_MINWAVES) void k_decompress(InvParams<T> p
     // tile k: flags + local scan -> issue the AC_exact gathers of k -> prefetch the
     // bin ids / DC of tile k+G -> store tile k-G (still in LDS) while the gathers
     // fly -> coefficients(k) to LDS -> IDCT(k).
-    unsigned tile_id = blockIdx.x;
+    const TileRange tr = tile_range(blockIdx.x, gridDim.x, p.ntiles);
+    unsigned tile_id = tr.lo;
+    unsigned run = p.tile_off[blockIdx.x];   // global index of this workgroup's first exact coefficient
     uint4 wv, wv_n;
     float dcv, dcv_n;
-    fetch(tile_id, wv, dcv);
+    fetch(tile_id < tr.hi ? tile_id : p.ntiles, wv, dcv);
     bool underrun = false;
-    while (tile_id < p.ntiles) {
+    while (tile_id < tr.hi) {
       const unsigned blks_here = min((unsigned)TILE_BLKS, p.nfull - tile_id * TILE_BLKS);
       const bool active = (unsigned)blk < blks_here;
       const unsigned w[4] = {wv.x, wv.y, wv.z, wv.w};
@@ -1099,7 +1127,8 @@ __global__ __launch_bounds__(WG, DCTZ_MINWAVES) void k_decompress(InvParams<T> p
       if (!active) mask = 0;
       __syncthreads();                   // sc[] of the previous tile is consumed
       unsigned total;
-      unsigned r = p.tile_off[tile_id] + tile_scan_local((unsigned)__popc(mask), sc, &total);
+      unsigned r = run + tile_scan_local((unsigned)__popc(mask), sc, &total);
+      run += total;
       float av[16];
 #pragma unroll
       for (int i = 0; i < 16; i++) {     // gathers first, uses later
@@ -1109,8 +1138,8 @@ __global__ __launch_bounds__(WG, DCTZ_MINWAVES) void k_decompress(InvParams<T> p
           r++;
         }
       }
-      const unsigned next_id = tile_id + gridDim.x;
-      fetch(next_id, wv_n, dcv_n);
+      const unsigned next_id = tile_id + 1;
+      fetch(next_id < tr.hi ? next_id : p.ntiles, wv_n, dcv_n);
       if (pending) {                     // flush the previous tile (uniform branch)
         const unsigned pv = min((unsigned)TILE_BLKS, p.nfull - prev_id * TILE_BLKS) * 64u;
         store_tile<T, SCALE>(tile, p.out, (size_t)prev_id * TILE_ELEMS, pv, p.sf);
@@ -1206,7 +1235,7 @@ __global__ __launch_bounds__(64) void k_decompress_rem(InvParams<T> p, int l) {
   const bool exc = (k < l) && (k != 0) && (b == 255u);
   const unsigned long long m = __ballot(exc);
   const unsigned rank = (unsigned)__popcll(m & ((1ull << k) - 1ull));
-  const unsigned start = p.tile_off ? p.tile_off[p.ntiles] : p.ctl->cnt_total;
+  const unsigned start = p.tile_off ? p.tile_off[p.nlists_main] : p.ctl->cnt_total;
   cr[k] = T(0); ci[k] = T(0); cr[k + 64] = T(0); ci[k + 64] = T(0);
   if (k < l) {
     T val;

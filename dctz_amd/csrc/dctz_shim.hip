@@ -106,7 +106,7 @@ extern "C" int dctzhip_ctx_create(dctzhip_ctx** out, int device) {
   if (const char* e = getenv("DCTZHIP_FEAT")) { c->feat = atoi(e) & 7; c->feat_d = c->feat; }
   if (const char* e = getenv("DCTZHIP_FASTDIV")) c->fastdiv = atoi(e);
   if (const char* e = getenv("DCTZHIP_STATS_GRID")) { int v = atoi(e); if (v >= 1 && v <= STATS_GRID_MAX) c->stats_grid = v; }
-  if (const char* e = getenv("DCTZHIP_WG_PER_CU")) { int v = atoi(e); if (v >= 1 && v <= 8) c->wg_per_cu = v; }
+  if (const char* e = getenv("DCTZHIP_WG_PER_CU")) { int v = atoi(e); if (v >= 1 && v <= 16) c->wg_per_cu = v; }
   HIPCHK(nullptr, hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
   c->stream = c->own_stream;
   HIPCHK(nullptr, hipStreamCreateWithFlags(&c->side_stream, hipStreamNonBlocking));
@@ -358,18 +358,19 @@ static int compress_impl(dctzhip_ctx* c, const T* d_in, size_t n, double eb, int
   if (rem) { int rc = upload_rtab<T>(c, rem); if (rc) return rc; }
 
   if (c->profiling) HIPCHK(c, hipEventRecord(c->ev[2], s));
+  const unsigned cap = (unsigned)(c->num_cu * (c->wg_per_cu ? c->wg_per_cu : (sizeof(T) == 8 ? 3 : 4) * 256 / WG));
+  const int grid = (int)(cap < ntiles ? cap : ntiles);
+  p.nlists_main = (unsigned)grid;
   if (ntiles) {
-    const unsigned cap = (unsigned)(c->num_cu * (c->wg_per_cu ? c->wg_per_cu : (sizeof(T) == 8 ? 3 : 4)));
-    const int grid = (int)(cap < ntiles ? cap : ntiles);
     p.ngroups = grid < 8 ? (unsigned)grid : 8u;
     launch_compress<T>(p, mode, scale, grid, c->feat, s);
   }
   if (c->profiling) HIPCHK(c, hipEventRecord(c->ev[3], s));
   if (rem) launch_compress_rem<T>(p, mode, scale, rem, s);
-  if (two_level) {                                  // stitch the tile-local lists into AC_exact[]
-    const unsigned nlists = ntiles + (rem ? 1u : 0u);
+  if (two_level) {                                  // stitch the workgroup-local lists into AC_exact[]
+    const unsigned nlists = (unsigned)grid + (rem ? 1u : 0u);
     launch_scan_tiles(c->tile_cnt, c->tile_off, nlists, c->ctl, s);
-    launch_compact_ac<T>(p, mode, eb, nlists, (int)((nlists + 3) / 4 < (unsigned)(c->num_cu * 32) ? (nlists + 3) / 4 : (unsigned)(c->num_cu * 32)), s);
+    launch_compact_ac<T>(p, mode, eb, nlists, (int)nlists, s);
   } else if (mode == DCTZHIP_QT) {
     launch_qt_finish<T>(p, eb, c->num_cu * 4, s);
   }
@@ -553,15 +554,16 @@ static int decompress_impl(dctzhip_ctx* c, const uint8_t* d_bin, const float* d_
   p.eb = eb;
   const bool scale = (p.sf != (T)1.0);            // :496 / :505
 
+  const unsigned cap = (unsigned)(c->num_cu * (c->wg_per_cu ? c->wg_per_cu : (sizeof(T) == 8 ? 3 : 4) * 256 / WG));
+  const int grid = (int)(cap < ntiles ? cap : ntiles);
+  p.nlists_main = (unsigned)grid;
   if (c->profiling) HIPCHK(c, hipEventRecord(c->ev[0], s));
-  if (two_level) {                                  // per-tile flag counts -> exclusive prefix
-    if (ntiles) launch_count_tiles(d_bin, nfull, ntiles, c->tile_cnt, c->num_cu * 8, s);
-    launch_scan_tiles(c->tile_cnt, c->tile_off, ntiles, c->ctl, s);
+  if (two_level) {                                  // per-workgroup-range flag counts -> exclusive prefix
+    if (ntiles) launch_count_tiles(d_bin, nfull, ntiles, c->tile_cnt, grid, s);
+    launch_scan_tiles(c->tile_cnt, c->tile_off, (unsigned)grid, c->ctl, s);
   }
   if (c->profiling) { HIPCHK(c, hipEventRecord(c->ev[1], s)); HIPCHK(c, hipEventRecord(c->ev[2], s)); }
   if (ntiles) {
-    const unsigned cap = (unsigned)(c->num_cu * (c->wg_per_cu ? c->wg_per_cu : (sizeof(T) == 8 ? 3 : 4)));
-    const int grid = (int)(cap < ntiles ? cap : ntiles);
     p.ngroups = grid < 8 ? (unsigned)grid : 8u;
     launch_decompress<T>(p, mode, scale, grid, c->feat_d, s);
   }
