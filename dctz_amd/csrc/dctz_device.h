@@ -20,6 +20,7 @@ namespace dctz {
 constexpr int TILE_BLKS = DCTZ_TILE_BLKS; // blocks per tile (one quad of lanes per block)
 constexpr int TILE_ELEMS = TILE_BLKS * 64;
 constexpr int WG = TILE_BLKS * 4;         // threads per workgroup
+constexpr int SWG = 256;                  // threads per workgroup of the streaming helpers (stats, count, compact, ...)
 
 template <typename T> struct Traits;
 template <> struct Traits<double> {

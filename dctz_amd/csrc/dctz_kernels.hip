@@ -610,7 +610,7 @@ __device__ __forceinline__ float qt_restore(float v, float q, double eb, float q
 // order (it is never used by the codec; the host wrapper recomputes it
 // serially for the header).
 template <typename T>
-__global__ __launch_bounds__(WG) void k_stats(const T* __restrict__ x, size_t n, double* __restrict__ part) {
+__global__ __launch_bounds__(SWG) void k_stats(const T* __restrict__ x, size_t n, double* __restrict__ part) {
   using Vec = typename Traits<T>::Vec;
   constexpr int EPV = Traits<T>::EPV;
   const size_t nvec = n / EPV;
@@ -618,16 +618,16 @@ __global__ __launch_bounds__(WG) void k_stats(const T* __restrict__ x, size_t n,
   T mx = T(0), mn = Traits<T>::huge();
   double sum = 0.0;
   constexpr int UN = 4;                            // each workgroup streams 16 KiB contiguous per trip
-  for (size_t i0 = (size_t)blockIdx.x * WG * UN + threadIdx.x; i0 < nvec; i0 += (size_t)gridDim.x * WG * UN) {
+  for (size_t i0 = (size_t)blockIdx.x * SWG * UN + threadIdx.x; i0 < nvec; i0 += (size_t)gridDim.x * SWG * UN) {
     Vec v[UN];
 #pragma unroll
     for (int u = 0; u < UN; u++) {
-      const size_t i = i0 + (size_t)u * WG;
+      const size_t i = i0 + (size_t)u * SWG;
       v[u] = (i < nvec) ? src[i] : src[i0];        // a repeated vector changes neither max nor min
     }
 #pragma unroll
     for (int u = 0; u < UN; u++) {
-      const size_t i = i0 + (size_t)u * WG;
+      const size_t i = i0 + (size_t)u * SWG;
       T e[EPV];
       Traits<T>::unpack(v[u], e);
 #pragma unroll
@@ -653,21 +653,21 @@ __global__ __launch_bounds__(WG) void k_stats(const T* __restrict__ x, size_t n,
     dmn = fmin(dmn, __shfl_down(dmn, d));
     sum += __shfl_down(sum, d);
   }
-  __shared__ double s[3][WG / 64];
+  __shared__ double s[3][SWG / 64];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   if (lane == 0) { s[0][wave] = dmx; s[1][wave] = dmn; s[2][wave] = sum; }
   __syncthreads();
   if (threadIdx.x == 0) {
-    for (int w = 1; w < WG / 64; w++) { dmx = fmax(dmx, s[0][w]); dmn = fmin(dmn, s[1][w]); sum += s[2][w]; }
+    for (int w = 1; w < SWG / 64; w++) { dmx = fmax(dmx, s[0][w]); dmn = fmin(dmn, s[1][w]); sum += s[2][w]; }
     part[3 * blockIdx.x + 0] = dmx;
     part[3 * blockIdx.x + 1] = dmn;
     part[3 * blockIdx.x + 2] = sum;
   }
 }
 
-__global__ __launch_bounds__(WG) void k_stats_final(const double* __restrict__ part, int nparts, double* __restrict__ out) {
+__global__ __launch_bounds__(SWG) void k_stats_final(const double* __restrict__ part, int nparts, double* __restrict__ out) {
   double dmx = 0.0, dmn = 1.79769313486231570815e308, sum = 0.0;
-  for (int i = threadIdx.x; i < nparts; i += WG) {
+  for (int i = threadIdx.x; i < nparts; i += SWG) {
     dmx = fmax(dmx, part[3 * i]); dmn = fmin(dmn, part[3 * i + 1]); sum += part[3 * i + 2];
   }
 #pragma unroll
@@ -676,12 +676,12 @@ __global__ __launch_bounds__(WG) void k_stats_final(const double* __restrict__ p
     dmn = fmin(dmn, __shfl_down(dmn, d));
     sum += __shfl_down(sum, d);
   }
-  __shared__ double s[3][WG / 64];
+  __shared__ double s[3][SWG / 64];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   if (lane == 0) { s[0][wave] = dmx; s[1][wave] = dmn; s[2][wave] = sum; }
   __syncthreads();
   if (threadIdx.x == 0) {
-    for (int w = 1; w < WG / 64; w++) { dmx = fmax(dmx, s[0][w]); dmn = fmin(dmn, s[1][w]); sum += s[2][w]; }
+    for (int w = 1; w < SWG / 64; w++) { dmx = fmax(dmx, s[0][w]); dmn = fmin(dmn, s[1][w]); sum += s[2][w]; }
     out[0] = dmx; out[1] = dmn; out[2] = sum;
   }
 }
@@ -714,12 +714,12 @@ __global__ __launch_bounds__(64) void k_serial_sum(const T* __restrict__ x, size
 // x[i] /= sf in place (dctz-comp-lib.c:193-216), for callers that need the
 // reference's in-place side effect on their own buffer.
 template <typename T>
-__global__ __launch_bounds__(WG) void k_scale(T* __restrict__ x, size_t n, T sf) {
+__global__ __launch_bounds__(SWG) void k_scale(T* __restrict__ x, size_t n, T sf) {
   using Vec = typename Traits<T>::Vec;
   constexpr int EPV = Traits<T>::EPV;
   const size_t nvec = n / EPV;
   Vec* v = reinterpret_cast<Vec*>(x);
-  for (size_t i = (size_t)blockIdx.x * WG + threadIdx.x; i < nvec; i += (size_t)gridDim.x * WG) {
+  for (size_t i = (size_t)blockIdx.x * SWG + threadIdx.x; i < nvec; i += (size_t)gridDim.x * SWG) {
     Vec a = v[i];
     Traits<T>::div(a, sf);
     v[i] = a;
@@ -933,7 +933,7 @@ __global__ __launch_bounds__(64) void k_compress_rem(FwdParams<T> p, int l) {
 // QT pass 2 for the single-pass kernels (dctz-comp-lib.c:450-461 clamp, :478-533
 // normalise + append): the flagged coefficients are already in global order.
 template <typename T>
-__global__ __launch_bounds__(WG) void k_qt_finish(FwdParams<T> p, double eb) {
+__global__ __launch_bounds__(SWG) void k_qt_finish(FwdParams<T> p, double eb) {
   using Bits = typename Traits<T>::Bits;
   __shared__ T q[64];
   if (threadIdx.x < 64) {
@@ -943,7 +943,7 @@ __global__ __launch_bounds__(WG) void k_qt_finish(FwdParams<T> p, double eb) {
   }
   __syncthreads();
   const unsigned cnt = p.ctl->cnt_total;
-  for (unsigned i = blockIdx.x * WG + threadIdx.x; i < cnt; i += gridDim.x * WG) {
+  for (unsigned i = blockIdx.x * SWG + threadIdx.x; i < cnt; i += gridDim.x * SWG) {
     const T item = p.qt_item[i];
     const int j = p.qt_j[i];
     // The in-range else-branch of :502-506 cannot fire for finite data and
@@ -1002,7 +1002,7 @@ __global__ __launch_bounds__(1024) void k_scan_tiles(const unsigned* __restrict_
 // (dctz-comp-lib.c:478-544 order: lists are already block-major, j ascending).
 // QT: clamp the table (:450-461) and normalise on the way (:488-518).
 template <typename T, int MODE>
-__global__ __launch_bounds__(WG) void k_compact_ac(FwdParams<T> p, double eb, unsigned nlists) {
+__global__ __launch_bounds__(SWG) void k_compact_ac(FwdParams<T> p, double eb, unsigned nlists) {
   using Bits = typename Traits<T>::Bits;
   __shared__ T q[64];
   if (MODE == DCTZHIP_QT) {
@@ -1019,7 +1019,7 @@ __global__ __launch_bounds__(WG) void k_compact_ac(FwdParams<T> p, double eb, un
   for (unsigned l = blockIdx.x; l < nlists; l += gridDim.x) {
     const unsigned n = p.tile_cnt[l], dst = p.tile_off[l];
     const size_t src = (size_t)(l < G ? tile_range(l, G, p.ntiles).lo : p.ntiles) * TILE_ELEMS;
-    for (unsigned i = threadIdx.x; i < n; i += WG) {
+    for (unsigned i = threadIdx.x; i < n; i += SWG) {
       if (MODE == DCTZHIP_EC) p.ac[dst + i] = p.ac_tmp[src + i];
       else p.ac[dst + i] = (float)qt_normalise(p.qt_item[src + i], q[p.qt_j[src + i]], eb, T(10), p.range_min, p.range_max);
     }
@@ -1031,21 +1031,22 @@ __global__ __launch_bounds__(WG) void k_compact_ac(FwdParams<T> p, double eb, un
 // binning.c:12-50) -> DCT-III per block (:428, dct.c:115-205) -> de-scale (:494-511).
 // Two-level scheme, decode side: per-tile count of "stored exactly" flags
 // (bin id 255 at j != 0, dctz-decomp-lib.c:400 / :446), 1 byte per element read.
-__global__ __launch_bounds__(WG) void k_count_tiles(const uint8_t* __restrict__ bin, unsigned nfull, unsigned ntiles,
-                                                    unsigned* __restrict__ tile_cnt) {
-  __shared__ unsigned part[WG / 64];
+__global__ __launch_bounds__(SWG) void k_count_tiles(const uint8_t* __restrict__ bin, unsigned nfull, unsigned ntiles,
+                                                     unsigned* __restrict__ tile_cnt) {
+  __shared__ unsigned part[SWG / 64];
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const TileRange tr = tile_range(blockIdx.x, gridDim.x, ntiles);     // the range k_decompress's workgroup b owns
+  // the range is one contiguous string of whole 64-byte blocks; 16 bytes per thread and trip
+  const size_t first = (size_t)tr.lo * TILE_ELEMS;
+  const size_t last = (size_t)min(nfull, tr.hi * (unsigned)TILE_BLKS) * 64;
   unsigned c = 0;
-  for (unsigned tile_id = tr.lo; tile_id < tr.hi; tile_id++) {
-    const unsigned blks_here = min((unsigned)TILE_BLKS, nfull - tile_id * TILE_BLKS);
-    if ((unsigned)(t >> 2) < blks_here) {
-      const uint4 wv = reinterpret_cast<const uint4*>(bin + (size_t)tile_id * TILE_ELEMS)[t];
-      const unsigned w[4] = {wv.x, wv.y, wv.z, wv.w};
+  for (size_t o = first + (size_t)t * 16; o < last; o += (size_t)SWG * 16) {
+    const uint4 wv = *reinterpret_cast<const uint4*>(bin + o);
+    const unsigned w[4] = {wv.x, wv.y, wv.z, wv.w};
+    const bool head = (o & 63) == 0;                                   // byte 0 of these 16 is a block's DC slot
 #pragma unroll
-      for (int i = 0; i < 16; i++)
-        if (((w[i >> 2] >> (8 * (i & 3))) & 255u) == 255u && ((t & 3) * 16 + i) != 0) c++;
-    }
+    for (int i = 0; i < 16; i++)
+      if (((w[i >> 2] >> (8 * (i & 3))) & 255u) == 255u && !(head && i == 0)) c++;
   }
 #pragma unroll
   for (int d = 32; d > 0; d >>= 1) c += __shfl_down(c, d);
@@ -1054,7 +1055,7 @@ __global__ __launch_bounds__(WG) void k_count_tiles(const uint8_t* __restrict__ 
   if (t == 0) {
     unsigned sum = 0;
 #pragma unroll
-    for (int w = 0; w < WG / 64; w++) sum += part[w];
+    for (int w = 0; w < SWG / 64; w++) sum += part[w];
     tile_cnt[blockIdx.x] = sum;
   }
 }
@@ -1276,11 +1277,11 @@ __global__ __launch_bounds__(64) void k_decompress_rem(InvParams<T> p, int l) {
 
 // Diagnostics: FastDiv against the compiler's own division, element by element.
 template <typename T>
-__global__ __launch_bounds__(WG) void k_debug_divide(const T* __restrict__ x, size_t n, T d, int ok,
+__global__ __launch_bounds__(SWG) void k_debug_divide(const T* __restrict__ x, size_t n, T d, int ok,
                                                      T* __restrict__ fast, T* __restrict__ ref) {
   FastDiv<T> fd;
   fd.init(d, ok != 0);
-  for (size_t i = (size_t)blockIdx.x * WG + threadIdx.x; i < n; i += (size_t)gridDim.x * WG) {
+  for (size_t i = (size_t)blockIdx.x * SWG + threadIdx.x; i < n; i += (size_t)gridDim.x * SWG) {
     fast[i] = fd.div(x[i]);
     ref[i] = x[i] / d;
   }
@@ -1370,13 +1371,13 @@ static size_t dct_smem() {
 
 template <typename T>
 void launch_stats(const T* x, size_t n, double* part, int nparts, double* out, hipStream_t s) {
-  hipLaunchKernelGGL(k_stats<T>, dim3(nparts), dim3(WG), 0, s, x, n, part);
-  hipLaunchKernelGGL(k_stats_final, dim3(1), dim3(WG), 0, s, (const double*)part, nparts, out);
+  hipLaunchKernelGGL(k_stats<T>, dim3(nparts), dim3(SWG), 0, s, x, n, part);
+  hipLaunchKernelGGL(k_stats_final, dim3(1), dim3(SWG), 0, s, (const double*)part, nparts, out);
 }
 
 template <typename T>
 void launch_debug_divide(const T* x, size_t n, T d, int ok, T* fast, T* ref, hipStream_t s) {
-  hipLaunchKernelGGL(k_debug_divide<T>, dim3(1024), dim3(WG), 0, s, x, n, d, ok, fast, ref);
+  hipLaunchKernelGGL(k_debug_divide<T>, dim3(1024), dim3(SWG), 0, s, x, n, d, ok, fast, ref);
 }
 
 template <typename T>
@@ -1386,7 +1387,7 @@ void launch_serial_sum(const T* x, size_t n, double* out, hipStream_t s) {
 
 template <typename T>
 void launch_scale(T* x, size_t n, T sf, int grid, hipStream_t s) {
-  hipLaunchKernelGGL(k_scale<T>, dim3(grid), dim3(WG), 0, s, x, n, sf);
+  hipLaunchKernelGGL(k_scale<T>, dim3(grid), dim3(SWG), 0, s, x, n, sf);
 }
 
 template <typename T, int FEAT>
@@ -1421,7 +1422,7 @@ void launch_compress_rem(const FwdParams<T>& p, int mode, bool scale, int l, hip
 
 template <typename T>
 void launch_qt_finish(const FwdParams<T>& p, double eb, int grid, hipStream_t s) {
-  hipLaunchKernelGGL(k_qt_finish<T>, dim3(grid), dim3(WG), 0, s, p, eb);
+  hipLaunchKernelGGL(k_qt_finish<T>, dim3(grid), dim3(SWG), 0, s, p, eb);
 }
 
 void launch_scan_tiles(const unsigned* cnt, unsigned* off, unsigned n, Ctl* ctl, hipStream_t s) {
@@ -1429,13 +1430,13 @@ void launch_scan_tiles(const unsigned* cnt, unsigned* off, unsigned n, Ctl* ctl,
 }
 
 void launch_count_tiles(const uint8_t* bin, unsigned nfull, unsigned ntiles, unsigned* tile_cnt, int grid, hipStream_t s) {
-  hipLaunchKernelGGL(k_count_tiles, dim3(grid), dim3(WG), 0, s, bin, nfull, ntiles, tile_cnt);
+  hipLaunchKernelGGL(k_count_tiles, dim3(grid), dim3(SWG), 0, s, bin, nfull, ntiles, tile_cnt);
 }
 
 template <typename T>
 void launch_compact_ac(const FwdParams<T>& p, int mode, double eb, unsigned nlists, int grid, hipStream_t s) {
-  if (mode == DCTZHIP_EC) hipLaunchKernelGGL((k_compact_ac<T, DCTZHIP_EC>), dim3(grid), dim3(WG), 0, s, p, eb, nlists);
-  else hipLaunchKernelGGL((k_compact_ac<T, DCTZHIP_QT>), dim3(grid), dim3(WG), 0, s, p, eb, nlists);
+  if (mode == DCTZHIP_EC) hipLaunchKernelGGL((k_compact_ac<T, DCTZHIP_EC>), dim3(grid), dim3(SWG), 0, s, p, eb, nlists);
+  else hipLaunchKernelGGL((k_compact_ac<T, DCTZHIP_QT>), dim3(grid), dim3(SWG), 0, s, p, eb, nlists);
 }
 
 template <typename T, int FEAT>

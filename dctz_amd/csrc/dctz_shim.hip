@@ -320,7 +320,7 @@ static int compress_impl(dctzhip_ctx* c, const T* d_in, size_t n, double eb, int
   double max_abs, min_abs, sum;
   {
     const size_t nvec = n / Traits<T>::EPV;
-    int sgrid = (int)((nvec + WG * 4 - 1) / (WG * 4));
+    int sgrid = (int)((nvec + SWG * 4 - 1) / (SWG * 4));
     if (sgrid < 1) sgrid = 1;
     if (sgrid > c->stats_grid) sgrid = c->stats_grid;
     launch_stats<T>(d_in, n, c->part, sgrid, c->stats_out, s);
@@ -418,7 +418,7 @@ template <typename T>
 static int stats_impl(dctzhip_ctx* c, const T* d_in, size_t n, double* max_abs, double* min_abs, double* sum) {
   hipStream_t s = c->stream;
   const size_t nvec = n / Traits<T>::EPV;
-  int sgrid = (int)((nvec + WG * 4 - 1) / (WG * 4));
+  int sgrid = (int)((nvec + SWG * 4 - 1) / (SWG * 4));
   if (sgrid < 1) sgrid = 1;
   if (sgrid > c->stats_grid) sgrid = c->stats_grid;
   launch_stats<T>(d_in, n, c->part, sgrid, c->stats_out, s);
