@@ -65,6 +65,8 @@ struct Ctl {
 };
 static_assert(sizeof(Ctl) % 16 == 0, "memset block must be a multiple of 16 bytes");
 
+enum : int { F_LOOKBACK = 1, F_GROUP = 2, F_STAMP = 4, F_STATS = 8 };   // kernel feature bits (dctz_kernels.hip)
+
 template <typename T>
 struct FwdParams {
   const T* x;                      // input
@@ -82,6 +84,7 @@ struct FwdParams {
   const T* rtab;                   // RTAB_* block (device), remainder block only
   Ctl* ctl;
   unsigned long long* desc;        // look-back descriptors, one per tile
+  double* stat_part;               // F_STATS: {max|x|, min|x|, sum} per workgroup (+1 slot for the remainder block), else NULL
   unsigned nfull;                  // number of full 64-element blocks
   unsigned ntiles;
   unsigned last_is_full;           // N % 64 == 0
@@ -111,6 +114,8 @@ struct InvParams {
 };
 
 template <typename T> void launch_stats(const T* x, size_t n, double* part, int nparts, double* out, hipStream_t s);
+template <typename T> void launch_stats_sample(const T* x, size_t n, unsigned group, double* part, int nparts, double* out, hipStream_t s);
+void launch_stats_final(const double* part, int nparts, double* out, hipStream_t s);
 template <typename T> void launch_debug_divide(const T* x, size_t n, T d, int ok, T* fast, T* ref, hipStream_t s);
 template <typename T> void launch_serial_sum(const T* x, size_t n, double* out, hipStream_t s);
 template <typename T> void launch_scale(T* x, size_t n, T sf, int grid, hipStream_t s);

@@ -45,13 +45,13 @@ namespace dctz {
 // ------------------------------------------------------------------ helpers --
 template <int CTRL>
 __device__ __forceinline__ float dpp(float v) {
-  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, false));
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, true));
 }
 template <int CTRL>
 __device__ __forceinline__ double dpp(double v) {
   int lo = __double2loint(v), hi = __double2hiint(v);
-  lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xf, 0xf, false);
-  hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xf, 0xf, false);
+  lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xf, 0xf, true);   // bound_ctrl: no "old" value to initialise (saves a v_mov per move)
+  hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xf, 0xf, true);
   return __hiloint2double(hi, lo);
 }
 // quad_perm control words: lane i reads from lane perm[i] of its quad
@@ -325,7 +325,8 @@ __device__ __forceinline__ unsigned tile_scan_local(unsigned cnt, unsigned* sc, 
 // two-level scheme: static tiles, tile-local exception lists, tiny scan, compaction.
 // F_GROUP: per-group ticket counters (look-back kernels).  F_STAMP: diagnostic phase
 // timers into Ctl::dbg (look-back kernels).
-enum : int { F_LOOKBACK = 1, F_GROUP = 2, F_STAMP = 4 };
+// F_STATS: k_compress also computes calc_data_stat's max|x|, min|x| and sum of the RAW input on the way (two-level
+// scheme only) -- the host launched it with a scaling factor guessed from a sample and verifies the guess afterwards.
 
 template <int FEAT>
 __device__ __forceinline__ unsigned take_ticket(Ctl* ctl, unsigned ngroups) {
@@ -385,13 +386,65 @@ __device__ __forceinline__ void issue_tile_loads(typename Traits<T>::Vec (&v)[TI
   }
 }
 
+// ---------------------------------------------------- statistics on the fly --
+// calc_data_stat's three reductions (util.c:18-25 / :31-38) over the vectors a
+// thread has just loaded for a tile; `skip0`: the vector holds x[0], which the
+// reference's loop (i = 1 ...) never adds to the sum.
+template <typename T>
+struct StatAcc {
+  T mx, mn;
+  double sum;                                      // raw-domain sum (or correction term)
+  double dcs;                                      // fused path: sum of the blocks' DC coefficients (see k_compress)
+  __device__ __forceinline__ void init() { mx = T(0); mn = Traits<T>::huge(); sum = 0.0; dcs = 0.0; }
+  // one v_max / v_min with the |x| source modifier each (a NaN operand is skipped, like `a > mx ? a : mx`)
+  __device__ __forceinline__ void add(T e, bool in_sum) {
+    minmax(e);
+    if (in_sum) sum += (double)e;
+  }
+  __device__ __forceinline__ void minmax(T e) {
+    if constexpr (sizeof(T) == 8) {
+      asm("v_max_f64 %0, %1, |%2|" : "=v"(mx) : "v"(mx), "v"(e));
+      asm("v_min_f64 %0, %1, |%2|" : "=v"(mn) : "v"(mn), "v"(e));
+    } else {
+      asm("v_max_f32 %0, %1, |%2|" : "=v"(mx) : "v"(mx), "v"(e));
+      asm("v_min_f32 %0, %1, |%2|" : "=v"(mn) : "v"(mn), "v"(e));
+    }
+  }
+  // workgroup reduction -> part[3*slot .. 3*slot+2]; `s` is scratch for 3 * (threads/64) doubles
+  // dc_scale: raw-domain value of one unit of DC (8 * sf for 64-element orthonormal blocks)
+  __device__ __forceinline__ void flush(double* part, unsigned slot, double* s, int nwaves, double dc_scale = 0.0) {
+    double dmx = (double)mx, dmn = (double)mn, sm = sum + dcs * dc_scale;
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) {
+      dmx = fmax(dmx, __shfl_down(dmx, d));
+      dmn = fmin(dmn, __shfl_down(dmn, d));
+      sm += __shfl_down(sm, d);
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) { s[wave] = dmx; s[nwaves + wave] = dmn; s[2 * nwaves + wave] = sm; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      for (int w = 1; w < nwaves; w++) { dmx = fmax(dmx, s[w]); dmn = fmin(dmn, s[nwaves + w]); sm += s[2 * nwaves + w]; }
+      part[3 * slot + 0] = dmx;
+      part[3 * slot + 1] = dmn;
+      part[3 * slot + 2] = sm;
+    }
+  }
+};
+
 // LEVEL 2: the host saw min|x| and max|x| of the whole array inside FastDiv's
 // window (k_stats), so every element takes the 3-operation path, no test.
 // LEVEL 1: window unknown (zeros, extreme exponents possible): per-element test,
 // exact fallback.  LEVEL 0: divisor outside the window: plain IEEE division.
-template <typename T, bool SCALE, int LEVEL>
+// STATS: calc_data_stat's max|x| / min|x| over the raw vectors on the way (speculative launch);
+// invalid vectors are guarded by `valid`.  The sum costs nothing here: an orthonormal 64-point
+// DCT has DC = (sum of the block)/8, so sum(x) = 8 sf * sum(DC) (emit_tile adds the DCs up; the
+// sum is tree-order in either path, only its decimal digits go into the header's `mean`).
+// skip0: v[0] of thread 0 starts with x[0], which util.c:22 never adds.
+template <typename T, bool SCALE, int LEVEL, bool STATS, bool FULL = false>
 __device__ __forceinline__ void stage_tile_l(T* tile, typename Traits<T>::Vec (&v)[TILE_ELEMS / Traits<T>::EPV / WG],
-                                             size_t ebase, unsigned valid, const FastDiv<T>& sfd, T* scaled) {
+                                             size_t ebase, unsigned valid, const FastDiv<T>& sfd, T* scaled,
+                                             StatAcc<T>* acc, bool skip0) {
   using Vec = typename Traits<T>::Vec;
   constexpr int EPV = Traits<T>::EPV, NV = TILE_ELEMS / EPV / WG;
   const int t = threadIdx.x;
@@ -399,6 +452,15 @@ __device__ __forceinline__ void stage_tile_l(T* tile, typename Traits<T>::Vec (&
   for (int i = 0; i < NV; i++) {
     const unsigned e = (unsigned)(i * WG + t) * EPV;
     Vec a = v[i];
+    if (STATS) {
+      T el[EPV];
+      Traits<T>::unpack(a, el);
+      if (FULL || e < valid) {                     // FULL: a whole tile (all but the array's last), no per-vector branch
+#pragma unroll
+        for (int k = 0; k < EPV; k++) acc->minmax(el[k]);
+      }
+      if (i == 0 && skip0) acc->sum -= (double)el[0];
+    }
     if (SCALE) {
       T el[EPV];
       Traits<T>::unpack(a, el);
@@ -414,12 +476,14 @@ __device__ __forceinline__ void stage_tile_l(T* tile, typename Traits<T>::Vec (&
   }
 }
 
-template <typename T, bool SCALE>
+template <typename T, bool SCALE, bool STATS = false>
 __device__ __forceinline__ void stage_tile(T* tile, typename Traits<T>::Vec (&v)[TILE_ELEMS / Traits<T>::EPV / WG],
-                                           size_t ebase, unsigned valid, const FastDiv<T>& sfd, T* scaled, unsigned level) {
-  if (level == 2) stage_tile_l<T, SCALE, 2>(tile, v, ebase, valid, sfd, scaled);
-  else if (level == 1) stage_tile_l<T, SCALE, 1>(tile, v, ebase, valid, sfd, scaled);
-  else stage_tile_l<T, SCALE, 0>(tile, v, ebase, valid, sfd, scaled);
+                                           size_t ebase, unsigned valid, const FastDiv<T>& sfd, T* scaled, unsigned level,
+                                           StatAcc<T>* acc = nullptr, bool skip0 = false) {
+  if (STATS && level == 2 && valid == (unsigned)TILE_ELEMS) stage_tile_l<T, SCALE, 2, STATS, true>(tile, v, ebase, valid, sfd, scaled, acc, skip0);
+  else if (level == 2) stage_tile_l<T, SCALE, 2, STATS>(tile, v, ebase, valid, sfd, scaled, acc, skip0);
+  else if (level == 1) stage_tile_l<T, SCALE, 1, STATS>(tile, v, ebase, valid, sfd, scaled, acc, skip0);
+  else stage_tile_l<T, SCALE, 0, STATS>(tile, v, ebase, valid, sfd, scaled, acc, skip0);
 }
 
 template <typename T, bool SCALE>
@@ -686,6 +750,31 @@ __global__ __launch_bounds__(SWG) void k_stats_final(const double* __restrict__ 
   }
 }
 
+// Sampled statistics for the speculative path: one 4 KiB chunk out of every group of
+// `group` chunks, at a hashed position inside the group (a fixed stride would alias with
+// the row structure of power-of-two volumes).  Same partials layout as k_stats.
+template <typename T>
+__global__ __launch_bounds__(SWG) void k_stats_sample(const T* __restrict__ x, size_t n, unsigned group,
+                                                       double* __restrict__ part) {
+  using Vec = typename Traits<T>::Vec;
+  constexpr int EPV = Traits<T>::EPV;
+  const size_t nchunks = n / ((size_t)SWG * EPV);                // whole chunks only; the tail is never sampled
+  const size_t ngroups = nchunks / group;
+  const Vec* src = reinterpret_cast<const Vec*>(x);
+  StatAcc<T> acc;
+  acc.init();
+  for (size_t g = blockIdx.x; g < ngroups; g += gridDim.x) {
+    const unsigned h = ((unsigned)g * 2654435761u) >> 8;
+    const size_t chunk = g * group + h % group;
+    T e[EPV];
+    Traits<T>::unpack(src[chunk * SWG + threadIdx.x], e);
+#pragma unroll
+    for (int k = 0; k < EPV; k++) acc.add(e[k], true);
+  }
+  __shared__ double ss[3 * (SWG / 64)];
+  acc.flush(part, blockIdx.x, ss, SWG / 64);
+}
+
 // Serial-order sum for the header's `mean` (util.c:18-28 / :31-41): the reference
 // adds x[1..N-1] one after the other in the data type, and a tree reduction
 // cannot reproduce those roundings.  One wavefront: all lanes stage a chunk in
@@ -737,7 +826,7 @@ template <typename T, int MODE, int FEAT>
 __device__ __forceinline__ void emit_tile(const FwdParams<T>& p, const T* tile, typename Traits<T>::Bits* qmax,
                                           unsigned* sc, const FastDiv<T>& bwd, unsigned tile_id, unsigned blks_here,
                                           bool publish, unsigned publish_value, Stamps* st, unsigned list_base = 0,
-                                          unsigned* run = nullptr) {
+                                          unsigned* run = nullptr, double* dcs = nullptr) {
   using Vec = typename Traits<T>::Vec;
   constexpr int EPV = Traits<T>::EPV;
   const int t = threadIdx.x;
@@ -790,6 +879,7 @@ __device__ __forceinline__ void emit_tile(const FwdParams<T>& p, const T* tile, 
     if (j0 == 0) {
       const unsigned gblk = tile_id * TILE_BLKS + blk;
       p.dc[gblk] = (float)c[0];                  // :350-351 USE_TRUNCATE
+      if (FEAT & F_STATS) *dcs += (double)c[0];
       if (p.last_is_full && gblk == p.nfull - 1) p.ctl->q0 = (unsigned long long)to_bits(c[0]);   // :355-360
     }
   }
@@ -828,20 +918,28 @@ __global__ __launch_bounds__(WG, DCTZ_MINWAVES) void k_compress(FwdParams<T> p) 
     const TileRange tr = tile_range(blockIdx.x, gridDim.x, p.ntiles);
     const unsigned list_base = tr.lo * TILE_ELEMS;   // this workgroup's exception list lives in its tiles' slots
     unsigned run = 0;                                // its length so far (uniform over the workgroup)
+    StatAcc<T> acc;
+    if (FEAT & F_STATS) acc.init();
     for (unsigned tile_id = tr.lo; tile_id < tr.hi; tile_id++) {
       const size_t ebase = (size_t)tile_id * TILE_ELEMS;
       const unsigned blks_here = min((unsigned)TILE_BLKS, p.nfull - tile_id * TILE_BLKS);
-      // (carrying the next tile's 32 KiB in registers across the emit phase was
-      // tried: it costs a wave per SIMD or spills, and loses -- DESIGN.md section 6)
+      // (Prefetching the next tile's 32 KiB into registers was tried twice: carried across the
+      // transform it costs a wave per SIMD; issued between transform and emit phase it still
+      // spills 4-10 VGPRs at the 168 cap and loses 4-10 % -- DESIGN.md section 6.)
       Vec v[NV];
       issue_tile_loads<T>(v, p.x, tile_id, p.ntiles, p.nfull);
       __syncthreads();                               // previous tile's LDS reads are done
-      stage_tile<T, SCALE>(tile, v, ebase, blks_here * 64u, sfd, p.scaled, p.fast_sf);
+      stage_tile<T, SCALE, (FEAT & F_STATS) != 0>(tile, v, ebase, blks_here * 64u, sfd, p.scaled, p.fast_sf, &acc,
+                                                  tile_id == 0 && t == 0);
       __syncthreads();
       tile_dct_fwd<T>(tile, tab);
-      emit_tile<T, MODE, FEAT>(p, tile, qmax, sc, bwd, tile_id, blks_here, false, 0u, nullptr, list_base, &run);
+      emit_tile<T, MODE, FEAT>(p, tile, qmax, sc, bwd, tile_id, blks_here, false, 0u, nullptr, list_base, &run, &acc.dcs);
     }
     if (t == 0) p.tile_cnt[blockIdx.x] = run;
+    if (FEAT & F_STATS) {
+      __syncthreads();                               // the tile buffer is free: scratch for the reduction
+      acc.flush(p.stat_part, blockIdx.x, reinterpret_cast<double*>(tile), WG / 64, SCALE ? 8.0 * (double)p.sf : 8.0);
+    }
   } else {
     Stamps st;
     if (FEAT & F_STAMP) st.start();
@@ -885,6 +983,13 @@ __global__ __launch_bounds__(64) void k_compress_rem(FwdParams<T> p, int l) {
   FastDiv<T> sfd, bwd;
   sfd.init(p.sf, p.fast_sf != 0);
   bwd.init(p.bin_width, p.fast_bw != 0);
+  if (p.stat_part != nullptr) {                                    // speculative launch: raw-input statistics of this block
+    __shared__ double ss[3];
+    StatAcc<T> acc;
+    acc.init();
+    if (k < l) acc.add(p.x[base + k], base + k != 0);
+    acc.flush(p.stat_part, p.nlists_main, ss, 1);
+  }
   if (k < l) {
     T a = p.x[base + k];
     if (SCALE) { a = sfd.div(a); if (p.scaled != nullptr) p.scaled[base + k] = a; }
@@ -1376,6 +1481,15 @@ void launch_stats(const T* x, size_t n, double* part, int nparts, double* out, h
 }
 
 template <typename T>
+void launch_stats_sample(const T* x, size_t n, unsigned group, double* part, int nparts, double* out, hipStream_t s) {
+  hipLaunchKernelGGL(k_stats_sample<T>, dim3(nparts), dim3(SWG), 0, s, x, n, group, part);
+  hipLaunchKernelGGL(k_stats_final, dim3(1), dim3(SWG), 0, s, (const double*)part, nparts, out);
+}
+void launch_stats_final(const double* part, int nparts, double* out, hipStream_t s) {
+  hipLaunchKernelGGL(k_stats_final, dim3(1), dim3(SWG), 0, s, part, nparts, out);
+}
+
+template <typename T>
 void launch_debug_divide(const T* x, size_t n, T d, int ok, T* fast, T* ref, hipStream_t s) {
   hipLaunchKernelGGL(k_debug_divide<T>, dim3(1024), dim3(SWG), 0, s, x, n, d, ok, fast, ref);
 }
@@ -1403,7 +1517,11 @@ static void launch_compress_f(const FwdParams<T>& p, int mode, bool scale, int g
 }
 template <typename T>
 void launch_compress(const FwdParams<T>& p, int mode, bool scale, int grid, int feat, hipStream_t s) {
-  if (!(feat & F_LOOKBACK)) { launch_compress_f<T, 0>(p, mode, scale, grid, s); return; }
+  if (!(feat & F_LOOKBACK)) {
+    if (feat & F_STATS) launch_compress_f<T, F_STATS>(p, mode, scale, grid, s);
+    else launch_compress_f<T, 0>(p, mode, scale, grid, s);
+    return;
+  }
   if (feat & F_STAMP) launch_compress_f<T, F_LOOKBACK | F_STAMP>(p, mode, scale, grid, s);
   else if (feat & F_GROUP) launch_compress_f<T, F_LOOKBACK | F_GROUP>(p, mode, scale, grid, s);
   else launch_compress_f<T, F_LOOKBACK>(p, mode, scale, grid, s);
@@ -1490,6 +1608,7 @@ void launch_dct_blocks(const T* x, T* out, const T* gtab, const T* rtab, size_t 
 // explicit instantiations used by dctz_shim.hip
 #define INST(T)                                                                                         \
   template void launch_stats<T>(const T*, size_t, double*, int, double*, hipStream_t);                  \
+  template void launch_stats_sample<T>(const T*, size_t, unsigned, double*, int, double*, hipStream_t); \
   template void launch_debug_divide<T>(const T*, size_t, T, int, T*, T*, hipStream_t);                  \
   template void launch_serial_sum<T>(const T*, size_t, double*, hipStream_t);                           \
   template void launch_scale<T>(T*, size_t, T, int, hipStream_t);                                       \

@@ -58,6 +58,11 @@ struct dctzhip_ctx {
   int fastdiv = 2;                  // hoisted-reciprocal division: 0 off, 1 per-tile window test, 2 + skip the test when k_stats proves it (DCTZHIP_FASTDIV)
   int stats_grid = 2048;            // workgroups of the statistics kernel (DCTZHIP_STATS_GRID, <= 2048)
   int wg_per_cu = 0;                // grid = CUs * this; 0 = resident workgroups per CU: 3 (fp64), 4 (fp32) (DCTZHIP_WG_PER_CU)
+  int speculate = 1;                // fused statistics behind a sampled guess of the scaling factor (DCTZHIP_SPECULATE, dctzhip_set_speculation)
+  size_t spec_min = (size_t)1 << 22; // elements below which the plain statistics pass is kept (DCTZHIP_SPEC_MIN)
+  unsigned spec_group = 64;         // one 4 KiB chunk sampled per group of this many (DCTZHIP_SPEC_GROUP)
+  int spec_cooldown = 0;            // calls left without speculation after a wrong guess
+  unsigned long long spec_hits = 0, spec_misses = 0;
   int profiling = 0;
   hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
   dctzhip_timings last = {0, 0, 0, 0};
@@ -67,6 +72,8 @@ struct dctzhip_ctx {
 
 static char g_create_err[512] = "";
 static constexpr int STATS_GRID_MAX = 2048;
+static constexpr int PART_SLOTS = 256 * 16 + 64;       // >= largest k_compress grid + 1 (fused statistics partials)
+static constexpr int SPEC_COOLDOWN = 8;
 static constexpr size_t PIN_STATS = 0, PIN_CTL = 64, PIN_TAB = 64 + sizeof(Ctl);
 static constexpr size_t PIN_BYTES = PIN_TAB + sizeof(double) * RTAB_SIZE + sizeof(double) * 64;
 
@@ -107,6 +114,9 @@ extern "C" int dctzhip_ctx_create(dctzhip_ctx** out, int device) {
   if (const char* e = getenv("DCTZHIP_FASTDIV")) c->fastdiv = atoi(e);
   if (const char* e = getenv("DCTZHIP_STATS_GRID")) { int v = atoi(e); if (v >= 1 && v <= STATS_GRID_MAX) c->stats_grid = v; }
   if (const char* e = getenv("DCTZHIP_WG_PER_CU")) { int v = atoi(e); if (v >= 1 && v <= 16) c->wg_per_cu = v; }
+  if (const char* e = getenv("DCTZHIP_SPECULATE")) c->speculate = atoi(e) != 0;
+  if (const char* e = getenv("DCTZHIP_SPEC_MIN")) { long long v = atoll(e); if (v >= 0) c->spec_min = (size_t)v; }
+  if (const char* e = getenv("DCTZHIP_SPEC_GROUP")) { int v = atoi(e); if (v >= 1 && v <= 4096) c->spec_group = (unsigned)v; }
   HIPCHK(nullptr, hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
   c->stream = c->own_stream;
   HIPCHK(nullptr, hipStreamCreateWithFlags(&c->side_stream, hipStreamNonBlocking));
@@ -116,7 +126,7 @@ extern "C" int dctzhip_ctx_create(dctzhip_ctx** out, int device) {
   HIPCHK(nullptr, hipMalloc(&c->rtab, sizeof(double) * RTAB_SIZE));
   HIPCHK(nullptr, hipMalloc(&c->qtab, sizeof(double) * 64));
   HIPCHK(nullptr, hipMalloc(&c->ctl, sizeof(Ctl)));
-  HIPCHK(nullptr, hipMalloc(&c->part, sizeof(double) * 3 * STATS_GRID_MAX));
+  HIPCHK(nullptr, hipMalloc(&c->part, sizeof(double) * 3 * PART_SLOTS));
   HIPCHK(nullptr, hipMalloc(&c->stats_out, sizeof(double) * 4));
   HIPCHK(nullptr, hipHostMalloc(&c->h_pin, PIN_BYTES, hipHostMallocDefault));
   {
@@ -154,6 +164,14 @@ extern "C" void* dctzhip_get_stream(dctzhip_ctx* c) { return c ? (void*)c->strea
 extern "C" int dctzhip_set_profiling(dctzhip_ctx* c, int on) {
   if (!c) return DCTZHIP_E_ARG;
   c->profiling = on ? 1 : 0;
+  return DCTZHIP_OK;
+}
+
+extern "C" int dctzhip_set_speculation(dctzhip_ctx* c, int on, size_t min_elements) {
+  if (!c) return DCTZHIP_E_ARG;
+  c->speculate = on != 0;
+  c->spec_cooldown = 0;
+  if (min_elements) c->spec_min = min_elements;
   return DCTZHIP_OK;
 }
 extern "C" int dctzhip_last_timings(dctzhip_ctx* c, dctzhip_timings* t) {
@@ -301,36 +319,23 @@ static int read_timings(dctzhip_ctx* c, int nev_main_start) {
   return DCTZHIP_OK;
 }
 
+struct HostStats { double max_abs, min_abs, sum; };
+
+// One pass of the compress kernels for a given set of statistics.  `fused`: the
+// statistics are a guess (from a sample); k_compress recomputes the true ones on
+// the way and leaves them in stats_out for the caller to check.
 template <typename T>
-static int compress_impl(dctzhip_ctx* c, const T* d_in, size_t n, double eb, int mode, uint8_t* d_bin, float* d_dc,
-                         float* d_ac, T* d_scaled, T* d_coef, dctzhip_cinfo* info) {
+static int compress_pass(dctzhip_ctx* c, const T* d_in, size_t n, double eb, int mode, uint8_t* d_bin, float* d_dc,
+                         float* d_ac, T* d_scaled, T* d_coef, const HostStats& st, bool fused, double* sf_out, T* sf_t_out,
+                         unsigned* fast_sf_out) {
   const int dtype = sizeof(T) == 8 ? DCTZHIP_F64 : DCTZHIP_F32;
   hipStream_t s = c->stream;
   const unsigned nfull = (unsigned)(n / 64);
   const int rem = (int)(n % 64);
   const unsigned ntiles = (nfull + TILE_BLKS - 1) / TILE_BLKS;
-  const unsigned nblk = nfull + (rem ? 1 : 0);
-
   const bool two_level = !(c->feat & 1);
-  HIPCHK(c, hipMemsetAsync(c->ctl, 0, sizeof(Ctl), s));
-  if (ntiles && !two_level) HIPCHK(c, hipMemsetAsync(c->desc, 0, ((ntiles + 1) & ~1u) * sizeof(unsigned long long), s));
-
-  // ---- calc_data_stat (util.c:12-44) ----------------------------------------
-  if (c->profiling) HIPCHK(c, hipEventRecord(c->ev[0], s));
-  double max_abs, min_abs, sum;
-  {
-    const size_t nvec = n / Traits<T>::EPV;
-    int sgrid = (int)((nvec + SWG * 4 - 1) / (SWG * 4));
-    if (sgrid < 1) sgrid = 1;
-    if (sgrid > c->stats_grid) sgrid = c->stats_grid;
-    launch_stats<T>(d_in, n, c->part, sgrid, c->stats_out, s);
-    if (c->profiling) HIPCHK(c, hipEventRecord(c->ev[1], s));
-    double* hs = reinterpret_cast<double*>(c->h_pin + PIN_STATS);
-    HIPCHK(c, hipMemcpyAsync(hs, c->stats_out, 3 * sizeof(double), hipMemcpyDeviceToHost, s));
-    HIPCHK(c, hipStreamSynchronize(s));
-    max_abs = hs[0]; min_abs = hs[1]; sum = hs[2];
-  }
-  const double sf = scaling_factor(dtype, max_abs);
+  const double sf = scaling_factor(dtype, st.max_abs);
+  *sf_out = sf;
 
   // ---- bin ranges, dctz-comp-lib.c:271-281 (computed in double, stored in T) --
   const int half = DCTZHIP_NBINS / 2;
@@ -342,15 +347,17 @@ static int compress_impl(dctzhip_ctx* c, const T* d_in, size_t n, double eb, int
   p.tile_off = two_level ? c->tile_off : nullptr;
   p.tab = tab_of<T>(c); p.rtab = reinterpret_cast<const T*>(c->rtab);
   p.ctl = c->ctl; p.desc = c->desc;
+  p.stat_part = fused ? c->part : nullptr;
   p.nfull = nfull; p.ntiles = ntiles; p.last_is_full = rem ? 0u : 1u; p.ngroups = 1;
   p.sf = (T)sf;
   p.bin_width = (T)(eb * 2.0 * 1.0);
   p.range_min = (T)(-(half * 2 + 1) * (eb * 1.0));
   p.range_max = (T)((half * 2 + 1) * (eb * 1.0));
-  // 2: every element is inside FastDiv's window (k_stats saw min|x| and max|x| there) -> no per-element test
+  // 2: every element is inside FastDiv's window (min|x| and max|x| are there) -> no per-element test
   p.fast_sf = c->fastdiv ? divisor_in_window(dtype, (double)p.sf) : 0u;
-  if (p.fast_sf && c->fastdiv >= 2 && value_in_window(dtype, min_abs) && value_in_window(dtype, max_abs)) p.fast_sf = 2;
+  if (p.fast_sf && c->fastdiv >= 2 && value_in_window(dtype, st.min_abs) && value_in_window(dtype, st.max_abs)) p.fast_sf = 2;
   p.fast_bw = c->fastdiv ? divisor_in_window(dtype, (double)p.bin_width) : 0u;
+  *sf_t_out = p.sf; *fast_sf_out = p.fast_sf;
   const bool scale = (p.sf != (T)1.0);              // :193 / :208
   if (!scale && d_scaled && d_scaled != d_in)       // sf == 1: "scaled" data is the input itself
     HIPCHK(c, hipMemcpyAsync(d_scaled, d_in, n * sizeof(T), hipMemcpyDeviceToDevice, s));
@@ -363,7 +370,7 @@ static int compress_impl(dctzhip_ctx* c, const T* d_in, size_t n, double eb, int
   p.nlists_main = (unsigned)grid;
   if (ntiles) {
     p.ngroups = grid < 8 ? (unsigned)grid : 8u;
-    launch_compress<T>(p, mode, scale, grid, c->feat, s);
+    launch_compress<T>(p, mode, scale, grid, c->feat | (fused ? F_STATS : 0), s);
   }
   if (c->profiling) HIPCHK(c, hipEventRecord(c->ev[3], s));
   if (rem) launch_compress_rem<T>(p, mode, scale, rem, s);
@@ -371,17 +378,100 @@ static int compress_impl(dctzhip_ctx* c, const T* d_in, size_t n, double eb, int
     const unsigned nlists = (unsigned)grid + (rem ? 1u : 0u);
     launch_scan_tiles(c->tile_cnt, c->tile_off, nlists, c->ctl, s);
     launch_compact_ac<T>(p, mode, eb, nlists, (int)nlists, s);
+    if (fused) launch_stats_final(c->part, (int)nlists, c->stats_out, s);
   } else if (mode == DCTZHIP_QT) {
     launch_qt_finish<T>(p, eb, c->num_cu * 4, s);
   }
   if (c->profiling) HIPCHK(c, hipEventRecord(c->ev[4], s));
   HIPCHK(c, hipGetLastError());
+  return DCTZHIP_OK;
+}
 
+template <typename T>
+static int compress_impl(dctzhip_ctx* c, const T* d_in, size_t n, double eb, int mode, uint8_t* d_bin, float* d_dc,
+                         float* d_ac, T* d_scaled, T* d_coef, dctzhip_cinfo* info) {
+  const int dtype = sizeof(T) == 8 ? DCTZHIP_F64 : DCTZHIP_F32;
+  hipStream_t s = c->stream;
+  const unsigned nfull = (unsigned)(n / 64);
+  const int rem = (int)(n % 64);
+  const unsigned ntiles = (nfull + TILE_BLKS - 1) / TILE_BLKS;
+  const unsigned nblk = nfull + (rem ? 1 : 0);
+  const bool two_level = !(c->feat & 1);
+  double* hs = reinterpret_cast<double*>(c->h_pin + PIN_STATS);    // [0..2] first statistics, [4..6] fused ones
   Ctl* hc = reinterpret_cast<Ctl*>(c->h_pin + PIN_CTL);
+
+  // Speculation: calc_data_stat needs the whole array before the first division, i.e. a second
+  // read of the input.  Only the DECADE of max|x| matters (util.c:29), so guess it from a sample,
+  // let k_compress compute the true statistics while it streams the data anyway, and check the
+  // guess afterwards; a wrong guess costs one re-run with the true values.  Never when the scaled
+  // data goes back into the input buffer (a wrong guess would have destroyed the input).
+  constexpr size_t chunk = (size_t)SWG * Traits<T>::EPV;
+  bool spec = c->speculate && two_level && ntiles && n >= c->spec_min && n >= 4 * chunk * c->spec_group &&
+              (const void*)d_scaled != (const void*)d_in;
+  if (spec && c->spec_cooldown > 0) { c->spec_cooldown--; spec = false; }
+
+  auto reset = [&]() -> int {
+    HIPCHK(c, hipMemsetAsync(c->ctl, 0, sizeof(Ctl), s));
+    if (ntiles && !two_level) HIPCHK(c, hipMemsetAsync(c->desc, 0, ((ntiles + 1) & ~1u) * sizeof(unsigned long long), s));
+    return DCTZHIP_OK;
+  };
+  { int rc = reset(); if (rc) return rc; }
+
+  // ---- calc_data_stat (util.c:12-44): the full pass, or the sample -------------
+  if (c->profiling) HIPCHK(c, hipEventRecord(c->ev[0], s));
+  if (spec) {
+    const size_t ngroups = n / chunk / c->spec_group;
+    const int sgrid = (int)(ngroups < (size_t)c->stats_grid ? ngroups : (size_t)c->stats_grid);
+    launch_stats_sample<T>(d_in, n, c->spec_group, c->part, sgrid, c->stats_out, s);
+  } else {
+    const size_t nvec = n / Traits<T>::EPV;
+    int sgrid = (int)((nvec + SWG * 4 - 1) / (SWG * 4));
+    if (sgrid < 1) sgrid = 1;
+    if (sgrid > c->stats_grid) sgrid = c->stats_grid;
+    launch_stats<T>(d_in, n, c->part, sgrid, c->stats_out, s);
+  }
+  if (c->profiling) HIPCHK(c, hipEventRecord(c->ev[1], s));
+  HIPCHK(c, hipMemcpyAsync(hs, c->stats_out, 3 * sizeof(double), hipMemcpyDeviceToHost, s));
+  HIPCHK(c, hipStreamSynchronize(s));
+  HostStats st = {hs[0], hs[1], hs[2]};
+
+  double sf = 1.0;
+  T sf_t = T(1);
+  unsigned fast_sf = 0;
+  unsigned flags = 0;
+  {
+    int rc = compress_pass<T>(c, d_in, n, eb, mode, d_bin, d_dc, d_ac, d_scaled, d_coef, st, spec, &sf, &sf_t, &fast_sf);
+    if (rc) return rc;
+  }
+  if (spec) HIPCHK(c, hipMemcpyAsync(hs + 4, c->stats_out, 3 * sizeof(double), hipMemcpyDeviceToHost, s));
   HIPCHK(c, hipMemcpyAsync(hc, c->ctl, sizeof(Ctl), hipMemcpyDeviceToHost, s));
   HIPCHK(c, hipStreamSynchronize(s));
   if (hc->error) return fail(c, DCTZHIP_E_INTERNAL, "in-kernel watchdog tripped (code %u)", hc->error);
   if (c->profiling) { int rc = read_timings(c, 2); if (rc) return rc; }
+
+  if (spec) {
+    const HostStats truth = {hs[4], hs[5], hs[6]};
+    const double true_sf = scaling_factor(dtype, truth.max_abs);
+    const bool window_ok = fast_sf != 2 || (value_in_window(dtype, truth.min_abs) && value_in_window(dtype, truth.max_abs));
+    st = truth;
+    if ((T)true_sf == sf_t && window_ok) {
+      sf = true_sf;
+      flags |= DCTZHIP_INFO_STATS_FUSED;
+      c->spec_hits++;
+    } else {                                        // wrong guess: everything again with the true statistics
+      c->spec_misses++;
+      c->spec_cooldown = SPEC_COOLDOWN;
+      flags |= DCTZHIP_INFO_RESPUN;
+      int rc = reset();
+      if (rc) return rc;
+      rc = compress_pass<T>(c, d_in, n, eb, mode, d_bin, d_dc, d_ac, d_scaled, d_coef, st, false, &sf, &sf_t, &fast_sf);
+      if (rc) return rc;
+      HIPCHK(c, hipMemcpyAsync(hc, c->ctl, sizeof(Ctl), hipMemcpyDeviceToHost, s));
+      HIPCHK(c, hipStreamSynchronize(s));
+      if (hc->error) return fail(c, DCTZHIP_E_INTERNAL, "in-kernel watchdog tripped (code %u)", hc->error);
+      if (c->profiling) { rc = read_timings(c, 2); if (rc) return rc; }
+    }
+  }
   if (c->feat & 4) {
     if ((c->feat & 1) && mode == DCTZHIP_EC)
       fprintf(stderr, "[dctzhip stamps] compress(pipe) cycles: stage %llu dct %llu bin %llu ticket+D %llu resolve %llu copyout %llu park+stores %llu\n",
@@ -394,9 +484,10 @@ static int compress_impl(dctzhip_ctx* c, const T* d_in, size_t n, double eb, int
   if (info) {
     memset(info, 0, sizeof(*info));
     info->sf = sf;
-    info->mean = (dtype == DCTZHIP_F64) ? sum / (double)(int)n : (double)((float)sum / (float)(int)n);
-    info->max_abs = max_abs; info->min_abs = min_abs;
+    info->mean = (dtype == DCTZHIP_F64) ? st.sum / (double)(int)n : (double)((float)st.sum / (float)(int)n);
+    info->max_abs = st.max_abs; info->min_abs = st.min_abs;
     info->cnt = hc->cnt_total; info->nblk = nblk;
+    info->flags = flags;
     if (mode == DCTZHIP_QT) {
       for (int j = 0; j < 64; j++) {
         double v;

@@ -24,7 +24,12 @@ def lib_path():
 class CompressInfo(C.Structure):
     _fields_ = [("sf", C.c_double), ("mean", C.c_double), ("max_abs", C.c_double),
                 ("min_abs", C.c_double), ("cnt", C.c_uint32), ("nblk", C.c_uint32),
-                ("qtable", C.c_double * 64), ("qtable_raw", C.c_double * 64)]
+                ("qtable", C.c_double * 64), ("qtable_raw", C.c_double * 64),
+                ("flags", C.c_uint32), ("reserved", C.c_uint32)]
+
+
+INFO_STATS_FUSED = 1   # sampled guess of sf verified: the separate statistics pass was saved
+INFO_RESPUN = 2        # guess wrong: the compress kernels ran a second time with the true statistics
 
 
 class Timings(C.Structure):
@@ -43,6 +48,7 @@ _PROTOS = {
     "dctzhip_get_stream": (C.c_void_p, [C.c_void_p]),
     "dctzhip_set_profiling": (C.c_int, [C.c_void_p, C.c_int]),
     "dctzhip_last_timings": (C.c_int, [C.c_void_p, C.POINTER(Timings)]),
+    "dctzhip_set_speculation": (C.c_int, [C.c_void_p, C.c_int, C.c_size_t]),
     "dctzhip_malloc": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.c_size_t]),
     "dctzhip_free": (C.c_int, [C.c_void_p, C.c_void_p]),
     "dctzhip_memcpy_h2d": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
@@ -129,6 +135,10 @@ class Context:
 
     def set_profiling(self, on=True):
         self._check(self.lib.dctzhip_set_profiling(self.h, int(on)), "set_profiling")
+
+    def set_speculation(self, on=True, min_elements=0):
+        """Fused statistics behind a sampled guess of sf (include/dctz_hip.h, DCTZHIP_INFO_*)."""
+        self._check(self.lib.dctzhip_set_speculation(self.h, int(on), int(min_elements)), "set_speculation")
 
     def timings(self):
         t = Timings()

@@ -51,7 +51,19 @@ typedef struct {
                                 (dctz-comp-lib.c:450-461, 815-820); slot 0 = DC of
                                 the last block (:355-360).  EC: zeros.             */
   double qtable_raw[64];     /* QT: table before clamping (= ./qtable.bin, :443-448) */
+  uint32_t flags;            /* DCTZHIP_INFO_*: how the statistics were obtained (below) */
+  uint32_t reserved;
 } dctzhip_cinfo;
+
+/* calc_data_stat (util.c:12-44) needs the whole array before the first division
+ * (dctz-comp-lib.c:193-216), i.e. a second read of the input.  Only the decade of
+ * max|x| enters sf (util.c:29), so for large inputs the library guesses sf from a
+ * sample, lets the compress kernel compute the TRUE max / min / sum while it
+ * streams the data anyway, and checks the guess afterwards.  The outputs never
+ * depend on the guess: a wrong one is detected and the kernels run again with
+ * the true statistics. */
+#define DCTZHIP_INFO_STATS_FUSED 1u   /* guess verified: the separate statistics pass was saved */
+#define DCTZHIP_INFO_RESPUN 2u        /* guess wrong: compress kernels were run a second time    */
 
 /* Per-kernel device time of the last compress / decompress call, milliseconds,
  * measured with HIP events on the context's stream (only when profiling is on). */
@@ -77,6 +89,11 @@ int dctzhip_reserve(dctzhip_ctx *ctx, size_t n, int dtype, int mode);
 int dctzhip_set_stream(dctzhip_ctx *ctx, void *hip_stream);
 void *dctzhip_get_stream(dctzhip_ctx *ctx);
 int dctzhip_set_profiling(dctzhip_ctx *ctx, int on);
+/* Speculative fused statistics (see DCTZHIP_INFO_*): on != 0 enables it for inputs of
+ * at least min_elements (0 keeps the current threshold, default 2^22); on == 0 always
+ * runs the separate statistics pass first.  Default: on (env DCTZHIP_SPECULATE=0 turns
+ * it off).  It is never used when d_scaled aliases d_in. */
+int dctzhip_set_speculation(dctzhip_ctx *ctx, int on, size_t min_elements);
 int dctzhip_last_timings(dctzhip_ctx *ctx, dctzhip_timings *t);
 
 /* ---- device memory helpers (so plain-C hosts need no HIP headers) --------- */
