@@ -188,3 +188,103 @@ def test_fast_division_is_exact(ctx, dtype):
         assert np.array_equal(np.isnan(fast), nan) and np.array_equal(np.isnan(ref), nan)
         assert np.array_equal(fast[~nan].view(np.uint8), ref[~nan].view(np.uint8)), f"fast != device '/' for d={d}"
         assert np.array_equal(ref[~nan].view(np.uint8), host[~nan].view(np.uint8)), f"device '/' != IEEE for d={d}"
+
+
+# ---- speculative fused statistics (include/dctz_hip.h, DCTZHIP_INFO_*) -------------------
+def _sampled_chunk(g, group=64):
+    """Chunk index k_stats_sample reads in group g (dctz_kernels.hip: hashed position)."""
+    return g * group + (((g * 2654435761) & 0xFFFFFFFF) >> 8) % group
+
+
+def _unsampled_element(dtype, group_index, group=64):
+    chunk_elems = 256 * (16 // np.dtype(dtype).itemsize)          # SWG threads x one 16-byte vector
+    g0 = _sampled_chunk(group_index, group)
+    c = group_index * group + (0 if g0 != group_index * group else 1)
+    assert c != g0
+    return c * chunk_elems + 17
+
+
+@pytest.fixture()
+def spec_ctx():
+    import dctz_amd
+    c = dctz_amd.Context(0)
+    c.set_speculation(True, 1 << 18)
+    yield c
+    c.close()
+
+
+def _check_against_oracle(ctx, x, eb, mode, out, info):
+    c = O.compress(x, eb, mode, O.FAST)
+    assert info.sf == c.sf and info.cnt == c.cnt
+    assert info.max_abs == float(np.abs(x).max()) and info.min_abs == float(np.abs(x).min())
+    assert np.array_equal(out["bin_index"].cpu().numpy(), c.bin_index)
+    assert _same(out["dc"].cpu().numpy(), c.dc)
+    assert _same(out["ac_exact"][:c.cnt].cpu().numpy(), c.ac_exact)
+    assert abs(info.mean - c.mean) <= 1e-5 * max(1.0, abs(c.mean))
+    if mode == O.QT:
+        assert _same(np.array(info.qtable[:], dtype=x.dtype), c.qtable)
+    return c
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+@pytest.mark.parametrize("mode", [O.EC, O.QT])
+@pytest.mark.parametrize("n", [1 << 20, (1 << 20) + 64 * 7 + 40, 300000])
+def test_speculation_hit_is_bit_exact(spec_ctx, dtype, mode, n):
+    import dctz_amd
+    x = W.ragged(n, dtype, scale=37.0)
+    out, info = spec_ctx.compress(_dev(spec_ctx, x), 1e-3, mode)
+    assert info.flags == dctz_amd.hip.INFO_STATS_FUSED, "smooth data: the sampled guess must verify"
+    _check_against_oracle(spec_ctx, x, 1e-3, mode, out, info)
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+@pytest.mark.parametrize("mode", [O.EC, O.QT])
+def test_speculation_wrong_decade_is_detected_and_rerun(spec_ctx, dtype, mode):
+    """A spike the sample cannot see moves max|x| into the next decade: the guess of sf is
+    wrong, the fused statistics say so, and the second run gives the reference's streams."""
+    import dctz_amd
+    n = 1 << 20
+    x = W.ragged(n, dtype, scale=37.0)
+    x[_unsampled_element(dtype, 5)] = 4321.0
+    out, info = spec_ctx.compress(_dev(spec_ctx, x), 1e-3, mode)
+    assert info.flags == dctz_amd.hip.INFO_RESPUN
+    c = _check_against_oracle(spec_ctx, x, 1e-3, mode, out, info)
+    assert c.sf == 1000.0
+    # cool-down: the next calls take the plain statistics pass, then speculation resumes
+    for i in range(9):
+        out, info = spec_ctx.compress(_dev(spec_ctx, x), 1e-3, mode)
+        assert info.flags == (0 if i < 8 else dctz_amd.hip.INFO_RESPUN), i
+        _check_against_oracle(spec_ctx, x, 1e-3, mode, out, info)
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_speculation_window_violation_is_detected(spec_ctx, dtype):
+    """An exact zero the sample cannot see: the guessed 'no per-element division test' level
+    would be unproven, so the call must fall back (zeros divide exactly either way, but the
+    proof obligation is on min|x|)."""
+    import dctz_amd
+    n = 1 << 20
+    x = W.ragged(n, dtype, scale=37.0)
+    x[x == 0] = 1.0
+    x[_unsampled_element(dtype, 9)] = 0.0
+    tiny = np.finfo(dtype).tiny
+    x[_unsampled_element(dtype, 11)] = tiny * 4          # far below FastDiv's window
+    out, info = spec_ctx.compress(_dev(spec_ctx, x), 1e-3, O.EC)
+    assert info.flags == dctz_amd.hip.INFO_RESPUN
+    _check_against_oracle(spec_ctx, x, 1e-3, O.EC, out, info)
+
+
+def test_speculation_is_off_for_in_place_scaling_and_small_inputs(spec_ctx):
+    import torch
+    x = W.ragged(1 << 20, np.float64, scale=37.0)
+    xd = _dev(spec_ctx, x)
+    out, info = spec_ctx.compress(xd, 1e-3, O.EC, scaled=xd)      # d_scaled aliases d_in
+    assert info.flags == 0
+    c = O.compress(x, 1e-3, O.EC, O.FAST)
+    assert _same(xd.cpu().numpy(), c.scaled) and info.cnt == c.cnt
+    y = W.ragged(1 << 16, np.float64, scale=37.0)                 # below the threshold
+    out, info = spec_ctx.compress(_dev(spec_ctx, y), 1e-3, O.EC)
+    assert info.flags == 0
+    spec_ctx.set_speculation(False)
+    out, info = spec_ctx.compress(_dev(spec_ctx, x), 1e-3, O.EC)
+    assert info.flags == 0 and info.cnt == c.cnt
