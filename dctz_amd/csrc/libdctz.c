@@ -29,6 +29,7 @@
 #include "dctz.h"
 
 #include <pthread.h>
+#include "pdeflate.h"
 #include <stdint.h>
 #include <sys/time.h>
 
@@ -61,6 +62,17 @@ static double now_s(void) {
 }
 
 static int quiet(void) { return getenv("DCTZ_QUIET") != NULL; }
+/* DCTZ_ZLIB_THREADS: unset / <= 3 = the reference's tail (three threads, one single-shot
+ * deflate each, dctz-comp-lib.c:620-732; three inflates one after the other,
+ * dctz-decomp-lib.c:244-322).  > 3: chunked deflate on that many threads (pdeflate.c;
+ * still one zlib stream per section) and the three inflates run concurrently.
+ * DCTZ_ZLIB_CHUNK: bytes per deflate job (default 256 KiB). */
+static int zlib_threads(void) { const char *e = getenv("DCTZ_ZLIB_THREADS"); return e ? atoi(e) : 0; }
+static size_t zlib_chunk(void) {
+  const char *e = getenv("DCTZ_ZLIB_CHUNK");
+  long long v = e ? atoll(e) : 0;
+  return v >= 32768 ? (size_t)v : (size_t)262144;
+}
 
 static void die(const char *what) {
   fprintf(stderr, "libdctz: %s: %s\n", what, dctzhip_last_error(g_ctx));
@@ -147,6 +159,28 @@ static uLong inflate_into(const Bytef *src, uLong src_len, void *dst, uLong dst_
   return produced;
 }
 
+typedef struct {
+  dctz_pd_section sec[3];
+  int threads, rc;
+  size_t chunk;
+} pd_args;
+static void *pd_main(void *arg) {
+  pd_args *a = (pd_args *)arg;
+  a->rc = dctz_pdeflate_many(a->sec, 3, a->threads, a->chunk);
+  return NULL;
+}
+
+typedef struct {
+  const Bytef *src;
+  uLong src_len, dst_len, produced;
+  void *dst;
+} inflate_job;
+static void *inflate_main(void *arg) {
+  inflate_job *j = (inflate_job *)arg;
+  j->produced = inflate_into(j->src, j->src_len, j->dst, j->dst_len);
+  return NULL;
+}
+
 static void dump_file(const char *name, const void *p, size_t bytes) {
   FILE *fp = fopen(name, "wb");
   if (!fp) return;
@@ -209,13 +243,30 @@ int dctz_compress(t_var *var, int N, size_t *outSize, t_var *var_z, double error
   }
 
   /* zlib tail: three streams on three threads (dctz-comp-lib.c:620-732) */
+  const int zthreads = zlib_threads();
+  const size_t sec_bytes[3] = {n * sizeof(t_bin_id), nblk * sizeof(float), (size_t)info.cnt * sizeof(float)};
+  const void *sec_src[3] = {bin_index, DC, AC_exact};
   pthread_attr_t attr;
   pthread_attr_init(&attr);
   pthread_attr_setdetachstate(&attr, PTHREAD_CREATE_JOINABLE);
   zjob jb[3];
-  zjob_start(&jb[0], bin_index, (uLong)(n * sizeof(t_bin_id)), &attr);
-  zjob_start(&jb[1], DC, (uLong)(nblk * sizeof(float)), &attr);
-  zjob_start(&jb[2], AC_exact, (uLong)((size_t)info.cnt * sizeof(float)), &attr);
+  memset(jb, 0, sizeof(jb));
+  pthread_t pd_thread;
+  pd_args pda;
+  size_t pd_len[3] = {0, 0, 0};
+  if (zthreads > 3) {                       /* chunked deflate, one pool for all three sections */
+    for (int i = 0; i < 3; i++) {
+      jb[i].bound = (uLong)dctz_pdeflate_bound(sec_bytes[i], zlib_chunk());
+      jb[i].dst = (Bytef *)malloc(jb[i].bound);
+      if (!jb[i].dst) { fprintf(stderr, "Out of memory: zlib buffer\n"); exit(1); }
+      pda.sec[i].src = sec_src[i]; pda.sec[i].n = sec_bytes[i];
+      pda.sec[i].dst = jb[i].dst; pda.sec[i].cap = jb[i].bound; pda.sec[i].out_len = &pd_len[i];
+    }
+    pda.threads = zthreads; pda.chunk = zlib_chunk(); pda.rc = 0;
+    if (pthread_create(&pd_thread, &attr, pd_main, &pda)) { fprintf(stderr, "Error creating thread\n"); exit(0); }
+  } else {
+    for (int i = 0; i < 3; i++) zjob_start(&jb[i], sec_src[i], (uLong)sec_bytes[i], &attr);
+  }
 
   /* while zlib runs: write x/sf back over the caller's buffer (:193-216) and
    * fetch the serial-order mean for the header */
@@ -227,7 +278,13 @@ int dctz_compress(t_var *var, int N, size_t *outSize, t_var *var_z, double error
   }
 
   uLong zsz[3];
-  for (int i = 0; i < 3; i++) zsz[i] = zjob_join(&jb[i]);
+  if (zthreads > 3) {
+    pthread_join(pd_thread, NULL);
+    if (pda.rc) { fprintf(stderr, "libdctz: parallel deflate failed (%d)\n", pda.rc); exit(1); }
+    for (int i = 0; i < 3; i++) zsz[i] = (uLong)pd_len[i];
+  } else {
+    for (int i = 0; i < 3; i++) zsz[i] = zjob_join(&jb[i]);
+  }
   pthread_attr_destroy(&attr);
   double t4 = now_s();
 
@@ -290,13 +347,28 @@ int dctz_decompress(t_var *var_z, t_var *var_r) {
 
   double t0 = now_s();
   /* three inflates, in order (dctz-decomp-lib.c:244-322) */
-  uLong got = inflate_into(cur, h.bindex_sz_compressed, bin_index, (uLong)n);
-  cur += h.bindex_sz_compressed;
+  uLong got;
+  if (zlib_threads() > 3) {                 /* the sections are independent streams: inflate them side by side */
+    inflate_job ij[3] = {{cur, h.bindex_sz_compressed, (uLong)n, 0, bin_index},
+                         {cur + h.bindex_sz_compressed, h.DC_sz_compressed, (uLong)(nblk * sizeof(float)), 0, DC},
+                         {cur + h.bindex_sz_compressed + h.DC_sz_compressed, h.AC_exact_sz_compressed,
+                          (uLong)((size_t)cnt * sizeof(float)), 0, AC_exact}};
+    pthread_t th[2];
+    int started = 0;
+    for (int i = 1; i < 3; i++) { if (pthread_create(&th[started], NULL, inflate_main, &ij[i])) inflate_main(&ij[i]); else started++; }
+    inflate_main(&ij[0]);
+    for (int i = 0; i < started; i++) pthread_join(th[i], NULL);
+    got = ij[0].produced;
+    cur += h.bindex_sz_compressed + h.DC_sz_compressed + h.AC_exact_sz_compressed;
+  } else {
+    got = inflate_into(cur, h.bindex_sz_compressed, bin_index, (uLong)n);
+    cur += h.bindex_sz_compressed;
+    inflate_into(cur, h.DC_sz_compressed, DC, (uLong)(nblk * sizeof(float)));
+    cur += h.DC_sz_compressed;
+    inflate_into(cur, h.AC_exact_sz_compressed, AC_exact, (uLong)((size_t)cnt * sizeof(float)));
+    cur += h.AC_exact_sz_compressed;
+  }
   if (!quiet()) printf("uncompressed bin_index size is: %lu\n", got); /* :260-262 */
-  inflate_into(cur, h.DC_sz_compressed, DC, (uLong)(nblk * sizeof(float)));
-  cur += h.DC_sz_compressed;
-  inflate_into(cur, h.AC_exact_sz_compressed, AC_exact, (uLong)((size_t)cnt * sizeof(float)));
-  cur += h.AC_exact_sz_compressed;
   const void *qtable = NULL;
 #ifdef USE_QTABLE
   double qd[BLK_SZ];
