@@ -128,6 +128,13 @@ typedef struct {
   double h2d_s, gpu_s, d2h_s, zlib_s, total_s;
 } dctz_stage_times;
 void dctz_last_stage_times(dctz_stage_times *t);
+/* The zlib tail (dctz-comp-lib.c:620-732) as a chunked multi-threaded deflate that still
+ * yields ONE standard zlib stream, so dctz-decomp-lib.c:244-322 inflates it unchanged
+ * (csrc/pdeflate.c).  dctz_compress uses it when the environment has
+ * DCTZ_ZLIB_THREADS > 3; exported for tools that write DCTZ containers themselves.
+ * cap >= dctz_pdeflate_bound(n, chunk); returns 0 on success. */
+size_t dctz_pdeflate_bound(size_t n, size_t chunk);
+int dctz_pdeflate(const void *src, size_t n, void *dst, size_t cap, size_t *out_len, int threads, size_t chunk);
 
 #ifdef __cplusplus
 }
