@@ -65,6 +65,19 @@ struct Ctl {
 };
 static_assert(sizeof(Ctl) % 16 == 0, "memset block must be a multiple of 16 bytes");
 
+// Result mailbox in fine-grained pinned HOST memory: the last kernel of a phase writes
+// the few words the host needs and then a sequence number, the host spins on that word
+// instead of paying a D2H copy kernel + hipStreamSynchronize wake-up per hand-off.
+struct HostBox {
+  volatile unsigned long long seq_stats;   // == call sequence number once stats[] is valid
+  double stats[3];                         // max|x|, min|x|, sum of the statistics pass / the sample
+  volatile unsigned long long seq_done;    // == call sequence number once everything below is valid
+  unsigned cnt_total, error;
+  unsigned long long q0;
+  unsigned long long qraw[64];
+  double fstats[3];                        // statistics fused into k_compress (F_STATS)
+};
+
 enum : int { F_LOOKBACK = 1, F_GROUP = 2, F_STAMP = 4, F_STATS = 8 };   // kernel feature bits (dctz_kernels.hip)
 
 template <typename T>
@@ -113,9 +126,12 @@ struct InvParams {
   double eb;
 };
 
-template <typename T> void launch_stats(const T* x, size_t n, double* part, int nparts, double* out, hipStream_t s);
-template <typename T> void launch_stats_sample(const T* x, size_t n, unsigned group, double* part, int nparts, double* out, hipStream_t s);
+template <typename T> void launch_stats(const T* x, size_t n, double* part, int nparts, double* out, hipStream_t s,
+                                        HostBox* box = nullptr, unsigned long long seq = 0);
+template <typename T> void launch_stats_sample(const T* x, size_t n, unsigned group, double* part, int nparts, double* out, hipStream_t s,
+                                               HostBox* box = nullptr, unsigned long long seq = 0);
 void launch_stats_final(const double* part, int nparts, double* out, hipStream_t s);
+void launch_finish(Ctl* ctl, const double* part, int nparts, HostBox* box, unsigned long long seq, hipStream_t s);
 template <typename T> void launch_debug_divide(const T* x, size_t n, T d, int ok, T* fast, T* ref, hipStream_t s);
 template <typename T> void launch_serial_sum(const T* x, size_t n, double* out, hipStream_t s);
 template <typename T> void launch_scale(T* x, size_t n, T sf, int grid, hipStream_t s);

@@ -668,6 +668,15 @@ __device__ __forceinline__ float qt_restore(float v, float q, double eb, float q
                  : (float)(((double)(v - rmin) / (eb * (double)qf)) * (double)q);
 }
 
+// ------------------------------------------------------------- host hand-off --
+// System-scope release of a sequence number into the HostBox (fine-grained pinned host
+// memory): everything this thread (and, after a barrier, its workgroup) wrote to the
+// box before is visible to the polling host thread once it reads the number.
+__device__ __forceinline__ void box_publish(volatile unsigned long long* flag, unsigned long long seq) {
+  __threadfence_system();
+  __hip_atomic_store(const_cast<unsigned long long*>(flag), seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
 // =============================================================== statistics ==
 // calc_data_stat (util.c:12-44): max|x|, min|x| and sum (x[0] is never added,
 // util.c:22 starts at i = 1).  Tree order: `sum` is NOT the reference's serial
@@ -729,7 +738,8 @@ __global__ __launch_bounds__(SWG) void k_stats(const T* __restrict__ x, size_t n
   }
 }
 
-__global__ __launch_bounds__(SWG) void k_stats_final(const double* __restrict__ part, int nparts, double* __restrict__ out) {
+__global__ __launch_bounds__(SWG) void k_stats_final(const double* __restrict__ part, int nparts, double* __restrict__ out,
+                                                    HostBox* box, unsigned long long seq) {
   double dmx = 0.0, dmn = 1.79769313486231570815e308, sum = 0.0;
   for (int i = threadIdx.x; i < nparts; i += SWG) {
     dmx = fmax(dmx, part[3 * i]); dmn = fmin(dmn, part[3 * i + 1]); sum += part[3 * i + 2];
@@ -747,7 +757,46 @@ __global__ __launch_bounds__(SWG) void k_stats_final(const double* __restrict__ 
   if (threadIdx.x == 0) {
     for (int w = 1; w < SWG / 64; w++) { dmx = fmax(dmx, s[0][w]); dmn = fmin(dmn, s[1][w]); sum += s[2][w]; }
     out[0] = dmx; out[1] = dmn; out[2] = sum;
+    if (box != nullptr) {                            // hand the three numbers straight to the polling host thread
+      box->stats[0] = dmx; box->stats[1] = dmn; box->stats[2] = sum;
+      box_publish(&box->seq_stats, seq);
+    }
   }
+}
+
+// Last kernel of a compress / decompress call (two-level scheme): final reduction of the
+// fused statistics (nparts > 0), results -> host box, control block back to all-zero for
+// the next call (replaces its hipMemsetAsync), then the sequence number.
+__global__ __launch_bounds__(SWG) void k_finish(Ctl* ctl, const double* __restrict__ part, int nparts, HostBox* box,
+                                               unsigned long long seq) {
+  const int t = threadIdx.x;
+  if (nparts > 0) {
+    double dmx = 0.0, dmn = 1.79769313486231570815e308, sum = 0.0;
+    for (int i = t; i < nparts; i += SWG) {
+      dmx = fmax(dmx, part[3 * i]); dmn = fmin(dmn, part[3 * i + 1]); sum += part[3 * i + 2];
+    }
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) {
+      dmx = fmax(dmx, __shfl_down(dmx, d));
+      dmn = fmin(dmn, __shfl_down(dmn, d));
+      sum += __shfl_down(sum, d);
+    }
+    __shared__ double s[3][SWG / 64];
+    const int lane = t & 63, wave = t >> 6;
+    if (lane == 0) { s[0][wave] = dmx; s[1][wave] = dmn; s[2][wave] = sum; }
+    __syncthreads();
+    if (t == 0) {
+      for (int w = 1; w < SWG / 64; w++) { dmx = fmax(dmx, s[0][w]); dmn = fmin(dmn, s[1][w]); sum += s[2][w]; }
+      box->fstats[0] = dmx; box->fstats[1] = dmn; box->fstats[2] = sum;
+    }
+  }
+  if (t < 64) box->qraw[t] = ctl->qraw[t];
+  if (t == 0) { box->cnt_total = ctl->cnt_total; box->error = ctl->error; box->q0 = ctl->q0; }
+  __threadfence_system();
+  __syncthreads();                                   // all box writes issued and fenced; all ctl reads done
+  unsigned long long* w = reinterpret_cast<unsigned long long*>(ctl);
+  for (int i = t; i < (int)(sizeof(Ctl) / 8); i += SWG) w[i] = 0ull;
+  if (t == 0) box_publish(&box->seq_done, seq);
 }
 
 // Sampled statistics for the speculative path: one 4 KiB chunk out of every group of
@@ -1475,18 +1524,22 @@ static size_t dct_smem() {
 }
 
 template <typename T>
-void launch_stats(const T* x, size_t n, double* part, int nparts, double* out, hipStream_t s) {
+void launch_stats(const T* x, size_t n, double* part, int nparts, double* out, hipStream_t s, HostBox* box, unsigned long long seq) {
   hipLaunchKernelGGL(k_stats<T>, dim3(nparts), dim3(SWG), 0, s, x, n, part);
-  hipLaunchKernelGGL(k_stats_final, dim3(1), dim3(SWG), 0, s, (const double*)part, nparts, out);
+  hipLaunchKernelGGL(k_stats_final, dim3(1), dim3(SWG), 0, s, (const double*)part, nparts, out, box, seq);
 }
 
 template <typename T>
-void launch_stats_sample(const T* x, size_t n, unsigned group, double* part, int nparts, double* out, hipStream_t s) {
+void launch_stats_sample(const T* x, size_t n, unsigned group, double* part, int nparts, double* out, hipStream_t s,
+                         HostBox* box, unsigned long long seq) {
   hipLaunchKernelGGL(k_stats_sample<T>, dim3(nparts), dim3(SWG), 0, s, x, n, group, part);
-  hipLaunchKernelGGL(k_stats_final, dim3(1), dim3(SWG), 0, s, (const double*)part, nparts, out);
+  hipLaunchKernelGGL(k_stats_final, dim3(1), dim3(SWG), 0, s, (const double*)part, nparts, out, box, seq);
 }
 void launch_stats_final(const double* part, int nparts, double* out, hipStream_t s) {
-  hipLaunchKernelGGL(k_stats_final, dim3(1), dim3(SWG), 0, s, part, nparts, out);
+  hipLaunchKernelGGL(k_stats_final, dim3(1), dim3(SWG), 0, s, part, nparts, out, (HostBox*)nullptr, 0ull);
+}
+void launch_finish(Ctl* ctl, const double* part, int nparts, HostBox* box, unsigned long long seq, hipStream_t s) {
+  hipLaunchKernelGGL(k_finish, dim3(1), dim3(SWG), 0, s, ctl, part, nparts, box, seq);
 }
 
 template <typename T>
@@ -1607,8 +1660,8 @@ void launch_dct_blocks(const T* x, T* out, const T* gtab, const T* rtab, size_t 
 
 // explicit instantiations used by dctz_shim.hip
 #define INST(T)                                                                                         \
-  template void launch_stats<T>(const T*, size_t, double*, int, double*, hipStream_t);                  \
-  template void launch_stats_sample<T>(const T*, size_t, unsigned, double*, int, double*, hipStream_t); \
+  template void launch_stats<T>(const T*, size_t, double*, int, double*, hipStream_t, HostBox*, unsigned long long); \
+  template void launch_stats_sample<T>(const T*, size_t, unsigned, double*, int, double*, hipStream_t, HostBox*, unsigned long long); \
   template void launch_debug_divide<T>(const T*, size_t, T, int, T*, T*, hipStream_t);                  \
   template void launch_serial_sum<T>(const T*, size_t, double*, hipStream_t);                           \
   template void launch_scale<T>(T*, size_t, T, int, hipStream_t);                                       \

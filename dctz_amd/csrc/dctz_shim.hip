@@ -7,6 +7,7 @@
 // the few scalars the host stage needs (cnt, QT table).  No CPU compute path
 // exists: if HIP is unavailable every call returns DCTZHIP_E_HIP.
 #include <hip/hip_runtime.h>
+#include <chrono>
 
 #include <climits>
 #include <cmath>
@@ -52,6 +53,11 @@ struct dctzhip_ctx {
   size_t qtj_cap = 0;
   // pinned host staging
   unsigned char* h_pin = nullptr;   // [0,64): stats, [64, 64+sizeof(Ctl)): ctl, then tables
+  HostBox* box = nullptr;           // result mailbox, fine-grained pinned host memory (kernels write, host spins)
+  HostBox* box_dev = nullptr;       // the same memory as the device sees it
+  unsigned long long seq = 0;       // sequence number of the last hand-off
+  int handoff = 1;                  // 1: mailbox + spin (two-level scheme); 0: D2H copy + hipStreamSynchronize (DCTZHIP_HANDOFF)
+  int ctl_dirty = 1;                // control block may be non-zero: memset it before the next call
   // profiling
   int feat = 0;                     // 0: two-level scheme (default); 1: single-pass look-back kernels,
   int feat_d = 0;                   //    +2 grouped tickets, +4 phase stamps (DCTZHIP_FEAT sets both)
@@ -129,6 +135,10 @@ extern "C" int dctzhip_ctx_create(dctzhip_ctx** out, int device) {
   HIPCHK(nullptr, hipMalloc(&c->part, sizeof(double) * 3 * PART_SLOTS));
   HIPCHK(nullptr, hipMalloc(&c->stats_out, sizeof(double) * 4));
   HIPCHK(nullptr, hipHostMalloc(&c->h_pin, PIN_BYTES, hipHostMallocDefault));
+  HIPCHK(nullptr, hipHostMalloc(reinterpret_cast<void**>(&c->box), sizeof(HostBox), hipHostMallocCoherent | hipHostMallocMapped));
+  memset(c->box, 0, sizeof(HostBox));
+  HIPCHK(nullptr, hipHostGetDevicePointer(reinterpret_cast<void**>(&c->box_dev), c->box, 0));
+  if (const char* e = getenv("DCTZHIP_HANDOFF")) c->handoff = atoi(e) != 0;
   {
     double t64[TAB_SIZE];
     float t32[TAB_SIZE];
@@ -150,6 +160,7 @@ extern "C" void dctzhip_ctx_destroy(dctzhip_ctx* c) {
   void* bufs[] = {c->ac_tmp, c->tile_cnt, c->tile_off, c->serial_out, c->tab_f64, c->tab_f32, c->rtab, c->qtab, c->ctl, c->desc, c->part, c->stats_out, c->qt_item, c->qt_j};
   for (void* b : bufs) if (b) (void)hipFree(b);
   if (c->h_pin) (void)hipHostFree(c->h_pin);
+  if (c->box) (void)hipHostFree(c->box);
   for (int i = 0; i < 6; i++) if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
   if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
   delete c;
@@ -300,6 +311,32 @@ template <typename T> static const T* tab_of(dctzhip_ctx* c);
 template <> const double* tab_of<double>(dctzhip_ctx* c) { return c->tab_f64; }
 template <> const float* tab_of<float>(dctzhip_ctx* c) { return c->tab_f32; }
 
+// Spin on a mailbox word until the kernels of this call have published `want`.  The stream is
+// queried now and then so that a faulted launch ends the wait; after 10 s the call gives up.
+static int wait_seq(dctzhip_ctx* c, volatile unsigned long long* word, unsigned long long want, const char* what) {
+  const auto t0 = std::chrono::steady_clock::now();
+  for (unsigned long long spins = 1;; spins++) {
+    if (__atomic_load_n(word, __ATOMIC_ACQUIRE) == want) return DCTZHIP_OK;
+    __builtin_ia32_pause();
+    if ((spins & 0xFFFF) == 0) {
+      const hipError_t q = hipStreamQuery(c->stream);
+      if (q == hipSuccess) {                        // everything ran: the word must be there now
+        if (__atomic_load_n(word, __ATOMIC_ACQUIRE) == want) return DCTZHIP_OK;
+        c->ctl_dirty = 1;
+        return fail(c, DCTZHIP_E_INTERNAL, "%s: stream drained without publishing its result", what);
+      }
+      if (q != hipErrorNotReady) {
+        c->ctl_dirty = 1;
+        return fail(c, DCTZHIP_E_HIP, "%s: %s", what, hipGetErrorString(q));
+      }
+      if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(10)) {
+        c->ctl_dirty = 1;
+        return fail(c, DCTZHIP_E_INTERNAL, "%s: no result after 10 s", what);
+      }
+    }
+  }
+}
+
 // util.c:29 / util.c:43, with the host libm exactly like the reference
 static double scaling_factor(int dtype, double max_abs) {
   if (max_abs == 0.0) return 1.0;               // documented deviation: reference divides by 0
@@ -327,7 +364,7 @@ struct HostStats { double max_abs, min_abs, sum; };
 template <typename T>
 static int compress_pass(dctzhip_ctx* c, const T* d_in, size_t n, double eb, int mode, uint8_t* d_bin, float* d_dc,
                          float* d_ac, T* d_scaled, T* d_coef, const HostStats& st, bool fused, double* sf_out, T* sf_t_out,
-                         unsigned* fast_sf_out) {
+                         unsigned* fast_sf_out, unsigned long long seq) {
   const int dtype = sizeof(T) == 8 ? DCTZHIP_F64 : DCTZHIP_F32;
   hipStream_t s = c->stream;
   const unsigned nfull = (unsigned)(n / 64);
@@ -378,7 +415,8 @@ static int compress_pass(dctzhip_ctx* c, const T* d_in, size_t n, double eb, int
     const unsigned nlists = (unsigned)grid + (rem ? 1u : 0u);
     launch_scan_tiles(c->tile_cnt, c->tile_off, nlists, c->ctl, s);
     launch_compact_ac<T>(p, mode, eb, nlists, (int)nlists, s);
-    if (fused) launch_stats_final(c->part, (int)nlists, c->stats_out, s);
+    if (seq) launch_finish(c->ctl, c->part, fused ? (int)nlists : 0, c->box_dev, seq, s);   // results -> host box, Ctl -> 0
+    else if (fused) launch_stats_final(c->part, (int)nlists, c->stats_out, s);
   } else if (mode == DCTZHIP_QT) {
     launch_qt_finish<T>(p, eb, c->num_cu * 4, s);
   }
@@ -410,44 +448,69 @@ static int compress_impl(dctzhip_ctx* c, const T* d_in, size_t n, double eb, int
               (const void*)d_scaled != (const void*)d_in;
   if (spec && c->spec_cooldown > 0) { c->spec_cooldown--; spec = false; }
 
+  // Host hand-off: mailbox + spin for the two-level scheme, D2H copy + stream sync otherwise
+  const bool box = c->handoff && two_level && !(c->feat & 4);
+  HostBox* hb = c->box;
   auto reset = [&]() -> int {
-    HIPCHK(c, hipMemsetAsync(c->ctl, 0, sizeof(Ctl), s));
+    if (!box || c->ctl_dirty) HIPCHK(c, hipMemsetAsync(c->ctl, 0, sizeof(Ctl), s));   // (k_finish leaves it zeroed)
+    c->ctl_dirty = 1;                               // until this call's k_finish has been seen
     if (ntiles && !two_level) HIPCHK(c, hipMemsetAsync(c->desc, 0, ((ntiles + 1) & ~1u) * sizeof(unsigned long long), s));
     return DCTZHIP_OK;
   };
   { int rc = reset(); if (rc) return rc; }
 
   // ---- calc_data_stat (util.c:12-44): the full pass, or the sample -------------
+  unsigned long long seq = box ? ++c->seq : 0ull;
   if (c->profiling) HIPCHK(c, hipEventRecord(c->ev[0], s));
   if (spec) {
     const size_t ngroups = n / chunk / c->spec_group;
     const int sgrid = (int)(ngroups < (size_t)c->stats_grid ? ngroups : (size_t)c->stats_grid);
-    launch_stats_sample<T>(d_in, n, c->spec_group, c->part, sgrid, c->stats_out, s);
+    launch_stats_sample<T>(d_in, n, c->spec_group, c->part, sgrid, c->stats_out, s, box ? c->box_dev : nullptr, seq);
   } else {
     const size_t nvec = n / Traits<T>::EPV;
     int sgrid = (int)((nvec + SWG * 4 - 1) / (SWG * 4));
     if (sgrid < 1) sgrid = 1;
     if (sgrid > c->stats_grid) sgrid = c->stats_grid;
-    launch_stats<T>(d_in, n, c->part, sgrid, c->stats_out, s);
+    launch_stats<T>(d_in, n, c->part, sgrid, c->stats_out, s, box ? c->box_dev : nullptr, seq);
   }
   if (c->profiling) HIPCHK(c, hipEventRecord(c->ev[1], s));
-  HIPCHK(c, hipMemcpyAsync(hs, c->stats_out, 3 * sizeof(double), hipMemcpyDeviceToHost, s));
-  HIPCHK(c, hipStreamSynchronize(s));
-  HostStats st = {hs[0], hs[1], hs[2]};
+  HostStats st;
+  if (box) {
+    int rc = wait_seq(c, &hb->seq_stats, seq, "statistics");
+    if (rc) return rc;
+    st = {hb->stats[0], hb->stats[1], hb->stats[2]};
+  } else {
+    HIPCHK(c, hipMemcpyAsync(hs, c->stats_out, 3 * sizeof(double), hipMemcpyDeviceToHost, s));
+    HIPCHK(c, hipStreamSynchronize(s));
+    st = {hs[0], hs[1], hs[2]};
+  }
 
   double sf = 1.0;
   T sf_t = T(1);
   unsigned fast_sf = 0;
   unsigned flags = 0;
-  {
-    int rc = compress_pass<T>(c, d_in, n, eb, mode, d_bin, d_dc, d_ac, d_scaled, d_coef, st, spec, &sf, &sf_t, &fast_sf);
+  // one pass of the kernels + the hand-off of its results into *hc / hs[4..6]
+  auto run = [&](const HostStats& stats, bool fused) -> int {
+    int rc = compress_pass<T>(c, d_in, n, eb, mode, d_bin, d_dc, d_ac, d_scaled, d_coef, stats, fused, &sf, &sf_t, &fast_sf, seq);
     if (rc) return rc;
-  }
-  if (spec) HIPCHK(c, hipMemcpyAsync(hs + 4, c->stats_out, 3 * sizeof(double), hipMemcpyDeviceToHost, s));
-  HIPCHK(c, hipMemcpyAsync(hc, c->ctl, sizeof(Ctl), hipMemcpyDeviceToHost, s));
-  HIPCHK(c, hipStreamSynchronize(s));
-  if (hc->error) return fail(c, DCTZHIP_E_INTERNAL, "in-kernel watchdog tripped (code %u)", hc->error);
-  if (c->profiling) { int rc = read_timings(c, 2); if (rc) return rc; }
+    if (box) {
+      rc = wait_seq(c, &hb->seq_done, seq, "compress");
+      if (rc) return rc;
+      c->ctl_dirty = 0;
+      hc->cnt_total = hb->cnt_total; hc->error = hb->error; hc->q0 = hb->q0;
+      for (int j = 0; j < 64; j++) hc->qraw[j] = hb->qraw[j];
+      hs[4] = hb->fstats[0]; hs[5] = hb->fstats[1]; hs[6] = hb->fstats[2];
+      if (c->profiling) HIPCHK(c, hipEventSynchronize(c->ev[4]));
+    } else {
+      if (fused) HIPCHK(c, hipMemcpyAsync(hs + 4, c->stats_out, 3 * sizeof(double), hipMemcpyDeviceToHost, s));
+      HIPCHK(c, hipMemcpyAsync(hc, c->ctl, sizeof(Ctl), hipMemcpyDeviceToHost, s));
+      HIPCHK(c, hipStreamSynchronize(s));
+    }
+    if (hc->error) return fail(c, DCTZHIP_E_INTERNAL, "in-kernel watchdog tripped (code %u)", hc->error);
+    if (c->profiling) { rc = read_timings(c, 2); if (rc) return rc; }
+    return DCTZHIP_OK;
+  };
+  { int rc = run(st, spec); if (rc) return rc; }
 
   if (spec) {
     const HostStats truth = {hs[4], hs[5], hs[6]};
@@ -464,12 +527,9 @@ static int compress_impl(dctzhip_ctx* c, const T* d_in, size_t n, double eb, int
       flags |= DCTZHIP_INFO_RESPUN;
       int rc = reset();
       if (rc) return rc;
-      rc = compress_pass<T>(c, d_in, n, eb, mode, d_bin, d_dc, d_ac, d_scaled, d_coef, st, false, &sf, &sf_t, &fast_sf);
+      if (box) seq = ++c->seq;
+      rc = run(st, false);
       if (rc) return rc;
-      HIPCHK(c, hipMemcpyAsync(hc, c->ctl, sizeof(Ctl), hipMemcpyDeviceToHost, s));
-      HIPCHK(c, hipStreamSynchronize(s));
-      if (hc->error) return fail(c, DCTZHIP_E_INTERNAL, "in-kernel watchdog tripped (code %u)", hc->error);
-      if (c->profiling) { rc = read_timings(c, 2); if (rc) return rc; }
     }
   }
   if (c->feat & 4) {
@@ -621,7 +681,9 @@ static int decompress_impl(dctzhip_ctx* c, const uint8_t* d_bin, const float* d_
   const int rem = (int)(n % 64);
   const unsigned ntiles = (nfull + TILE_BLKS - 1) / TILE_BLKS;
   const bool two_level = !(c->feat_d & 1);
-  HIPCHK(c, hipMemsetAsync(c->ctl, 0, sizeof(Ctl), s));
+  const bool box = c->handoff && two_level && !(c->feat_d & 4);   // mailbox + spin instead of D2H copy + stream sync
+  if (!box || c->ctl_dirty) HIPCHK(c, hipMemsetAsync(c->ctl, 0, sizeof(Ctl), s));      // (k_finish leaves it zeroed)
+  c->ctl_dirty = 1;
   if (ntiles && !two_level) HIPCHK(c, hipMemsetAsync(c->desc, 0, ((ntiles + 1) & ~1u) * sizeof(unsigned long long), s));
   if (mode == DCTZHIP_QT) {
     T* hq = reinterpret_cast<T*>(c->h_pin + PIN_TAB + sizeof(double) * RTAB_SIZE);
@@ -660,11 +722,21 @@ static int decompress_impl(dctzhip_ctx* c, const uint8_t* d_bin, const float* d_
   }
   if (c->profiling) HIPCHK(c, hipEventRecord(c->ev[3], s));
   if (rem) launch_decompress_rem<T>(p, mode, scale, rem, s);
+  const unsigned long long seq = box ? ++c->seq : 0ull;
+  if (box) launch_finish(c->ctl, nullptr, 0, c->box_dev, seq, s);
   if (c->profiling) HIPCHK(c, hipEventRecord(c->ev[4], s));
   HIPCHK(c, hipGetLastError());
   Ctl* hc = reinterpret_cast<Ctl*>(c->h_pin + PIN_CTL);
-  HIPCHK(c, hipMemcpyAsync(hc, c->ctl, (c->feat_d & 4) ? sizeof(Ctl) : 16, hipMemcpyDeviceToHost, s));
-  HIPCHK(c, hipStreamSynchronize(s));
+  if (box) {
+    int rc = wait_seq(c, &c->box->seq_done, seq, "decompress");
+    if (rc) return rc;
+    c->ctl_dirty = 0;
+    hc->error = c->box->error;
+    if (c->profiling) HIPCHK(c, hipEventSynchronize(c->ev[4]));
+  } else {
+    HIPCHK(c, hipMemcpyAsync(hc, c->ctl, (c->feat_d & 4) ? sizeof(Ctl) : 16, hipMemcpyDeviceToHost, s));
+    HIPCHK(c, hipStreamSynchronize(s));
+  }
   if (c->feat_d & 4)
     fprintf(stderr, "[dctzhip stamps] decompress cycles: ticket %llu binload %llu scan+lookback %llu (scan %llu lookback %llu) store %llu gather %llu idct %llu\n",
             hc->dbg[0], hc->dbg[1], hc->dbg[2] + hc->dbg[4] + hc->dbg[5], hc->dbg[4], hc->dbg[5], hc->dbg[3], hc->dbg[6], hc->dbg[7]);
