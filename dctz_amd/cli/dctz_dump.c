@@ -1,0 +1,86 @@
+/* dctz_dump.c -- inspect a DCTZ container.
+ *
+ *   dctz-dump <file.z>            the reference tool's six lines (tools/dctz-dump.c:41-50)
+ *   dctz-dump -v <file.z>         + section sizes, offsets, a bounds check of the whole layout
+ *                                   against the file size, and (QT files) the table's first entries
+ *
+ * The header is `struct header` of dctz.h:96-119: 56 bytes, native little-endian, then
+ * deflate(bin_index[N]) | deflate(DC[nblk] as float) | deflate(AC_exact[cnt] as float)
+ * [| qtable[64] in the data type]  (dctz-comp-lib.c:775-820).  EC and QT headers have the
+ * same size (the QT-only bindex_count sits in what is padding in the EC layout), so one
+ * binary reads both; -v tells them apart by the file size.
+ */
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#define USE_QTABLE 1 /* the larger view of the header: bindex_count is readable for both variants */
+#include "dctz.h"
+
+int main(int argc, char *argv[]) {
+  int verbose = 0;
+  const char *path = NULL;
+  if (argc == 2) path = argv[1];
+  else if (argc == 3 && strcmp(argv[1], "-v") == 0) { verbose = 1; path = argv[2]; }
+  if (!path) {
+    printf("Usage: %s filename\n", argv[0]);
+    exit(0);
+  }
+  FILE *fp = fopen(path, "rb");
+  if (!fp) {
+    perror("Failed: ");
+    printf("File Not Found\n");
+    return 0;
+  }
+  struct header h;
+  if (fread(&h, sizeof(h), 1, fp) != 1) {
+    printf("%s: shorter than a DCTZ header (%zu bytes)\n", path, sizeof(h));
+    fclose(fp);
+    return 1;
+  }
+  printf("File Name=%s\n", path);
+  printf("data type=%s\n", (h.datatype == DOUBLE) ? "double" : "float");
+  printf("N=%d\n", h.num_elements);
+  printf("error_bound=%f\n", h.error_bound);
+  printf("total # of AC_exact=%d\n", h.tot_AC_exact_count);
+  printf("SF=%f\n", h.datatype == DOUBLE ? h.scaling_factor.d : (double)h.scaling_factor.f);
+
+  int rc = 0;
+  if (verbose) {
+    fseek(fp, 0, SEEK_END);
+    const long fsz = ftell(fp);
+    const size_t ts = h.datatype == DOUBLE ? sizeof(double) : sizeof(float);
+    const size_t nblk = ((size_t)h.num_elements + BLK_SZ - 1) / BLK_SZ;
+    const size_t o0 = sizeof(h), o1 = o0 + h.bindex_sz_compressed, o2 = o1 + h.DC_sz_compressed,
+                 end = o2 + h.AC_exact_sz_compressed;
+    printf("mean=%.17g\n", h.datatype == DOUBLE ? h.mean.d : (double)h.mean.f);
+    printf("blocks=%zu (last one %zu elements)\n", nblk, h.num_elements % BLK_SZ ? (size_t)(h.num_elements % BLK_SZ) : (size_t)BLK_SZ);
+    printf("bin_index: offset %zu, %u bytes deflated (%u raw)\n", o0, h.bindex_sz_compressed, h.num_elements);
+    printf("DC:        offset %zu, %u bytes deflated (%zu raw)\n", o1, h.DC_sz_compressed, nblk * sizeof(float));
+    printf("AC_exact:  offset %zu, %u bytes deflated (%zu raw)\n", o2, h.AC_exact_sz_compressed,
+           (size_t)h.tot_AC_exact_count * sizeof(float));
+    if ((size_t)fsz == end) {
+      printf("variant=ec (no table), file size %ld = layout\n", fsz);
+    } else if ((size_t)fsz == end + BLK_SZ * ts) {
+      printf("variant=qt, bindex_count=%u, table at offset %zu, file size %ld = layout\n", h.bindex_count, end, fsz);
+      unsigned char q[BLK_SZ * sizeof(double)];
+      fseek(fp, (long)end, SEEK_SET);
+      if (fread(q, ts, BLK_SZ, fp) == BLK_SZ) {
+        printf("qtable[1..4]=");
+        for (int j = 1; j <= 4; j++) {
+          double v;
+          if (ts == 8) memcpy(&v, q + 8 * j, 8);
+          else { float f; memcpy(&f, q + 4 * j, 4); v = f; }
+          printf("%s%.9g", j > 1 ? ", " : "", v);
+        }
+        printf("\n");
+      }
+    } else {
+      printf("LAYOUT MISMATCH: header describes %zu bytes (ec) or %zu (qt), file has %ld\n", end, end + BLK_SZ * ts, fsz);
+      rc = 2;
+    }
+    printf("compression ratio=%.2f\n", (double)h.num_elements * ts / (double)fsz);
+  }
+  fclose(fp);
+  return rc;
+}
