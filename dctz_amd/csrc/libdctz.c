@@ -159,6 +159,34 @@ static uLong inflate_into(const Bytef *src, uLong src_len, void *dst, uLong dst_
   return produced;
 }
 
+/* The header's `mean` in the reference's own summation order (util.c:18-28 / :31-41: x[1] + x[2] + ...
+ * one after the other, in the data type).  That chain of roundings is inherently sequential:
+ * one GPU lane needs ~30 ns per dependent add (k_serial_sum: 4 s per GiB, fine underneath the
+ * reference's 7 s zlib tail), a host core ~1 ns.  With the chunked tail the zlib stage is too
+ * short to hide the GPU version, so the sum runs on one host thread over the caller's array,
+ * which is where the reference computes it too; it must finish before x/sf is copied back. */
+typedef struct {
+  const void *x;
+  size_t n;
+  int is_d;
+  double mean;
+} host_mean_job;
+static void *host_mean_main(void *arg) {
+  host_mean_job *j = (host_mean_job *)arg;
+  if (j->is_d) {
+    const double *x = (const double *)j->x;
+    double sum = 0.0;
+    for (size_t i = 1; i < j->n; i++) sum += x[i];          /* util.c:22: starts at i = 1 */
+    j->mean = sum / (double)(int)j->n;
+  } else {
+    const float *x = (const float *)j->x;
+    float sum = 0.0f;
+    for (size_t i = 1; i < j->n; i++) sum += x[i];          /* util.c:35 */
+    j->mean = (double)(sum / (float)(int)j->n);
+  }
+  return NULL;
+}
+
 typedef struct {
   dctz_pd_section sec[3];
   int threads, rc;
@@ -217,7 +245,12 @@ int dctz_compress(t_var *var, int N, size_t *outSize, t_var *var_z, double error
   /* a2..a9 on the GPU; the scaled array is produced in place on the device and
    * copied back over the caller's buffer (the reference's in-place "/= sf") */
   dctzhip_cinfo info;
-  if (dctzhip_serial_mean_begin(c, g_dev.in, n, dtype) != DCTZHIP_OK) die("serial mean");
+  const int fast_tail = zlib_threads() > 3;
+  pthread_t mean_thread;
+  host_mean_job mj = {host_in, n, is_d, 0.0};
+  int mean_on_host = 0;
+  if (fast_tail && pthread_create(&mean_thread, NULL, host_mean_main, &mj) == 0) mean_on_host = 1;
+  if (!mean_on_host && dctzhip_serial_mean_begin(c, g_dev.in, n, dtype) != DCTZHIP_OK) die("serial mean");
   int rc = dctzhip_compress(c, g_dev.in, n, dtype, error_bound, DCTZ_MODE, g_dev.bin, (float *)g_dev.dc,
                             (float *)g_dev.ac, NULL, NULL, &info);
   if (rc != DCTZHIP_OK) die("dctzhip_compress");
@@ -271,7 +304,8 @@ int dctz_compress(t_var *var, int N, size_t *outSize, t_var *var_z, double error
   /* while zlib runs: write x/sf back over the caller's buffer (:193-216) and
    * fetch the serial-order mean for the header */
   double mean_serial = 0.0;
-  if (dctzhip_serial_mean_end(c, &mean_serial) != DCTZHIP_OK) die("serial mean");
+  if (mean_on_host) { pthread_join(mean_thread, NULL); mean_serial = mj.mean; }   /* before host_in is overwritten */
+  else if (dctzhip_serial_mean_end(c, &mean_serial) != DCTZHIP_OK) die("serial mean");
   if (info.sf != 1.0) {   /* only now may the device copy of the input change */
     if (dctzhip_scale_inplace(c, g_dev.in, n, dtype, info.sf) != DCTZHIP_OK) die("scale");
     if (dctzhip_memcpy_d2h(c, host_in, g_dev.in, n * ts) != DCTZHIP_OK) die("D2H scaled input");
