@@ -82,3 +82,65 @@ def test_full_shard_matches_oracle_digests(shard):
     rec = ctx.decompress(out, info.cnt, x.numel(), torch.float64, 1e-3, info.sf, 0)
     assert _digest(rec) == hashlib.sha256(O.decompress(c, O.FAST).tobytes()).hexdigest()
     ctx.close()
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_maximum_size_array_is_periodic(dtype):
+    """Largest legal input: N is an int (dctz.h:126), so N <= 2^31 - 1 (16 GiB of doubles).
+    The oracle cannot run that, but a PERIODIC input must give periodic streams: the array is a
+    pattern of 64*16383 elements (whole blocks, deliberately not a multiple of the 1024-element
+    tile) repeated 2047 times plus a ragged tail with a short last block, and a small array
+    [pattern | tail] -- checked against the oracle -- predicts every period of the big one.
+    Exercises 64-bit addressing (> 2^32 bytes), the u32 exception counters near their top and
+    the remainder block at the far end."""
+    import torch
+    import dctz_amd
+    ctx = dctz_amd.Context(0)
+    tdt = torch.float64 if dtype == np.float64 else torch.float32
+    eb = 1e-3
+    chunk = 64 * 16383
+    n = 2**31 - 9                                        # N % 64 = 55: a short last block at the very end
+    reps, tail = divmod(n, chunk)
+    assert tail % 64 == 55 and reps == 2048
+    pat = W.ragged(chunk, dtype, scale=37.0)
+    small = np.concatenate([pat, pat[:tail]])
+    c = O.compress(small, eb, O.EC, O.FAST)               # the oracle on [pattern | tail]
+    ref_small = O.decompress(c, O.FAST)
+    out_s, info_s = ctx.compress(torch.from_numpy(small).cuda(), eb, O.EC)
+    assert info_s.cnt == c.cnt and info_s.sf == c.sf
+    assert np.array_equal(out_s["bin_index"].cpu().numpy(), c.bin_index)
+    # exceptions of the pattern period and of the tail
+    nb_pat = chunk // 64
+    flags = c.bin_index == 255
+    flags[::64] = False
+    cnt_pat = int(flags[:chunk].sum())
+    cnt_tail = c.cnt - cnt_pat
+
+    p_dev = torch.from_numpy(pat).cuda()
+    x = torch.empty(n, dtype=tdt, device="cuda")
+    x[:reps * chunk].view(reps, chunk).copy_(p_dev.unsqueeze(0).expand(reps, chunk))
+    x[reps * chunk:] = p_dev[:tail]
+    out, info = ctx.compress(x, eb, O.EC)
+    assert info.sf == c.sf
+    assert info.cnt == reps * cnt_pat + cnt_tail
+    assert info.cnt > 2**27                               # a few 10^8 exceptions: counters well exercised
+    b = out["bin_index"]
+    assert bool((b[:reps * chunk].view(reps, chunk) == out_s["bin_index"][:chunk].unsqueeze(0)).all().item())
+    assert torch.equal(b[reps * chunk:], out_s["bin_index"][chunk:])
+    d = out["dc"]
+    assert torch.equal(d[:reps * nb_pat].view(reps, nb_pat).view(torch.int32),
+                       out_s["dc"][:nb_pat].view(torch.int32).unsqueeze(0).expand(reps, nb_pat))
+    assert torch.equal(d[reps * nb_pat:].view(torch.int32), out_s["dc"][nb_pat:].view(torch.int32))
+    a = out["ac_exact"][:info.cnt]
+    a_s = out_s["ac_exact"][:c.cnt]
+    assert torch.equal(a[:reps * cnt_pat].view(reps, cnt_pat).view(torch.int32),
+                       a_s[:cnt_pat].view(torch.int32).unsqueeze(0).expand(reps, cnt_pat))
+    assert torch.equal(a[reps * cnt_pat:].view(torch.int32), a_s[cnt_pat:].view(torch.int32))
+
+    del x
+    rec = ctx.decompress(out, info.cnt, n, tdt, eb, info.sf, O.EC)
+    r_s = torch.from_numpy(ref_small).cuda()
+    it = torch.int64 if dtype == np.float64 else torch.int32
+    assert torch.equal(rec[:reps * chunk].view(reps, chunk).view(it), r_s[:chunk].view(it).unsqueeze(0).expand(reps, chunk))
+    assert torch.equal(rec[reps * chunk:].view(it), r_s[chunk:].view(it))
+    ctx.close()
