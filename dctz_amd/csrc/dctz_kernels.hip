@@ -54,6 +54,45 @@ __device__ __forceinline__ double dpp(double v) {
   hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xf, 0xf, true);
   return __hiloint2double(hi, lo);
 }
+// Streaming (read-once / write-once) 16-byte accesses: the `nt` policy.  A pure 1 GiB read stream
+// runs at 6.8-7.1 TB/s with nt loads against 6.0-6.3 TB/s with plain ones (tools/ubench/stream_read.hip).
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+template <typename V>
+__device__ __forceinline__ V load_stream(const V* p) {
+  static_assert(sizeof(V) == 16, "16-byte vectors only");
+#ifndef DCTZ_NO_NT
+  const u32x4 r = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(p));
+  V v;
+  __builtin_memcpy(&v, &r, 16);
+  return v;
+#else
+  return *p;
+#endif
+}
+template <typename V>
+__device__ __forceinline__ void store_stream(V* p, const V& v) {
+  static_assert(sizeof(V) == 16, "16-byte vectors only");
+#ifndef DCTZ_NO_NT_STORE
+  u32x4 r;
+  __builtin_memcpy(&r, &v, 16);
+  __builtin_nontemporal_store(r, reinterpret_cast<u32x4*>(p));
+#else
+  *p = v;
+#endif
+}
+
+// Inclusive prefix sum over the 64 lanes of a wavefront with DPP row shifts / row broadcasts
+// (six dependent VALU steps instead of six ds_bpermute round trips through the LDS pipe).
+__device__ __forceinline__ unsigned wave_incl_scan(unsigned v) {
+  v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, true);    // row_shr:1
+  v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, true);    // row_shr:2
+  v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, true);    // row_shr:4
+  v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, true);    // row_shr:8
+  v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false);   // row_bcast:15 -> rows 1, 3
+  v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false);   // row_bcast:31 -> rows 2, 3
+  return v;
+}
+
 // quad_perm control words: lane i reads from lane perm[i] of its quad
 constexpr int QP_XOR1 = 0xB1;     // [1,0,3,2]
 constexpr int QP_XOR2 = 0x4E;     // [2,3,0,1]
@@ -291,6 +330,12 @@ __host__ __device__ __forceinline__ TileRange tile_range(unsigned b, unsigned G,
 // Intra-tile exclusive scan only (two-level scheme): returns this thread's offset
 // inside the tile's exception list and the tile total.  One barrier.
 __device__ __forceinline__ unsigned tile_scan_local(unsigned cnt, unsigned* sc, unsigned* total) {
+  if constexpr (WG == 64) {                        // one wavefront: no LDS, no barrier
+    (void)sc;
+    const unsigned incl = wave_incl_scan(cnt);
+    *total = (unsigned)__builtin_amdgcn_readlane((int)incl, 63);
+    return incl - cnt;
+  }
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   unsigned incl = cnt;
 #pragma unroll
@@ -381,7 +426,7 @@ __device__ __forceinline__ void issue_tile_loads(typename Traits<T>::Vec (&v)[TI
 #pragma unroll
   for (int i = 0; i < NV; i++) {
     const unsigned e = (unsigned)(i * WG + t) * EPV;
-    if (e < valid) v[i] = src[i * WG + t];
+    if (e < valid) v[i] = load_stream(&src[i * WG + t]);
     else v[i] = Traits<T>::zero();
   }
 }
