@@ -567,7 +567,7 @@ __device__ __forceinline__ void store_tile(const T* tile, T* __restrict__ out, s
     const unsigned e = (unsigned)(i * WG + t) * EPV;
     Vec v = lds_load_vec<T>(tile + tile_idx<T>(t * EPV) + i * (WG * EPV / 64) * Traits<T>::PITCH);
     if (SCALE) Traits<T>::mul(v, sf);             // dctz-decomp-lib.c:494-511
-    if (e < valid) dst[i * WG + t] = v;
+    if (e < valid) store_stream(&dst[i * WG + t], v);
   }
 }
 
@@ -741,7 +741,7 @@ __global__ __launch_bounds__(SWG) void k_stats(const T* __restrict__ x, size_t n
 #pragma unroll
     for (int u = 0; u < UN; u++) {
       const size_t i = i0 + (size_t)u * SWG;
-      v[u] = (i < nvec) ? src[i] : src[i0];        // a repeated vector changes neither max nor min
+      v[u] = load_stream((i < nvec) ? &src[i] : &src[i0]);   // a repeated vector changes neither max nor min
     }
 #pragma unroll
     for (int u = 0; u < UN; u++) {
@@ -861,7 +861,7 @@ __global__ __launch_bounds__(SWG) void k_stats_sample(const T* __restrict__ x, s
     const unsigned h = ((unsigned)g * 2654435761u) >> 8;
     const size_t chunk = g * group + h % group;
     T e[EPV];
-    Traits<T>::unpack(src[chunk * SWG + threadIdx.x], e);
+    Traits<T>::unpack(load_stream(&src[chunk * SWG + threadIdx.x]), e);
 #pragma unroll
     for (int k = 0; k < EPV; k++) acc.add(e[k], true);
   }
