@@ -431,6 +431,25 @@ __device__ __forceinline__ void issue_tile_loads(typename Traits<T>::Vec (&v)[TI
   }
 }
 
+// The same through a buffer descriptor (two-level kernels): one VGPR (lane * 16) addresses all
+// vectors of a tile, the tile's offset inside the workgroup's range rides in an SGPR, and the
+// range check of the descriptor zero-fills whatever lies beyond the last whole block -- no
+// 64-bit per-vector pointers to keep (or spill) across the loop, no per-vector predicate.
+template <typename T>
+__device__ __forceinline__ void issue_tile_loads_buf(typename Traits<T>::Vec (&v)[TILE_ELEMS / Traits<T>::EPV / WG],
+                                                     __amdgpu_buffer_rsrc_t rsrc, unsigned tile_rel) {
+  using Vec = typename Traits<T>::Vec;
+  constexpr int EPV = Traits<T>::EPV, NV = TILE_ELEMS / EPV / WG;
+  const int voff = (int)threadIdx.x * 16;
+  const int soff = (int)(tile_rel * (unsigned)(TILE_ELEMS * sizeof(T)));
+#pragma unroll
+  for (int i = 0; i < NV; i++) {
+    constexpr int STEP = WG * 16;                    // bytes between a lane's consecutive vectors
+    const u32x4 r = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff + ((i * STEP) & 4095), soff + ((i * STEP) & ~4095), 2 /* nt */);
+    __builtin_memcpy(&v[i], &r, 16);
+  }
+}
+
 // ---------------------------------------------------- statistics on the fly --
 // calc_data_stat's three reductions (util.c:18-25 / :31-38) over the vectors a
 // thread has just loaded for a tile; `skip0`: the vector holds x[0], which the
@@ -1014,20 +1033,27 @@ __global__ __launch_bounds__(WG, DCTZ_MINWAVES) void k_compress(FwdParams<T> p) 
     unsigned run = 0;                                // its length so far (uniform over the workgroup)
     StatAcc<T> acc;
     if (FEAT & F_STATS) acc.init();
+    // The input of the workgroup's tile range sits behind one buffer descriptor; the loads of tile
+    // k+1 are issued right after the emit phase of tile k.  (Issuing them BEFORE the emit phase --
+    // a register prefetch under the binning -- was measured three times and never won: with 64-bit
+    // pointers it spilled and serialised the loads behind scratch reloads; with descriptor loads it
+    // costs 32 more live VGPRs (166 vs 134) for no gain, 0.289 vs 0.284 ms.  DESIGN.md section 6.)
+    const size_t first_el = (size_t)tr.lo * TILE_ELEMS;
+    const size_t end_el = min((size_t)p.nfull * 64, (size_t)tr.hi * TILE_ELEMS);
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<T*>(p.x + first_el), 0, tr.lo < tr.hi ? (int)((end_el - first_el) * sizeof(T)) : 0, 0x00020000);
+    Vec v[NV];
+    if (tr.lo < tr.hi) issue_tile_loads_buf<T>(v, rsrc, 0u);
     for (unsigned tile_id = tr.lo; tile_id < tr.hi; tile_id++) {
       const size_t ebase = (size_t)tile_id * TILE_ELEMS;
       const unsigned blks_here = min((unsigned)TILE_BLKS, p.nfull - tile_id * TILE_BLKS);
-      // (Prefetching the next tile's 32 KiB into registers was tried twice: carried across the
-      // transform it costs a wave per SIMD; issued between transform and emit phase it still
-      // spills 4-10 VGPRs at the 168 cap and loses 4-10 % -- DESIGN.md section 6.)
-      Vec v[NV];
-      issue_tile_loads<T>(v, p.x, tile_id, p.ntiles, p.nfull);
       __syncthreads();                               // previous tile's LDS reads are done
       stage_tile<T, SCALE, (FEAT & F_STATS) != 0>(tile, v, ebase, blks_here * 64u, sfd, p.scaled, p.fast_sf, &acc,
                                                   tile_id == 0 && t == 0);
       __syncthreads();
       tile_dct_fwd<T>(tile, tab);
       emit_tile<T, MODE, FEAT>(p, tile, qmax, sc, bwd, tile_id, blks_here, false, 0u, nullptr, list_base, &run, &acc.dcs);
+      if (tile_id + 1 < tr.hi) issue_tile_loads_buf<T>(v, rsrc, tile_id + 1 - tr.lo);
     }
     if (t == 0) p.tile_cnt[blockIdx.x] = run;
     if (FEAT & F_STATS) {
