@@ -590,6 +590,32 @@ __device__ __forceinline__ void store_tile(const T* tile, T* __restrict__ out, s
   }
 }
 
+// store_tile through a buffer descriptor over the workgroup's output range: nt policy, and the
+// range check drops whatever lies beyond the last whole block (no predicate, no 64-bit pointers).
+template <typename T, bool SCALE>
+__device__ __forceinline__ void store_tile_buf(const T* tile, __amdgpu_buffer_rsrc_t rsrc, unsigned tile_rel, T sf) {
+  using Vec = typename Traits<T>::Vec;
+  constexpr int EPV = Traits<T>::EPV, NV = TILE_ELEMS / EPV / WG;
+  const int t = threadIdx.x;
+  const int voff = t * 16;
+  const int soff = (int)(tile_rel * (unsigned)(TILE_ELEMS * sizeof(T)));
+  Vec v[NV];
+#pragma unroll
+  for (int i = 0; i < NV; i++) {
+    v[i] = lds_load_vec<T>(tile + tile_idx<T>(t * EPV) + i * (WG * EPV / 64) * Traits<T>::PITCH);
+    if (SCALE) Traits<T>::mul(v[i], sf);          // dctz-decomp-lib.c:494-511
+  }
+  SCHED_FENCE();                                  // every vector in its own registers before the first store issues
+#pragma unroll
+  for (int i = 0; i < NV; i++) {
+    constexpr int STEP = WG * 16;
+    u32x4 r;
+    __builtin_memcpy(&r, &v[i], 16);
+    __builtin_amdgcn_raw_buffer_store_b128(r, rsrc, voff + ((i * STEP) & 4095), soff + ((i * STEP) & ~4095), 2 /* nt */);
+  }
+  SCHED_FENCE();
+}
+
 // ------------------------------------------------------- in-tile transforms --
 // Forward DCT-II of the 64 blocks of the tile, in place in LDS (dct.c:55-103).
 // Two workgroup barriers inside (after reads, after writes).
@@ -1336,9 +1362,22 @@ __global__ __launch_bounds__(WG, DCTZ_MINWAVES) void k_decompress(InvParams<T> p
     const TileRange tr = tile_range(blockIdx.x, gridDim.x, p.ntiles);
     unsigned tile_id = tr.lo;
     unsigned run = p.tile_off[blockIdx.x];   // global index of this workgroup's first exact coefficient
+    // descriptors over this workgroup's ranges of out[] / bin[] / dc[]: hardware range checks replace
+    // the per-vector predicates, one VGPR of addressing each
+    const size_t first_el = (size_t)tr.lo * TILE_ELEMS;
+    const size_t end_el = min((size_t)p.nfull * 64, (size_t)tr.hi * TILE_ELEMS);
+    const int range_el = tr.lo < tr.hi ? (int)(end_el - first_el) : 0;
+    const __amdgpu_buffer_rsrc_t r_out = __builtin_amdgcn_make_buffer_rsrc(p.out + first_el, 0, range_el * (int)sizeof(T), 0x00020000);
+    const __amdgpu_buffer_rsrc_t r_bin = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(p.bin + first_el), 0, range_el, 0x00020000);
+    const __amdgpu_buffer_rsrc_t r_dc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.dc + first_el / 64), 0, range_el / 64 * 4, 0x00020000);
+    auto fetch_buf = [&](unsigned rel, uint4& wv, float& dcv) {   // rel beyond the range: zeros
+      const u32x4 r = __builtin_amdgcn_raw_buffer_load_b128(r_bin, t * 16, (int)(rel * (unsigned)TILE_ELEMS), 0);
+      wv = make_uint4(r.x, r.y, r.z, r.w);
+      dcv = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r_dc, blk * 4, (int)(rel * (unsigned)(TILE_BLKS * 4)), 0));
+    };
     uint4 wv, wv_n;
     float dcv, dcv_n;
-    fetch(tile_id < tr.hi ? tile_id : p.ntiles, wv, dcv);
+    fetch_buf(0u, wv, dcv);
     bool underrun = false;
     while (tile_id < tr.hi) {
       const unsigned blks_here = min((unsigned)TILE_BLKS, p.nfull - tile_id * TILE_BLKS);
@@ -1365,10 +1404,13 @@ __global__ __launch_bounds__(WG, DCTZ_MINWAVES) void k_decompress(InvParams<T> p
         }
       }
       const unsigned next_id = tile_id + 1;
-      fetch(next_id < tr.hi ? next_id : p.ntiles, wv_n, dcv_n);
+      fetch_buf(next_id - tr.lo, wv_n, dcv_n);
       if (pending) {                     // flush the previous tile (uniform branch)
-        const unsigned pv = min((unsigned)TILE_BLKS, p.nfull - prev_id * TILE_BLKS) * 64u;
-        store_tile<T, SCALE>(tile, p.out, (size_t)prev_id * TILE_ELEMS, pv, p.sf);
+#ifdef DCTZ_DBG_PLAINSTORE
+        store_tile<T, SCALE>(tile, p.out, (size_t)prev_id * TILE_ELEMS, min((unsigned)TILE_BLKS, p.nfull - prev_id * TILE_BLKS) * 64u, p.sf);
+#else
+        store_tile_buf<T, SCALE>(tile, r_out, prev_id - tr.lo, p.sf);
+#endif
         __syncthreads();                 // LDS tile free for the next coefficients
       }
       T c[16];
@@ -1385,6 +1427,8 @@ __global__ __launch_bounds__(WG, DCTZ_MINWAVES) void k_decompress(InvParams<T> p
       tile_id = next_id; wv = wv_n; dcv = dcv_n;
     }
     if (underrun) atomicExch(&p.ctl->error, 2u);
+    if (pending) store_tile_buf<T, SCALE>(tile, r_out, prev_id - tr.lo, p.sf);
+    pending = false;
   } else {
     Stamps st;
     if (FEAT & F_STAMP) st.start();

@@ -288,3 +288,26 @@ def test_speculation_is_off_for_in_place_scaling_and_small_inputs(spec_ctx):
     spec_ctx.set_speculation(False)
     out, info = spec_ctx.compress(_dev(spec_ctx, x), 1e-3, O.EC)
     assert info.flags == 0 and info.cnt == c.cnt
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+@pytest.mark.parametrize("mode", [O.EC, O.QT])
+def test_multi_tile_workgroup_ranges_bit_exact(ctx, dtype, mode):
+    """More tiles than workgroups (every workgroup walks a RANGE of tiles and flushes tile k while
+    it builds tile k+1).  Regression test: a reconstruction whose store data registers were reused
+    by the next LDS reads came out corrupted in a few blocks per million, QT mode only, and not on
+    every run -- hence three repetitions against the oracle, bit for bit."""
+    import torch
+    n = (1 << 23) + 64 * 9 + 21
+    x = W.ragged(n, dtype, scale=37.0)
+    c = O.compress(x, 1e-3, mode, O.FAST)
+    ref = O.decompress(c, O.FAST)
+    tdt = torch.float64 if dtype == np.float64 else torch.float32
+    out, info = ctx.compress(_dev(ctx, x), 1e-3, mode)
+    assert info.cnt == c.cnt and np.array_equal(out["bin_index"].cpu().numpy(), c.bin_index)
+    assert _same(out["ac_exact"][:c.cnt].cpu().numpy(), c.ac_exact)
+    for _ in range(3):
+        r = ctx.decompress(out, info.cnt, n, tdt, 1e-3, info.sf, mode, qtable=np.array(info.qtable[:])).cpu().numpy()
+        it = np.uint64 if dtype == np.float64 else np.uint32
+        bad = np.flatnonzero(r.view(it) != ref.view(it))
+        assert bad.size == 0, f"{bad.size} mismatches, first {bad[:8]} (tiles {np.unique(bad // 1024)[:6]})"
