@@ -40,6 +40,11 @@
 #define SCHED_FENCE() ((void)0)
 #endif
 
+// Exactly the occupancy the LDS budget allows (12 single-wave workgroups per CU for fp64, 16 for
+// fp32): with only a lower bound the compiler, seeing 127 VGPRs within reach, trades ILP for a
+// fourth wave that the LDS cannot host (k_compress 0.281 -> 0.313 ms).
+#define DCTZ_WAVES_PER_EU(T) __attribute__((amdgpu_waves_per_eu(sizeof(T) == 8 ? DCTZ_MINWAVES : 4, sizeof(T) == 8 ? DCTZ_MINWAVES : 4)))
+
 namespace dctz {
 
 // ------------------------------------------------------------------ helpers --
@@ -581,13 +586,22 @@ __device__ __forceinline__ void store_tile(const T* tile, T* __restrict__ out, s
   constexpr int EPV = Traits<T>::EPV, NV = TILE_ELEMS / EPV / WG;
   const int t = threadIdx.x;
   Vec* dst = reinterpret_cast<Vec*>(out + ebase);
+  // every vector in its own registers before the first store issues: with several 16-byte stores
+  // queued, an LDS read that reused the registers of a store two back was seen to land before that
+  // store had read its data (k_decompress, QT mode) -- see store_tile_buf
+  Vec v[NV];
+#pragma unroll
+  for (int i = 0; i < NV; i++) {
+    v[i] = lds_load_vec<T>(tile + tile_idx<T>(t * EPV) + i * (WG * EPV / 64) * Traits<T>::PITCH);
+    if (SCALE) Traits<T>::mul(v[i], sf);          // dctz-decomp-lib.c:494-511
+  }
+  SCHED_FENCE();
 #pragma unroll
   for (int i = 0; i < NV; i++) {
     const unsigned e = (unsigned)(i * WG + t) * EPV;
-    Vec v = lds_load_vec<T>(tile + tile_idx<T>(t * EPV) + i * (WG * EPV / 64) * Traits<T>::PITCH);
-    if (SCALE) Traits<T>::mul(v, sf);             // dctz-decomp-lib.c:494-511
-    if (e < valid) store_stream(&dst[i * WG + t], v);
+    if (e < valid) store_stream(&dst[i * WG + t], v[i]);
   }
+  SCHED_FENCE();
 }
 
 // store_tile through a buffer descriptor over the workgroup's output range: nt policy, and the
@@ -961,11 +975,18 @@ __global__ __launch_bounds__(SWG) void k_scale(T* __restrict__ x, size_t n, T sf
 // -> DC (:350-351) -> pass-1 binning (:361-414) -> ordered exception stream
 // (:478-544) [-> QT per-position max (:371-372)], full 64-element blocks only.
 // emit phase of one tile: thread t owns elements [16t, 16t+16)
+// Two-level kernels: the outputs of a workgroup's tile range behind buffer descriptors (range
+// checks instead of predicates, 32-bit offsets instead of 64-bit pointers per store).
+struct EmitBufs {
+  __amdgpu_buffer_rsrc_t bin, dc, ac, qi, qj;      // bin_index / DC of the range; the workgroup's exception list(s)
+  unsigned tile_rel;                               // tile index inside the range
+};
+
 template <typename T, int MODE, int FEAT>
 __device__ __forceinline__ void emit_tile(const FwdParams<T>& p, const T* tile, typename Traits<T>::Bits* qmax,
                                           unsigned* sc, const FastDiv<T>& bwd, unsigned tile_id, unsigned blks_here,
                                           bool publish, unsigned publish_value, Stamps* st, unsigned list_base = 0,
-                                          unsigned* run = nullptr, double* dcs = nullptr) {
+                                          unsigned* run = nullptr, double* dcs = nullptr, const EmitBufs* eb = nullptr) {
   using Vec = typename Traits<T>::Vec;
   constexpr int EPV = Traits<T>::EPV;
   const int t = threadIdx.x;
@@ -1003,8 +1024,41 @@ __device__ __forceinline__ void emit_tile(const FwdParams<T>& p, const T* tile, 
                   (FEAT & F_STAMP) ? st : nullptr);
   } else {                                           // workgroup-local list; k_compact_ac places it later
     unsigned total;
-    r = list_base + *run + tile_scan_local((unsigned)__popc(mask), sc, &total);
+    r = *run + tile_scan_local((unsigned)__popc(mask), sc, &total);     // index inside the workgroup's list
     *run += total;
+    // stores through the range descriptors (inactive blocks fall outside them and are dropped)
+    u32x4 wq = {w[0], w[1], w[2], w[3]};
+    __builtin_amdgcn_raw_buffer_store_b128(wq, eb->bin, t * 16, (int)(eb->tile_rel * (unsigned)TILE_ELEMS), 0);
+    if (p.coef != nullptr && active) {
+#pragma unroll
+      for (int i = 0; i < 16 / EPV; i++)
+        reinterpret_cast<Vec*>(p.coef + ebase + (size_t)t * 16)[i] = Traits<T>::pack(&c[i * EPV]);
+    }
+    if (j0 == 0) {
+      const unsigned gblk = tile_id * TILE_BLKS + blk;
+      __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, (float)c[0]), eb->dc, blk * 4,
+                                            (int)(eb->tile_rel * (unsigned)(TILE_BLKS * 4)), 0);     // :350-351 USE_TRUNCATE
+      if (FEAT & F_STATS) { if (active) *dcs += (double)c[0]; }
+      if (active && p.last_is_full && gblk == p.nfull - 1) p.ctl->q0 = (unsigned long long)to_bits(c[0]);   // :355-360
+    }
+#pragma unroll
+    for (int i = 0; i < 16; i++) {
+      if (mask & (1u << i)) {
+        if (MODE == DCTZHIP_EC) {
+          __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, (float)c[i]), eb->ac, (int)(r * 4u), 0, 0);   // :535-537
+        } else {
+          if constexpr (sizeof(T) == 8) {
+            typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+            __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, c[i]), eb->qi, (int)(r * 8u), 0, 0);
+          } else {
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, c[i]), eb->qi, (int)(r * 4u), 0, 0);
+          }
+          __builtin_amdgcn_raw_buffer_store_b8((unsigned char)(j0 + i), eb->qj, (int)r, 0, 0);
+        }
+        r++;
+      }
+    }
+    return;
   }
   // all global stores of the tile go out AFTER the look-back, so that the polling
   // wave's vmcnt(0) waits never sit behind its own stores
@@ -1034,7 +1088,7 @@ __device__ __forceinline__ void emit_tile(const FwdParams<T>& p, const T* tile, 
 }
 
 template <typename T, int MODE, bool SCALE, int FEAT>
-__global__ __launch_bounds__(WG, DCTZ_MINWAVES) void k_compress(FwdParams<T> p) {
+__global__ __launch_bounds__(WG) DCTZ_WAVES_PER_EU(T) void k_compress(FwdParams<T> p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   using Vec = typename Traits<T>::Vec;
   using Bits = typename Traits<T>::Bits;
@@ -1068,6 +1122,17 @@ __global__ __launch_bounds__(WG, DCTZ_MINWAVES) void k_compress(FwdParams<T> p) 
     const size_t end_el = min((size_t)p.nfull * 64, (size_t)tr.hi * TILE_ELEMS);
     const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<T*>(p.x + first_el), 0, tr.lo < tr.hi ? (int)((end_el - first_el) * sizeof(T)) : 0, 0x00020000);
+    EmitBufs eb;
+    {
+      const int range_el = tr.lo < tr.hi ? (int)(end_el - first_el) : 0;     // whole blocks only
+      eb.bin = __builtin_amdgcn_make_buffer_rsrc(p.bin + first_el, 0, range_el, 0x00020000);
+      eb.dc = __builtin_amdgcn_make_buffer_rsrc(p.dc + first_el / 64, 0, range_el / 64 * 4, 0x00020000);
+      // the workgroup's list lives in the slots of its own tiles (cannot outgrow them: <= 63 per block)
+      const int list_el = (int)((size_t)(tr.hi - tr.lo) * TILE_ELEMS);
+      eb.ac = __builtin_amdgcn_make_buffer_rsrc(p.ac_tmp + list_base, 0, list_el * 4, 0x00020000);
+      eb.qi = __builtin_amdgcn_make_buffer_rsrc(p.qt_item + list_base, 0, MODE == DCTZHIP_QT ? list_el * (int)sizeof(T) : 0, 0x00020000);
+      eb.qj = __builtin_amdgcn_make_buffer_rsrc(p.qt_j + list_base, 0, MODE == DCTZHIP_QT ? list_el : 0, 0x00020000);
+    }
     Vec v[NV];
     if (tr.lo < tr.hi) issue_tile_loads_buf<T>(v, rsrc, 0u);
     for (unsigned tile_id = tr.lo; tile_id < tr.hi; tile_id++) {
@@ -1078,7 +1143,8 @@ __global__ __launch_bounds__(WG, DCTZ_MINWAVES) void k_compress(FwdParams<T> p) 
                                                   tile_id == 0 && t == 0);
       __syncthreads();
       tile_dct_fwd<T>(tile, tab);
-      emit_tile<T, MODE, FEAT>(p, tile, qmax, sc, bwd, tile_id, blks_here, false, 0u, nullptr, list_base, &run, &acc.dcs);
+      eb.tile_rel = tile_id - tr.lo;
+      emit_tile<T, MODE, FEAT>(p, tile, qmax, sc, bwd, tile_id, blks_here, false, 0u, nullptr, list_base, &run, &acc.dcs, &eb);
       if (tile_id + 1 < tr.hi) issue_tile_loads_buf<T>(v, rsrc, tile_id + 1 - tr.lo);
     }
     if (t == 0) p.tile_cnt[blockIdx.x] = run;
@@ -1317,7 +1383,7 @@ __global__ __launch_bounds__(SWG) void k_count_tiles(const uint8_t* __restrict__
 // tile k, so the polling wave never waits behind them, and they drain under the
 // gather + IDCT of tile k.
 template <typename T, int MODE, bool SCALE, int FEAT>
-__global__ __launch_bounds__(WG, DCTZ_MINWAVES) void k_decompress(InvParams<T> p) {
+__global__ __launch_bounds__(WG) DCTZ_WAVES_PER_EU(T) void k_decompress(InvParams<T> p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   using Vec = typename Traits<T>::Vec;
   constexpr int EPV = Traits<T>::EPV;
