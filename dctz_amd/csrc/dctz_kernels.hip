@@ -1472,11 +1472,7 @@ __global__ __launch_bounds__(WG) DCTZ_WAVES_PER_EU(T) void k_decompress(InvParam
       const unsigned next_id = tile_id + 1;
       fetch_buf(next_id - tr.lo, wv_n, dcv_n);
       if (pending) {                     // flush the previous tile (uniform branch)
-#ifdef DCTZ_DBG_PLAINSTORE
-        store_tile<T, SCALE>(tile, p.out, (size_t)prev_id * TILE_ELEMS, min((unsigned)TILE_BLKS, p.nfull - prev_id * TILE_BLKS) * 64u, p.sf);
-#else
         store_tile_buf<T, SCALE>(tile, r_out, prev_id - tr.lo, p.sf);
-#endif
         __syncthreads();                 // LDS tile free for the next coefficients
       }
       T c[16];
