@@ -311,3 +311,47 @@ def test_multi_tile_workgroup_ranges_bit_exact(ctx, dtype, mode):
         it = np.uint64 if dtype == np.float64 else np.uint32
         bad = np.flatnonzero(r.view(it) != ref.view(it))
         assert bad.size == 0, f"{bad.size} mismatches, first {bad[:8]} (tiles {np.unique(bad // 1024)[:6]})"
+
+
+def _special(kind, n, dtype):
+    """Inputs that take the less-travelled branches: division levels 1 / 0 (zeros, extreme
+    exponents), sf == 1 (no scaling kernels), constant / sign-uniform data, tight and loose bounds."""
+    rng = np.random.default_rng(99)
+    base = W.ragged(n, np.float64, scale=37.0)
+    if kind == "zeros_sprinkled":              # land-mask-like: exact zeros -> per-element window test
+        base[rng.random(n) < 0.3] = 0.0
+    elif kind == "constant":
+        base[:] = 2.5
+    elif kind == "sf_is_one":                  # max|x| in (1, 10]: sf == 1, SCALE = false variants
+        base = base / 37.0 * 5.0
+    elif kind == "negative":
+        base = -np.abs(base) - 1.0
+    elif kind == "huge":                       # near the top of the exponent range (fp32: 1e30)
+        base = base * (1e290 if dtype == np.float64 else 1e28)
+    elif kind == "tiny":                       # below FastDiv's window: plain IEEE division path
+        base = base * (1e-290 if dtype == np.float64 else 1e-30)
+    elif kind == "spiky":                      # heavy tails: most coefficients out of range
+        base = base + 200.0 * rng.standard_cauchy(n).clip(-1e3, 1e3)
+    return base.astype(dtype)
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+@pytest.mark.parametrize("mode", [O.EC, O.QT])
+@pytest.mark.parametrize("kind,eb", [("zeros_sprinkled", 1e-3), ("constant", 1e-3), ("sf_is_one", 1e-3), ("negative", 1e-4),
+                                     ("huge", 1e-3), ("tiny", 1e-3), ("spiky", 1e-2), ("spiky", 1e-6)])
+def test_special_inputs_bit_exact(ctx, dtype, mode, kind, eb):
+    import torch
+    n = (1 << 22) + 64 * 11 + 5                # multi-tile workgroup ranges + a short last block
+    x = _special(kind, n, dtype)
+    c = O.compress(x, eb, mode, O.FAST)
+    ref = O.decompress(c, O.FAST)
+    tdt = torch.float64 if dtype == np.float64 else torch.float32
+    out, info = ctx.compress(_dev(ctx, x), eb, mode)
+    assert info.sf == c.sf and info.cnt == c.cnt
+    assert np.array_equal(out["bin_index"].cpu().numpy(), c.bin_index)
+    assert _same(out["dc"].cpu().numpy(), c.dc)
+    assert _same(out["ac_exact"][:c.cnt].cpu().numpy(), c.ac_exact)
+    if mode == O.QT:
+        assert _same(np.array(info.qtable[:], dtype=dtype), c.qtable)
+    r = ctx.decompress(out, info.cnt, n, tdt, eb, info.sf, mode, qtable=np.array(info.qtable[:])).cpu().numpy()
+    assert _same(r, ref), f"maxdiff={np.abs(r - ref).max()}"
