@@ -33,8 +33,8 @@ enum : int {
   TAB_SW = 96,      // [32]    sin(2 pi k / 64)
   TAB_HS = 128,     // [64]    0.5*as[k]   (dct.c:37-47)
   TAB_HX = 192,     // [64]    0.5*ax[k]
-  TAB_IAS = 256,    // [64]    ias[k], ias[0] pre-divided by sqrt(2)  (dct.c:130-134,166)
-  TAB_IAX = 320,    // [64]    iax[k]
+  TAB_IAS = 256,    // [64]    ias[k] / 128, ias[0] pre-divided by sqrt(2)  (dct.c:130-134,166,185)
+  TAB_IAX = 320,    // [64]    iax[k] / 128
   TAB_R = 384,      // [1]     sqrt(1/2)
   TAB_SIZE = 392
 };
@@ -216,8 +216,8 @@ DCTZ_HD void inv_cross_b(T (&yr)[8], T (&yi)[8], const T (&pr)[8], const T (&pi)
   for (int k = 0; k < 8; k++) { yr[k] = bfly(yr[k], pr[k], up); yi[k] = bfly(yi[k], pi[k], up); }
 }
 
-// I4: 32-point twiddle + in-lane radix-8 backward + 1/128 (the reference's
-// "/dn", dct.c:185-186, and the factor 2 carried by G).  On exit y = packed
+// I4: 32-point twiddle + in-lane radix-8 backward (the reference's 1/128 --
+// "/dn", dct.c:185-186, and the factor 2 carried by G -- rides in the input tables).  On exit y = packed
 // points z[4*n1 + n2] of quad lane n2: re -> pack_pos(m,0), im -> pack_pos(m,1).
 template <typename T>
 DCTZ_HD void inv_stage_lane(T (&yr)[8], T (&yi)[8], int n2, const T* tab) {
@@ -228,10 +228,7 @@ DCTZ_HD void inv_stage_lane(T (&yr)[8], T (&yi)[8], int n2, const T* tab) {
     yr[k1] = a * wr - b * wi;       // times exp(+i 2 pi n2 k1/32)
     yi[k1] = a * wi + b * wr;
   }
-  fft8<T, false>(yr, yi, tab[TAB_R]);
-  const T S = T(1.0 / 128.0);
-#pragma unroll
-  for (int n1 = 0; n1 < 8; n1++) { yr[n1] = yr[n1] * S; yi[n1] = yi[n1] * S; }
+  fft8<T, false>(yr, yi, tab[TAB_R]);   // (the 1/128 is already inside TAB_IAS / TAB_IAX: dctz_tables.h)
 }
 
 }  // namespace dctz

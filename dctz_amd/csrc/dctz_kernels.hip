@@ -116,6 +116,12 @@ __device__ __forceinline__ unsigned conv_bin(unsigned t) {
   const int u = 127 - (int)t;
   return (unsigned)((u << 1) ^ (u >> 31));
 }
+// The same from nt = -t, as the kernels get it for free from the conversion's negate modifier:
+// 2u = 2 nt + 254 is one shift-add, and 2u has the sign of u  (|u| <= 128).
+__device__ __forceinline__ unsigned conv_bin_neg(int nt) {
+  const int u2 = (nt << 1) + 254;
+  return (unsigned)(u2 ^ (u2 >> 31));
+}
 
 // Pass-1 binning of one coefficient (dctz-comp-lib.c:363-414).  Returns the bin
 // id; *out_of_range tells whether the QT table must see it (:367-373).
@@ -127,9 +133,9 @@ __device__ __forceinline__ unsigned bin_of(T item, T range_min, T range_max, con
   const bool out = fabs(item) > range_max;
   // in range: 0 <= item - range_min <= 510 eb, far inside the fast window; the
   // quotient of an out-of-range item is never used
-  const int ti = (int)bw.div_small(item - range_min);     // (t_bin_id) cast: trunc toward 0
+  const int nt = (int)(-bw.div_small(item - range_min));  // -(t_bin_id) cast: trunc toward 0 is symmetric
   *out_of_range = out;
-  return out ? 255u : conv_bin((unsigned)ti & 255u);
+  return out ? 255u : conv_bin_neg(nt);              // in range: 0 <= t <= 255 (t = 255 only for item == range_max: bin 255)
 }
 
 // ----------------------------------------------- division by a kernel constant --
@@ -210,9 +216,9 @@ template <> struct FastDiv<float> {
 template <typename T>
 __device__ __forceinline__ unsigned bin_from_quotient(T item, T range_max, T q, bool* out_of_range) {
   const bool out = fabs(item) > range_max;          // == (item < range_min || item > range_max): range_min = -range_max
-  const int ti = (int)q;                            // (t_bin_id) cast: trunc toward 0
+  const int nt = (int)(-q);                         // -(t_bin_id) cast: trunc toward 0 is symmetric
   *out_of_range = out;
-  return out ? 255u : conv_bin((unsigned)ti & 255u);
+  return out ? 255u : conv_bin_neg(nt);             // in range: 0 <= t <= 255 (t = 255 only for item == range_max: bin 255)
 }
 
 // diagnostic phase timers (F_STAMP builds only)
