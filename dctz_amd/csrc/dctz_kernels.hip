@@ -1,18 +1,22 @@
 // dctz_kernels.hip -- gfx950 (MI355X) kernels of the DCTZ hot path.
 //
 // Work decomposition (both directions):
-//   * a TILE is 64 consecutive 64-element blocks (4096 elements, 32 KiB fp64); one
-//     256-thread workgroup owns a tile at a time; the grid is persistent (as many
-//     workgroups as are resident: 3 per CU fp64, 4 fp32) and strides over the tiles;
-//   * the tile is staged in LDS once; HBM is touched with 16-byte-per-lane, fully
-//     coalesced accesses only;
+//   * a TILE is 16 consecutive 64-element blocks (1024 elements, 8 KiB fp64) = the work of
+//     ONE wavefront; workgroups of the two big kernels are single wavefronts, the grid is
+//     persistent (12 workgroups per CU for fp64, 16 for fp32 = what registers and LDS admit)
+//     and workgroup b owns the contiguous tile range [b*ntiles/G, (b+1)*ntiles/G);
+//   * the tile is staged in LDS once; HBM is touched with 16-byte-per-lane, fully coalesced
+//     accesses only, through buffer descriptors over the workgroup's range (one VGPR of
+//     addressing, hardware range check instead of predicates), nt policy on the read-once /
+//     write-once streams;
 //   * inside the tile a QUAD of lanes owns a block and runs the 64-point DCT of
 //     dct64_lane.h in registers, exchanging partners with DPP quad_perm moves;
-//   * the ordered stream of "stored exactly" coefficients (AC_exact) is placed by
-//     the TWO-LEVEL scheme: every tile leaves a tile-local list + a count,
-//     k_scan_tiles turns counts into offsets, k_compact_ac moves the lists; the big
-//     kernels have no inter-workgroup traffic.  A single-pass variant (tickets +
-//     decoupled look-back, FEAT & F_LOOKBACK) is kept and is byte-identical.
+//   * the ordered stream of "stored exactly" coefficients (AC_exact) is placed by the
+//     TWO-LEVEL scheme: every workgroup appends the exceptions of its tiles to its own list
+//     and leaves a count, k_scan_tiles turns counts into offsets, k_compact_ac moves the
+//     lists; the big kernels have no inter-workgroup traffic.  A single-pass variant
+//     (tickets + decoupled look-back, FEAT & F_LOOKBACK) is kept and is byte-identical;
+//   * calc_data_stat rides inside k_compress (F_STATS) behind a sampled, verified guess of sf.
 //
 // Reference code replaced: see include/dctz_hip.h (per entry point) and the
 // comment on each kernel.  Built with -ffp-contract=off: the arithmetic that
@@ -27,7 +31,7 @@
 #include "dctz_device.h"
 
 // minimum waves per SIMD the register allocator must leave room for in the two
-// big kernels (256-thread workgroups: N waves/SIMD <=> N workgroups per CU)
+// big kernels (single-wave workgroups: N waves/SIMD <=> 4 N workgroups per CU)
 #ifndef DCTZ_MINWAVES
 #define DCTZ_MINWAVES 3
 #endif
