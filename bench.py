@@ -79,9 +79,11 @@ def main():
     if a.no_speculation:
         ctx.set_speculation(False)
 
+    qt = mode == dctz_amd.QT
+
     def step():
         _, info = ctx.compress(x, a.eb, mode, out=out)
-        ctx.decompress(out, info.cnt, n, t_dtype, a.eb, info.sf, mode, qtable=np.array(info.qtable[:]), dst=rec)
+        ctx.decompress(out, info.cnt, n, t_dtype, a.eb, info.sf, mode, qtable=info.qtable if qt else None, dst=rec)
         return info
 
     info = None
@@ -119,7 +121,7 @@ def main():
         tm = ctx.timings()
         acc["c_stats"] += tm["stats_ms"]; acc["c_main"] += tm["main_ms"]; acc["c_tail"] += tm["tail_ms"]
         s2 = time.perf_counter()
-        ctx.decompress(out, info.cnt, n, t_dtype, a.eb, info.sf, mode, qtable=np.array(info.qtable[:]), dst=rec)
+        ctx.decompress(out, info.cnt, n, t_dtype, a.eb, info.sf, mode, qtable=info.qtable if qt else None, dst=rec)
         s3 = time.perf_counter()
         tm = ctx.timings()
         acc["d_main"] += tm["main_ms"]; acc["d_tail"] += tm["tail_ms"]

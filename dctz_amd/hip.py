@@ -112,11 +112,19 @@ class Context:
         if rc != 0:
             raise DctzHipError(f"dctzhip_ctx_create: {self.lib.dctzhip_last_error(None).decode()}")
         self.h = h
+        self._bound = object()            # nothing bound yet
         self._bind_stream()
 
     def _bind_stream(self):
-        s = self.torch.cuda.current_stream(self.device).cuda_stream
-        self.lib.dctzhip_set_stream(self.h, C.c_void_p(s))
+        # the raw handle of torch's current stream on this device (the private accessor skips the
+        # Stream object; fall back to the public API if it is not there)
+        try:
+            s = self.torch._C._cuda_getCurrentRawStream(self.device.index)
+        except AttributeError:
+            s = self.torch.cuda.current_stream(self.device).cuda_stream
+        if s != self._bound:
+            self.lib.dctzhip_set_stream(self.h, C.c_void_p(s))
+            self._bound = s
 
     def close(self):
         if getattr(self, "h", None):
