@@ -1124,10 +1124,10 @@ __global__ __launch_bounds__(WG) DCTZ_WAVES_PER_EU(T) void k_compress(FwdParams<
     StatAcc<T> acc;
     if (FEAT & F_STATS) acc.init();
     // The input of the workgroup's tile range sits behind one buffer descriptor; the loads of tile
-    // k+1 are issued right after the emit phase of tile k.  (Issuing them BEFORE the emit phase --
-    // a register prefetch under the binning -- was measured three times and never won: with 64-bit
-    // pointers it spilled and serialised the loads behind scratch reloads; with descriptor loads it
-    // costs 32 more live VGPRs (166 vs 134) for no gain, 0.289 vs 0.284 ms.  DESIGN.md section 6.)
+    // k+1 are issued as soon as tile k has been staged, so they have the whole transform + emit phase
+    // to land.  With descriptor addressing the 32 extra live VGPRs fit (164-168, no spills) and the
+    // prefetch is worth 1-2 %; with 64-bit pointers it spilled and serialised the loads behind scratch
+    // reloads (-5 %), issued only before the emit phase it was a wash.  DESIGN.md section 6.
     const size_t first_el = (size_t)tr.lo * TILE_ELEMS;
     const size_t end_el = min((size_t)p.nfull * 64, (size_t)tr.hi * TILE_ELEMS);
     const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
@@ -1152,10 +1152,12 @@ __global__ __launch_bounds__(WG) DCTZ_WAVES_PER_EU(T) void k_compress(FwdParams<
       stage_tile<T, SCALE, (FEAT & F_STATS) != 0>(tile, v, ebase, blks_here * 64u, sfd, p.scaled, p.fast_sf, &acc,
                                                   tile_id == 0 && t == 0);
       __syncthreads();
+      SCHED_FENCE();
+      if (tile_id + 1 < tr.hi) issue_tile_loads_buf<T>(v, rsrc, tile_id + 1 - tr.lo);
+      SCHED_FENCE();
       tile_dct_fwd<T>(tile, tab);
       eb.tile_rel = tile_id - tr.lo;
       emit_tile<T, MODE, FEAT>(p, tile, qmax, sc, bwd, tile_id, blks_here, false, 0u, nullptr, list_base, &run, &acc.dcs, &eb);
-      if (tile_id + 1 < tr.hi) issue_tile_loads_buf<T>(v, rsrc, tile_id + 1 - tr.lo);
     }
     if (t == 0) p.tile_cnt[blockIdx.x] = run;
     if (FEAT & F_STATS) {
