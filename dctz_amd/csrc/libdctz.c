@@ -359,6 +359,56 @@ int dctz_compress(t_var *var, int N, size_t *outSize, t_var *var_z, double error
   return 1;
 }
 
+/* ------------------------------------------------------- container check --- */
+/* dctz_decompress() trusts the header the way the reference does (dctz-decomp-lib.c:84-100:
+ * no size is checked against the buffer, a corrupt file reads out of bounds).  A caller that
+ * knows how many bytes it holds runs this first: it checks the layout of dctz-comp-lib.c:775-820
+ * against `zbytes`, the plausibility of the header fields, and -- deep != 0 -- that the three
+ * sections really inflate to N, 4*nblk and 4*cnt bytes (no GPU involved). */
+int dctz_check_container(const void *z, size_t zbytes, int max_elements, int deep) {
+  struct header h;
+  if (!z || zbytes < sizeof(h)) return DCTZ_CHECK_TRUNCATED;
+  memcpy(&h, z, sizeof(h));
+  if (h.datatype != FLOAT && h.datatype != DOUBLE) return DCTZ_CHECK_BAD_HEADER;
+  if (h.num_elements == 0 || h.num_elements > 0x7FFFFFFFu) return DCTZ_CHECK_BAD_HEADER;     /* N is an int, dctz.h:126 */
+  if (max_elements > 0 && h.num_elements > (unsigned int)max_elements) return DCTZ_CHECK_TOO_LARGE;
+  if (!(h.error_bound >= 1E-6) || h.error_bound != h.error_bound) return DCTZ_CHECK_BAD_HEADER;   /* :135-138 */
+  const size_t n = h.num_elements, nblk = CEIL(n, BLK_SZ), ts = h.datatype == DOUBLE ? sizeof(double) : sizeof(float);
+  if ((size_t)h.tot_AC_exact_count > n - nblk) return DCTZ_CHECK_BAD_HEADER;                   /* at most 63 per block */
+  const size_t body = (size_t)h.bindex_sz_compressed + h.DC_sz_compressed + h.AC_exact_sz_compressed;
+  size_t want = sizeof(h) + body;
+#ifdef USE_QTABLE
+  want += BLK_SZ * ts;
+  if (h.bindex_count != h.num_elements) return DCTZ_CHECK_BAD_HEADER;                           /* :798 */
+#else
+  (void)ts;
+#endif
+  if (zbytes < want) return DCTZ_CHECK_TRUNCATED;
+  if (!deep) return DCTZ_CHECK_OK;
+  const unsigned char *cur = (const unsigned char *)z + sizeof(h);
+  const size_t raw[3] = {n, nblk * sizeof(float), (size_t)h.tot_AC_exact_count * sizeof(float)};
+  const unsigned int zs[3] = {h.bindex_sz_compressed, h.DC_sz_compressed, h.AC_exact_sz_compressed};
+  for (int i = 0; i < 3; i++) {
+    /* inflate into a small window, counting: the section must end exactly at `raw[i]` bytes */
+    z_stream st;
+    unsigned char win[65536];
+    memset(&st, 0, sizeof(st));
+    if (inflateInit(&st) != Z_OK) return DCTZ_CHECK_BAD_STREAM;
+    st.next_in = (Bytef *)cur; st.avail_in = zs[i];
+    size_t produced = 0;
+    int rc;
+    do {
+      st.next_out = win; st.avail_out = sizeof(win);
+      rc = inflate(&st, Z_NO_FLUSH);
+      produced += sizeof(win) - st.avail_out;
+    } while (rc == Z_OK && produced <= raw[i]);
+    inflateEnd(&st);
+    if (rc != Z_STREAM_END || produced != raw[i]) return DCTZ_CHECK_BAD_STREAM;
+    cur += zs[i];
+  }
+  return DCTZ_CHECK_OK;
+}
+
 /* ------------------------------------------------------------ decompress --- */
 int dctz_decompress(t_var *var_z, t_var *var_r) {
   const double t_begin = now_s();

@@ -133,6 +133,17 @@ void dctz_last_stage_times(dctz_stage_times *t);
  * (csrc/pdeflate.c).  dctz_compress uses it when the environment has
  * DCTZ_ZLIB_THREADS > 3; exported for tools that write DCTZ containers themselves.
  * cap >= dctz_pdeflate_bound(n, chunk); returns 0 on success. */
+/* Bounds / plausibility check of a DCTZ container held in `zbytes` bytes, to be run before
+ * dctz_decompress(), which -- like the reference (dctz-decomp-lib.c:84-100) -- trusts the header.
+ * max_elements > 0 additionally bounds N (the size of the caller's output buffer); deep != 0 also
+ * inflates the three sections and checks their sizes.  No GPU involved.  The library variant must
+ * match the file's (EC vs QT): the QT check expects the trailing table and bindex_count. */
+#define DCTZ_CHECK_OK 0
+#define DCTZ_CHECK_TRUNCATED (-1)     /* fewer bytes than the header describes                */
+#define DCTZ_CHECK_BAD_HEADER (-2)    /* a field is impossible (datatype, N, error bound, cnt) */
+#define DCTZ_CHECK_TOO_LARGE (-3)     /* N exceeds max_elements                                */
+#define DCTZ_CHECK_BAD_STREAM (-4)    /* a section does not inflate to its expected size       */
+int dctz_check_container(const void *z, size_t zbytes, int max_elements, int deep);
 size_t dctz_pdeflate_bound(size_t n, size_t chunk);
 int dctz_pdeflate(const void *src, size_t n, void *dst, size_t cap, size_t *out_len, int threads, size_t chunk);
 

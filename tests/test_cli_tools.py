@@ -118,3 +118,29 @@ def test_cli_harness_matches_the_reference_contract(tmp_path, variant, case):
             assert len(z) == 3763394 and out[-2].startswith("CR = 2.23")
     d = subprocess.run([os.path.join(BIN, "dctz-dump"), "-v", zpath], capture_output=True, text=True)
     assert d.returncode == 0 and f"total # of AC_exact={c.cnt}" in d.stdout and f"variant={variant}" in d.stdout
+
+
+@pytest.mark.parametrize("mode", [O.EC, O.QT])
+def test_container_check(mode):
+    """dctz_check_container: the bounds / plausibility check a caller runs before dctz_decompress
+    (which trusts the header like the reference, dctz-decomp-lib.c:84-100).  Host only."""
+    import ctypes as C
+    _ensure_built()
+    lib = C.CDLL(os.path.join(ROOT, "dctz_amd", "lib", f"libdctz-{'qt' if mode == O.QT else 'ec'}.so"))
+    lib.dctz_check_container.restype = C.c_int
+    lib.dctz_check_container.argtypes = [C.c_char_p, C.c_size_t, C.c_int, C.c_int]
+    x = W.ragged(64 * 50 + 9, np.float64, scale=37.0)
+    blob, c = _container(x, 1e-3, mode)
+    chk = lambda b, nmax=0, deep=1: lib.dctz_check_container(bytes(b), len(b), nmax, deep)
+    assert chk(blob) == 0 and chk(blob, x.size) == 0 and chk(blob + b"\0" * 7) == 0
+    assert chk(blob, x.size - 1) == -3                                      # caller's buffer too small
+    assert chk(blob[:40]) == -1 and chk(blob[:-1]) == -1                    # truncated
+    bad = bytearray(blob); struct.pack_into("<I", bad, 0, 7); assert chk(bad) == -2          # datatype
+    bad = bytearray(blob); struct.pack_into("<I", bad, 4, 0); assert chk(bad) == -2          # N = 0
+    bad = bytearray(blob); struct.pack_into("<d", bad, 8, 1e-9); assert chk(bad) == -2       # error bound
+    bad = bytearray(blob); struct.pack_into("<I", bad, 16, x.size); assert chk(bad) == -2    # cnt > N - nblk
+    bad = bytearray(blob); struct.pack_into("<I", bad, 40, len(blob)); assert chk(bad) == -1 # section runs past the end
+    bad = bytearray(blob); bad[56 + 20] ^= 0x5A; assert chk(bad, 0, 0) == 0 and chk(bad) == -4   # corrupt deflate data
+    bad = bytearray(blob); struct.pack_into("<I", bad, 4, x.size + 64); assert chk(bad) in (-2, -4)  # N does not match the streams
+    other = _container(x, 1e-3, O.EC if mode == O.QT else O.QT)[0]
+    assert chk(other) != 0 or mode == O.EC                                   # an EC library does not see a QT file's table as an error
