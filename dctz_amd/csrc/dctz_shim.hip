@@ -135,10 +135,18 @@ extern "C" int dctzhip_ctx_create(dctzhip_ctx** out, int device) {
   HIPCHK(nullptr, hipMalloc(&c->part, sizeof(double) * 3 * PART_SLOTS));
   HIPCHK(nullptr, hipMalloc(&c->stats_out, sizeof(double) * 4));
   HIPCHK(nullptr, hipHostMalloc(&c->h_pin, PIN_BYTES, hipHostMallocDefault));
-  HIPCHK(nullptr, hipHostMalloc(reinterpret_cast<void**>(&c->box), sizeof(HostBox), hipHostMallocCoherent | hipHostMallocMapped));
-  memset(c->box, 0, sizeof(HostBox));
-  HIPCHK(nullptr, hipHostGetDevicePointer(reinterpret_cast<void**>(&c->box_dev), c->box, 0));
-  if (const char* e = getenv("DCTZHIP_HANDOFF")) c->handoff = atoi(e) != 0;
+  // the mailbox needs fine-grained (coherent) pinned host memory that kernels can write; where the
+  // platform cannot provide it the library falls back to D2H copies + stream synchronisation
+  if (hipHostMalloc(reinterpret_cast<void**>(&c->box), sizeof(HostBox), hipHostMallocCoherent | hipHostMallocMapped) == hipSuccess &&
+      hipHostGetDevicePointer(reinterpret_cast<void**>(&c->box_dev), c->box, 0) == hipSuccess) {
+    memset(c->box, 0, sizeof(HostBox));
+  } else {
+    (void)hipGetLastError();
+    if (c->box) { (void)hipHostFree(c->box); c->box = nullptr; }
+    c->box_dev = nullptr;
+    c->handoff = 0;
+  }
+  if (const char* e = getenv("DCTZHIP_HANDOFF")) c->handoff = (atoi(e) != 0) && c->box != nullptr;
   {
     double t64[TAB_SIZE];
     float t32[TAB_SIZE];
