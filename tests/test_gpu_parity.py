@@ -355,3 +355,22 @@ def test_special_inputs_bit_exact(ctx, dtype, mode, kind, eb):
         assert _same(np.array(info.qtable[:], dtype=dtype), c.qtable)
     r = ctx.decompress(out, info.cnt, n, tdt, eb, info.sf, mode, qtable=np.array(info.qtable[:])).cpu().numpy()
     assert _same(r, ref), f"maxdiff={np.abs(r - ref).max()}"
+
+
+@pytest.mark.parametrize("hit", [True, False])
+def test_speculation_with_scaled_and_coefficient_taps(spec_ctx, hit):
+    """The optional outputs (x/sf and the raw coefficients) must be right on the speculative path
+    too -- after a verified guess and after a re-run with the true statistics."""
+    import torch, dctz_amd
+    n = (1 << 20) + 64 * 3 + 17
+    x = W.ragged(n, np.float64, scale=37.0)
+    if not hit:
+        x[_unsampled_element(np.float64, 7)] = -7777.0
+    xd = _dev(spec_ctx, x)
+    scaled, coef = torch.empty_like(xd), torch.empty_like(xd)
+    out, info = spec_ctx.compress(xd, 1e-3, O.EC, scaled=scaled, coef=coef)
+    assert info.flags == (dctz_amd.hip.INFO_STATS_FUSED if hit else dctz_amd.hip.INFO_RESPUN)
+    c = O.compress(x, 1e-3, O.EC, O.FAST, want_coef=True)
+    assert info.sf == c.sf and info.cnt == c.cnt
+    assert _same(scaled.cpu().numpy(), c.scaled) and _same(coef.cpu().numpy(), c.coef)
+    assert np.array_equal(xd.cpu().numpy(), x), "input must not be modified"
