@@ -66,7 +66,8 @@ static int quiet(void) { return getenv("DCTZ_QUIET") != NULL; }
  * deflate each, dctz-comp-lib.c:620-732; three inflates one after the other,
  * dctz-decomp-lib.c:244-322).  > 3: chunked deflate on that many threads (pdeflate.c;
  * still one zlib stream per section) and the three inflates run concurrently.
- * DCTZ_ZLIB_CHUNK: bytes per deflate job (default 256 KiB). */
+ * DCTZ_ZLIB_CHUNK: bytes per deflate job (default 256 KiB).  DCTZ_ZLIB_LEVEL: 1..9 for the chunked tail
+ * only (default: zlib's default level, as the reference; a lower level trades ratio for host time). */
 static int zlib_threads(void) { const char *e = getenv("DCTZ_ZLIB_THREADS"); return e ? atoi(e) : 0; }
 static size_t zlib_chunk(void) {
   const char *e = getenv("DCTZ_ZLIB_CHUNK");
@@ -296,6 +297,7 @@ int dctz_compress(t_var *var, int N, size_t *outSize, t_var *var_z, double error
       pda.sec[i].dst = jb[i].dst; pda.sec[i].cap = jb[i].bound; pda.sec[i].out_len = &pd_len[i];
     }
     pda.threads = zthreads; pda.chunk = zlib_chunk(); pda.rc = 0;
+    { const char *e = getenv("DCTZ_ZLIB_LEVEL"); dctz_pdeflate_set_level(e ? atoi(e) : -1); }
     if (pthread_create(&pd_thread, &attr, pd_main, &pda)) { fprintf(stderr, "Error creating thread\n"); exit(0); }
   } else {
     for (int i = 0; i < 3; i++) zjob_start(&jb[i], sec_src[i], (uLong)sec_bytes[i], &attr);

@@ -51,10 +51,15 @@ typedef struct {
   pthread_mutex_t mu;
 } pd_queue;
 
+/* deflate level of the chunk jobs: the reference's Z_DEFAULT_COMPRESSION (dctz-comp-lib.c:642)
+ * unless dctz_pdeflate_set_level() chose another (DCTZ_ZLIB_LEVEL in the drop-in library) */
+static int g_level = Z_DEFAULT_COMPRESSION;
+void dctz_pdeflate_set_level(int level) { g_level = (level >= 1 && level <= 9) ? level : Z_DEFAULT_COMPRESSION; }
+
 static void pd_do_chunk(pd_chunk *c) {
   z_stream zs;
   memset(&zs, 0, sizeof(zs));
-  if (deflateInit2(&zs, Z_DEFAULT_COMPRESSION, Z_DEFLATED, -15, DEF_MEM_LEVEL, Z_DEFAULT_STRATEGY) != Z_OK) {
+  if (deflateInit2(&zs, g_level, Z_DEFLATED, -15, DEF_MEM_LEVEL, Z_DEFAULT_STRATEGY) != Z_OK) {
     c->err = 1;
     return;
   }
@@ -141,7 +146,7 @@ int dctz_pdeflate_many(const dctz_pd_section *sec, int nsec, int threads, size_t
     uLong adler = adler32(0L, Z_NULL, 0);
     if (sec[s].cap < 6) { rc = -2; break; }
     out[pos++] = 0x78;                             /* CMF: deflate, 32 KiB window            */
-    out[pos++] = 0x9C;                             /* FLG: default level, no preset dictionary */
+    out[pos++] = 0x9C;                             /* FLG: "default level" hint (informative only), no preset dictionary */
     for (size_t i = 0; i < nch; i++, k++) {
       const pd_chunk *c = &chunks[k];
       if (c->err) { rc = -3; break; }

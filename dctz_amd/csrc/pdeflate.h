@@ -20,6 +20,8 @@ size_t dctz_pdeflate_bound(size_t n, size_t chunk);
 /* Deflate all sections with one shared pool of `threads` workers (the calling thread is
  * one of them); chunk = bytes per job (>= 32 KiB).  0 on success. */
 int dctz_pdeflate_many(const dctz_pd_section *sec, int nsec, int threads, size_t chunk);
+/* deflate level of subsequent calls: 1..9, anything else = zlib's default (what the reference uses) */
+void dctz_pdeflate_set_level(int level);
 int dctz_pdeflate(const void *src, size_t n, void *dst, size_t cap, size_t *out_len, int threads, size_t chunk);
 
 #ifdef __cplusplus

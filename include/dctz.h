@@ -146,6 +146,7 @@ void dctz_last_stage_times(dctz_stage_times *t);
 int dctz_check_container(const void *z, size_t zbytes, int max_elements, int deep);
 size_t dctz_pdeflate_bound(size_t n, size_t chunk);
 int dctz_pdeflate(const void *src, size_t n, void *dst, size_t cap, size_t *out_len, int threads, size_t chunk);
+void dctz_pdeflate_set_level(int level);   /* 1..9; anything else = zlib's default level (the reference's) */
 
 #ifdef __cplusplus
 }

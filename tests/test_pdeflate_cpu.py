@@ -68,3 +68,14 @@ def test_deterministic_across_thread_counts(lib):
     a = _pdeflate(lib, data, 1, 1 << 18)
     b = _pdeflate(lib, data, 7, 1 << 18)
     assert a == b, "output depends on the chunking only, never on scheduling"
+
+
+def test_level_knob(lib):
+    lib.dctz_pdeflate_set_level.argtypes = [C.c_int]
+    data = _bin_like(2 << 20, 9)
+    lib.dctz_pdeflate_set_level(1)
+    fast = _pdeflate(lib, data, 4, 1 << 18)
+    lib.dctz_pdeflate_set_level(-1)
+    dflt = _pdeflate(lib, data, 4, 1 << 18)
+    assert zlib.decompress(fast) == data and zlib.decompress(dflt) == data
+    assert len(fast) >= len(dflt)
