@@ -1,0 +1,92 @@
+"""Property tests (hypothesis) of the host-side pieces: the oracle's stream invariants and error
+bound, the shard planner, the chunked deflate.  CPU only, bounded example counts."""
+import ctypes as C
+import os
+import zlib
+
+import numpy as np
+import pytest
+from hypothesis import HealthCheck, given, settings, strategies as st
+
+from oracle import oracle as O
+from dctz_amd import shard
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SET = dict(max_examples=40, deadline=None, suppress_health_check=[HealthCheck.too_slow])
+
+
+def _field(seed, n, amp, noise):
+    rng = np.random.default_rng(seed)
+    t = np.arange(n) / 53.0
+    return amp * (np.sin(t) + 0.4 * np.cos(3.3 * t)) + noise * amp * rng.standard_normal(n)
+
+
+@settings(**SET)
+@given(seed=st.integers(0, 2**31), n=st.integers(1, 3000), log_amp=st.floats(-3, 6), noise=st.sampled_from([0.0, 1e-4, 0.05, 1.0]),
+       eb=st.sampled_from([1e-2, 1e-3, 1e-5, 1e-6]), mode=st.sampled_from([O.EC, O.QT]), dtype=st.sampled_from([np.float64, np.float32]))
+def test_oracle_stream_invariants_and_error_bound(seed, n, log_amp, noise, eb, mode, dtype):
+    x = _field(seed, n, 10.0 ** log_amp, noise).astype(dtype)
+    c = O.compress(x, eb, mode, O.FAST)
+    nblk = (n + 63) // 64
+    # structure of the three streams (dctz-comp-lib.c:361, :478-544)
+    assert c.bin_index.size == n and c.dc.size == nblk and c.ac_exact.size == c.cnt
+    assert np.all(c.bin_index[::64] == 255), "every block head is the DC marker"
+    assert int((c.bin_index == 255).sum()) == c.cnt + nblk
+    # sf is the decade of max|x| (util.c:29), scaled data in [1, 10] unless the array is all zero
+    m = np.abs(x).max()
+    if m > 0 and np.isfinite(c.sf) and c.sf > 0:
+        assert 0.99 <= np.abs(c.scaled).max() <= 10.0 * (1 + 1e-6)
+    # round trip: orthonormal transform, so the l2 error per block is bounded by the bin width
+    r = O.decompress(c, O.FAST)
+    err = np.abs(r.astype(np.float64) - c.scaled.astype(np.float64) * c.sf)
+    tol = 8.5 * eb * c.sf * (1.0 if dtype == np.float64 else 1.5) + (0 if dtype == np.float64 else 2e-6 * m * 64)
+    assert err.max() <= tol, (err.max(), tol)
+    # the fast flow and the definition-order flow agree to rounding
+    c2 = O.compress(x, eb, mode, O.NAIVE)
+    flips = int((c.bin_index != c2.bin_index).sum())
+    assert flips <= max(2, n // 200), flips
+
+
+@settings(**SET)
+@given(n=st.integers(0, 2**34), world=st.integers(1, 16))
+def test_plan_shards_partition(n, world):
+    """(offset, length) per rank: contiguous, in order, interior cuts on block boundaries, every shard an int."""
+    try:
+        plan = shard.plan_shards(n, world)
+    except ValueError:
+        assert (n + world - 1) // world > 2**31 - 1 - 64     # only when a shard cannot fit an int
+        return
+    assert len(plan) == world
+    pos = 0
+    for off, length in plan:
+        assert off == pos and length >= 0 and length <= 2**31 - 1
+        pos += length
+        if pos < n:
+            assert pos % 64 == 0
+    assert pos == n
+
+
+@pytest.fixture(scope="module")
+def pd():
+    so = os.path.join(ROOT, "dctz_amd", "lib", "libdctz-ec.so")
+    if not os.path.exists(so):
+        import __graft_entry__ as g
+        g.build()
+    L = C.CDLL(so)
+    L.dctz_pdeflate_bound.restype = C.c_size_t
+    L.dctz_pdeflate_bound.argtypes = [C.c_size_t, C.c_size_t]
+    L.dctz_pdeflate.restype = C.c_int
+    L.dctz_pdeflate.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t), C.c_int, C.c_size_t]
+    return L
+
+
+@settings(max_examples=30, deadline=None, suppress_health_check=[HealthCheck.too_slow, HealthCheck.function_scoped_fixture])
+@given(data=st.binary(min_size=0, max_size=200000), threads=st.integers(1, 6), chunk=st.sampled_from([32768, 40000, 65536]))
+def test_pdeflate_roundtrip_any_bytes(pd, data, threads, chunk):
+    cap = pd.dctz_pdeflate_bound(len(data), chunk)
+    dst = (C.c_ubyte * cap)()
+    n = C.c_size_t(0)
+    src = (C.c_ubyte * max(1, len(data))).from_buffer_copy(data if data else b"\0")
+    assert pd.dctz_pdeflate(src, len(data), dst, cap, C.byref(n), threads, chunk) == 0
+    d = zlib.decompressobj()
+    assert d.decompress(bytes(dst[:n.value])) == data and d.eof and d.unused_data == b""
