@@ -374,3 +374,31 @@ def test_speculation_with_scaled_and_coefficient_taps(spec_ctx, hit):
     assert info.sf == c.sf and info.cnt == c.cnt
     assert _same(scaled.cpu().numpy(), c.scaled) and _same(coef.cpu().numpy(), c.coef)
     assert np.array_equal(xd.cpu().numpy(), x), "input must not be modified"
+
+
+# ---- fuzz: random shapes / magnitudes / bounds, HIP path vs oracle, bit for bit ------------------
+from hypothesis import HealthCheck, given, settings, strategies as st   # noqa: E402
+
+
+@settings(max_examples=60, deadline=None, suppress_health_check=[HealthCheck.too_slow, HealthCheck.function_scoped_fixture])
+@given(seed=st.integers(0, 2**31), n=st.integers(1, 400000), log_amp=st.floats(-6, 8), noise=st.sampled_from([0.0, 1e-5, 0.02, 1.0]),
+       eb=st.sampled_from([1e-2, 1e-3, 1e-4, 1e-6]), mode=st.sampled_from([O.EC, O.QT]), dtype=st.sampled_from([np.float64, np.float32]),
+       zeros=st.booleans())
+def test_fuzz_against_oracle(ctx, seed, n, log_amp, noise, eb, mode, dtype, zeros):
+    import torch
+    rng = np.random.default_rng(seed)
+    t = np.arange(n) / 41.0
+    amp = 10.0 ** log_amp
+    x = amp * (np.sin(t) + 0.3 * np.cos(4.7 * t)) + noise * amp * rng.standard_normal(n)
+    if zeros:
+        x[rng.random(n) < 0.1] = 0.0
+    x = x.astype(dtype)
+    c = O.compress(x, eb, mode, O.FAST)
+    out, info = ctx.compress(_dev(ctx, x), eb, mode)
+    assert info.sf == c.sf and info.cnt == c.cnt
+    assert np.array_equal(out["bin_index"].cpu().numpy(), c.bin_index)
+    assert _same(out["dc"].cpu().numpy(), c.dc)
+    assert _same(out["ac_exact"][:c.cnt].cpu().numpy(), c.ac_exact)
+    tdt = torch.float64 if dtype == np.float64 else torch.float32
+    r = ctx.decompress(out, info.cnt, n, tdt, eb, info.sf, mode, qtable=np.array(info.qtable[:])).cpu().numpy()
+    assert _same(r, O.decompress(c, O.FAST))
