@@ -174,3 +174,46 @@ def test_plain_c_caller_links_and_runs(mode, tmp_path):
         psnr, maxerr = float(line[4]), float(line[5])
         assert int(line[1]) == n and float(line[3]) > 1.0
         assert psnr > 60.0 and maxerr <= 8.5 * eb * 10.0      # sf = 10 for |x| up to ~50
+
+
+# ---- fuzz of the drop-in boundary: host buffers in, container out, both zlib tails ------------------
+from hypothesis import HealthCheck, given, settings, strategies as st   # noqa: E402
+
+
+@settings(max_examples=25, deadline=None, suppress_health_check=[HealthCheck.too_slow])
+@given(seed=st.integers(0, 2**31), n=st.integers(1, 300000), log_amp=st.floats(-4, 6), eb=st.sampled_from([1e-2, 1e-3, 1e-5]),
+       mode=st.sampled_from(["ec", "qt"]), dtype=st.sampled_from([np.float64, np.float32]), zthreads=st.sampled_from([0, 5]))
+def test_dropin_fuzz(seed, n, log_amp, eb, mode, dtype, zthreads):
+    if zthreads:
+        os.environ["DCTZ_ZLIB_THREADS"] = str(zthreads)
+        os.environ["DCTZ_ZLIB_CHUNK"] = "32768"
+    else:
+        os.environ.pop("DCTZ_ZLIB_THREADS", None)
+    try:
+        lib = _lib(mode)
+        qt = mode == "qt"
+        rng = np.random.default_rng(seed)
+        t = np.arange(n) / 37.0
+        amp = 10.0 ** log_amp
+        x = (amp * (np.sin(t) + 0.2 * np.cos(3.1 * t)) + 0.01 * amp * rng.standard_normal(n)).astype(dtype)
+        orig = x.copy()
+        zbuf = np.zeros(n * x.itemsize + 8192, np.uint8)
+        rec = np.zeros(n, dtype)
+        var, var_z, var_r = _tvar(x), TVar(), _tvar(rec)
+        var_z.datatype = var.datatype
+        var_z.buf.d = zbuf.ctypes.data_as(C.POINTER(C.c_double))
+        out_size = C.c_size_t(0)
+        assert lib.dctz_compress(C.byref(var), n, C.byref(out_size), C.byref(var_z), eb) == 1
+        c = O.compress(orig, eb, O.QT if qt else O.EC, O.FAST)
+        h = _parse(zbuf[:out_size.value], dtype, qt)
+        assert (h["n"], h["cnt"], h["sf"]) == (n, c.cnt, c.sf) and h["mean"] == dtype(c.mean)
+        assert h["streams"] == [c.bin_index.tobytes(), c.dc.tobytes(), c.ac_exact.tobytes()]
+        assert np.array_equal(x.view(np.uint8), c.scaled.view(np.uint8))
+        lib.dctz_check_container.restype = C.c_int
+        lib.dctz_check_container.argtypes = [C.c_void_p, C.c_size_t, C.c_int, C.c_int]
+        assert lib.dctz_check_container(zbuf.ctypes.data_as(C.c_void_p), out_size.value, n, 1) == 0
+        assert lib.dctz_decompress(C.byref(var_z), C.byref(var_r)) == 1
+        assert np.array_equal(rec.view(np.uint8), O.decompress(c, O.FAST).view(np.uint8))
+    finally:
+        os.environ.pop("DCTZ_ZLIB_THREADS", None)
+        os.environ.pop("DCTZ_ZLIB_CHUNK", None)
