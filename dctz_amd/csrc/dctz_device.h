@@ -7,27 +7,25 @@
 #include <stdint.h>
 
 #include "../../include/dctz_hip.h"
-#include "dct64_lane.h"
+#include "dct64_block.h"
 
 namespace dctz {
 
-#ifndef DCTZ_PITCH
-#define DCTZ_PITCH 66      // LDS elements per block (fp64); fp32 uses DCTZ_PITCH + 2 when even
-#endif
-#ifndef DCTZ_TILE_BLKS
-#define DCTZ_TILE_BLKS 16      // 16 blocks = one wavefront per workgroup: barriers cost nothing, 12 workgroups per CU (fp64)
-#endif
-constexpr int TILE_BLKS = DCTZ_TILE_BLKS; // blocks per tile (one quad of lanes per block)
-constexpr int TILE_ELEMS = TILE_BLKS * 64;
-constexpr int WG = TILE_BLKS * 4;         // threads per workgroup
-constexpr int SWG = 256;                  // threads per workgroup of the streaming helpers (stats, count, compact, ...)
+// A TILE = 64 consecutive 64-element blocks = the work of ONE wavefront per loop trip: lane b owns block b
+// of the tile and runs its whole transform in registers (dct64_block.h).  Workgroups of the two big kernels
+// are single wavefronts.
+constexpr int TILE_BLKS = 64;
+constexpr int TILE_ELEMS = TILE_BLKS * 64;   // 4096
+constexpr int WG = 64;                       // threads per workgroup of k_compress / k_decompress
+constexpr int SWG = 256;                     // threads per workgroup of the streaming helpers (stats, count, compact, ...)
+constexpr int EXC_BYTES = 4096;              // lane-private exception staging per wave: 64 lanes x 64 bytes
+constexpr int DEC_EXC_CAP = 1024;            // decode: exact coefficients of one tile staged in LDS (floats); more -> direct gathers
 
 template <typename T> struct Traits;
 template <> struct Traits<double> {
   using Vec = double2;
   using Bits = unsigned long long;
   static constexpr int EPV = 2;           // elements per 16-byte vector
-  static constexpr int PITCH = DCTZ_PITCH;   // LDS elements per block
   __host__ __device__ static Vec zero() { return make_double2(0.0, 0.0); }
   __device__ static void div(Vec& v, double s) { v.x = v.x / s; v.y = v.y / s; }
   __device__ static void mul(Vec& v, double s) { v.x = v.x * s; v.y = v.y * s; }
@@ -40,7 +38,6 @@ template <> struct Traits<float> {
   using Vec = float4;
   using Bits = unsigned int;
   static constexpr int EPV = 4;
-  static constexpr int PITCH = (DCTZ_PITCH % 2) ? DCTZ_PITCH : DCTZ_PITCH + 2;
   __host__ __device__ static Vec zero() { return make_float4(0.f, 0.f, 0.f, 0.f); }
   __device__ static void div(Vec& v, float s) { v.x = v.x / s; v.y = v.y / s; v.z = v.z / s; v.w = v.w / s; }
   __device__ static void mul(Vec& v, float s) { v.x = v.x * s; v.y = v.y * s; v.z = v.z * s; v.w = v.w * s; }
@@ -50,20 +47,29 @@ template <> struct Traits<float> {
   __device__ static float from_bits(Bits b) { return __uint_as_float(b); }
 };
 
-// Per-call control block in device memory; zeroed by ONE hipMemsetAsync before
-// every call (ticket, look-back total, watchdog flag, QT table accumulators).
+// Geometry of a tile in bytes for element type T.
+template <typename T> struct Geo {
+  static constexpr int BLKB = 64 * (int)sizeof(T);      // bytes per block (512 / 256)
+  static constexpr int NSEG = BLKB / 128;               // 128-byte segments per block (4 / 2)
+  static constexpr int NCH = BLKB / 16;                 // 16-byte chunks per block (32 / 16)
+  static constexpr int TILEB = TILE_BLKS * BLKB;        // bytes per tile (32 KiB / 16 KiB)
+  static constexpr int NROW = TILEB / 1024;             // 1 KiB LDS rows per tile (32 / 16)
+  // exceptions a lane can park per tile before the tile takes the direct-store path
+  static constexpr int EC_DEPTH = EXC_BYTES / 64 / 4;                  // 16 floats
+  static constexpr int QT_DEPTH = EXC_BYTES / 64 / (int)sizeof(T);     // 8 doubles / 16 floats
+};
+
+// Per-call control block in device memory; left all-zero by the last kernel of every call.
 struct Ctl {
-  unsigned ticket;                 // next tile to hand out
+  unsigned pad_ticket;
   unsigned cnt_total;              // exceptions emitted / consumed so far
-  unsigned error;                  // 1: look-back watchdog, 2: AC_exact underrun
+  unsigned error;                  // 2: AC_exact underrun on decode
   unsigned pad0;
   unsigned long long qraw[64];     // max |coef| per position, raw bits of T (dctz-comp-lib.c:371-372)
   unsigned long long q0;           // bits of the last block's DC (qtable[0], :355-360)
   unsigned long long pad1;
-  unsigned gticket[8 * 32];        // per-group tile tickets, one 128-byte line each
-  unsigned long long dbg[8];       // F_STAMP builds: summed phase cycles of thread 0 of every workgroup
 };
-static_assert(sizeof(Ctl) % 16 == 0, "memset block must be a multiple of 16 bytes");
+static_assert(sizeof(Ctl) % 16 == 0, "control block must be a multiple of 16 bytes");
 
 // Result mailbox in fine-grained pinned HOST memory: the last kernel of a phase writes
 // the few words the host needs and then a sequence number, the host spins on that word
@@ -75,10 +81,9 @@ struct HostBox {
   unsigned cnt_total, error;
   unsigned long long q0;
   unsigned long long qraw[64];
-  double fstats[3];                        // statistics fused into k_compress (F_STATS)
+  double fstats[3];                        // statistics fused into k_compress
+  double psnr[6];                          // calc_psnr reduction: min, max, sum e^2, max |e|, max |e/x| (k_psnr_final)
 };
-
-enum : int { F_LOOKBACK = 1, F_GROUP = 2, F_STAMP = 4, F_STATS = 8 };   // kernel feature bits (dctz_kernels.hip)
 
 template <typename T>
 struct FwdParams {
@@ -86,24 +91,21 @@ struct FwdParams {
   uint8_t* bin;                    // bin_index out
   float* dc;                       // DC out
   float* ac;                       // AC_exact out
-  T* scaled;                       // optional x/sf out
-  T* coef;                         // optional coefficient tap
-  float* ac_tmp;                   // two-level scheme: tile-local AC_exact lists, slot = tile * 4096
-  unsigned* tile_cnt;              // two-level scheme: list lengths (NULL selects the single-pass kernels' rules)
-  const unsigned* tile_off;        // two-level scheme: exclusive prefix of tile_cnt (k_scan_tiles)
-  T* qt_item;                      // QT scratch: flagged coefficients, full precision
+  T* coef;                         // optional coefficient tap (tests)
+  float* ac_tmp;                   // workgroup-local AC_exact lists, list of workgroup b starts at the slot of its first tile
+  unsigned* tile_cnt;              // list lengths, one per workgroup (+1 for the remainder block)
+  const unsigned* tile_off;        // exclusive prefix of tile_cnt (k_scan_tiles)
+  T* qt_item;                      // QT scratch: flagged coefficients, full precision (same list layout as ac_tmp)
   uint8_t* qt_j;                   // QT scratch: their position j
-  const T* tab;                    // TAB_* block (device)
+  const T* tab;                    // TB_* block (device)
   const T* rtab;                   // RTAB_* block (device), remainder block only
   Ctl* ctl;
-  unsigned long long* desc;        // look-back descriptors, one per tile
-  double* stat_part;               // F_STATS: {max|x|, min|x|, sum} per workgroup (+1 slot for the remainder block), else NULL
+  double* stat_part;               // fused statistics: {max|x|, min|x|, sum} per workgroup (+1 slot for the remainder block), else NULL
   unsigned nfull;                  // number of full 64-element blocks
   unsigned ntiles;
   unsigned last_is_full;           // N % 64 == 0
-  unsigned fast_sf, fast_bw;       // divisor inside FastDiv's exponent window (host check)
-  unsigned ngroups;                // ticket groups, min(8, grid)
-  unsigned nlists_main;            // two-level scheme: number of workgroup lists = grid of k_compress
+  unsigned fast_sf, fast_bw;       // divisor inside FastDiv's exponent window (host check); fast_sf == 2: every element too
+  unsigned nlists_main;            // number of workgroup lists = grid of k_compress
   T sf, bin_width, range_min, range_max;
 };
 
@@ -116,12 +118,9 @@ struct InvParams {
   const T* tab;
   const T* rtab;
   const T* qtab;                   // QT: clamped table (device)
-  const unsigned* tile_off;        // two-level scheme: exclusive prefix of per-tile flag counts (else NULL)
+  const unsigned* tile_off;        // exclusive prefix of the per-TILE counts of "stored exactly" flags; [ntiles] = the remainder block's start
   Ctl* ctl;
-  unsigned long long* desc;
   unsigned nfull, ntiles, ac_count;
-  unsigned ngroups;                // ticket groups, min(8, grid)
-  unsigned nlists_main;            // two-level scheme: number of workgroup ranges = grid of k_decompress
   T sf, bin_width, range_min, range_max;
   double eb;
 };
@@ -134,16 +133,19 @@ void launch_stats_final(const double* part, int nparts, double* out, hipStream_t
 void launch_finish(Ctl* ctl, const double* part, int nparts, HostBox* box, unsigned long long seq, hipStream_t s);
 template <typename T> void launch_debug_divide(const T* x, size_t n, T d, int ok, T* fast, T* ref, hipStream_t s);
 template <typename T> void launch_serial_sum(const T* x, size_t n, double* out, hipStream_t s);
-template <typename T> void launch_scale(T* x, size_t n, T sf, int grid, hipStream_t s);
-template <typename T> void launch_compress(const FwdParams<T>& p, int mode, bool scale, int grid, int feat, hipStream_t s);
+template <typename T> void launch_scale(const T* x, T* out, size_t n, T sf, int grid, hipStream_t s);
+template <typename T> void launch_compress(const FwdParams<T>& p, int mode, bool stats, int grid, hipStream_t s);
 template <typename T> void launch_compress_rem(const FwdParams<T>& p, int mode, bool scale, int l, hipStream_t s);
-template <typename T> void launch_qt_finish(const FwdParams<T>& p, double eb, int grid, hipStream_t s);
+template <typename T> void launch_qt_max(const FwdParams<T>& p, unsigned nlists, int grid, hipStream_t s);
 template <typename T> void launch_compact_ac(const FwdParams<T>& p, int mode, double eb, unsigned nlists, int grid, hipStream_t s);
 void launch_scan_tiles(const unsigned* cnt, unsigned* off, unsigned n, Ctl* ctl, hipStream_t s);
 void launch_count_tiles(const uint8_t* bin, unsigned nfull, unsigned ntiles, unsigned* tile_cnt, int grid, hipStream_t s);
-template <typename T> void launch_decompress(const InvParams<T>& p, int mode, bool scale, int grid, int feat, hipStream_t s);
+template <typename T> void launch_decompress(const InvParams<T>& p, int mode, int grid, hipStream_t s);
 template <typename T> void launch_decompress_rem(const InvParams<T>& p, int mode, bool scale, int l, hipStream_t s);
 template <typename T> void launch_dct_blocks(const T* x, T* out, const T* gtab, const T* rtab, size_t n,
                                              bool inverse, int grid, hipStream_t s);
+template <typename T> void launch_psnr(const T* x, const T* r, size_t n, double* part, int nparts, double* out, hipStream_t s);
+template <typename T> size_t compress_lds_bytes();
+template <typename T> size_t decompress_lds_bytes();
 
 }  // namespace dctz

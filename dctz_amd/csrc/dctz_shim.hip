@@ -38,13 +38,11 @@ struct dctzhip_ctx {
   void* qtab = nullptr;             // 64 doubles
   // per-call state
   Ctl* ctl = nullptr;
-  unsigned long long* desc = nullptr;
-  size_t desc_cap = 0;              // tiles
   double* part = nullptr;           // stats partials
   double* stats_out = nullptr;      // 4 doubles
-  float* ac_tmp = nullptr;          // two-level scheme: tile-local AC_exact lists
+  float* ac_tmp = nullptr;          // workgroup-local AC_exact lists (list of workgroup b at the slot of its first tile)
   size_t ac_tmp_cap = 0;            // floats
-  unsigned* tile_cnt = nullptr;     // two-level scheme: per-tile counts / exclusive prefix
+  unsigned* tile_cnt = nullptr;     // list lengths (compress) / per-tile flag counts (decode) and their exclusive prefix
   unsigned* tile_off = nullptr;
   size_t tile_cap = 0;              // entries
   void* qt_item = nullptr;
@@ -56,14 +54,13 @@ struct dctzhip_ctx {
   HostBox* box = nullptr;           // result mailbox, fine-grained pinned host memory (kernels write, host spins)
   HostBox* box_dev = nullptr;       // the same memory as the device sees it
   unsigned long long seq = 0;       // sequence number of the last hand-off
-  int handoff = 1;                  // 1: mailbox + spin (two-level scheme); 0: D2H copy + hipStreamSynchronize (DCTZHIP_HANDOFF)
+  int handoff = 1;                  // 1: mailbox + spin; 0: D2H copy + hipStreamSynchronize (DCTZHIP_HANDOFF)
   int ctl_dirty = 1;                // control block may be non-zero: memset it before the next call
   // profiling
-  int feat = 0;                     // 0: two-level scheme (default); 1: single-pass look-back kernels,
-  int feat_d = 0;                   //    +2 grouped tickets, +4 phase stamps (DCTZHIP_FEAT sets both)
   int fastdiv = 2;                  // hoisted-reciprocal division: 0 off, 1 per-tile window test, 2 + skip the test when k_stats proves it (DCTZHIP_FASTDIV)
   int stats_grid = 2048;            // workgroups of the statistics kernel (DCTZHIP_STATS_GRID, <= 2048)
-  int wg_per_cu = 0;                // grid = CUs * this; 0 = resident workgroups per CU: 3 (fp64), 4 (fp32) (DCTZHIP_WG_PER_CU)
+  int wg_per_cu = 0;                // grid = CUs * this; 0 = as many single-wave workgroups as a CU's LDS admits (DCTZHIP_WG_PER_CU)
+  int occ[2][2] = {{0, 0}, {0, 0}}; // resident workgroups per CU of k_compress / k_decompress, per dtype (occupancy query)
   int speculate = 1;                // fused statistics behind a sampled guess of the scaling factor (DCTZHIP_SPECULATE, dctzhip_set_speculation)
   size_t spec_min = (size_t)1 << 22; // elements below which the plain statistics pass is kept (DCTZHIP_SPEC_MIN)
   unsigned spec_group = 64;         // one 4 KiB chunk sampled per group of this many (DCTZHIP_SPEC_GROUP)
@@ -78,7 +75,7 @@ struct dctzhip_ctx {
 
 static char g_create_err[512] = "";
 static constexpr int STATS_GRID_MAX = 2048;
-static constexpr int PART_SLOTS = 256 * 16 + 64;       // >= largest k_compress grid + 1 (fused statistics partials)
+static constexpr int PART_SLOTS = 256 * 16 + 64;       // >= largest k_compress grid + 1 (fused statistics partials), >= 4/3 of the PSNR grid
 static constexpr int SPEC_COOLDOWN = 8;
 static constexpr size_t PIN_STATS = 0, PIN_CTL = 64, PIN_TAB = 64 + sizeof(Ctl);
 static constexpr size_t PIN_BYTES = PIN_TAB + sizeof(double) * RTAB_SIZE + sizeof(double) * 64;
@@ -116,7 +113,6 @@ extern "C" int dctzhip_ctx_create(dctzhip_ctx** out, int device) {
   hipDeviceProp_t prop;
   HIPCHK(nullptr, hipGetDeviceProperties(&prop, device));
   c->num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-  if (const char* e = getenv("DCTZHIP_FEAT")) { c->feat = atoi(e) & 7; c->feat_d = c->feat; }
   if (const char* e = getenv("DCTZHIP_FASTDIV")) c->fastdiv = atoi(e);
   if (const char* e = getenv("DCTZHIP_STATS_GRID")) { int v = atoi(e); if (v >= 1 && v <= STATS_GRID_MAX) c->stats_grid = v; }
   if (const char* e = getenv("DCTZHIP_WG_PER_CU")) { int v = atoi(e); if (v >= 1 && v <= 16) c->wg_per_cu = v; }
@@ -127,8 +123,8 @@ extern "C" int dctzhip_ctx_create(dctzhip_ctx** out, int device) {
   c->stream = c->own_stream;
   HIPCHK(nullptr, hipStreamCreateWithFlags(&c->side_stream, hipStreamNonBlocking));
   HIPCHK(nullptr, hipMalloc(&c->serial_out, 16));
-  HIPCHK(nullptr, hipMalloc(&c->tab_f64, sizeof(double) * TAB_SIZE));
-  HIPCHK(nullptr, hipMalloc(&c->tab_f32, sizeof(float) * TAB_SIZE));
+  HIPCHK(nullptr, hipMalloc(&c->tab_f64, sizeof(double) * TB_SIZE));
+  HIPCHK(nullptr, hipMalloc(&c->tab_f32, sizeof(float) * TB_SIZE));
   HIPCHK(nullptr, hipMalloc(&c->rtab, sizeof(double) * RTAB_SIZE));
   HIPCHK(nullptr, hipMalloc(&c->qtab, sizeof(double) * 64));
   HIPCHK(nullptr, hipMalloc(&c->ctl, sizeof(Ctl)));
@@ -148,10 +144,10 @@ extern "C" int dctzhip_ctx_create(dctzhip_ctx** out, int device) {
   }
   if (const char* e = getenv("DCTZHIP_HANDOFF")) c->handoff = (atoi(e) != 0) && c->box != nullptr;
   {
-    double t64[TAB_SIZE];
-    float t32[TAB_SIZE];
-    fill_tab64<double>(t64);
-    fill_tab64<float>(t32);
+    double t64[TB_SIZE];
+    float t32[TB_SIZE];
+    fill_tab_block<double>(t64);
+    fill_tab_block<float>(t32);
     HIPCHK(nullptr, hipMemcpy(c->tab_f64, t64, sizeof(t64), hipMemcpyHostToDevice));
     HIPCHK(nullptr, hipMemcpy(c->tab_f32, t32, sizeof(t32), hipMemcpyHostToDevice));
   }
@@ -165,7 +161,7 @@ extern "C" void dctzhip_ctx_destroy(dctzhip_ctx* c) {
   (void)hipSetDevice(c->device);
   (void)hipStreamSynchronize(c->stream);
   if (c->side_stream) { (void)hipStreamSynchronize(c->side_stream); (void)hipStreamDestroy(c->side_stream); }
-  void* bufs[] = {c->ac_tmp, c->tile_cnt, c->tile_off, c->serial_out, c->tab_f64, c->tab_f32, c->rtab, c->qtab, c->ctl, c->desc, c->part, c->stats_out, c->qt_item, c->qt_j};
+  void* bufs[] = {c->ac_tmp, c->tile_cnt, c->tile_off, c->serial_out, c->tab_f64, c->tab_f32, c->rtab, c->qtab, c->ctl, c->part, c->stats_out, c->qt_item, c->qt_j};
   for (void* b : bufs) if (b) (void)hipFree(b);
   if (c->h_pin) (void)hipHostFree(c->h_pin);
   if (c->box) (void)hipHostFree(c->box);
@@ -174,9 +170,16 @@ extern "C" void dctzhip_ctx_destroy(dctzhip_ctx* c) {
   delete c;
 }
 
+// NULL is the legacy default stream (what a caller that never created a stream works on), exactly like a
+// NULL hipStream_t anywhere else in HIP; the context's private stream is selected with dctzhip_use_own_stream.
 extern "C" int dctzhip_set_stream(dctzhip_ctx* c, void* s) {
   if (!c) return DCTZHIP_E_ARG;
-  c->stream = s ? (hipStream_t)s : c->own_stream;
+  c->stream = (hipStream_t)s;
+  return DCTZHIP_OK;
+}
+extern "C" int dctzhip_use_own_stream(dctzhip_ctx* c) {
+  if (!c) return DCTZHIP_E_ARG;
+  c->stream = c->own_stream;
   return DCTZHIP_OK;
 }
 extern "C" void* dctzhip_get_stream(dctzhip_ctx* c) { return c ? (void*)c->stream : nullptr; }
@@ -257,30 +260,25 @@ static int regrow(dctzhip_ctx* c, P** ptr, size_t* cap, size_t need, size_t elem
   return DCTZHIP_OK;
 }
 
-// compress = true: scratch of the compress stage (tile-local lists); else decode (counts only)
+// compress = true: scratch of the compress stage (workgroup-local lists); else decode (per-tile counts only)
 static int ensure_scratch(dctzhip_ctx* c, size_t n, int dtype, int mode, bool compress = true) {
   const size_t ntiles = (n / 64 + TILE_BLKS - 1) / TILE_BLKS;
-  const size_t lists = ntiles + 1;                     // + the remainder block's list
+  const size_t entries = (ntiles > (size_t)PART_SLOTS ? ntiles : (size_t)PART_SLOTS) + 2;   // lists (<= grid + 1) or tiles, + the total
   int rc;
-  if ((c->feat | c->feat_d) & 1) {                     // single-pass kernels: look-back descriptors
-    size_t cap = (ntiles + 2) & ~(size_t)1;            // even -> bytes are a multiple of 16
-    if ((rc = regrow(c, &c->desc, &c->desc_cap, cap, sizeof(unsigned long long)))) return rc;
-  }
   {
     size_t cap = c->tile_cap;
-    if ((rc = regrow(c, &c->tile_cnt, &cap, lists + 1, sizeof(unsigned)))) return rc;
-    if ((rc = regrow(c, &c->tile_off, &c->tile_cap, lists + 1, sizeof(unsigned)))) return rc;
+    if ((rc = regrow(c, &c->tile_cnt, &cap, entries, sizeof(unsigned)))) return rc;
+    if ((rc = regrow(c, &c->tile_off, &c->tile_cap, entries, sizeof(unsigned)))) return rc;
   }
   if (!compress) return DCTZHIP_OK;
-  const size_t slots = lists * TILE_ELEMS;             // two-level: list l lives at l * 4096
-  const size_t items = (c->feat & 1) ? n : slots;
+  const size_t slots = (ntiles + 1) * TILE_ELEMS;      // list of workgroup b at the slot of its first tile; the remainder block's behind them
   if (mode == DCTZHIP_QT) {
     size_t cap_b = c->qt_cap;
     char* qi = (char*)c->qt_item;
-    if ((rc = regrow(c, &qi, &cap_b, items * elem_size(dtype), 1))) return rc;
+    if ((rc = regrow(c, &qi, &cap_b, slots * elem_size(dtype), 1))) return rc;
     c->qt_item = qi; c->qt_cap = cap_b;
-    if ((rc = regrow(c, &c->qt_j, &c->qtj_cap, items, 1))) return rc;
-  } else if (!(c->feat & 1)) {
+    if ((rc = regrow(c, &c->qt_j, &c->qtj_cap, slots, 1))) return rc;
+  } else {
     if ((rc = regrow(c, &c->ac_tmp, &c->ac_tmp_cap, slots, sizeof(float)))) return rc;
   }
   return DCTZHIP_OK;
@@ -366,34 +364,46 @@ static int read_timings(dctzhip_ctx* c, int nev_main_start) {
 
 struct HostStats { double max_abs, min_abs, sum; };
 
+// resident single-wave workgroups per CU of the two big kernels (LDS-limited: 4 for fp64, 7 for fp32)
+template <typename T>
+static int wg_per_cu(dctzhip_ctx* c, bool decode) {
+  if (c->wg_per_cu) return c->wg_per_cu;
+  int& o = c->occ[sizeof(T) == 8 ? 1 : 0][decode ? 1 : 0];
+  if (!o) {
+    const size_t lds = decode ? decompress_lds_bytes<T>() : compress_lds_bytes<T>();
+    int v = (int)((size_t)160 * 1024 / lds);
+    o = v < 1 ? 1 : (v > 8 ? 8 : v);
+  }
+  return o;
+}
+
 // One pass of the compress kernels for a given set of statistics.  `fused`: the
 // statistics are a guess (from a sample); k_compress recomputes the true ones on
 // the way and leaves them in stats_out for the caller to check.
 template <typename T>
 static int compress_pass(dctzhip_ctx* c, const T* d_in, size_t n, double eb, int mode, uint8_t* d_bin, float* d_dc,
-                         float* d_ac, T* d_scaled, T* d_coef, const HostStats& st, bool fused, double* sf_out, T* sf_t_out,
+                         float* d_ac, T* d_coef, const HostStats& st, bool fused, double* sf_out, T* sf_t_out,
                          unsigned* fast_sf_out, unsigned long long seq) {
   const int dtype = sizeof(T) == 8 ? DCTZHIP_F64 : DCTZHIP_F32;
   hipStream_t s = c->stream;
   const unsigned nfull = (unsigned)(n / 64);
   const int rem = (int)(n % 64);
   const unsigned ntiles = (nfull + TILE_BLKS - 1) / TILE_BLKS;
-  const bool two_level = !(c->feat & 1);
   const double sf = scaling_factor(dtype, st.max_abs);
   *sf_out = sf;
 
   // ---- bin ranges, dctz-comp-lib.c:271-281 (computed in double, stored in T) --
   const int half = DCTZHIP_NBINS / 2;
   FwdParams<T> p;
-  p.x = d_in; p.bin = d_bin; p.dc = d_dc; p.ac = d_ac; p.scaled = d_scaled; p.coef = d_coef;
+  p.x = d_in; p.bin = d_bin; p.dc = d_dc; p.ac = d_ac; p.coef = d_coef;
   p.qt_item = reinterpret_cast<T*>(c->qt_item); p.qt_j = c->qt_j;
   p.ac_tmp = c->ac_tmp;
-  p.tile_cnt = two_level ? c->tile_cnt : nullptr;
-  p.tile_off = two_level ? c->tile_off : nullptr;
+  p.tile_cnt = c->tile_cnt;
+  p.tile_off = c->tile_off;
   p.tab = tab_of<T>(c); p.rtab = reinterpret_cast<const T*>(c->rtab);
-  p.ctl = c->ctl; p.desc = c->desc;
+  p.ctl = c->ctl;
   p.stat_part = fused ? c->part : nullptr;
-  p.nfull = nfull; p.ntiles = ntiles; p.last_is_full = rem ? 0u : 1u; p.ngroups = 1;
+  p.nfull = nfull; p.ntiles = ntiles; p.last_is_full = rem ? 0u : 1u;
   p.sf = (T)sf;
   p.bin_width = (T)(eb * 2.0 * 1.0);
   p.range_min = (T)(-(half * 2 + 1) * (eb * 1.0));
@@ -402,32 +412,33 @@ static int compress_pass(dctzhip_ctx* c, const T* d_in, size_t n, double eb, int
   p.fast_sf = c->fastdiv ? divisor_in_window(dtype, (double)p.sf) : 0u;
   if (p.fast_sf && c->fastdiv >= 2 && value_in_window(dtype, st.min_abs) && value_in_window(dtype, st.max_abs)) p.fast_sf = 2;
   p.fast_bw = c->fastdiv ? divisor_in_window(dtype, (double)p.bin_width) : 0u;
+  {
+    // bit 1: "item > range_max  =>  (item - range_min) / bin_width >= 255" holds for these launch constants, in T
+    // arithmetic, so k_compress needs no separate range test (dctz_kernels.hip, bin_value): the smallest such
+    // numerator is fl(range_max - range_min) = 2 range_max, and rounding is monotonic.
+    volatile T u = (T)(p.range_max - p.range_min);
+    volatile T q = (T)(u / p.bin_width);
+    if (p.fast_bw && c->fastdiv >= 2 && q >= (T)255) p.fast_bw |= 2u;
+  }
   *sf_t_out = p.sf; *fast_sf_out = p.fast_sf;
   const bool scale = (p.sf != (T)1.0);              // :193 / :208
-  if (!scale && d_scaled && d_scaled != d_in)       // sf == 1: "scaled" data is the input itself
-    HIPCHK(c, hipMemcpyAsync(d_scaled, d_in, n * sizeof(T), hipMemcpyDeviceToDevice, s));
 
   if (rem) { int rc = upload_rtab<T>(c, rem); if (rc) return rc; }
 
   if (c->profiling) HIPCHK(c, hipEventRecord(c->ev[2], s));
-  const unsigned cap = (unsigned)(c->num_cu * (c->wg_per_cu ? c->wg_per_cu : (sizeof(T) == 8 ? 3 : 4) * 256 / WG));
+  const unsigned cap = (unsigned)(c->num_cu * wg_per_cu<T>(c, false));
   const int grid = (int)(cap < ntiles ? cap : ntiles);
   p.nlists_main = (unsigned)grid;
-  if (ntiles) {
-    p.ngroups = grid < 8 ? (unsigned)grid : 8u;
-    launch_compress<T>(p, mode, scale, grid, c->feat | (fused ? F_STATS : 0), s);
-  }
+  if (ntiles) launch_compress<T>(p, mode, fused, grid, s);
   if (c->profiling) HIPCHK(c, hipEventRecord(c->ev[3], s));
   if (rem) launch_compress_rem<T>(p, mode, scale, rem, s);
-  if (two_level) {                                  // stitch the workgroup-local lists into AC_exact[]
-    const unsigned nlists = (unsigned)grid + (rem ? 1u : 0u);
-    launch_scan_tiles(c->tile_cnt, c->tile_off, nlists, c->ctl, s);
-    launch_compact_ac<T>(p, mode, eb, nlists, (int)nlists, s);
-    if (seq) launch_finish(c->ctl, c->part, fused ? (int)nlists : 0, c->box_dev, seq, s);   // results -> host box, Ctl -> 0
-    else if (fused) launch_stats_final(c->part, (int)nlists, c->stats_out, s);
-  } else if (mode == DCTZHIP_QT) {
-    launch_qt_finish<T>(p, eb, c->num_cu * 4, s);
-  }
+  // stitch the workgroup-local lists into AC_exact[]
+  const unsigned nlists = (unsigned)grid + (rem ? 1u : 0u);
+  if (mode == DCTZHIP_QT) launch_qt_max<T>(p, nlists, (int)(nlists < 1024u ? nlists : 1024u), s);   // :371-372 over the lists
+  launch_scan_tiles(c->tile_cnt, c->tile_off, nlists, c->ctl, s);
+  launch_compact_ac<T>(p, mode, eb, nlists, (int)nlists, s);
+  if (seq) launch_finish(c->ctl, c->part, fused ? (int)nlists : 0, c->box_dev, seq, s);   // results -> host box, Ctl -> 0
+  else if (fused) launch_stats_final(c->part, (int)nlists, c->stats_out, s);
   if (c->profiling) HIPCHK(c, hipEventRecord(c->ev[4], s));
   HIPCHK(c, hipGetLastError());
   return DCTZHIP_OK;
@@ -442,27 +453,24 @@ static int compress_impl(dctzhip_ctx* c, const T* d_in, size_t n, double eb, int
   const int rem = (int)(n % 64);
   const unsigned ntiles = (nfull + TILE_BLKS - 1) / TILE_BLKS;
   const unsigned nblk = nfull + (rem ? 1 : 0);
-  const bool two_level = !(c->feat & 1);
   double* hs = reinterpret_cast<double*>(c->h_pin + PIN_STATS);    // [0..2] first statistics, [4..6] fused ones
   Ctl* hc = reinterpret_cast<Ctl*>(c->h_pin + PIN_CTL);
 
   // Speculation: calc_data_stat needs the whole array before the first division, i.e. a second
   // read of the input.  Only the DECADE of max|x| matters (util.c:29), so guess it from a sample,
   // let k_compress compute the true statistics while it streams the data anyway, and check the
-  // guess afterwards; a wrong guess costs one re-run with the true values.  Never when the scaled
-  // data goes back into the input buffer (a wrong guess would have destroyed the input).
+  // guess afterwards; a wrong guess costs one re-run with the true values.  (The scaled copy the
+  // reference's in-place semantics ask for is written at the very end, with the verified sf.)
   constexpr size_t chunk = (size_t)SWG * Traits<T>::EPV;
-  bool spec = c->speculate && two_level && ntiles && n >= c->spec_min && n >= 4 * chunk * c->spec_group &&
-              (const void*)d_scaled != (const void*)d_in;
+  bool spec = c->speculate && ntiles && n >= c->spec_min && n >= 4 * chunk * c->spec_group;
   if (spec && c->spec_cooldown > 0) { c->spec_cooldown--; spec = false; }
 
-  // Host hand-off: mailbox + spin for the two-level scheme, D2H copy + stream sync otherwise
-  const bool box = c->handoff && two_level && !(c->feat & 4);
+  // Host hand-off: mailbox + spin, or D2H copy + stream sync
+  const bool box = c->handoff != 0;
   HostBox* hb = c->box;
   auto reset = [&]() -> int {
     if (!box || c->ctl_dirty) HIPCHK(c, hipMemsetAsync(c->ctl, 0, sizeof(Ctl), s));   // (k_finish leaves it zeroed)
     c->ctl_dirty = 1;                               // until this call's k_finish has been seen
-    if (ntiles && !two_level) HIPCHK(c, hipMemsetAsync(c->desc, 0, ((ntiles + 1) & ~1u) * sizeof(unsigned long long), s));
     return DCTZHIP_OK;
   };
   { int rc = reset(); if (rc) return rc; }
@@ -499,7 +507,7 @@ static int compress_impl(dctzhip_ctx* c, const T* d_in, size_t n, double eb, int
   unsigned flags = 0;
   // one pass of the kernels + the hand-off of its results into *hc / hs[4..6]
   auto run = [&](const HostStats& stats, bool fused) -> int {
-    int rc = compress_pass<T>(c, d_in, n, eb, mode, d_bin, d_dc, d_ac, d_scaled, d_coef, stats, fused, &sf, &sf_t, &fast_sf, seq);
+    int rc = compress_pass<T>(c, d_in, n, eb, mode, d_bin, d_dc, d_ac, d_coef, stats, fused, &sf, &sf_t, &fast_sf, seq);
     if (rc) return rc;
     if (box) {
       rc = wait_seq(c, &hb->seq_done, seq, "compress");
@@ -514,7 +522,7 @@ static int compress_impl(dctzhip_ctx* c, const T* d_in, size_t n, double eb, int
       HIPCHK(c, hipMemcpyAsync(hc, c->ctl, sizeof(Ctl), hipMemcpyDeviceToHost, s));
       HIPCHK(c, hipStreamSynchronize(s));
     }
-    if (hc->error) return fail(c, DCTZHIP_E_INTERNAL, "in-kernel watchdog tripped (code %u)", hc->error);
+    if (hc->error) return fail(c, DCTZHIP_E_INTERNAL, "in-kernel error flag set (code %u)", hc->error);
     if (c->profiling) { rc = read_timings(c, 2); if (rc) return rc; }
     return DCTZHIP_OK;
   };
@@ -540,13 +548,12 @@ static int compress_impl(dctzhip_ctx* c, const T* d_in, size_t n, double eb, int
       if (rc) return rc;
     }
   }
-  if (c->feat & 4) {
-    if ((c->feat & 1) && mode == DCTZHIP_EC)
-      fprintf(stderr, "[dctzhip stamps] compress(pipe) cycles: stage %llu dct %llu bin %llu ticket+D %llu resolve %llu copyout %llu park+stores %llu\n",
-              hc->dbg[0], hc->dbg[1], hc->dbg[2], hc->dbg[3], hc->dbg[4], hc->dbg[5], hc->dbg[6]);
-    else
-    fprintf(stderr, "[dctzhip stamps] compress cycles: ticket %llu load %llu dct %llu bin %llu scan %llu lookback %llu acwrite %llu\n",
-            hc->dbg[0], hc->dbg[1], hc->dbg[2], hc->dbg[3], hc->dbg[4], hc->dbg[5], hc->dbg[6]);
+  // dctz-comp-lib.c:193-216: the reference divides the caller's array by sf in place; here on request, into
+  // d_scaled (which may be d_in itself), once sf is final
+  if (d_scaled) {
+    if (sf_t != (T)1.0) launch_scale<T>(d_in, d_scaled, n, sf_t, c->num_cu * 8, s);
+    else if ((const void*)d_scaled != (const void*)d_in) HIPCHK(c, hipMemcpyAsync(d_scaled, d_in, n * sizeof(T), hipMemcpyDeviceToDevice, s));
+    HIPCHK(c, hipGetLastError());
   }
 
   if (info) {
@@ -653,8 +660,8 @@ extern "C" int dctzhip_scale_inplace(dctzhip_ctx* c, void* d_x, size_t n, int dt
   if (!d_x || !aligned16(d_x)) return fail(c, DCTZHIP_E_ARG, "bad buffer");
   HIPCHK(c, hipSetDevice(c->device));
   if (sf == 1.0) return DCTZHIP_OK;                 // dctz-comp-lib.c:193 / :208
-  if (dtype == DCTZHIP_F64) launch_scale<double>((double*)d_x, n, sf, c->num_cu * 8, c->stream);
-  else launch_scale<float>((float*)d_x, n, (float)sf, c->num_cu * 8, c->stream);
+  if (dtype == DCTZHIP_F64) launch_scale<double>((const double*)d_x, (double*)d_x, n, sf, c->num_cu * 8, c->stream);
+  else launch_scale<float>((const float*)d_x, (float*)d_x, n, (float)sf, c->num_cu * 8, c->stream);
   HIPCHK(c, hipGetLastError());
   HIPCHK(c, hipStreamSynchronize(c->stream));
   return DCTZHIP_OK;
@@ -688,12 +695,12 @@ static int decompress_impl(dctzhip_ctx* c, const uint8_t* d_bin, const float* d_
   const unsigned nfull = (unsigned)(n / 64);
   const int rem = (int)(n % 64);
   const unsigned ntiles = (nfull + TILE_BLKS - 1) / TILE_BLKS;
-  const bool two_level = !(c->feat_d & 1);
-  const bool box = c->handoff && two_level && !(c->feat_d & 4);   // mailbox + spin instead of D2H copy + stream sync
+  const bool box = c->handoff != 0;                 // mailbox + spin instead of D2H copy + stream sync
   if (!box || c->ctl_dirty) HIPCHK(c, hipMemsetAsync(c->ctl, 0, sizeof(Ctl), s));      // (k_finish leaves it zeroed)
   c->ctl_dirty = 1;
-  if (ntiles && !two_level) HIPCHK(c, hipMemsetAsync(c->desc, 0, ((ntiles + 1) & ~1u) * sizeof(unsigned long long), s));
   if (mode == DCTZHIP_QT) {
+    // staged through pinned memory that the NEXT call may rewrite: safe because every call ends with a host
+    // wait on this stream (mailbox or stream sync) before it returns
     T* hq = reinterpret_cast<T*>(c->h_pin + PIN_TAB + sizeof(double) * RTAB_SIZE);
     memcpy(hq, qtable_host, sizeof(T) * 64);
     HIPCHK(c, hipMemcpyAsync(c->qtab, hq, sizeof(T) * 64, hipMemcpyHostToDevice, s));
@@ -703,9 +710,9 @@ static int decompress_impl(dctzhip_ctx* c, const uint8_t* d_bin, const float* d_
   InvParams<T> p;
   p.bin = d_bin; p.dc = d_dc; p.ac = d_ac; p.out = d_out;
   p.tab = tab_of<T>(c); p.rtab = reinterpret_cast<const T*>(c->rtab); p.qtab = reinterpret_cast<const T*>(c->qtab);
-  p.ctl = c->ctl; p.desc = c->desc;
-  p.tile_off = two_level ? c->tile_off : nullptr;
-  p.nfull = nfull; p.ntiles = ntiles; p.ac_count = ac_count; p.ngroups = 1;
+  p.ctl = c->ctl;
+  p.tile_off = c->tile_off;
+  p.nfull = nfull; p.ntiles = ntiles; p.ac_count = ac_count;
   p.sf = (T)sf;
   // gen_bins / gen_bins_f (binning.c:17 / :37): bin_width = error_bound*2*BRSF in
   // the data type (gen_bins_f receives error_bound already rounded to float)
@@ -715,19 +722,14 @@ static int decompress_impl(dctzhip_ctx* c, const uint8_t* d_bin, const float* d_
   p.eb = eb;
   const bool scale = (p.sf != (T)1.0);            // :496 / :505
 
-  const unsigned cap = (unsigned)(c->num_cu * (c->wg_per_cu ? c->wg_per_cu : (sizeof(T) == 8 ? 3 : 4) * 256 / WG));
+  const unsigned cap = (unsigned)(c->num_cu * wg_per_cu<T>(c, true));
   const int grid = (int)(cap < ntiles ? cap : ntiles);
-  p.nlists_main = (unsigned)grid;
   if (c->profiling) HIPCHK(c, hipEventRecord(c->ev[0], s));
-  if (two_level) {                                  // per-workgroup-range flag counts -> exclusive prefix
-    if (ntiles) launch_count_tiles(d_bin, nfull, ntiles, c->tile_cnt, grid, s);
-    launch_scan_tiles(c->tile_cnt, c->tile_off, (unsigned)grid, c->ctl, s);
-  }
+  // per-tile counts of "stored exactly" flags -> exclusive prefix: where every tile's piece of AC_exact starts
+  if (ntiles) launch_count_tiles(d_bin, nfull, ntiles, c->tile_cnt, (int)(ntiles < (unsigned)(c->num_cu * 8) ? ntiles : (unsigned)(c->num_cu * 8)), s);
+  launch_scan_tiles(c->tile_cnt, c->tile_off, ntiles, c->ctl, s);
   if (c->profiling) { HIPCHK(c, hipEventRecord(c->ev[1], s)); HIPCHK(c, hipEventRecord(c->ev[2], s)); }
-  if (ntiles) {
-    p.ngroups = grid < 8 ? (unsigned)grid : 8u;
-    launch_decompress<T>(p, mode, scale, grid, c->feat_d, s);
-  }
+  if (ntiles) launch_decompress<T>(p, mode, grid, s);
   if (c->profiling) HIPCHK(c, hipEventRecord(c->ev[3], s));
   if (rem) launch_decompress_rem<T>(p, mode, scale, rem, s);
   const unsigned long long seq = box ? ++c->seq : 0ull;
@@ -742,14 +744,11 @@ static int decompress_impl(dctzhip_ctx* c, const uint8_t* d_bin, const float* d_
     hc->error = c->box->error;
     if (c->profiling) HIPCHK(c, hipEventSynchronize(c->ev[4]));
   } else {
-    HIPCHK(c, hipMemcpyAsync(hc, c->ctl, (c->feat_d & 4) ? sizeof(Ctl) : 16, hipMemcpyDeviceToHost, s));
+    HIPCHK(c, hipMemcpyAsync(hc, c->ctl, 16, hipMemcpyDeviceToHost, s));
     HIPCHK(c, hipStreamSynchronize(s));
   }
-  if (c->feat_d & 4)
-    fprintf(stderr, "[dctzhip stamps] decompress cycles: ticket %llu binload %llu scan+lookback %llu (scan %llu lookback %llu) store %llu gather %llu idct %llu\n",
-            hc->dbg[0], hc->dbg[1], hc->dbg[2] + hc->dbg[4] + hc->dbg[5], hc->dbg[4], hc->dbg[5], hc->dbg[3], hc->dbg[6], hc->dbg[7]);
   if (hc->error == 2) return fail(c, DCTZHIP_E_ARG, "bin_index flags more exact coefficients than ac_count provides");
-  if (hc->error) return fail(c, DCTZHIP_E_INTERNAL, "in-kernel watchdog tripped (code %u)", hc->error);
+  if (hc->error) return fail(c, DCTZHIP_E_INTERNAL, "in-kernel error flag set (code %u)", hc->error);
   if (c->profiling) { int rc = read_timings(c, 2); if (rc) return rc; }
   return DCTZHIP_OK;
 }
@@ -788,5 +787,24 @@ extern "C" int dctzhip_dct_blocks(dctzhip_ctx* c, const void* d_in, void* d_out,
   }
   HIPCHK(c, hipGetLastError());
   HIPCHK(c, hipStreamSynchronize(c->stream));
+  return DCTZHIP_OK;
+}
+
+// calc_psnr's reductions (util.c:54-104) on device-resident arrays: out = {min(x), max(x), max |x - r|, sum (x - r)^2}
+extern "C" int dctzhip_psnr_terms(dctzhip_ctx* c, const void* d_x, const void* d_r, size_t n, int dtype, double out[4]) {
+  int rc = check_common(c, n, dtype, DCTZHIP_EC);
+  if (rc) return rc;
+  if (!d_x || !d_r || !out) return fail(c, DCTZHIP_E_ARG, "null buffer");
+  HIPCHK(c, hipSetDevice(c->device));
+  int grid = (int)((n + SWG * 8 - 1) / (SWG * 8));
+  if (grid < 1) grid = 1;
+  if (grid > 3 * PART_SLOTS / 4) grid = 3 * PART_SLOTS / 4;       // 4 doubles per partial in the 3-per-slot array
+  if (dtype == DCTZHIP_F64) launch_psnr<double>((const double*)d_x, (const double*)d_r, n, c->part, grid, c->stats_out, c->stream);
+  else launch_psnr<float>((const float*)d_x, (const float*)d_r, n, c->part, grid, c->stats_out, c->stream);
+  HIPCHK(c, hipGetLastError());
+  double* hs = reinterpret_cast<double*>(c->h_pin + PIN_STATS);
+  HIPCHK(c, hipMemcpyAsync(hs, c->stats_out, 4 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  for (int i = 0; i < 4; i++) out[i] = hs[i];
   return DCTZHIP_OK;
 }

@@ -11,7 +11,7 @@
 #include <cstring>
 #include <type_traits>
 
-#include "dct64_lane.h"
+#include "dct64_block.h"
 
 #ifndef M_PI
 #define M_PI 3.14159265358979323846 /* dct.h:13-15 */
@@ -55,71 +55,72 @@ inline void reference_twiddles(int n, T* as, T* ax, T* ias, T* iax) {
 template <typename T>
 inline T sqrt2() { return std::is_same<T, double>::value ? (T)sqrt(2.0) : (T)sqrtf(2.0); }
 
-// The TAB_* block of dct64_lane.h for the 64-point fast path.
+// The TB_* block of dct64_block.h for the 64-point fast path.  Exact definitions (theta_j = j pi / 128,
+// cw = cos(2 pi k / 64), sw = sin(2 pi k / 64)):
+//   forward:  alpha_j = cos(theta_j) / sqrt(128) = as[j] / 2,  beta_j = sin(theta_j) / sqrt(128) = -ax[j] / 2   (dct.c:37-47)
+//   inverse:  C_j = sqrt(128) cos(theta_j) = ias[j],           S_j = sqrt(128) sin(theta_j) = iax[j]            (dct.c:130-134)
+// and the merged split constants are products / sums of those, evaluated in long double and rounded to T
+// ONCE (the reference rounds every factor to T first; both are rounding-level restatements of the same
+// real numbers, and neither can reproduce FFTW's own internal twiddles).
 template <typename T>
-inline void fill_tab64(T* tab) {
-  std::memset(tab, 0, sizeof(T) * TAB_SIZE);
-  T as[64], ax[64], ias[64], iax[64];
-  reference_twiddles<T>(64, as, ax, ias, iax);
-  for (int k = 0; k < 64; k++) {
-    tab[TAB_HS + k] = (T)0.5 * as[k];
-    tab[TAB_HX + k] = (T)0.5 * ax[k];
-    tab[TAB_IAS + k] = ias[k];
-    tab[TAB_IAX + k] = iax[k];
-  }
-  tab[TAB_IAS + 0] = ias[0] / sqrt2<T>();          // dct.c:166  ias_0 = ias[0]/sqrt(2)
-  // The inverse transform ends with a division by 2n = 128 (dct.c:185-186 "/dn" and the factor 2
-  // carried by G).  A power of two commutes exactly with every rounding on the way (no underflow:
-  // |coef| >= FLT_MIN or 0, the table entries are O(10)), so it is folded into these two tables:
-  // same bits out, 16 multiplications per block and lane less.
-  for (int k = 0; k < 64; k++) {
-    tab[TAB_IAS + k] = tab[TAB_IAS + k] * (T)(1.0 / 128.0);
-    tab[TAB_IAX + k] = tab[TAB_IAX + k] * (T)(1.0 / 128.0);
-  }
-  const T r = (T)sqrt(0.5);
-  tab[TAB_R] = r;
-  for (int n2 = 0; n2 < 4; n2++)
-    for (int k1 = 0; k1 < 8; k1++) {
-      const int t = n2 * k1;
-      T c, s;
-      if (t % 8 == 0) {                            // multiples of pi/2: exact
+inline void fill_tab_block(T* tab) {
+  typedef long double L;
+  std::memset(tab, 0, sizeof(T) * TB_SIZE);
+  const L pi = 3.141592653589793238462643383279502884L;
+  const L rt128 = sqrtl((L)128);
+  auto al = [&](int j) { return cosl(j * pi / 128) / rt128; };
+  auto be = [&](int j) { return sinl(j * pi / 128) / rt128; };
+  auto Cc = [&](int j) { return cosl(j * pi / 128) * rt128 / 128; };      // inverse: the final 1/128 is folded in
+  auto Ss = [&](int j) { return sinl(j * pi / 128) * rt128 / 128; };
+  tab[TB_R] = (T)sqrtl((L)0.5);
+  for (int n2 = 1; n2 < 4; n2++)
+    for (int k1 = 1; k1 < 8; k1++) {
+      const int t = n2 * k1;                        // exp(-+ 2 pi i t / 32)
+      L c = cosl(2 * pi * t / 32), s = sinl(2 * pi * t / 32);
+      if (t % 8 == 0) {                             // multiples of pi/2: exact
         const int quad = (t / 8) % 4;
-        c = (T)(quad == 0 ? 1 : quad == 2 ? -1 : 0);
-        s = (T)(quad == 1 ? 1 : quad == 3 ? -1 : 0);
-      } else if (t % 4 == 0) {                     // odd multiples of pi/4: +-r
-        const int o = (t / 4) % 8;
-        c = (o == 1 || o == 7) ? r : -r;
-        s = (o == 1 || o == 3) ? r : -r;
-      } else {
-        double cd, sd;
-        ::sincos(2.0 * M_PI * t / 32.0, &sd, &cd);
-        c = (T)cd;
-        s = (T)sd;
+        c = (quad == 0) ? 1 : (quad == 2) ? -1 : 0;
+        s = (quad == 1) ? 1 : (quad == 3) ? -1 : 0;
       }
-      tab[TAB_W32R + n2 * 8 + k1] = c;
-      tab[TAB_W32I + n2 * 8 + k1] = s;
+      tab[TB_TW + ((n2 - 1) * 7 + (k1 - 1)) * 2] = (T)c;
+      tab[TB_TW + ((n2 - 1) * 7 + (k1 - 1)) * 2 + 1] = (T)s;
     }
-  for (int k = 0; k <= 16; k++) {
-    double cd, sd;
-    ::sincos(2.0 * M_PI * k / 64.0, &sd, &cd);
-    T c = (T)cd, s = (T)sd;
-    if (k == 0) { c = (T)1; s = (T)0; }
-    if (k == 8) { c = r; s = r; }
-    if (k == 16) { c = (T)0; s = (T)1; }
-    tab[TAB_CW + k] = c;
-    tab[TAB_SW + k] = s;
+  for (int k = 1; k < 16; k++) {
+    const L cw = cosl(2 * pi * k / 64), sw = sinl(2 * pi * k / 64), m = 1 - sw, pl = 1 + sw;
+    T* f = tab + TB_FS + 16 * (k - 1);
+    // rows over (Re Z[k], Im Z[k], Re Z[32-k], Im Z[32-k])
+    auto rowA = [&](T* o, L a, L b) {              // b[k]-type row: own pair first
+      o[0] = (T)(a * m - b * cw); o[1] = (T)(a * cw + b * m); o[2] = (T)(a * pl + b * cw); o[3] = (T)(a * cw - b * pl);
+    };
+    auto rowB = [&](T* o, L a, L b) {              // b[32-k]-type row: roles of the pair swapped, cw -> -cw
+      o[0] = (T)(a * pl - b * cw); o[1] = (T)(-a * cw - b * pl); o[2] = (T)(a * m + b * cw); o[3] = (T)(-a * cw + b * m);
+    };
+    rowA(f + 0, al(k), be(k));                     // b[k]    = alpha_k Re V[k] + beta_k Im V[k]          (dct.c:100-102)
+    rowA(f + 4, al(64 - k), -be(64 - k));          // b[64-k]: V[64-k] = conj V[k]
+    rowB(f + 8, al(32 - k), be(32 - k));           // b[32-k]
+    rowB(f + 12, al(32 + k), -be(32 + k));         // b[32+k]: V[32+k] = conj V[32-k]
+    T* g = tab + TB_IS + 16 * (k - 1);
+    // rows over (a[k], a[64-k], a[32-k], a[32+k])
+    g[0] = (T)(Cc(k) * m - cw * Ss(k));            g[1] = (T)(Cc(64 - k) * m + cw * Ss(64 - k));
+    g[2] = (T)(Cc(32 - k) * pl - cw * Ss(32 - k)); g[3] = (T)(Cc(32 + k) * pl + cw * Ss(32 + k));          // Re Zb[k]
+    g[4] = (T)(Ss(k) * m + cw * Cc(k));            g[5] = (T)(-Ss(64 - k) * m + cw * Cc(64 - k));
+    g[6] = (T)(-Ss(32 - k) * pl - cw * Cc(32 - k)); g[7] = (T)(Ss(32 + k) * pl - cw * Cc(32 + k));         // Im Zb[k]
+    g[8] = (T)(Cc(k) * pl + cw * Ss(k));           g[9] = (T)(Cc(64 - k) * pl - cw * Ss(64 - k));
+    g[10] = (T)(Cc(32 - k) * m + cw * Ss(32 - k)); g[11] = (T)(Cc(32 + k) * m - cw * Ss(32 + k));          // Re Zb[32-k]
+    g[12] = (T)(-Ss(k) * pl + cw * Cc(k));         g[13] = (T)(Ss(64 - k) * pl + cw * Cc(64 - k));
+    g[14] = (T)(Ss(32 - k) * m - cw * Cc(32 - k)); g[15] = (T)(-Ss(32 + k) * m - cw * Cc(32 + k));         // Im Zb[32-k]
   }
-  for (int k = 17; k < 32; k++) {                  // exact mirror symmetry
-    tab[TAB_CW + k] = -tab[TAB_CW + 32 - k];
-    tab[TAB_SW + k] = tab[TAB_SW + 32 - k];
-  }
+  tab[TB_FS16 + 0] = (T)(2 * al(16)); tab[TB_FS16 + 1] = (T)(-2 * be(16));     // b[16]
+  tab[TB_FS16 + 2] = (T)(2 * al(48)); tab[TB_FS16 + 3] = (T)(2 * be(48));      // b[48]
+  tab[TB_IS16 + 0] = (T)(2 * Cc(16)); tab[TB_IS16 + 1] = (T)(2 * Cc(48));      // Re Zb[16]
+  tab[TB_IS16 + 2] = (T)(-2 * Ss(16)); tab[TB_IS16 + 3] = (T)(2 * Ss(48));     // Im Zb[16]
 }
 
 // Tables for the remainder block (length l = 1..63, transformed with an l- or
 // 2l-point DFT exactly like dct.c:59-72 / 144-164 do through FFTW).
 // Layout (elements of T): as[64] ax[64] ias[64] iax[64] wr[128] wi[128];
 // ias[0] is stored already adjusted (/sqrt2 for even l, *sqrt2 for odd l).
-// (offsets RTAB_* live in dct64_lane.h)
+// (offsets RTAB_* live in dct64_block.h)
 template <typename T>
 inline void fill_rem_tab(int l, T* tab) {
   std::memset(tab, 0, sizeof(T) * RTAB_SIZE);

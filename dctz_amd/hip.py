@@ -45,6 +45,7 @@ _PROTOS = {
     "dctzhip_last_error": (C.c_char_p, [C.c_void_p]),
     "dctzhip_reserve": (C.c_int, [C.c_void_p, C.c_size_t, C.c_int, C.c_int]),
     "dctzhip_set_stream": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "dctzhip_use_own_stream": (C.c_int, [C.c_void_p]),
     "dctzhip_get_stream": (C.c_void_p, [C.c_void_p]),
     "dctzhip_set_profiling": (C.c_int, [C.c_void_p, C.c_int]),
     "dctzhip_last_timings": (C.c_int, [C.c_void_p, C.POINTER(Timings)]),
@@ -67,6 +68,7 @@ _PROTOS = {
     "dctzhip_scale_inplace": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_double]),
     "dctzhip_debug_divide": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_double, C.c_void_p,
                                        C.c_void_p]),
+    "dctzhip_psnr_terms": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.POINTER(C.c_double)]),
     "dctzhip_version": (C.c_char_p, []),
 }
 
@@ -97,7 +99,8 @@ def _dt(torch_dtype):
 
 
 class Context:
-    """One dctzhip context on a GPU; kernels run on torch's current stream."""
+    """One dctzhip context on a GPU; kernels run on torch's current stream (bound before every call: the raw
+    handle, where 0 = the legacy default stream, goes to dctzhip_set_stream as is)."""
 
     def __init__(self, device=0):
         import torch
@@ -194,6 +197,15 @@ class Context:
             float(eb), float(sf), mode, dst.data_ptr())
         self._check(rc, "dctzhip_decompress")
         return dst
+
+    def psnr_terms(self, x, r):
+        """calc_psnr's reductions (util.c:54-104) on the GPU: (min x, max x, max |x - r|, sum (x - r)^2)."""
+        assert x.is_cuda and r.is_cuda and x.dtype == r.dtype and x.numel() == r.numel()
+        self._bind_stream()
+        out = (C.c_double * 4)()
+        rc = self.lib.dctzhip_psnr_terms(self.h, x.data_ptr(), r.data_ptr(), x.numel(), _dt(x.dtype), out)
+        self._check(rc, "dctzhip_psnr_terms")
+        return tuple(out)
 
     def debug_divide(self, x, divisor):
         self._bind_stream()

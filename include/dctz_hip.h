@@ -84,15 +84,18 @@ int dctzhip_ctx_create(dctzhip_ctx **out, int device);
 void dctzhip_ctx_destroy(dctzhip_ctx *ctx);
 const char *dctzhip_last_error(const dctzhip_ctx *ctx);   /* ctx may be NULL: last create error */
 int dctzhip_reserve(dctzhip_ctx *ctx, size_t n, int dtype, int mode);
-/* Use a caller-owned hipStream_t (e.g. torch's current stream) instead of the
- * context's own; NULL restores the context stream. */
+/* Run on a caller-owned hipStream_t (e.g. torch's current stream) instead of the
+ * context's own.  NULL is the legacy default stream, as everywhere in HIP (what a
+ * caller that never created a stream runs on -- ordered against its other work);
+ * dctzhip_use_own_stream goes back to the context's private non-blocking stream. */
 int dctzhip_set_stream(dctzhip_ctx *ctx, void *hip_stream);
+int dctzhip_use_own_stream(dctzhip_ctx *ctx);
 void *dctzhip_get_stream(dctzhip_ctx *ctx);
 int dctzhip_set_profiling(dctzhip_ctx *ctx, int on);
 /* Speculative fused statistics (see DCTZHIP_INFO_*): on != 0 enables it for inputs of
  * at least min_elements (0 keeps the current threshold, default 2^22); on == 0 always
  * runs the separate statistics pass first.  Default: on (env DCTZHIP_SPECULATE=0 turns
- * it off).  It is never used when d_scaled aliases d_in. */
+ * it off).  d_scaled (which may alias d_in) is written last, with the verified sf. */
 int dctzhip_set_speculation(dctzhip_ctx *ctx, int on, size_t min_elements);
 int dctzhip_last_timings(dctzhip_ctx *ctx, dctzhip_timings *t);
 
@@ -161,6 +164,14 @@ int dctzhip_decompress(dctzhip_ctx *ctx, const void *d_bin_index, const float *d
  * 64-element block of d_in, last block of length n % 64 if non-zero. */
 int dctzhip_dct_blocks(dctzhip_ctx *ctx, const void *d_in, void *d_out, size_t n,
                        int dtype, int inverse);
+
+/* ---- harness metric ------------------------------------------------------- */
+/* The reductions of calc_psnr (util.c:54-104) over device-resident arrays:
+ * out[0] = min x, out[1] = max x (util.c:61-66 / :77-82), out[2] = max |x - r|,
+ * out[3] = sum (x - r)^2 with the difference and its square taken in the data type
+ * (util.c:67-73 / :83-89).  The sum is a tree reduction: its last digits differ from
+ * the reference's serial loop (relative 1e-15), min / max / maxdiff are exact. */
+int dctzhip_psnr_terms(dctzhip_ctx *ctx, const void *d_x, const void *d_r, size_t n, int dtype, double out[4]);
 
 /* Diagnostics: element-wise x / divisor computed (a) by the kernels' hoisted-
  * reciprocal division and (b) by the compiler's IEEE division; the two outputs

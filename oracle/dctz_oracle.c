@@ -1,7 +1,8 @@
 /*
  * dctz_oracle.c -- CPU restatement of the DCTZ hot path (TEST INFRASTRUCTURE;
  * see dctz_oracle.h for scope, parity status and the FFTW note).
- * Build: make -C oracle   (gcc -O2 -ffp-contract=off, no -ffast-math, no -mfma)
+ * Build: make -C oracle   (gcc -O2 -ffp-contract=off -mfma, no -ffast-math: -mfma only turns the explicit fma()
+ * calls of the pinned transform flow into one instruction; nothing is contracted implicitly)
  */
 #define _GNU_SOURCE /* sincos(), sincosf() */
 #include "dctz_oracle.h"
@@ -19,16 +20,19 @@
 #define IS_F64 1
 #define M_SQRT sqrt
 #define M_FABS fabs
+#define M_FMA __builtin_fma
 #include "dctz_oracle_impl.inc"
 #undef T
 #undef SUF
 #undef IS_F64
 #undef M_SQRT
 #undef M_FABS
+#undef M_FMA
 
 #define T float
 #define SUF(x) x##_f32
 #define IS_F64 0
 #define M_SQRT sqrtf
 #define M_FABS fabsf
+#define M_FMA __builtin_fmaf
 #include "dctz_oracle_impl.inc"

@@ -10,6 +10,7 @@ from hypothesis import HealthCheck, given, settings, strategies as st
 
 from oracle import oracle as O
 from dctz_amd import shard
+from tests.noise import classify_flips
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SET = dict(max_examples=40, deadline=None, suppress_health_check=[HealthCheck.too_slow])
@@ -26,7 +27,7 @@ def _field(seed, n, amp, noise):
        eb=st.sampled_from([1e-2, 1e-3, 1e-5, 1e-6]), mode=st.sampled_from([O.EC, O.QT]), dtype=st.sampled_from([np.float64, np.float32]))
 def test_oracle_stream_invariants_and_error_bound(seed, n, log_amp, noise, eb, mode, dtype):
     x = _field(seed, n, 10.0 ** log_amp, noise).astype(dtype)
-    c = O.compress(x, eb, mode, O.FAST)
+    c = O.compress(x, eb, mode, O.FAST, want_coef=True)
     nblk = (n + 63) // 64
     # structure of the three streams (dctz-comp-lib.c:361, :478-544)
     assert c.bin_index.size == n and c.dc.size == nblk and c.ac_exact.size == c.cnt
@@ -41,10 +42,15 @@ def test_oracle_stream_invariants_and_error_bound(seed, n, log_amp, noise, eb, m
     err = np.abs(r.astype(np.float64) - c.scaled.astype(np.float64) * c.sf)
     tol = 8.5 * eb * c.sf * (1.0 if dtype == np.float64 else 1.5) + (0 if dtype == np.float64 else 2e-6 * m * 64)
     assert err.max() <= tol, (err.max(), tol)
-    # the fast flow and the definition-order flow agree to rounding
-    c2 = O.compress(x, eb, mode, O.NAIVE)
-    flips = int((c.bin_index != c2.bin_index).sum())
-    assert flips <= max(2, n // 200), flips
+    # the fast flow and the definition-order flow agree to rounding: coefficients within the noise bound, and a bin
+    # id may differ only where that noise reaches a bin edge or the range limit (tests/noise.py).  How MANY flip is
+    # a property of dtype and eb, not of correctness: for fp32 at eb <= 1e-5 the bin width is below the transform's
+    # noise and most in-range bins move (tests/test_noise_floor.py holds the table).
+    c2 = O.compress(x, eb, mode, O.NAIVE, want_coef=True)
+    flips, illegal = classify_flips(c, c2, eb)
+    assert illegal == 0, (flips, illegal)
+    if dtype == np.float64 and eb >= 1e-5:
+        assert flips <= max(2, n // 200), flips
 
 
 @settings(**SET)
