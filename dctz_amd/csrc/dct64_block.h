@@ -27,6 +27,16 @@
 #define DCTZ_HD inline
 #endif
 
+// Scheduling fence between the stages of the transform (GPU builds only): without it the compiler hoists the scalar
+// loads of ALL later constants and the first operations of later stages to the top, which costs a hundred SGPR spills
+// and pushes the kernel past the 256 registers that two waves per SIMD allow.
+// (Template flag FENCED: a kernel that runs one wave per SIMD wants the hoisting -- it is its only latency cover.)
+#if defined(__HIP_DEVICE_COMPILE__)
+#define DCT64_FENCE() do { if (FENCED) __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define DCT64_FENCE() ((void)0)
+#endif
+
 namespace dctz {
 
 // Constant block shared by host and device (filled by dctz_tables.h: fill_tab_block).  Offsets in elements of T.
@@ -79,8 +89,8 @@ DCTZ_HD void fft8(T (&xr)[8], T (&xi)[8], T r) {
 }
 
 // c0 p + c1 q + c2 r + c3 s, accumulated left to right: one product, three fused multiply-adds
-template <typename T>
-DCTZ_HD T lin4(const T* c, T p, T q, T r, T s) {
+template <typename T, typename TabPtr>
+DCTZ_HD T lin4(TabPtr c, T p, T q, T r, T s) {
   return fma_(c[3], s, fma_(c[2], r, fma_(c[1], q, c[0] * p)));
 }
 
@@ -90,8 +100,10 @@ DCTZ_HD constexpr int pack_pos(int m, int c) { return (m < 16) ? (4 * m + 2 * c)
 
 // ------------------------------------------------------------------ forward --
 // x[0..63]: one block (already scaled) in, its 64 DCT-II coefficients out (dct.c:55-103).
-template <typename T>
-DCTZ_HD void dct64_fwd(T (&x)[64], const T* __restrict__ tab) {
+// TabPtr: const T* on the host; on the GPU a pointer into the CONSTANT address space, so that the (wave-uniform)
+// table reads become scalar loads.
+template <typename T, typename TabPtr, bool FENCED = false>
+DCTZ_HD void dct64_fwd(T (&x)[64], TabPtr tab) {
   T Yr[4][8], Yi[4][8];
   const T r = tab[TB_R];
 #pragma unroll
@@ -108,6 +120,7 @@ DCTZ_HD void dct64_fwd(T (&x)[64], const T* __restrict__ tab) {
       Yr[n2][k1] = fma_(yi[k1], wi, yr[k1] * wr);        // times exp(-i 2 pi n2 k1 / 32)
       Yi[n2][k1] = fma_(-yr[k1], wi, yi[k1] * wr);
     }
+    DCT64_FENCE();
   }
   T Zr[32], Zi[32];
 #pragma unroll
@@ -119,6 +132,7 @@ DCTZ_HD void dct64_fwd(T (&x)[64], const T* __restrict__ tab) {
     Zr[k1 + 8] = br + di;  Zi[k1 + 8] = bi - dr;     // b - i d
     Zr[k1 + 24] = br - di; Zi[k1 + 24] = bi + dr;    // b + i d
   }
+  DCT64_FENCE();
   // split + twiddle, merged (header comment); the two self-paired bins are exact scalings:
   // b[0] = (Re Z[0] + Im Z[0]) / 8  (= sum of the block / 8), b[32] = (Re Z[0] - Im Z[0]) / 8
   x[0] = (Zr[0] + Zi[0]) * T(0.125);
@@ -127,18 +141,19 @@ DCTZ_HD void dct64_fwd(T (&x)[64], const T* __restrict__ tab) {
   x[48] = fma_(tab[TB_FS16 + 3], Zi[16], tab[TB_FS16 + 2] * Zr[16]);
 #pragma unroll
   for (int k = 1; k < 16; k++) {
-    const T* c = tab + TB_FS + 16 * (k - 1);
-    x[k] = lin4<T>(c, Zr[k], Zi[k], Zr[32 - k], Zi[32 - k]);
-    x[64 - k] = lin4<T>(c + 4, Zr[k], Zi[k], Zr[32 - k], Zi[32 - k]);
-    x[32 - k] = lin4<T>(c + 8, Zr[k], Zi[k], Zr[32 - k], Zi[32 - k]);
-    x[32 + k] = lin4<T>(c + 12, Zr[k], Zi[k], Zr[32 - k], Zi[32 - k]);
+    const TabPtr c = tab + TB_FS + 16 * (k - 1);
+    x[k] = lin4<T, TabPtr>(c, Zr[k], Zi[k], Zr[32 - k], Zi[32 - k]);
+    x[64 - k] = lin4<T, TabPtr>(c + 4, Zr[k], Zi[k], Zr[32 - k], Zi[32 - k]);
+    x[32 - k] = lin4<T, TabPtr>(c + 8, Zr[k], Zi[k], Zr[32 - k], Zi[32 - k]);
+    x[32 + k] = lin4<T, TabPtr>(c + 12, Zr[k], Zi[k], Zr[32 - k], Zi[32 - k]);
+    if (k % 2 == 0) DCT64_FENCE();
   }
 }
 
 // ------------------------------------------------------------------ inverse --
 // x[0..63]: 64 coefficients in, the reconstructed block out (dct.c:115-205, even n).
-template <typename T>
-DCTZ_HD void dct64_inv(T (&x)[64], const T* __restrict__ tab) {
+template <typename T, typename TabPtr, bool FENCED = false>
+DCTZ_HD void dct64_inv(T (&x)[64], TabPtr tab) {
   T Zr[32], Zi[32];
   Zr[0] = (x[0] + x[32]) * T(0.125);
   Zi[0] = (x[0] - x[32]) * T(0.125);
@@ -146,12 +161,14 @@ DCTZ_HD void dct64_inv(T (&x)[64], const T* __restrict__ tab) {
   Zi[16] = fma_(tab[TB_IS16 + 3], x[48], tab[TB_IS16 + 2] * x[16]);
 #pragma unroll
   for (int k = 1; k < 16; k++) {
-    const T* c = tab + TB_IS + 16 * (k - 1);
-    Zr[k] = lin4<T>(c, x[k], x[64 - k], x[32 - k], x[32 + k]);
-    Zi[k] = lin4<T>(c + 4, x[k], x[64 - k], x[32 - k], x[32 + k]);
-    Zr[32 - k] = lin4<T>(c + 8, x[k], x[64 - k], x[32 - k], x[32 + k]);
-    Zi[32 - k] = lin4<T>(c + 12, x[k], x[64 - k], x[32 - k], x[32 + k]);
+    const TabPtr c = tab + TB_IS + 16 * (k - 1);
+    Zr[k] = lin4<T, TabPtr>(c, x[k], x[64 - k], x[32 - k], x[32 + k]);
+    Zi[k] = lin4<T, TabPtr>(c + 4, x[k], x[64 - k], x[32 - k], x[32 + k]);
+    Zr[32 - k] = lin4<T, TabPtr>(c + 8, x[k], x[64 - k], x[32 - k], x[32 + k]);
+    Zi[32 - k] = lin4<T, TabPtr>(c + 12, x[k], x[64 - k], x[32 - k], x[32 + k]);
+    if (k % 2 == 0) DCT64_FENCE();
   }
+  DCT64_FENCE();
   const T r = tab[TB_R];
   T Yr[4][8], Yi[4][8];
 #pragma unroll
@@ -171,6 +188,7 @@ DCTZ_HD void dct64_inv(T (&x)[64], const T* __restrict__ tab) {
       Yr[n2][k1] = fma_(-ti[n2], wi, tr[n2] * wr);       // times exp(+i 2 pi n2 k1 / 32)
       Yi[n2][k1] = fma_(tr[n2], wi, ti[n2] * wr);
     }
+    if (k1 % 2 == 1) DCT64_FENCE();
   }
 #pragma unroll
   for (int n2 = 0; n2 < 4; n2++) {                 // backward radix-8 over k1 -> z[4 n1 + n2]
@@ -180,6 +198,7 @@ DCTZ_HD void dct64_inv(T (&x)[64], const T* __restrict__ tab) {
     fft8<T, false>(yr, yi, r);
 #pragma unroll
     for (int n1 = 0; n1 < 8; n1++) { x[pack_pos(4 * n1 + n2, 0)] = yr[n1]; x[pack_pos(4 * n1 + n2, 1)] = yi[n1]; }
+    DCT64_FENCE();
   }
 }
 

@@ -47,17 +47,33 @@ template <> struct Traits<float> {
   __device__ static float from_bits(Bits b) { return __uint_as_float(b); }
 };
 
-// Geometry of a tile in bytes for element type T.
-template <typename T> struct Geo {
+// Geometry of a tile in bytes for element type T, moved through LDS in PH phases (elements [64 p / PH, 64 (p + 1) / PH)
+// of every block per phase).  PH = 2 halves a wave's LDS footprint (fp64: 16 KiB), which leaves room for two waves per
+// SIMD: one issues instructions while the other waits.
+template <typename T, int PHASES = 1> struct Geo {
   static constexpr int BLKB = 64 * (int)sizeof(T);      // bytes per block (512 / 256)
   static constexpr int NSEG = BLKB / 128;               // 128-byte segments per block (4 / 2)
   static constexpr int NCH = BLKB / 16;                 // 16-byte chunks per block (32 / 16)
   static constexpr int TILEB = TILE_BLKS * BLKB;        // bytes per tile (32 KiB / 16 KiB)
   static constexpr int NROW = TILEB / 1024;             // 1 KiB LDS rows per tile (32 / 16)
+  static constexpr int PH = PHASES;
+  static constexpr int SEGP = NSEG / PH;                 // 128-byte segments of a block per phase
+  static constexpr int CHP = NCH / PH;                   // 16-byte chunks of a block per phase
+  static constexpr int PHB = TILEB / PH;                 // bytes of a phase image
+  static_assert(NSEG % PH == 0, "a phase is a whole number of 128-byte segments");
   // exceptions a lane can park per tile before the tile takes the direct-store path
   static constexpr int EC_DEPTH = EXC_BYTES / 64 / 4;                  // 16 floats
   static constexpr int QT_DEPTH = EXC_BYTES / 64 / (int)sizeof(T);     // 8 doubles / 16 floats
 };
+// phases of k_compress / k_decompress per element type (build knobs for A/B runs)
+#ifndef DCTZ_PHC64
+#define DCTZ_PHC64 2
+#endif
+#ifndef DCTZ_PHD64
+#define DCTZ_PHD64 1
+#endif
+template <typename T> struct Phases { static constexpr int C = 1, D = 1; };
+template <> struct Phases<double> { static constexpr int C = DCTZ_PHC64, D = DCTZ_PHD64; };
 
 // Per-call control block in device memory; left all-zero by the last kernel of every call.
 struct Ctl {

@@ -43,6 +43,12 @@ namespace dctz {
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 #define LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
+// The twiddle block is written once at context creation and never by a kernel: reading it through the constant
+// address space lets the compiler use scalar loads (the table indices are compile-time constants, the base is a
+// kernel argument: wave-uniform).  A plain global pointer gets VECTOR loads here, because the kernels also store to
+// global memory and nothing tells the compiler that the table is not among the targets.
+template <typename T> using CTab = const __attribute__((address_space(4))) T*;
+template <typename T> __device__ __forceinline__ CTab<T> as_ctab(const T* p) { return (CTab<T>)(p); }
 // LDS-DMA: 16 bytes per lane, HBM -> LDS (lane l lands at lds + 16 l), through a buffer descriptor (range-checked: zeros
 // beyond the end).  Device pass only (the host pass of hipcc does not know the builtin).
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -167,50 +173,55 @@ __host__ __device__ __forceinline__ TileRange tile_range(unsigned b, unsigned G,
 // with ds_read_b128 at lds_a[ch & 7] + (ch >> 3) * 1024: inside each group of 16 lanes that the LDS
 // services together, the 16 addresses fall into 16 different 16-byte bank groups (conflict-free; the
 // same for the ds_write_b128 of the inverse direction).
-template <typename T>
+template <typename T, int PH>
 struct TileMap {
+  using G = Geo<T, PH>;
   int lds_a[8];        // LDS byte offset of chunk class g = ch & 7 of this lane's block (row part of segment 0)
   int g_even, g_odd;   // HBM byte offset (inside a tile) of this lane's 16 bytes of row (jg, 0), jg even / odd
   __device__ __forceinline__ void init(int lane) {
     const int f = (lane >> 1) & 7;
 #pragma unroll
-    for (int g = 0; g < 8; g++) lds_a[g] = (lane >> 3) * Geo<T>::NSEG * 1024 + (lane & 7) * 128 + ((g ^ f) * 16);
+    for (int g = 0; g < 8; g++) lds_a[g] = (lane >> 3) * G::SEGP * 1024 + (lane & 7) * 128 + ((g ^ f) * 16);
     const int beta = lane >> 3, gam = lane & 7;
-    g_even = beta * Geo<T>::BLKB + ((gam ^ (beta >> 1)) * 16);
+    g_even = beta * G::BLKB + ((gam ^ (beta >> 1)) * 16);
     g_odd = g_even ^ 64;
   }
 };
 
-// HBM -> LDS, one tile, no registers.  rsrc covers the workgroup's input range; the range check
+// HBM -> LDS, one phase of a tile, no registers.  rsrc covers the workgroup's input range; the range check
 // zero-fills whatever lies beyond the last whole block.
-template <typename T>
-__device__ __forceinline__ void issue_tile_dma(__amdgpu_buffer_rsrc_t rsrc, unsigned rel, unsigned char* tilebuf, const TileMap<T>& tm) {
-  const int base = (int)(rel * (unsigned)Geo<T>::TILEB);
+template <typename T, int PH>
+__device__ __forceinline__ void issue_phase_dma(__amdgpu_buffer_rsrc_t rsrc, unsigned rel, int phase, unsigned char* tilebuf, const TileMap<T, PH>& tm) {
+  using G = Geo<T, PH>;
+  const int base = (int)(rel * (unsigned)G::TILEB) + phase * G::SEGP * 128;
 #pragma unroll
   for (int jg = 0; jg < 8; jg++)
 #pragma unroll
-    for (int s = 0; s < Geo<T>::NSEG; s++)
-      DMA16(rsrc, tilebuf + (jg * Geo<T>::NSEG + s) * 1024, (jg & 1) ? tm.g_odd : tm.g_even, base + jg * 8 * Geo<T>::BLKB + s * 128, 2 /* nt */);
+    for (int s = 0; s < G::SEGP; s++)
+      DMA16(rsrc, tilebuf + (jg * G::SEGP + s) * 1024, (jg & 1) ? tm.g_odd : tm.g_even, base + jg * 8 * G::BLKB + s * 128, 2 /* nt */);
 }
 
-template <typename T>
-__device__ __forceinline__ void read_tile(T (&x)[64], const unsigned char* tilebuf, const TileMap<T>& tm) {
+// LDS image of phase PHASE -> this lane's elements [PHASE * 64 / PH, (PHASE + 1) * 64 / PH) of its block
+template <typename T, int PH, int PHASE>
+__device__ __forceinline__ void read_phase(T (&x)[64], const unsigned char* tilebuf, const TileMap<T, PH>& tm) {
   using Vec = typename Traits<T>::Vec;
+  using G = Geo<T, PH>;
   constexpr int EPV = Traits<T>::EPV;
 #pragma unroll
-  for (int ch = 0; ch < Geo<T>::NCH; ch++) {
+  for (int ch = 0; ch < G::CHP; ch++) {
     const Vec v = *reinterpret_cast<const Vec*>(tilebuf + tm.lds_a[ch & 7] + (ch >> 3) * 1024);
-    Traits<T>::unpack(v, &x[ch * EPV]);
+    Traits<T>::unpack(v, &x[(PHASE * G::CHP + ch) * EPV]);
   }
 }
 
-template <typename T>
-__device__ __forceinline__ void write_tile(const T (&x)[64], unsigned char* tilebuf, const TileMap<T>& tm) {
+template <typename T, int PH, int PHASE>
+__device__ __forceinline__ void write_phase(const T (&x)[64], unsigned char* tilebuf, const TileMap<T, PH>& tm) {
   using Vec = typename Traits<T>::Vec;
+  using G = Geo<T, PH>;
   constexpr int EPV = Traits<T>::EPV;
 #pragma unroll
-  for (int ch = 0; ch < Geo<T>::NCH; ch++)
-    *reinterpret_cast<Vec*>(tilebuf + tm.lds_a[ch & 7] + (ch >> 3) * 1024) = Traits<T>::pack(&x[ch * EPV]);
+  for (int ch = 0; ch < G::CHP; ch++)
+    *reinterpret_cast<Vec*>(tilebuf + tm.lds_a[ch & 7] + (ch >> 3) * 1024) = Traits<T>::pack(&x[(PHASE * G::CHP + ch) * EPV]);
 }
 
 // ---------------------------------------------------- statistics on the fly --
@@ -491,20 +502,28 @@ __device__ __forceinline__ float bin_value(T item, T q, T range_max) {
 }
 
 template <typename T>
-size_t compress_lds_bytes() { return (size_t)Geo<T>::TILEB + EXC_BYTES + 512 + 1088; }
+size_t compress_lds_bytes() { return (size_t)Geo<T, Phases<T>::C>::PHB + EXC_BYTES + 1024 + 1152; }
 
-template <typename T, int MODE, bool STATS>
-__global__ __launch_bounds__(WG) void k_compress(FwdParams<T> p) {
-  using Bits = typename Traits<T>::Bits;
-  constexpr int DEPTH = (MODE == DCTZHIP_EC) ? Geo<T>::EC_DEPTH : Geo<T>::QT_DEPTH;
+// PH = 1: the whole tile (32 KiB fp64) sits in LDS, one wave per SIMD, and the outputs of tile k are flushed only
+// after the DMA of tile k + 2 has been issued, so that the wait for tile k + 1 never sits behind tile k's stores.
+// PH = 2: half a tile at a time (16 KiB), two waves per SIMD cover each other's waits, outputs flushed at once.
+template <typename T, int MODE, bool STATS, int PH>
+__global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(PH))) void k_compress(FwdParams<T> p) {
+  using G = Geo<T, PH>;
+  constexpr bool DEFER = (PH == 1);
+  constexpr int DEPTH = (MODE == DCTZHIP_EC) ? G::EC_DEPTH : G::QT_DEPTH;
   using Item = typename std::conditional<MODE == DCTZHIP_EC, float, T>::type;        // what a parked exception is
   // separate arrays, so that the compiler can tell the DMA target from the staging strips (a pending LDS-DMA
   // forces a vmcnt(0) in front of every LDS read it may alias)
-  __shared__ __attribute__((aligned(1024))) unsigned char tilebuf[Geo<T>::TILEB];
-  // lane l parks its exceptions at excbuf[64 l ...]; a lane with more than DEPTH of them runs into its neighbours'
-  // strips (such a tile is written directly, the strips are ignored): 63 of them at most, hence the slack
-  __shared__ __attribute__((aligned(16))) unsigned char excbuf[EXC_BYTES + 512];
-  __shared__ __attribute__((aligned(16))) unsigned char jbuf[1088];                  // QT: position j of every parked item
+  __shared__ __attribute__((aligned(1024))) unsigned char tilebuf[G::PHB];
+  // lane l parks its exceptions in a strip of STRIDE = DEPTH + 1 items (the last one only ever holds the coefficient
+  // parked "in case", and the odd stride in dwords spreads the lanes over the banks); a lane with more than DEPTH of
+  // them runs into its neighbours' strips (such a tile is written directly, the strips are ignored): 63 of them at
+  // most, hence the slack
+  constexpr int STRIDE = DEPTH + 1;
+  __shared__ __attribute__((aligned(16))) unsigned char excbuf[EXC_BYTES + 1024];
+  __shared__ __attribute__((aligned(16))) unsigned char jbuf[1152];                  // QT: position j of every parked item
+  static_assert((63 * STRIDE + 64) * sizeof(Item) <= sizeof(excbuf) && 63 * STRIDE + 64 <= (int)sizeof(jbuf), "runaway lanes stay inside the strips");
   const int lane = threadIdx.x;
   const TileRange tr = tile_range(blockIdx.x, gridDim.x, p.ntiles);
   const unsigned list_base = tr.lo * TILE_ELEMS;     // this workgroup's exception list lives in its tiles' slots
@@ -514,33 +533,30 @@ __global__ __launch_bounds__(WG) void k_compress(FwdParams<T> p) {
   const __amdgpu_buffer_rsrc_t r_in = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(p.x + first_el), 0, range_el * (int)sizeof(T), 0x00020000);
   const __amdgpu_buffer_rsrc_t r_bin = __builtin_amdgcn_make_buffer_rsrc(p.bin + first_el, 0, range_el, 0x00020000);
   const __amdgpu_buffer_rsrc_t r_dc = __builtin_amdgcn_make_buffer_rsrc(p.dc + first_el / 64, 0, range_el / 64 * 4, 0x00020000);
-  TileMap<T> tm;
-  tm.init(lane);
   FastDiv<T> sfd, bwd;
   sfd.init(p.sf, p.fast_sf != 0);
   bwd.init(p.bin_width, (p.fast_bw & 1u) != 0);
   const bool scale = (p.sf != T(1));                 // dctz-comp-lib.c:193 / :208
   const T rmin = p.range_min, rmax = p.range_max;
-  const T* __restrict__ tab = p.tab;
+  const CTab<T> tab = as_ctab<T>(p.tab);
   StatAcc<T> acc;
   acc.init();
   unsigned run = 0;                                  // length of the workgroup's list so far (uniform)
 
-  // outputs of the previous tile, flushed one DMA issue later
+  // outputs of a tile on their way out (DEFER: those of the previous tile)
   bool pend = false, p_staged = false;
   unsigned p_rel = 0, p_n = 0, p_dst = 0;
   unsigned pw[16];
   float p_dc = 0.f;
-  const int bin_goff = (lane >> 2) * 64 + (((lane & 3) ^ ((lane >> 3) & 3)) * 16);   // see flush()
 
   auto flush = [&]() {
     if (p_staged) {                                  // parked exceptions -> the workgroup's list, block after block
       for (int e = 0; e < DEPTH; e++) {
         if (!__builtin_amdgcn_ballot_w64((unsigned)e < p_n)) break;
         if ((unsigned)e < p_n) {
-          const Item v = reinterpret_cast<const Item*>(excbuf)[lane * DEPTH + e];
+          const Item v = reinterpret_cast<const Item*>(excbuf)[lane * STRIDE + e];
           if (MODE == DCTZHIP_EC) p.ac_tmp[p_dst + e] = (float)v;                      // :535-537
-          else { p.qt_item[p_dst + e] = (T)v; p.qt_j[p_dst + e] = jbuf[lane * DEPTH + e]; }
+          else { p.qt_item[p_dst + e] = (T)v; p.qt_j[p_dst + e] = jbuf[lane * STRIDE + e]; }
         }
       }
     }
@@ -549,6 +565,7 @@ __global__ __launch_bounds__(WG) void k_compress(FwdParams<T> p) {
 #pragma unroll
     for (int i = 0; i < 4; i++)
       *reinterpret_cast<u32x4*>(excbuf + (lane * 4 + (i ^ f2)) * 16) = u32x4{pw[4 * i], pw[4 * i + 1], pw[4 * i + 2], pw[4 * i + 3]};
+    const int bin_goff = (lane >> 2) * 64 + (((lane & 3) ^ ((lane >> 3) & 3)) * 16);
     const int voff = (int)(p_rel * (unsigned)TILE_ELEMS) + bin_goff;
 #pragma unroll
     for (int i = 0; i < 4; i++) {
@@ -558,38 +575,71 @@ __global__ __launch_bounds__(WG) void k_compress(FwdParams<T> p) {
     __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, p_dc), r_dc, (int)(p_rel * 64u + (unsigned)lane) * 4, 0, 0);   // :350-351 USE_TRUNCATE
   };
 
-  if (tr.lo < tr.hi) issue_tile_dma<T>(r_in, 0u, tilebuf, tm);
+  // one phase of the block in registers: calc_data_stat's max|x| / min|x| over the raw values (util.c:18-25), then the
+  // scaling (dctz-comp-lib.c:197-199 / :212-214)
+  auto stats_scale = [&](T (&x)[64], auto phase, bool active, bool first) {
+    constexpr int J0 = decltype(phase)::value * (64 / PH), J1 = J0 + 64 / PH;
+    if (STATS) {
+      if (active) {
+#pragma unroll
+        for (int j = J0; j < J1; j++) acc.minmax(x[j]);
+      }
+      if (J0 == 0 && first && lane == 0) acc.sum -= (double)x[0];      // util.c:22 starts at i = 1
+    }
+    if (scale) {
+      if (p.fast_sf == 2) {
+#pragma unroll
+        for (int j = J0; j < J1; j++) x[j] = sfd.core(x[j]);
+      } else if (p.fast_sf == 1) {
+#pragma unroll
+        for (int j = J0; j < J1; j++) x[j] = sfd.div(x[j]);
+      } else {
+#pragma unroll
+        for (int j = J0; j < J1; j++) x[j] = x[j] / sfd.d;
+      }
+    }
+  };
+
+  // the lane's addresses inside the tile image are re-derived every trip from a value the compiler cannot see through:
+  // kept alive across the loop they are spilled to scratch, and a scratch reload waits behind the DMA in flight
+  auto tile_map = [&]() {
+    int l = lane;
+    asm volatile("" : "+v"(l));
+    TileMap<T, PH> tm;
+    tm.init(l);
+    return tm;
+  };
+
+  if (tr.lo < tr.hi) issue_phase_dma<T, PH>(r_in, 0u, 0, tilebuf, tile_map());
   for (unsigned tile = tr.lo; tile < tr.hi; tile++) {
     const unsigned rel = tile - tr.lo;
     const unsigned blks_here = min((unsigned)TILE_BLKS, p.nfull - tile * TILE_BLKS);
     const bool active = (unsigned)lane < blks_here;
+    const TileMap<T, PH> tm = tile_map();
     T x[64];
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // this tile's DMA has landed (and everything older is done)
-    read_tile<T>(x, tilebuf, tm);
+    // phase 0: landed while the previous tile was being computed
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // the DMA has landed (and everything older is done)
+    read_phase<T, PH, 0>(x, tilebuf, tm);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          // ... and is in registers: the buffer is free
-    if (tile + 1 < tr.hi) issue_tile_dma<T>(r_in, rel + 1, tilebuf, tm);
-    if (pend) flush();
-
-    if (STATS) {                                     // calc_data_stat's max|x| / min|x| over the raw values (util.c:18-25)
-      if (active) {
-#pragma unroll
-        for (int j = 0; j < 64; j++) acc.minmax(x[j]);
-      }
-      if (tile == 0 && lane == 0) acc.sum -= (double)x[0];      // util.c:22 starts at i = 1
+    if (PH == 2) issue_phase_dma<T, PH>(r_in, rel, 1, tilebuf, tm);
+    else if (tile + 1 < tr.hi) issue_phase_dma<T, PH>(r_in, rel + 1, 0, tilebuf, tm);
+    if (DEFER && pend) flush();
+    stats_scale(x, std::integral_constant<int, 0>{}, active, tile == 0);
+    if (PH == 2) {                                   // phase 1: the wait is covered by the SIMD's other wave
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      read_phase<T, PH, PH - 1>(x, tilebuf, tm);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      if (tile + 1 < tr.hi) issue_phase_dma<T, PH>(r_in, rel + 1, 0, tilebuf, tm);
+      stats_scale(x, std::integral_constant<int, PH - 1>{}, active, false);
     }
-    if (scale) {                                     // dctz-comp-lib.c:197-199 / :212-214
-      if (p.fast_sf == 2) {
-#pragma unroll
-        for (int j = 0; j < 64; j++) x[j] = sfd.core(x[j]);
-      } else if (p.fast_sf == 1) {
-#pragma unroll
-        for (int j = 0; j < 64; j++) x[j] = sfd.div(x[j]);
-      } else {
-#pragma unroll
-        for (int j = 0; j < 64; j++) x[j] = x[j] / sfd.d;
-      }
-    }
-    dct64_fwd<T>(x, tab);
+#if defined(DCTZ_CUT) && DCTZ_CUT == 2
+    { T sx = x[0]; for (int j = 1; j < 64; j++) sx += x[j]; if (sx == T(1.2345e300)) p.dc[0] = (float)sx; pend = false; continue; }
+#endif
+    __builtin_amdgcn_sched_barrier(0);
+    dct64_fwd<T, CTab<T>, (PH > 1)>(x, tab);
+#if defined(DCTZ_CUT) && DCTZ_CUT == 3
+    { T sx = x[0]; for (int j = 1; j < 64; j++) sx += x[j]; if (sx == T(1.2345e300)) p.dc[0] = (float)sx; pend = false; continue; }
+#endif
     if (p.coef != nullptr && active) {               // test tap: the coefficients as computed
 #pragma unroll
       for (int j = 0; j < 64; j++) p.coef[((size_t)tile * TILE_BLKS + lane) * 64 + j] = x[j];
@@ -600,21 +650,45 @@ __global__ __launch_bounds__(WG) void k_compress(FwdParams<T> p) {
     }
 
     unsigned w[16];
-#pragma unroll
-    for (int i = 0; i < 16; i++) w[i] = 0u;
     unsigned n = 0;
+    __builtin_amdgcn_sched_barrier(0);               // the binning phase is scheduled on its own (the transform before it peaks in registers)
     auto bin_loop = [&](auto fast, auto safe) {
+      // four coefficients = one dword of bin ids at a time, stage by stage, so that the four dependent chains
+      // (subtract, divide, floor, map, convert, pack) interleave; the coefficients of a group are only parked in the
+      // lane's strip when SOME lane of the wave has an exception in that group (the high-frequency groups of a
+      // smooth field never do)
 #pragma unroll
-      for (int j = 1; j < 64; j++) {
-        const T u = x[j] - rmin;                     // :377 / :402
-        const T q = decltype(fast)::value ? bwd.core(u) : u / bwd.d;
-        const float h = bin_value<T, decltype(safe)::value>(x[j], q, rmax);
-        w[j >> 2] = __builtin_amdgcn_cvt_pk_u8_f32(h, j & 3, w[j >> 2]);
-        // park the coefficient at the lane's current slot whether it is an exception or not: the slot only
-        // advances when it is, so the next one overwrites it
-        reinterpret_cast<Item*>(excbuf)[lane * DEPTH + n] = (Item)x[j];
-        if (MODE == DCTZHIP_QT) jbuf[lane * DEPTH + n] = (unsigned char)j;
-        n += (h >= 255.0f) ? 1u : 0u;
+      for (int g = 0; g < 16; g++) {
+        float h[4];
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+          const int j = 4 * g + i;
+          const T u = x[j] - rmin;                   // :377 / :402
+          const T q = decltype(fast)::value ? bwd.core(u) : u / bwd.d;
+          h[i] = bin_value<T, decltype(safe)::value>(x[j], q, rmax);
+        }
+        if (g == 0) h[0] = 0.0f;                     // j = 0 is the DC slot (:361): never an exception, its id is set below
+        unsigned wg = 0u;
+#pragma unroll
+        for (int i = 0; i < 4; i++) wg = __builtin_amdgcn_cvt_pk_u8_f32(h[i], i, wg);
+        asm volatile("" : "+v"(wg));                 // packed HERE: left alone, the compiler sinks all 64 conversions below the
+        w[g] = wg;                                   // last group and keeps 64 fp64 bin values alive (128 registers) until then
+        const bool any = (h[0] >= 255.0f) | (h[1] >= 255.0f) | (h[2] >= 255.0f) | (h[3] >= 255.0f);
+#if !(defined(DCTZ_CUT) && DCTZ_CUT == 4)
+        if (__builtin_amdgcn_ballot_w64(any)) {
+#pragma unroll
+          for (int i = 0; i < 4; i++) {
+            const int j = 4 * g + i;
+            if (j == 0) continue;
+            // park the coefficient at the lane's current slot whether it is an exception or not: the slot only
+            // advances when it is, so the next one overwrites it
+            reinterpret_cast<Item*>(excbuf)[lane * STRIDE + n] = (Item)x[j];
+            if (MODE == DCTZHIP_QT) jbuf[lane * STRIDE + n] = (unsigned char)j;
+            n += (h[i] >= 255.0f) ? 1u : 0u;
+          }
+        }
+#endif
+        __builtin_amdgcn_sched_barrier(0);           // keep the groups apart: hoisting all 64 quotients first costs 128 registers
       }
     };
     if (bwd.ok) { if (p.fast_bw & 2u) bin_loop(std::true_type{}, std::false_type{}); else bin_loop(std::true_type{}, std::true_type{}); }
@@ -641,6 +715,7 @@ __global__ __launch_bounds__(WG) void k_compress(FwdParams<T> p) {
     pend = true; p_staged = staged; p_rel = rel; p_n = n; p_dst = dst; p_dc = (float)x[0];
 #pragma unroll
     for (int i = 0; i < 16; i++) pw[i] = w[i];
+    if (!DEFER) { flush(); pend = false; }
   }
   if (pend) flush();
   if (lane == 0) p.tile_cnt[blockIdx.x] = run;
@@ -849,11 +924,12 @@ __global__ __launch_bounds__(SWG) void k_count_tiles(const uint8_t* __restrict__
 // exact coefficients AC_exact[S, S + total) (S from the prefix over the per-tile counts) are staged in LDS by
 // LDS-DMA one tile ahead, like the bin ids / DC (plain loads into registers).
 template <typename T>
-size_t decompress_lds_bytes() { return (size_t)Geo<T>::TILEB + 256 * sizeof(T) + DEC_EXC_CAP * 4 + 64 * sizeof(T); }
+size_t decompress_lds_bytes() { return (size_t)Geo<T, Phases<T>::D>::PHB + 256 * sizeof(T) + DEC_EXC_CAP * 4 + 64 * sizeof(T); }
 
-template <typename T, int MODE>
-__global__ __launch_bounds__(WG) void k_decompress(InvParams<T> p) {
-  __shared__ __attribute__((aligned(1024))) unsigned char outbuf[Geo<T>::TILEB];
+template <typename T, int MODE, int PH>
+__global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(PH))) void k_decompress(InvParams<T> p) {
+  using G = Geo<T, PH>;
+  __shared__ __attribute__((aligned(1024))) unsigned char outbuf[G::PHB];
   __shared__ __attribute__((aligned(16))) T bctab[256];               // bin_center[] of gen_bins
   __shared__ __attribute__((aligned(16))) float excbuf[DEC_EXC_CAP];
   __shared__ T qt[64];
@@ -869,9 +945,9 @@ __global__ __launch_bounds__(WG) void k_decompress(InvParams<T> p) {
   const unsigned S_wg = tr.lo < tr.hi ? p.tile_off[tr.lo] : 0u;
   const size_t ac_left = S_wg < p.ac_count ? (size_t)(p.ac_count - S_wg) * 4 : 0;
   const __amdgpu_buffer_rsrc_t r_ac = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.ac + (ac_left ? S_wg : 0u)), 0, (int)min(ac_left, (size_t)0x7ffffffc), 0x00020000);
-  TileMap<T> tm;
+  TileMap<T, PH> tm;
   tm.init(lane);
-  const T* __restrict__ tab = p.tab;
+  const CTab<T> tab = as_ctab<T>(p.tab);
   // gen_bins / gen_bins_f (binning.c:17-23 / :37-43): bin_center[b] = (b odd ? b/2 + 1 : -(b/2)) * bin_width
   for (int b = lane; b < 256; b += WG) {
     const int ti = (b & 1) ? (b >> 1) + 1 : -(b >> 1);
@@ -911,7 +987,7 @@ __global__ __launch_bounds__(WG) void k_decompress(InvParams<T> p) {
     const bool in_lds = total_t <= (unsigned)DEC_EXC_CAP;
     // this tile's inputs have landed: everything but the previous tile's row stores (the youngest NROW operations)
     if (tile == tr.lo) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(%0)" :: "n"(Geo<T>::NROW) : "memory");
+    else asm volatile("s_waitcnt vmcnt(%0)" :: "n"(G::NROW) : "memory");
     unsigned w[16] = {bw[0].x, bw[0].y, bw[0].z, bw[0].w, bw[1].x, bw[1].y, bw[1].z, bw[1].w,
                       bw[2].x, bw[2].y, bw[2].z, bw[2].w, bw[3].x, bw[3].y, bw[3].z, bw[3].w};
     const float dc_t = dcv;
@@ -946,23 +1022,29 @@ __global__ __launch_bounds__(WG) void k_decompress(InvParams<T> p) {
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                  // the staged coefficients are consumed: the strip is free
     if (tile + 1 < tr.hi) prefetch(tile + 1);
-    dct64_inv<T>(x, tab);
+    dct64_inv<T, CTab<T>, (PH > 1)>(x, tab);
     if (scale) {
 #pragma unroll
       for (int j = 0; j < 64; j++) x[j] = x[j] * p.sf;                 // dctz-decomp-lib.c:494-511
     }
-    write_tile<T>(x, outbuf, tm);
-    // LDS image -> HBM, one 1 KiB row (8 whole 128-byte lines) per instruction; blocks beyond the end fall outside r_out
-    const int vbase = (int)(rel * (unsigned)Geo<T>::TILEB);
+    // registers -> LDS image -> HBM, one 1 KiB row (8 whole 128-byte lines) per instruction, a phase at a time; blocks
+    // beyond the end fall outside r_out
+    const int vbase = (int)(rel * (unsigned)G::TILEB);
+    auto store_phase = [&](auto phase) {
+      constexpr int PHASE = decltype(phase)::value;
+      write_phase<T, PH, PHASE>(x, outbuf, tm);
 #pragma unroll
-    for (int jg = 0; jg < 8; jg++) {
-      const int vo = vbase + jg * 8 * Geo<T>::BLKB + ((jg & 1) ? tm.g_odd : tm.g_even);
+      for (int jg = 0; jg < 8; jg++) {
+        const int vo = vbase + jg * 8 * G::BLKB + ((jg & 1) ? tm.g_odd : tm.g_even);
 #pragma unroll
-      for (int s = 0; s < Geo<T>::NSEG; s++) {
-        const u32x4 v = *reinterpret_cast<const u32x4*>(outbuf + (jg * Geo<T>::NSEG + s) * 1024 + lane * 16);
-        __builtin_amdgcn_raw_buffer_store_b128(v, r_out, vo + s * 128, 0, 2 /* nt */);
+        for (int s = 0; s < G::SEGP; s++) {
+          const u32x4 v = *reinterpret_cast<const u32x4*>(outbuf + (jg * G::SEGP + s) * 1024 + lane * 16);
+          __builtin_amdgcn_raw_buffer_store_b128(v, r_out, vo + (PHASE * G::SEGP + s) * 128, 0, 2 /* nt */);
+        }
       }
-    }
+    };
+    store_phase(std::integral_constant<int, 0>{});
+    if (PH == 2) store_phase(std::integral_constant<int, PH - 1>{});
   }
   if (underrun) atomicExch(&p.ctl->error, 2u);
 }
@@ -1045,7 +1127,7 @@ __global__ __launch_bounds__(WG) void k_dct_blocks(const T* __restrict__ x, T* _
     const Vec* src = reinterpret_cast<const Vec*>(x + (size_t)blk * 64);
 #pragma unroll
     for (int c = 0; c < 64 / EPV; c++) Traits<T>::unpack(src[c], &v[c * EPV]);
-    if (INVERSE) dct64_inv<T>(v, tab); else dct64_fwd<T>(v, tab);
+    if (INVERSE) dct64_inv<T, CTab<T>>(v, as_ctab<T>(tab)); else dct64_fwd<T, CTab<T>>(v, as_ctab<T>(tab));
     Vec* dst = reinterpret_cast<Vec*>(out + (size_t)blk * 64);
 #pragma unroll
     for (int c = 0; c < 64 / EPV; c++) dst[c] = Traits<T>::pack(&v[c * EPV]);
@@ -1185,11 +1267,11 @@ void launch_scale(const T* x, T* out, size_t n, T sf, int grid, hipStream_t s) {
 template <typename T>
 void launch_compress(const FwdParams<T>& p, int mode, bool stats, int grid, hipStream_t s) {
   if (mode == DCTZHIP_EC) {
-    if (stats) hipLaunchKernelGGL((k_compress<T, DCTZHIP_EC, true>), dim3(grid), dim3(WG), 0, s, p);
-    else hipLaunchKernelGGL((k_compress<T, DCTZHIP_EC, false>), dim3(grid), dim3(WG), 0, s, p);
+    if (stats) hipLaunchKernelGGL((k_compress<T, DCTZHIP_EC, true, Phases<T>::C>), dim3(grid), dim3(WG), 0, s, p);
+    else hipLaunchKernelGGL((k_compress<T, DCTZHIP_EC, false, Phases<T>::C>), dim3(grid), dim3(WG), 0, s, p);
   } else {
-    if (stats) hipLaunchKernelGGL((k_compress<T, DCTZHIP_QT, true>), dim3(grid), dim3(WG), 0, s, p);
-    else hipLaunchKernelGGL((k_compress<T, DCTZHIP_QT, false>), dim3(grid), dim3(WG), 0, s, p);
+    if (stats) hipLaunchKernelGGL((k_compress<T, DCTZHIP_QT, true, Phases<T>::C>), dim3(grid), dim3(WG), 0, s, p);
+    else hipLaunchKernelGGL((k_compress<T, DCTZHIP_QT, false, Phases<T>::C>), dim3(grid), dim3(WG), 0, s, p);
   }
 }
 
@@ -1225,8 +1307,8 @@ void launch_compact_ac(const FwdParams<T>& p, int mode, double eb, unsigned nlis
 
 template <typename T>
 void launch_decompress(const InvParams<T>& p, int mode, int grid, hipStream_t s) {
-  if (mode == DCTZHIP_EC) hipLaunchKernelGGL((k_decompress<T, DCTZHIP_EC>), dim3(grid), dim3(WG), 0, s, p);
-  else hipLaunchKernelGGL((k_decompress<T, DCTZHIP_QT>), dim3(grid), dim3(WG), 0, s, p);
+  if (mode == DCTZHIP_EC) hipLaunchKernelGGL((k_decompress<T, DCTZHIP_EC, Phases<T>::D>), dim3(grid), dim3(WG), 0, s, p);
+  else hipLaunchKernelGGL((k_decompress<T, DCTZHIP_QT, Phases<T>::D>), dim3(grid), dim3(WG), 0, s, p);
 }
 
 template <typename T>

@@ -18,7 +18,7 @@ class DctzHipError(RuntimeError):
 
 
 def lib_path():
-    return os.path.join(_HERE, "lib", "libdctzhip.so")
+    return os.environ.get("DCTZHIP_LIBRARY") or os.path.join(_HERE, "lib", "libdctzhip.so")   # override: A/B builds of the library
 
 
 class CompressInfo(C.Structure):

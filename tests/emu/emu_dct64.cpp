@@ -14,7 +14,7 @@ static void emu(const T* a, T* b, bool inverse) {
   if (!ready) { fill_tab_block<T>(tab); ready = true; }
   T x[64];
   for (int i = 0; i < 64; i++) x[i] = a[i];
-  if (inverse) dct64_inv<T>(x, tab); else dct64_fwd<T>(x, tab);
+  if (inverse) dct64_inv<T, const T*>(x, tab); else dct64_fwd<T, const T*>(x, tab);
   for (int i = 0; i < 64; i++) b[i] = x[i];
 }
 

@@ -8,6 +8,7 @@ properties plus one oracle comparison of the streams' digests:
   * EC and QT agree on everything that does not depend on the table;
   * (slow, still bounded) the HIP streams equal the oracle's on the full shard."""
 import hashlib
+import dctz_amd
 import os
 
 import numpy as np
