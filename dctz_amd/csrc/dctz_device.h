@@ -18,7 +18,7 @@ constexpr int TILE_BLKS = 64;
 constexpr int TILE_ELEMS = TILE_BLKS * 64;   // 4096
 constexpr int WG = 64;                       // threads per workgroup of k_compress / k_decompress
 constexpr int SWG = 256;                     // threads per workgroup of the streaming helpers (stats, count, compact, ...)
-constexpr int EXC_BYTES = 4096;              // lane-private exception staging per wave: 64 lanes x 64 bytes
+constexpr int EXC_BYTES = 4096;              // k_compress: the lanes' exception strips, then the 64 x 64 bin ids of the tile on their way out
 constexpr int DEC_EXC_CAP = 1024;            // decode: exact coefficients of one tile staged in LDS (floats); more -> direct gathers
 
 template <typename T> struct Traits;
@@ -61,9 +61,10 @@ template <typename T, int PHASES = 1> struct Geo {
   static constexpr int CHP = NCH / PH;                   // 16-byte chunks of a block per phase
   static constexpr int PHB = TILEB / PH;                 // bytes of a phase image
   static_assert(NSEG % PH == 0, "a phase is a whole number of 128-byte segments");
-  // exceptions a lane can park per tile before the tile takes the direct-store path
-  static constexpr int EC_DEPTH = EXC_BYTES / 64 / 4;                  // 16 floats
-  static constexpr int QT_DEPTH = EXC_BYTES / 64 / (int)sizeof(T);     // 8 doubles / 16 floats
+  // exceptions a lane can park per tile before the tile takes the direct-store path: strips of DEPTH + 1 items, and a
+  // lane that overruns its strip (at most 63 items in all) must stay inside EXC_BYTES: (63 (DEPTH + 1) + 64) items
+  static constexpr int EC_DEPTH = 12;                                  // floats:  (63 * 13 + 64) * 4 = 3532 bytes
+  static constexpr int QT_DEPTH = sizeof(T) == 8 ? 6 : 12;             // doubles: (63 * 7 + 64) * 8 = 4040 bytes
 };
 // phases of k_compress / k_decompress per element type (build knobs for A/B runs)
 #ifndef DCTZ_PHC64
@@ -161,7 +162,7 @@ template <typename T> void launch_decompress_rem(const InvParams<T>& p, int mode
 template <typename T> void launch_dct_blocks(const T* x, T* out, const T* gtab, const T* rtab, size_t n,
                                              bool inverse, int grid, hipStream_t s);
 template <typename T> void launch_psnr(const T* x, const T* r, size_t n, double* part, int nparts, double* out, hipStream_t s);
-template <typename T> size_t compress_lds_bytes();
+template <typename T> size_t compress_lds_bytes(int mode);
 template <typename T> size_t decompress_lds_bytes();
 
 }  // namespace dctz

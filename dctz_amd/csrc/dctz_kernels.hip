@@ -502,15 +502,16 @@ __device__ __forceinline__ float bin_value(T item, T q, T range_max) {
 }
 
 template <typename T>
-size_t compress_lds_bytes() { return (size_t)Geo<T, Phases<T>::C>::PHB + EXC_BYTES + 1024 + 1152; }
+size_t compress_lds_bytes(int mode) { return (size_t)Geo<T, Phases<T>::C>::PHB + EXC_BYTES + (mode == DCTZHIP_QT ? 1024 : 0); }   // the positions strip is dead code in EC builds
 
-// PH = 1: the whole tile (32 KiB fp64) sits in LDS, one wave per SIMD, and the outputs of tile k are flushed only
-// after the DMA of tile k + 2 has been issued, so that the wait for tile k + 1 never sits behind tile k's stores.
-// PH = 2: half a tile at a time (16 KiB), two waves per SIMD cover each other's waits, outputs flushed at once.
+// PH = 1: the whole tile (fp32: 16 KiB) sits in LDS.  PH = 2 (fp64): half a tile at a time (16 KiB), eight single-wave
+// workgroups per CU = two waves per SIMD that cover each other's waits.  Either way the outputs of tile k are flushed
+// only after the next DMA of tile k + 1 has been issued, so that the wait for tile k + 1's first phase never sits
+// behind tile k's stores.
 template <typename T, int MODE, bool STATS, int PH>
 __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(PH))) void k_compress(FwdParams<T> p) {
   using G = Geo<T, PH>;
-  constexpr bool DEFER = (PH == 1);
+  constexpr bool DEFER = true;
   constexpr int DEPTH = (MODE == DCTZHIP_EC) ? G::EC_DEPTH : G::QT_DEPTH;
   using Item = typename std::conditional<MODE == DCTZHIP_EC, float, T>::type;        // what a parked exception is
   // separate arrays, so that the compiler can tell the DMA target from the staging strips (a pending LDS-DMA
@@ -521,9 +522,9 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(PH))) void k
   // them runs into its neighbours' strips (such a tile is written directly, the strips are ignored): 63 of them at
   // most, hence the slack
   constexpr int STRIDE = DEPTH + 1;
-  __shared__ __attribute__((aligned(16))) unsigned char excbuf[EXC_BYTES + 1024];
-  __shared__ __attribute__((aligned(16))) unsigned char jbuf[1152];                  // QT: position j of every parked item
-  static_assert((63 * STRIDE + 64) * sizeof(Item) <= sizeof(excbuf) && 63 * STRIDE + 64 <= (int)sizeof(jbuf), "runaway lanes stay inside the strips");
+  __shared__ __attribute__((aligned(16))) unsigned char excbuf[EXC_BYTES];
+  __shared__ __attribute__((aligned(16))) unsigned char jbuf[MODE == DCTZHIP_QT ? 1024 : 16];   // QT: position j of every parked item
+  static_assert((63 * STRIDE + 64) * sizeof(Item) <= sizeof(excbuf) && (MODE != DCTZHIP_QT || 63 * STRIDE + 64 <= (int)sizeof(jbuf)), "runaway lanes stay inside the strips");
   const int lane = threadIdx.x;
   const TileRange tr = tile_range(blockIdx.x, gridDim.x, p.ntiles);
   const unsigned list_base = tr.lo * TILE_ELEMS;     // this workgroup's exception list lives in its tiles' slots
@@ -1361,7 +1362,7 @@ void launch_psnr(const T* x, const T* r, size_t n, double* part, int nparts, dou
   template void launch_decompress_rem<T>(const InvParams<T>&, int, bool, int, hipStream_t);             \
   template void launch_dct_blocks<T>(const T*, T*, const T*, const T*, size_t, bool, int, hipStream_t); \
   template void launch_psnr<T>(const T*, const T*, size_t, double*, int, double*, hipStream_t);         \
-  template size_t compress_lds_bytes<T>();                                                              \
+  template size_t compress_lds_bytes<T>(int);                                                              \
   template size_t decompress_lds_bytes<T>();
 INST(double)
 INST(float)

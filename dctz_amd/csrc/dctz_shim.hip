@@ -60,7 +60,6 @@ struct dctzhip_ctx {
   int fastdiv = 2;                  // hoisted-reciprocal division: 0 off, 1 per-tile window test, 2 + skip the test when k_stats proves it (DCTZHIP_FASTDIV)
   int stats_grid = 2048;            // workgroups of the statistics kernel (DCTZHIP_STATS_GRID, <= 2048)
   int wg_per_cu = 0;                // grid = CUs * this; 0 = as many single-wave workgroups as a CU's LDS admits (DCTZHIP_WG_PER_CU)
-  int occ[2][2] = {{0, 0}, {0, 0}}; // resident workgroups per CU of k_compress / k_decompress, per dtype (occupancy query)
   int speculate = 1;                // fused statistics behind a sampled guess of the scaling factor (DCTZHIP_SPECULATE, dctzhip_set_speculation)
   size_t spec_min = (size_t)1 << 22; // elements below which the plain statistics pass is kept (DCTZHIP_SPEC_MIN)
   unsigned spec_group = 64;         // one 4 KiB chunk sampled per group of this many (DCTZHIP_SPEC_GROUP)
@@ -366,15 +365,11 @@ struct HostStats { double max_abs, min_abs, sum; };
 
 // resident single-wave workgroups per CU of the two big kernels (LDS-limited: 4 for fp64, 7 for fp32)
 template <typename T>
-static int wg_per_cu(dctzhip_ctx* c, bool decode) {
+static int wg_per_cu(dctzhip_ctx* c, bool decode, int mode) {
   if (c->wg_per_cu) return c->wg_per_cu;
-  int& o = c->occ[sizeof(T) == 8 ? 1 : 0][decode ? 1 : 0];
-  if (!o) {
-    const size_t lds = decode ? decompress_lds_bytes<T>() : compress_lds_bytes<T>();
-    int v = (int)((size_t)160 * 1024 / lds);
-    o = v < 1 ? 1 : (v > 8 ? 8 : v);
-  }
-  return o;
+  const size_t lds = decode ? decompress_lds_bytes<T>() : compress_lds_bytes<T>(mode);
+  const int v = (int)((size_t)160 * 1024 / lds);
+  return v < 1 ? 1 : (v > 8 ? 8 : v);
 }
 
 // One pass of the compress kernels for a given set of statistics.  `fused`: the
@@ -426,7 +421,7 @@ static int compress_pass(dctzhip_ctx* c, const T* d_in, size_t n, double eb, int
   if (rem) { int rc = upload_rtab<T>(c, rem); if (rc) return rc; }
 
   if (c->profiling) HIPCHK(c, hipEventRecord(c->ev[2], s));
-  const unsigned cap = (unsigned)(c->num_cu * wg_per_cu<T>(c, false));
+  const unsigned cap = (unsigned)(c->num_cu * wg_per_cu<T>(c, false, mode));
   const int grid = (int)(cap < ntiles ? cap : ntiles);
   p.nlists_main = (unsigned)grid;
   if (ntiles) launch_compress<T>(p, mode, fused, grid, s);
@@ -722,7 +717,7 @@ static int decompress_impl(dctzhip_ctx* c, const uint8_t* d_bin, const float* d_
   p.eb = eb;
   const bool scale = (p.sf != (T)1.0);            // :496 / :505
 
-  const unsigned cap = (unsigned)(c->num_cu * wg_per_cu<T>(c, true));
+  const unsigned cap = (unsigned)(c->num_cu * wg_per_cu<T>(c, true, mode));
   const int grid = (int)(cap < ntiles ? cap : ntiles);
   if (c->profiling) HIPCHK(c, hipEventRecord(c->ev[0], s));
   // per-tile counts of "stored exactly" flags -> exclusive prefix: where every tile's piece of AC_exact starts
