@@ -8,6 +8,7 @@ import pytest
 
 from oracle import oracle as O
 from tests import workloads as W
+from dctz_amd import hip as H
 
 pytestmark = pytest.mark.gpu
 
@@ -274,14 +275,23 @@ def test_speculation_window_violation_is_detected(spec_ctx, dtype):
     _check_against_oracle(spec_ctx, x, 1e-3, O.EC, out, info)
 
 
-def test_speculation_is_off_for_in_place_scaling_and_small_inputs(spec_ctx):
+def test_in_place_scaling_under_speculation_and_small_inputs(spec_ctx):
+    """d_scaled may alias d_in (the reference's in-place division, dctz-comp-lib.c:193-216): the scaled copy is
+    written last, with the verified sf, so a wrong guess cannot destroy the input."""
     import torch
     x = W.ragged(1 << 20, np.float64, scale=37.0)
-    xd = _dev(spec_ctx, x)
-    out, info = spec_ctx.compress(xd, 1e-3, O.EC, scaled=xd)      # d_scaled aliases d_in
-    assert info.flags == 0
     c = O.compress(x, 1e-3, O.EC, O.FAST)
-    assert _same(xd.cpu().numpy(), c.scaled) and info.cnt == c.cnt
+    for spike in (False, True):
+        z = x.copy()
+        if spike:
+            z[12345] = 4.0e4                                         # the sample cannot see it: wrong decade, re-run
+        cz = O.compress(z, 1e-3, O.EC, O.FAST)
+        xd = _dev(spec_ctx, z)
+        out, info = spec_ctx.compress(xd, 1e-3, O.EC, scaled=xd)    # d_scaled aliases d_in
+        assert info.flags in ((H.INFO_RESPUN,) if spike else (H.INFO_STATS_FUSED,))
+        assert info.sf == cz.sf and info.cnt == cz.cnt
+        assert _same(xd.cpu().numpy(), cz.scaled)
+        assert np.array_equal(out["bin_index"].cpu().numpy(), cz.bin_index)
     y = W.ragged(1 << 16, np.float64, scale=37.0)                 # below the threshold
     out, info = spec_ctx.compress(_dev(spec_ctx, y), 1e-3, O.EC)
     assert info.flags == 0

@@ -1,0 +1,47 @@
+"""The built gfx950 code object must not contain the store form that corrupted data in round 1: a 12/16-byte
+buffer store with a REGISTER soffset (no hazard wait states are inserted for it, yet the hardware needs one before a
+VALU write of the data registers; tools/ubench/probe_r2.hip measures it, DESIGN.md section 6 has the numbers)."""
+import importlib.util
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _tool():
+    spec = importlib.util.spec_from_file_location("check_isa", os.path.join(ROOT, "tools", "check_isa.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    return m
+
+
+def test_lint_recognises_the_hazardous_sequence():
+    m = _tool()
+    bad = """
+0000000000001000 <k>:
+	buffer_store_dwordx4 v[20:23], v1, s[4:7], s2 offen nt
+	v_mul_f64 v[20:21], v[24:25], v[24:25]
+	s_endpgm
+"""
+    ok = """
+0000000000001000 <k>:
+	buffer_store_dwordx4 v[20:23], v1, s[4:7], 0 offen offset:1024
+	v_mul_f64 v[20:21], v[24:25], v[24:25]
+	buffer_store_dword v3, v1, s[4:7], s9 offen
+	s_endpgm
+"""
+    seen, v = m.lint(bad)
+    assert seen == 1 and len(v) == 2 and "followed after 0 instruction" in v[0]
+    seen, v = m.lint(ok)
+    assert seen == 1 and v == []
+
+
+def test_built_library_is_clean():
+    so = os.path.join(ROOT, "dctz_amd", "lib", "libdctzhip.so")
+    if not os.path.exists(so):
+        import __graft_entry__ as g
+        g.build()
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "check_isa.py"), so], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "0 violation" in r.stdout and not r.stdout.startswith("0 wide"), r.stdout

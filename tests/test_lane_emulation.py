@@ -1,7 +1,8 @@
-"""Runs the PRODUCT's lane arithmetic (dctz_amd/csrc/dct64_lane.h + dctz_tables.h)
-on the CPU by walking the four quad lanes in a loop (tests/emu/emu_dct64.cpp),
-and requires bit-identity with the oracle's pinned fast flow.  This is what lets
-kernel-vs-oracle GPU comparisons be exact rather than tolerance-based."""
+"""Runs the PRODUCT's per-block transform (dctz_amd/csrc/dct64_block.h + dctz_tables.h: the code one GPU lane
+executes, fused multiply-adds included) on the CPU (tests/emu/emu_dct64.cpp) and requires bit-identity with the
+oracle's pinned fast flow.  This is what lets kernel-vs-oracle GPU comparisons be exact rather than tolerance-based;
+independence from the kernel's own arithmetic comes from the oracle's definition-order flow and scipy (test_oracle.py,
+test_noise_floor.py)."""
 import ctypes as C
 import os
 import subprocess
@@ -18,7 +19,7 @@ SO = os.path.join(HERE, "emu", "emu_dct64.so")
 @pytest.fixture(scope="module")
 def emu():
     src = os.path.join(HERE, "emu", "emu_dct64.cpp")
-    subprocess.check_call(["g++", "-std=c++17", "-O1", "-ffp-contract=off", "-shared", "-fPIC", "-o", SO, src])
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-ffp-contract=off", "-mfma", "-shared", "-fPIC", "-o", SO, src])
     return C.CDLL(SO)
 
 
