@@ -8,15 +8,30 @@ dctz_decompress; zlib tail excluded -- it stays on the host
 Workload (BASELINE.json metric "fp64 1e-3 EC"): one C4 shard per GPU = synthetic
 fp64 512^3 volume (C3 formula, seed 512+rank), EC mode, error bound 1e-3.
 Weak scaling: every rank owns its shard, no data-path collective (shards are
-independent dctz_compress calls).  `--gather` additionally times the one real
-exchange step (RCCL send/recv of the pre-zlib streams to rank 0), outside the
-timed steps.
+independent dctz_compress calls).
+
+Ranks.  `--gpus N` with N > 1 needs N processes, one per GPU:
+  * launched by `python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...`
+    (RANK / LOCAL_RANK / WORLD_SIZE in the environment): this process IS a rank;
+  * launched plainly (`python bench.py --gpus N`): this process touches no GPU, starts N
+    children (itself, with the rank environment set), forwards rank 0's JSON line and
+    exits non-zero if any child fails.
+A rank whose world size differs from --gpus exits non-zero: a number is never scaled by a
+GPU count that did not run.  The line carries "ranks_seen" and every rank's device.
+For N > 1 a second timed region puts the one real exchange step -- the gather of the
+pre-zlib streams to rank 0 over RCCL (dctzhip_comm_gather) -- INSIDE the step
+("with_gather").
+
+`--plumbing-only`: the launcher, the rendezvous and the gather alone (gloo, synthetic byte
+streams, no kernels, no GPU, no `value`): what the CPU test of the N > 1 path runs.
 
 Prints ONE JSON line on rank 0.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -27,7 +42,7 @@ if ROOT not in sys.path:
 HBM_PEAK_GBPS = 8000.0      # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 
 
-def parse():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
@@ -36,26 +51,84 @@ def parse():
     ap.add_argument("--eb", type=float, default=1e-3)
     ap.add_argument("--mode", choices=["ec", "qt"], default="ec")
     ap.add_argument("--dtype", choices=["f64", "f32"], default="f64")
-    ap.add_argument("--gather", action="store_true", help="also time the RCCL gather of the streams to rank 0")
+    ap.add_argument("--plumbing-only", action="store_true", help="launcher + rendezvous + gather on gloo; no kernels, no value")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-speculation", action="store_true", help="always run the separate statistics pass first")
     ap.add_argument("--cpu-sample", type=int, default=1 << 27, help="elements of the shard the CPU oracle is timed on")
     ap.add_argument("--cpu-repeats", type=int, default=4, help="passes of the CPU oracle over the sample (about 10 s in all)")
-    return ap.parse_args()
+    return ap.parse_args(argv)
 
 
-def main():
-    a = parse()
+# ------------------------------------------------------------------ launcher --
+def launch(a):
+    """Parent of an N-rank run.  Makes NO GPU call (imports neither the array framework nor the library): it only
+    starts the ranks."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(a.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(a.gpus), LOCAL_WORLD_SIZE=str(a.gpus),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0", DCTZ_BENCH_LAUNCHED="1")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    out0, _ = procs[0].communicate()
+    rcs = [procs[0].returncode] + [p.wait() for p in procs[1:]]
+    sys.stdout.write(out0.decode())
+    sys.stdout.flush()
+    if any(rcs):
+        print(f"bench.py: rank exit codes {rcs}", file=sys.stderr)
+        return 1
+    return 0
+
+
+# ------------------------------------------------------------ plumbing only --
+def plumbing(a, rank, world):
+    """Rendezvous + the stream gather on gloo with synthetic byte streams: no kernels, no oracle, no GPU."""
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    from dctz_amd import shard
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    if dist.get_world_size() != a.gpus:
+        print(f"bench.py: world size {dist.get_world_size()} != --gpus {a.gpus}", file=sys.stderr)
+        sys.exit(2)
+    rng = np.random.default_rng(1000 + rank)
+    n = 64 * (50 + 7 * rank) + 13 * rank                      # ragged, different per rank
+    nblk = (n + 63) // 64
+    cnt = int(rng.integers(1, n // 2))
+    streams = {"bin_index": torch.from_numpy(rng.integers(0, 256, n, dtype=np.uint8)),
+               "dc": torch.from_numpy(rng.standard_normal(nblk).astype(np.float32)),
+               "ac_exact": torch.from_numpy(rng.standard_normal(cnt + 3).astype(np.float32))}
+
+    def digest(s, c):
+        return [int(s["bin_index"].to(torch.int64).sum()), float(s["dc"].double().sum()), float(s["ac_exact"][:c].double().sum())]
+
+    mine = [rank, n, cnt] + digest(streams, cnt)
+    seen = [None] * world
+    dist.all_gather_object(seen, mine)
+    got = shard.gather_streams(streams, cnt, dst=0)
+    ok = True
+    if rank == 0:
+        ok = len(got) == world
+        for r in range(world):
+            ok = ok and got[r]["n"] == seen[r][1] and got[r]["cnt"] == seen[r][2] and digest(got[r], got[r]["cnt"]) == seen[r][3:]
+        print(json.dumps({"plumbing_only": True, "n_gpus": a.gpus, "ranks_seen": len({s[0] for s in seen}), "backend": "gloo",
+                          "gather_ok": bool(ok), "shards": [{"rank": s[0], "n": s[1], "cnt": s[2]} for s in seen]}), flush=True)
+    dist.barrier()
+    dist.destroy_process_group()
+    return 0 if ok else 3
+
+
+# ----------------------------------------------------------------- one rank --
+def run_rank(a, rank, local_rank, world):
     import numpy as np
     import torch
     import dctz_amd
+    from dctz_amd import shard
     from tests import workloads as W
 
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != a.gpus and world > 1:
-        a.gpus = world
     dist = None
     if world > 1:
         import torch.distributed as dist
@@ -63,8 +136,18 @@ def main():
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         torch.cuda.set_device(local_rank)
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+    seen_world = dist.get_world_size() if dist is not None else 1
+    if seen_world != a.gpus:
+        print(f"bench.py: world size {seen_world} != --gpus {a.gpus}: refusing to report a scaled number", file=sys.stderr)
+        sys.exit(2)
     dev = local_rank if world > 1 else 0
     ctx = dctz_amd.Context(dev)
+    devices = [None] * world
+    me = {"rank": rank, "device": f"cuda:{dev}", "name": torch.cuda.get_device_name(dev), "pid": os.getpid()}
+    if dist is not None:
+        dist.all_gather_object(devices, me)
+    else:
+        devices = [me]
 
     np_dtype = np.float64 if a.dtype == "f64" else np.float32
     t_dtype = torch.float64 if a.dtype == "f64" else torch.float32
@@ -78,7 +161,6 @@ def main():
     ctx.reserve(n, t_dtype, mode)
     if a.no_speculation:
         ctx.set_speculation(False)
-
     qt = mode == dctz_amd.QT
 
     def step():
@@ -104,14 +186,29 @@ def main():
     for _ in range(a.steps):
         info = step()
     barrier()
-    elapsed = time.perf_counter() - t0
-    from dctz_amd import shard
-    elapsed = shard.max_over_ranks(elapsed, ctx.device)
+    elapsed = shard.max_over_ranks(time.perf_counter() - t0, ctx.device)
     ms_per_step = elapsed * 1e3 / a.steps
+
+    # ---- N > 1: the same K steps with the gather of the streams to rank 0 inside the step ----
+    with_gather = None
+    if dist is not None:
+        ids = [dctz_amd.Context.comm_unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(ids, src=0)
+        ctx.comm_create(rank, world, ids[0])
+        ctx.comm_gather(out, info.cnt, n, root=0)              # warm-up (communicator set-up, receive buffers)
+        barrier()
+        g0 = time.perf_counter()
+        for _ in range(a.steps):
+            info = step()
+            ctx.comm_gather(out, info.cnt, n, root=0)
+        barrier()
+        g_ms = shard.max_over_ranks(time.perf_counter() - g0, ctx.device) * 1e3 / a.steps
+        with_gather = {"ms_per_step": g_ms, "value": n * es * world / (g_ms * 1e-3) / 1e9,
+                       "note": "compress + decompress + RCCL gather of bin_index / DC / AC_exact of every shard to rank 0 per step"}
 
     # ---- per-kernel durations (HIP events on the launch stream), same K steps --
     ctx.set_profiling(True)
-    acc = {"c_stats": 0.0, "c_main": 0.0, "c_tail": 0.0, "d_main": 0.0, "d_tail": 0.0}
+    acc = {"c_stats": 0.0, "c_main": 0.0, "c_tail": 0.0, "d_pre": 0.0, "d_main": 0.0, "d_tail": 0.0}
     t_c = t_d = 0.0
     for _ in range(a.steps):
         torch.cuda.synchronize()
@@ -124,7 +221,7 @@ def main():
         ctx.decompress(out, info.cnt, n, t_dtype, a.eb, info.sf, mode, qtable=info.qtable if qt else None, dst=rec)
         s3 = time.perf_counter()
         tm = ctx.timings()
-        acc["d_main"] += tm["main_ms"]; acc["d_tail"] += tm["tail_ms"]
+        acc["d_pre"] += tm["stats_ms"]; acc["d_main"] += tm["main_ms"]; acc["d_tail"] += tm["tail_ms"]
         t_c += s1 - s0; t_d += s3 - s2
     ctx.set_profiling(False)
     for k in acc:
@@ -136,111 +233,133 @@ def main():
     p = info.cnt / n                                            # exception fraction
     # algorithmic bytes per element: transform pass of compress reads s,
     # writes 1 (bin) + 4/64 (DC) + 4p (AC_exact); decompress reads 1 + 4/64 + 4p, writes s
-    bytes_c_main = n * (es + 1.0 + 4.0 / 64.0 + 4.0 * p)
+    bytes_main = n * (es + 1.0 + 4.0 / 64.0 + 4.0 * p)
     bytes_stats = n * es
-    bytes_d_main = n * (es + 1.0 + 4.0 / 64.0 + 4.0 * p)
-    ach_c = bytes_c_main / (acc["c_main"] * 1e-3) / 1e9
-    ach_d = bytes_d_main / (acc["d_main"] * 1e-3) / 1e9
+    ach_c = bytes_main / (acc["c_main"] * 1e-3) / 1e9
+    ach_d = bytes_main / (acc["d_main"] * 1e-3) / 1e9
     ach_s = bytes_stats / (acc["c_stats"] * 1e-3) / 1e9
+    dominant = "k_compress" if acc["c_main"] >= acc["d_main"] else "k_decompress"
 
-    # HBM traffic of the dominant kernel from the PMC pass of the SAME command
-    # (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate runs, gfx950 correction
-    # applied: profiles/r01_pmc_traffic.json says how); null if no matching record
-    traffic = None
+    # HBM traffic of the dominant kernel: NOT measured in this run (PMC counters need rocprofv3 passes of their own);
+    # the committed record of the same command on the same build is quoted with its source, or null
+    traffic, traffic_source = None, None
     try:
-        rec_t = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
-        key = f"{a.dtype}_{a.n}_{a.mode}_{a.eb:g}" + ("_fused" if fused else "")
-        if key in rec_t.get("k_compress", {}):
-            traffic = rec_t["k_compress"][key]["hbm_bytes_per_launch"]
+        src = os.path.join("profiles", "r02_pmc_traffic.json")
+        rec_t = json.load(open(os.path.join(ROOT, src)))
+        key = f"{a.dtype}_{a.n}_{a.mode}_{a.eb:g}"
+        if key in rec_t.get(dominant, {}):
+            traffic = rec_t[dominant][key]["hbm_bytes_per_launch"]
+            traffic_source = src + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, gfx950 correction applied)"
     except (OSError, ValueError):
         pass
 
-    # ---- optional: the one real exchange step (streams -> rank 0 over RCCL) ----
-    gather_ms = None
-    if a.gather and dist is not None:
-        from dctz_amd import shard
-        barrier()
-        g0 = time.perf_counter()
-        shard.gather_streams(out, info.cnt, dst=0)
-        barrier()
-        gather_ms = (time.perf_counter() - g0) * 1e3
-
-    # ---- CPU baseline: the oracle (a port), one core, bounded sample, rank 0 ---
+    # ---- CPU baseline: the oracle (a port), bounded sample, rank 0 only ---
     cpu = None
-    if rank == 0 and not a.no_cpu_baseline:
+    if rank == 0 and world == 1 and not a.no_cpu_baseline:
         from oracle import oracle as O
         m = min(n, a.cpu_sample)
         xs = x_host[:m]
+        omode = O.QT if a.mode == "qt" else O.EC
         tc = td = 0.0
-        for _ in range(max(1, a.cpu_repeats)):
+        reps = max(1, a.cpu_repeats)
+        for _ in range(reps):
             c0 = time.perf_counter()
-            c = O.compress(xs, a.eb, O.QT if a.mode == "qt" else O.EC, O.FAST)
+            c = O.compress(xs, a.eb, omode, O.FAST)
             c1 = time.perf_counter()
             O.decompress(c, O.FAST)
             c2 = time.perf_counter()
             tc += c1 - c0
             td += c2 - c1
-        reps = max(1, a.cpu_repeats)
-        # the same port on several host cores at once ("all cores via one process per shard"):
+        # the same port on ALL host cores at once ("all cores via one process per shard", core count stated):
         # contiguous block-aligned slices of the sample, one thread each (the C oracle runs outside the GIL)
         from concurrent.futures import ThreadPoolExecutor
-        nthr = max(1, min(16, os.cpu_count() or 1))
+        nthr = max(1, len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1))
         cuts = [(m * i // nthr) // 64 * 64 for i in range(nthr)] + [m]
 
         def one(i):
             sl = xs[cuts[i]:cuts[i + 1]]
             if sl.size:
-                O.decompress(O.compress(sl, a.eb, O.QT if a.mode == "qt" else O.EC, O.FAST), O.FAST)
+                O.decompress(O.compress(sl, a.eb, omode, O.FAST), O.FAST)
 
         with ThreadPoolExecutor(nthr) as ex:
+            list(ex.map(one, range(nthr)))                  # warm the threads / page in
             m0 = time.perf_counter()
             list(ex.map(one, range(nthr)))
-            tm = time.perf_counter() - m0
+            tm_all = time.perf_counter() - m0
         cpu = {"value": reps * m * es / (tc + td) / 1e9, "unit": "GB/s (input bytes, compress+decompress)",
                "cores": 1, "kind": "port",
                "sample": f"first {m} elements of the rank-0 shard ({m * es / 2**20:.0f} MiB) x {reps} passes, oracle FAST "
                          f"flow, compress {tc:.2f} s + decompress {td:.2f} s in all; zlib excluded on both sides",
                "compress_GBps": reps * m * es / tc / 1e9, "decompress_GBps": reps * m * es / td / 1e9,
-               "multi_core": {"cores": nthr, "value": m * es / tm / 1e9,
-                              "note": "same port, one pass, the sample cut into one slice per thread (each slice its own sf)"}}
+               "all_cores": {"cores": nthr, "host_cpu_count": os.cpu_count(), "value": m * es / tm_all / 1e9,
+                             "note": "same port, one pass, the sample cut into one slice per available core (each slice its own sf)"}}
 
     if rank == 0:
-        value = n * es * a.gpus / (ms_per_step * 1e-3) / 1e9
+        value = n * es * world / (ms_per_step * 1e-3) / 1e9
+        kern_sum = acc["c_stats"] + acc["c_main"] + acc["c_tail"] + acc["d_pre"] + acc["d_main"] + acc["d_tail"]
+        dom = {"k_compress": (acc["c_main"], ach_c), "k_decompress": (acc["d_main"], ach_d)}[dominant]
         line = {
             "metric": "compress+decompress GB/s (input bytes), fp64 1e-3 EC" if (a.dtype == "f64" and a.mode == "ec")
                       else f"compress+decompress GB/s (input bytes), {a.dtype} {a.eb:g} {a.mode.upper()}",
-            "value": value, "unit": "GB/s", "n_gpus": a.gpus, "steps": a.steps, "warmup": a.warmup,
+            "value": value, "unit": "GB/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": a.dtype, "data": "synthetic",
             "config": {"workload": f"C4 shard per GPU: synthetic {a.dtype} {a.n}^3 volume (C3 formula, seed 512+rank), "
                                    f"{a.mode.upper()} eb={a.eb:g}; step = dctzhip_compress + dctzhip_decompress, "
                                    "inputs resident in HBM",
-                       "elements_per_gpu": n, "exception_fraction": p, "parallelism": f"shard-per-gpu x{a.gpus}"},
+                       "elements_per_gpu": n, "exception_fraction": p, "parallelism": f"shard-per-gpu x{world}"},
+            "ranks_seen": len({d["rank"] for d in devices}), "devices": devices,
             "pct_hbm_peak_input": 100.0 * (n * es / (ms_per_step * 1e-3) / 1e9) / HBM_PEAK_GBPS,
-            "roofline": {"bound": "hbm", "kernel": "k_compress (fused scale+DCT-II+binning+ordered AC_exact" + ("+max/min/sum)" if fused else ")"),
-                         "achieved": ach_c, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": ach_c / HBM_PEAK_GBPS,
-                         "traffic": traffic, "algorithmic_bytes_per_launch": bytes_c_main,
-                         "avg_launch_ms": acc["c_main"]},
+            "roofline": {"bound": "hbm", "kernel": dominant + " (the longer of the two big kernels in THIS run)",
+                         "achieved": dom[1], "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": dom[1] / HBM_PEAK_GBPS,
+                         "traffic": traffic, "traffic_source": traffic_source,
+                         "algorithmic_bytes_per_launch": bytes_main, "avg_launch_ms": dom[0],
+                         "k_compress_frac": ach_c / HBM_PEAK_GBPS, "k_decompress_frac": ach_d / HBM_PEAK_GBPS},
             "statistics": ("fused into k_compress behind a sampled guess of sf, verified every step "
                            "(k_stats below = the 1/64 sample + final reduction)") if fused else "separate k_stats pass",
             "kernels": {"k_stats": ({"ms": acc["c_stats"], "sampled_fraction": 1.0 / 64.0} if fused else
                                     {"ms": acc["c_stats"], "GBps": ach_s, "frac": ach_s / HBM_PEAK_GBPS}),
                         "k_compress": {"ms": acc["c_main"], "GBps": ach_c, "frac": ach_c / HBM_PEAK_GBPS},
                         "k_decompress": {"ms": acc["d_main"], "GBps": ach_d, "frac": ach_d / HBM_PEAK_GBPS},
-                        "compress_tail_ms": acc["c_tail"], "decompress_tail_ms": acc["d_tail"]},
+                        "compress_tail_ms": acc["c_tail"], "decompress_count_scan_ms": acc["d_pre"], "decompress_tail_ms": acc["d_tail"],
+                        "sum_ms": kern_sum},
+            "host_gap_ms": ms_per_step - kern_sum,
             "host_call_ms": {"compress": t_c, "decompress": t_d},
             "compress_GBps_input": n * es / (t_c * 1e-3) / 1e9,
             "decompress_GBps_input": n * es / (t_d * 1e-3) / 1e9,
             "cpu_baseline": cpu,
         }
-        if gather_ms is not None:
-            line["gather_ms"] = gather_ms
+        if with_gather is not None:
+            line["with_gather"] = with_gather
         print(json.dumps(line), flush=True)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
     ctx.close()
+    return 0
+
+
+def main():
+    a = parse()
+    if a.gpus < 1:
+        print("bench.py: --gpus must be >= 1", file=sys.stderr)
+        return 2
+    env_world = os.environ.get("WORLD_SIZE")
+    if a.gpus > 1 and env_world is None:
+        return launch(a)                                     # plain invocation: become the launcher (no GPU call here)
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(env_world or "1")
+    if world != a.gpus:
+        print(f"bench.py: WORLD_SIZE={world} but --gpus {a.gpus}: refusing to report a scaled number", file=sys.stderr)
+        return 2
+    if a.plumbing_only:
+        if world == 1:
+            print(json.dumps({"plumbing_only": True, "n_gpus": 1, "ranks_seen": 1, "gather_ok": True, "shards": []}), flush=True)
+            return 0
+        return plumbing(a, rank, world)
+    return run_rank(a, rank, local_rank, world)
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

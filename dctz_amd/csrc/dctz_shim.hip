@@ -7,6 +7,7 @@
 // the few scalars the host stage needs (cnt, QT table).  No CPU compute path
 // exists: if HIP is unavailable every call returns DCTZHIP_E_HIP.
 #include <hip/hip_runtime.h>
+#include <dlfcn.h>
 #include <chrono>
 
 #include <climits>
@@ -69,6 +70,10 @@ struct dctzhip_ctx {
   hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
   dctzhip_timings last = {0, 0, 0, 0};
   int have_timings = 0;
+  // multi-GPU gather (RCCL, loaded on first use)
+  void* comm = nullptr;             // ncclComm_t
+  int comm_rank = 0, comm_world = 0;
+  unsigned long long* comm_sizes_dev = nullptr;   // 3 * world u64 (all-gather target) + 3 (this rank's)
   char err[512] = {0};
 };
 
@@ -155,9 +160,11 @@ extern "C" int dctzhip_ctx_create(dctzhip_ctx** out, int device) {
   return DCTZHIP_OK;
 }
 
+extern "C" int dctzhip_comm_destroy(dctzhip_ctx* c);
 extern "C" void dctzhip_ctx_destroy(dctzhip_ctx* c) {
   if (!c) return;
   (void)hipSetDevice(c->device);
+  (void)dctzhip_comm_destroy(c);
   (void)hipStreamSynchronize(c->stream);
   if (c->side_stream) { (void)hipStreamSynchronize(c->side_stream); (void)hipStreamDestroy(c->side_stream); }
   void* bufs[] = {c->ac_tmp, c->tile_cnt, c->tile_off, c->serial_out, c->tab_f64, c->tab_f32, c->rtab, c->qtab, c->ctl, c->part, c->stats_out, c->qt_item, c->qt_j};
@@ -801,5 +808,131 @@ extern "C" int dctzhip_psnr_terms(dctzhip_ctx* c, const void* d_x, const void* d
   HIPCHK(c, hipMemcpyAsync(hs, c->stats_out, 4 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
   for (int i = 0; i < 4; i++) out[i] = hs[i];
+  return DCTZHIP_OK;
+}
+
+// ---- multi-GPU gather over RCCL -----------------------------------------------------------------------------------
+// The few RCCL entry points used, resolved with dlopen so that libdctzhip.so itself has no RCCL dependency.
+namespace {
+typedef int (*fn_get_id)(void*);
+typedef int (*fn_init_rank)(void**, int, struct rccl_id, int);
+struct rccl_id { char internal[DCTZHIP_COMM_ID_BYTES]; };
+struct Rccl {
+  void* h = nullptr;
+  int (*GetUniqueId)(rccl_id*) = nullptr;
+  int (*CommInitRank)(void**, int, rccl_id, int) = nullptr;
+  int (*CommDestroy)(void*) = nullptr;
+  int (*AllGather)(const void*, void*, size_t, int, void*, hipStream_t) = nullptr;
+  int (*Send)(const void*, size_t, int, int, void*, hipStream_t) = nullptr;
+  int (*Recv)(void*, size_t, int, int, void*, hipStream_t) = nullptr;
+  int (*GroupStart)() = nullptr;
+  int (*GroupEnd)() = nullptr;
+  const char* (*GetErrorString)(int) = nullptr;
+  bool ok = false;
+};
+Rccl g_rccl;
+constexpr int NCCL_UINT8 = 1, NCCL_UINT64 = 5, NCCL_FLOAT32 = 7;     // ncclDataType_t (rccl.h)
+
+bool rccl_load(dctzhip_ctx* c) {
+  if (g_rccl.ok) return true;
+  const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+  for (const char* n : names) { g_rccl.h = dlopen(n, RTLD_NOW | RTLD_GLOBAL); if (g_rccl.h) break; }
+  if (!g_rccl.h) { fail(c, DCTZHIP_E_HIP, "RCCL not found (dlopen librccl.so): %s", dlerror()); return false; }
+#define SYM(field, name) *(void**)(&g_rccl.field) = dlsym(g_rccl.h, name); if (!g_rccl.field) { fail(c, DCTZHIP_E_HIP, "RCCL symbol %s missing", name); return false; }
+  SYM(GetUniqueId, "ncclGetUniqueId") SYM(CommInitRank, "ncclCommInitRank") SYM(CommDestroy, "ncclCommDestroy")
+  SYM(AllGather, "ncclAllGather") SYM(Send, "ncclSend") SYM(Recv, "ncclRecv") SYM(GroupStart, "ncclGroupStart")
+  SYM(GroupEnd, "ncclGroupEnd") SYM(GetErrorString, "ncclGetErrorString")
+#undef SYM
+  g_rccl.ok = true;
+  return true;
+}
+}  // namespace
+
+#define RCCLCHK(c, call)                                                                                  \
+  do {                                                                                                    \
+    int r_ = (call);                                                                                      \
+    if (r_ != 0) return fail((c), DCTZHIP_E_HIP, "%s failed: %s", #call, g_rccl.GetErrorString(r_));      \
+  } while (0)
+
+extern "C" int dctzhip_comm_unique_id(void* id_out) {
+  if (!id_out) return fail(nullptr, DCTZHIP_E_ARG, "dctzhip_comm_unique_id: id_out is NULL");
+  if (!rccl_load(nullptr)) return DCTZHIP_E_HIP;
+  rccl_id id;
+  RCCLCHK(nullptr, g_rccl.GetUniqueId(&id));
+  memcpy(id_out, id.internal, DCTZHIP_COMM_ID_BYTES);
+  return DCTZHIP_OK;
+}
+
+extern "C" int dctzhip_comm_create(dctzhip_ctx* c, int rank, int world, const void* id_in) {
+  if (!c || !id_in) return DCTZHIP_E_ARG;
+  if (world < 1 || rank < 0 || rank >= world) return fail(c, DCTZHIP_E_ARG, "rank %d of %d", rank, world);
+  if (c->comm) return fail(c, DCTZHIP_E_ARG, "the context already has a communicator");
+  if (!rccl_load(c)) return DCTZHIP_E_HIP;
+  HIPCHK(c, hipSetDevice(c->device));
+  rccl_id id;
+  memcpy(id.internal, id_in, DCTZHIP_COMM_ID_BYTES);
+  RCCLCHK(c, g_rccl.CommInitRank(&c->comm, world, id, rank));
+  c->comm_rank = rank; c->comm_world = world;
+  HIPCHK(c, hipMalloc(&c->comm_sizes_dev, sizeof(unsigned long long) * 3 * (size_t)(world + 1)));
+  return DCTZHIP_OK;
+}
+
+extern "C" int dctzhip_comm_destroy(dctzhip_ctx* c) {
+  if (!c) return DCTZHIP_E_ARG;
+  if (c->comm) { (void)g_rccl.CommDestroy(c->comm); c->comm = nullptr; }
+  if (c->comm_sizes_dev) { (void)hipFree(c->comm_sizes_dev); c->comm_sizes_dev = nullptr; }
+  c->comm_world = 0;
+  return DCTZHIP_OK;
+}
+
+extern "C" int dctzhip_comm_sizes(dctzhip_ctx* c, uint64_t n, uint64_t cnt, uint64_t* sizes) {
+  if (!c || !sizes) return DCTZHIP_E_ARG;
+  if (!c->comm) return fail(c, DCTZHIP_E_ARG, "dctzhip_comm_create was not called");
+  HIPCHK(c, hipSetDevice(c->device));
+  const int W = c->comm_world;
+  unsigned long long mine[3] = {n, (n + 63) / 64, cnt};
+  unsigned long long* d_mine = c->comm_sizes_dev + 3 * (size_t)W;
+  HIPCHK(c, hipMemcpyAsync(d_mine, mine, sizeof(mine), hipMemcpyHostToDevice, c->stream));
+  RCCLCHK(c, g_rccl.AllGather(d_mine, c->comm_sizes_dev, 3, NCCL_UINT64, c->comm, c->stream));
+  HIPCHK(c, hipMemcpyAsync(sizes, c->comm_sizes_dev, sizeof(unsigned long long) * 3 * (size_t)W, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return DCTZHIP_OK;
+}
+
+extern "C" int dctzhip_comm_gather(dctzhip_ctx* c, int root, const void* d_bin, const float* d_dc, const float* d_ac,
+                                   const uint64_t* sizes, void* d_bin_all, float* d_dc_all, float* d_ac_all) {
+  if (!c || !sizes) return DCTZHIP_E_ARG;
+  if (!c->comm) return fail(c, DCTZHIP_E_ARG, "dctzhip_comm_create was not called");
+  const int W = c->comm_world, me = c->comm_rank;
+  if (root < 0 || root >= W) return fail(c, DCTZHIP_E_ARG, "root %d of %d", root, W);
+  if (me == root && (!d_bin_all || !d_dc_all || (!d_ac_all && [&] { uint64_t t = 0; for (int r = 0; r < W; r++) t += sizes[3 * r + 2]; return t; }() > 0)))
+    return fail(c, DCTZHIP_E_ARG, "the root needs the three receive buffers");
+  if (!d_bin || !d_dc || (sizes[3 * me + 2] && !d_ac)) return fail(c, DCTZHIP_E_ARG, "null stream buffer");
+  HIPCHK(c, hipSetDevice(c->device));
+  hipStream_t s = c->stream;
+  RCCLCHK(c, g_rccl.GroupStart());
+  if (me == root) {
+    uint64_t ob = 0, od = 0, oa = 0;
+    for (int r = 0; r < W; r++) {
+      const uint64_t n = sizes[3 * r], nb = sizes[3 * r + 1], cn = sizes[3 * r + 2];
+      if (r == me) {
+        HIPCHK(c, hipMemcpyAsync((char*)d_bin_all + ob, d_bin, n, hipMemcpyDeviceToDevice, s));
+        HIPCHK(c, hipMemcpyAsync(d_dc_all + od, d_dc, nb * 4, hipMemcpyDeviceToDevice, s));
+        if (cn) HIPCHK(c, hipMemcpyAsync(d_ac_all + oa, d_ac, cn * 4, hipMemcpyDeviceToDevice, s));
+      } else {
+        RCCLCHK(c, g_rccl.Recv((char*)d_bin_all + ob, n, NCCL_UINT8, r, c->comm, s));
+        RCCLCHK(c, g_rccl.Recv(d_dc_all + od, nb, NCCL_FLOAT32, r, c->comm, s));
+        if (cn) RCCLCHK(c, g_rccl.Recv(d_ac_all + oa, cn, NCCL_FLOAT32, r, c->comm, s));
+      }
+      ob += n; od += nb; oa += cn;
+    }
+  } else {
+    const uint64_t n = sizes[3 * me], nb = sizes[3 * me + 1], cn = sizes[3 * me + 2];
+    RCCLCHK(c, g_rccl.Send(d_bin, n, NCCL_UINT8, root, c->comm, s));
+    RCCLCHK(c, g_rccl.Send(d_dc, nb, NCCL_FLOAT32, root, c->comm, s));
+    if (cn) RCCLCHK(c, g_rccl.Send(d_ac, cn, NCCL_FLOAT32, root, c->comm, s));
+  }
+  RCCLCHK(c, g_rccl.GroupEnd());
+  HIPCHK(c, hipStreamSynchronize(s));
   return DCTZHIP_OK;
 }

@@ -69,6 +69,12 @@ _PROTOS = {
     "dctzhip_debug_divide": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_double, C.c_void_p,
                                        C.c_void_p]),
     "dctzhip_psnr_terms": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.POINTER(C.c_double)]),
+    "dctzhip_comm_unique_id": (C.c_int, [C.c_void_p]),
+    "dctzhip_comm_create": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
+    "dctzhip_comm_destroy": (C.c_int, [C.c_void_p]),
+    "dctzhip_comm_sizes": (C.c_int, [C.c_void_p, C.c_uint64, C.c_uint64, C.POINTER(C.c_uint64)]),
+    "dctzhip_comm_gather": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_uint64),
+                                      C.c_void_p, C.c_void_p, C.c_void_p]),
     "dctzhip_version": (C.c_char_p, []),
 }
 
@@ -206,6 +212,42 @@ class Context:
         rc = self.lib.dctzhip_psnr_terms(self.h, x.data_ptr(), r.data_ptr(), x.numel(), _dt(x.dtype), out)
         self._check(rc, "dctzhip_psnr_terms")
         return tuple(out)
+
+    # ---- multi-GPU gather of the pre-zlib streams over RCCL (include/dctz_hip.h, dctzhip_comm_*) ----
+    @staticmethod
+    def comm_unique_id():
+        """Rank 0 makes the 128-byte id; the caller hands it to the other ranks."""
+        lib = load_library()
+        buf = C.create_string_buffer(128)
+        if lib.dctzhip_comm_unique_id(buf) != 0:
+            raise DctzHipError(f"dctzhip_comm_unique_id: {lib.dctzhip_last_error(None).decode()}")
+        return buf.raw
+
+    def comm_create(self, rank, world, unique_id):
+        assert len(unique_id) == 128
+        self._bind_stream()
+        self._check(self.lib.dctzhip_comm_create(self.h, int(rank), int(world), C.c_char_p(unique_id)), "dctzhip_comm_create")
+        self.comm = (int(rank), int(world))
+
+    def comm_gather(self, out, cnt, n, root=0):
+        """Collective.  Returns on `root` a dict of the concatenated streams of all ranks (device tensors) plus
+        "sizes" = [(n, nblk, cnt)] per rank; None elsewhere."""
+        t = self.torch
+        rank, world = self.comm
+        self._bind_stream()
+        sizes = (C.c_uint64 * (3 * world))()
+        self._check(self.lib.dctzhip_comm_sizes(self.h, int(n), int(cnt), sizes), "dctzhip_comm_sizes")
+        sz = [(sizes[3 * r], sizes[3 * r + 1], sizes[3 * r + 2]) for r in range(world)]
+        res = None
+        ptrs = (None, None, None)
+        if rank == root:
+            res = {"bin_index": t.empty(sum(s[0] for s in sz), dtype=t.uint8, device=self.device),
+                   "dc": t.empty(sum(s[1] for s in sz), dtype=t.float32, device=self.device),
+                   "ac_exact": t.empty(max(1, sum(s[2] for s in sz)), dtype=t.float32, device=self.device), "sizes": sz}
+            ptrs = (res["bin_index"].data_ptr(), res["dc"].data_ptr(), res["ac_exact"].data_ptr())
+        self._check(self.lib.dctzhip_comm_gather(self.h, int(root), out["bin_index"].data_ptr(), out["dc"].data_ptr(),
+                                                 out["ac_exact"].data_ptr(), sizes, *ptrs), "dctzhip_comm_gather")
+        return res
 
     def debug_divide(self, x, divisor):
         self._bind_stream()

@@ -165,6 +165,27 @@ int dctzhip_decompress(dctzhip_ctx *ctx, const void *d_bin_index, const float *d
 int dctzhip_dct_blocks(dctzhip_ctx *ctx, const void *d_in, void *d_out, size_t n,
                        int dtype, int inverse);
 
+/* ---- multi-GPU: gather of the pre-zlib streams ------------------------------ */
+/* Shards are independent dctz_compress calls (own sf, own header; nothing in the reference couples them,
+ * dctz-comp-lib.c:186): one process or thread per GPU, one context each, no data-path collective.  The one exchange
+ * step is bringing the three streams of every shard to the rank whose host runs the zlib tail
+ * (dctz-comp-lib.c:620-760).  It runs over RCCL (loaded with dlopen on first use: single-GPU users need no RCCL):
+ * an all-gather of three 64-bit sizes per rank, then grouped point-to-point sends straight to the root, so that
+ * all seven inbound xGMI links of the root carry data at once (a ring would be bound by one link).
+ *   dctzhip_comm_unique_id   rank 0 makes the 128-byte id and hands it to the other ranks (file, socket, MPI, ...)
+ *   dctzhip_comm_create      collective over all ranks; the communicator lives in the context
+ *   dctzhip_comm_sizes       collective: sizes[3 r .. 3 r + 2] = {n, nblk, cnt} of rank r, on every rank (host memory)
+ *   dctzhip_comm_gather      collective: on `root`, d_*_all receive the streams of all ranks back to back in rank
+ *                            order (offsets = prefix sums of `sizes`; root's own streams are copied); the other
+ *                            ranks pass NULL.  Synchronous with respect to the host on return. */
+#define DCTZHIP_COMM_ID_BYTES 128
+int dctzhip_comm_unique_id(void *id_out);
+int dctzhip_comm_create(dctzhip_ctx *ctx, int rank, int world, const void *id);
+int dctzhip_comm_destroy(dctzhip_ctx *ctx);
+int dctzhip_comm_sizes(dctzhip_ctx *ctx, uint64_t n, uint64_t cnt, uint64_t *sizes);
+int dctzhip_comm_gather(dctzhip_ctx *ctx, int root, const void *d_bin, const float *d_dc, const float *d_ac,
+                        const uint64_t *sizes, void *d_bin_all, float *d_dc_all, float *d_ac_all);
+
 /* ---- harness metric ------------------------------------------------------- */
 /* The reductions of calc_psnr (util.c:54-104) over device-resident arrays:
  * out[0] = min x, out[1] = max x (util.c:61-66 / :77-82), out[2] = max |x - r|,

@@ -2,8 +2,6 @@
 The oracle takes ~20 s on this size, so parity here is by size-independent
 properties plus one oracle comparison of the streams' digests:
   * stream consistency: #(bin == 255) = cnt + nblk, block heads are 255;
-  * the two independent exception-placement schemes (two-level vs single-pass
-    look-back) give byte-identical streams and reconstructions;
   * round trip honours the error bound;
   * EC and QT agree on everything that does not depend on the table;
   * (slow, still bounded) the HIP streams equal the oracle's on the full shard."""
@@ -58,18 +56,22 @@ def test_full_shard_properties(shard):
     ctx.close()
 
 
-def test_full_shard_matches_oracle_digests(shard):
-    """~25 s of CPU: the whole 1 GiB shard through the oracle, compared by digest."""
+@pytest.mark.parametrize("mode", [O.EC, O.QT], ids=["C4_shard_EC", "C3_QT"])
+def test_full_shard_matches_oracle_digests(shard, mode):
+    """~25 s of CPU per mode: the whole 1 GiB volume through the oracle, compared by digest -- EC (the C4 shard of
+    BASELINE.json's metric) and QT (config C3)."""
     import torch
     ctx = _ctx(0)
     x = torch.from_numpy(shard).cuda()
-    out, info = ctx.compress(x, 1e-3, 0)
-    c = O.compress(shard, 1e-3, O.EC, O.FAST)
+    out, info = ctx.compress(x, 1e-3, mode)
+    c = O.compress(shard, 1e-3, mode, O.FAST)
     assert (info.cnt, info.sf) == (c.cnt, c.sf)
     assert _digest(out["bin_index"]) == hashlib.sha256(c.bin_index.tobytes()).hexdigest()
     assert _digest(out["dc"]) == hashlib.sha256(c.dc.tobytes()).hexdigest()
     assert _digest(out["ac_exact"][:c.cnt]) == hashlib.sha256(c.ac_exact.tobytes()).hexdigest()
-    rec = ctx.decompress(out, info.cnt, x.numel(), torch.float64, 1e-3, info.sf, 0)
+    if mode == O.QT:
+        assert np.array_equal(np.array(info.qtable[:]).view(np.uint8), c.qtable.view(np.uint8))
+    rec = ctx.decompress(out, info.cnt, x.numel(), torch.float64, 1e-3, info.sf, mode, qtable=np.array(info.qtable[:]))
     assert _digest(rec) == hashlib.sha256(O.decompress(c, O.FAST).tobytes()).hexdigest()
     ctx.close()
 
@@ -79,7 +81,7 @@ def test_maximum_size_array_is_periodic(dtype):
     """Largest legal input: N is an int (dctz.h:126), so N <= 2^31 - 1 (16 GiB of doubles).
     The oracle cannot run that, but a PERIODIC input must give periodic streams: the array is a
     pattern of 64*16383 elements (whole blocks, deliberately not a multiple of the 1024-element
-    tile) repeated 2047 times plus a ragged tail with a short last block, and a small array
+    tile) repeated 2048 times plus a ragged tail with a short last block, and a small array
     [pattern | tail] -- checked against the oracle -- predicts every period of the big one.
     Exercises 64-bit addressing (> 2^32 bytes), the u32 exception counters near their top and
     the remainder block at the far end."""
