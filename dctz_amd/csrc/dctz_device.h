@@ -61,10 +61,9 @@ template <typename T, int PHASES = 1> struct Geo {
   static constexpr int CHP = NCH / PH;                   // 16-byte chunks of a block per phase
   static constexpr int PHB = TILEB / PH;                 // bytes of a phase image
   static_assert(NSEG % PH == 0, "a phase is a whole number of 128-byte segments");
-  // exceptions a lane can park per tile before the tile takes the direct-store path: strips of DEPTH + 1 items, and a
-  // lane that overruns its strip (at most 63 items in all) must stay inside EXC_BYTES: (63 (DEPTH + 1) + 64) items
-  static constexpr int EC_DEPTH = 12;                                  // floats:  (63 * 13 + 64) * 4 = 3532 bytes
-  static constexpr int QT_DEPTH = sizeof(T) == 8 ? 6 : 12;             // doubles: (63 * 7 + 64) * 8 = 4040 bytes
+  // exceptions of a block that a lane parks in its LDS strip (DEPTH + 1 items); the rest goes to global overflow strips
+  static constexpr int EC_DEPTH = 12;                                  // floats:  64 * 13 * 4 = 3328 bytes per wave
+  static constexpr int QT_DEPTH = sizeof(T) == 8 ? 14 : 12;            // full-precision items: 64 * 15 * 8 = 7680 bytes
 };
 // phases of k_compress / k_decompress per element type (build knobs for A/B runs)
 #ifndef DCTZ_PHC64
@@ -114,6 +113,8 @@ struct FwdParams {
   const unsigned* tile_off;        // exclusive prefix of tile_cnt (k_scan_tiles)
   T* qt_item;                      // QT scratch: flagged coefficients, full precision (same list layout as ac_tmp)
   uint8_t* qt_j;                   // QT scratch: their position j
+  void* ovf;                       // overflow strips: 64 items per lane of every workgroup (blocks with more exceptions than a strip holds)
+  uint8_t* ovf_j;                  // QT: their positions
   const T* tab;                    // TB_* block (device)
   const T* rtab;                   // RTAB_* block (device), remainder block only
   Ctl* ctl;

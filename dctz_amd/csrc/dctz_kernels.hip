@@ -501,8 +501,25 @@ __device__ __forceinline__ float bin_value(T item, T q, T range_max) {
   return h;
 }
 
+// diagnostic phase timers (-DDCTZ_STAMP builds only): cycles of thread 0 of every workgroup, summed into the first
+// 16 words of the positions overflow buffer (unused by EC runs)
+#ifdef DCTZ_STAMP
+#define STAMP_DECL unsigned long long st_last = __builtin_amdgcn_s_memtime(), st_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}
+#define STAMP(i) do { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); st_acc[i] += t_ - st_last; st_last = t_; } while (0)
+#define STAMP_FLUSH(ptr) do { if (threadIdx.x == 0) for (int i_ = 0; i_ < 12; i_++) atomicAdd(reinterpret_cast<unsigned long long*>(ptr) + i_, st_acc[i_]); } while (0)
+#else
+#define STAMP_DECL ((void)0)
+#define STAMP(i) ((void)0)
+#define STAMP_FLUSH(ptr) ((void)0)
+#endif
+
 template <typename T>
-size_t compress_lds_bytes(int mode) { return (size_t)Geo<T, Phases<T>::C>::PHB + EXC_BYTES + (mode == DCTZHIP_QT ? 1024 : 0); }   // the positions strip is dead code in EC builds
+size_t compress_lds_bytes(int mode) {              // tile image + strips (+ positions, QT); must match k_compress's static arrays
+  using G = Geo<T, Phases<T>::C>;
+  if (mode != DCTZHIP_QT) return (size_t)G::PHB + EXC_BYTES;
+  const size_t strips = 64 * (size_t)(G::QT_DEPTH + 1) * sizeof(T);
+  return (size_t)G::PHB + (strips > EXC_BYTES ? strips : (size_t)EXC_BYTES) + 1024;
+}
 
 // PH = 1: the whole tile (fp32: 16 KiB) sits in LDS.  PH = 2 (fp64): half a tile at a time (16 KiB), eight single-wave
 // workgroups per CU = two waves per SIMD that cover each other's waits.  Either way the outputs of tile k are flushed
@@ -517,14 +534,17 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(PH))) void k
   // separate arrays, so that the compiler can tell the DMA target from the staging strips (a pending LDS-DMA
   // forces a vmcnt(0) in front of every LDS read it may alias)
   __shared__ __attribute__((aligned(1024))) unsigned char tilebuf[G::PHB];
-  // lane l parks its exceptions in a strip of STRIDE = DEPTH + 1 items (the last one only ever holds the coefficient
-  // parked "in case", and the odd stride in dwords spreads the lanes over the banks); a lane with more than DEPTH of
-  // them runs into its neighbours' strips (such a tile is written directly, the strips are ignored): 63 of them at
-  // most, hence the slack
+  // lane l parks the exceptions of its block in a strip of STRIDE = DEPTH + 1 items in LDS (the last slot only ever
+  // holds a coefficient parked "in case"; the odd stride in dwords spreads the lanes over the banks); what does not fit
+  // (a block with more than DEPTH exceptions: rare on smooth data) goes to the lane's overflow strip in global memory
   constexpr int STRIDE = DEPTH + 1;
-  __shared__ __attribute__((aligned(16))) unsigned char excbuf[EXC_BYTES];
+  constexpr int STRIP_BYTES = 64 * STRIDE * (int)sizeof(Item) > EXC_BYTES ? 64 * STRIDE * (int)sizeof(Item) : EXC_BYTES;
+  __shared__ __attribute__((aligned(16))) unsigned char excbuf[STRIP_BYTES];        // also: the tile's bin ids on their way out
   __shared__ __attribute__((aligned(16))) unsigned char jbuf[MODE == DCTZHIP_QT ? 1024 : 16];   // QT: position j of every parked item
-  static_assert((63 * STRIDE + 64) * sizeof(Item) <= sizeof(excbuf) && (MODE != DCTZHIP_QT || 63 * STRIDE + 64 <= (int)sizeof(jbuf)), "runaway lanes stay inside the strips");
+  static_assert(MODE != DCTZHIP_QT || 64 * STRIDE <= (int)sizeof(jbuf), "positions strip");
+  // (the addresses are formed where they are used: kept in registers across the loop they cost four VGPRs for a rare path)
+  auto ovf_at = [&](unsigned k) -> Item* { return reinterpret_cast<Item*>(p.ovf) + ((size_t)blockIdx.x * 64 + threadIdx.x) * 64 + k; };
+  auto ovfj_at = [&](unsigned k) -> unsigned char* { return p.ovf_j + ((size_t)blockIdx.x * 64 + threadIdx.x) * 64 + k; };
   const int lane = threadIdx.x;
   const TileRange tr = tile_range(blockIdx.x, gridDim.x, p.ntiles);
   const unsigned list_base = tr.lo * TILE_ELEMS;     // this workgroup's exception list lives in its tiles' slots
@@ -534,6 +554,12 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(PH))) void k
   const __amdgpu_buffer_rsrc_t r_in = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(p.x + first_el), 0, range_el * (int)sizeof(T), 0x00020000);
   const __amdgpu_buffer_rsrc_t r_bin = __builtin_amdgcn_make_buffer_rsrc(p.bin + first_el, 0, range_el, 0x00020000);
   const __amdgpu_buffer_rsrc_t r_dc = __builtin_amdgcn_make_buffer_rsrc(p.dc + first_el / 64, 0, range_el / 64 * 4, 0x00020000);
+  // the workgroup's exception list(s) behind descriptors too: 32-bit offsets, no 64-bit pointers to keep alive (or spill)
+  const int list_slots = (int)((tr.hi - tr.lo) * (unsigned)TILE_ELEMS);
+  const __amdgpu_buffer_rsrc_t r_list = (MODE == DCTZHIP_EC)
+      ? __builtin_amdgcn_make_buffer_rsrc(p.ac_tmp + list_base, 0, list_slots * 4, 0x00020000)
+      : __builtin_amdgcn_make_buffer_rsrc(p.qt_item + list_base, 0, list_slots * (int)sizeof(T), 0x00020000);
+  const __amdgpu_buffer_rsrc_t r_listj = __builtin_amdgcn_make_buffer_rsrc(p.qt_j + (MODE == DCTZHIP_QT ? list_base : 0u), 0, MODE == DCTZHIP_QT ? list_slots : 0, 0x00020000);
   FastDiv<T> sfd, bwd;
   sfd.init(p.sf, p.fast_sf != 0);
   bwd.init(p.bin_width, (p.fast_bw & 1u) != 0);
@@ -545,35 +571,51 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(PH))) void k
   unsigned run = 0;                                  // length of the workgroup's list so far (uniform)
 
   // outputs of a tile on their way out (DEFER: those of the previous tile)
-  bool pend = false, p_staged = false;
+  bool pend = false;
   unsigned p_rel = 0, p_n = 0, p_dst = 0;
   unsigned pw[16];
   float p_dc = 0.f;
 
   auto flush = [&]() {
-    if (p_staged) {                                  // parked exceptions -> the workgroup's list, block after block
-      for (int e = 0; e < DEPTH; e++) {
+    // parked exceptions -> the workgroup's list, block after block (dctz-comp-lib.c:478-544 order).  Two loops on
+    // purpose: one loop that picks the LDS strip or the global overflow strip per trip turns into FLAT loads, and a
+    // flat access waits for vmcnt(0) -- i.e. for the tile DMA that has just been issued
+    auto put = [&](int e, Item v, unsigned char jj) {
+      const int at = (int)(p_dst + (unsigned)e);                                        // index inside the workgroup's list
+      if (MODE == DCTZHIP_EC) {
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, (float)v), r_list, at * 4, 0, 0);   // :535-537
+      } else {
+        if constexpr (sizeof(T) == 8) __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, (double)v), r_list, at * 8, 0, 0);
+        else __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, (float)v), r_list, at * 4, 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b8(jj, r_listj, at, 0, 0);
+      }
+    };
+#pragma unroll
+    for (int e = 0; e < DEPTH; e++) {
+      if (!__builtin_amdgcn_ballot_w64((unsigned)e < p_n)) break;
+      if ((unsigned)e < p_n) put(e, reinterpret_cast<const Item*>(excbuf)[lane * STRIDE + e], MODE == DCTZHIP_QT ? jbuf[lane * STRIDE + e] : (unsigned char)0);
+    }
+    if (__builtin_amdgcn_ballot_w64(p_n > (unsigned)DEPTH)) {                             // rare: blocks that overflowed their strip
+      for (int e = DEPTH; e < 63; e++) {
         if (!__builtin_amdgcn_ballot_w64((unsigned)e < p_n)) break;
-        if ((unsigned)e < p_n) {
-          const Item v = reinterpret_cast<const Item*>(excbuf)[lane * STRIDE + e];
-          if (MODE == DCTZHIP_EC) p.ac_tmp[p_dst + e] = (float)v;                      // :535-537
-          else { p.qt_item[p_dst + e] = (T)v; p.qt_j[p_dst + e] = jbuf[lane * STRIDE + e]; }
-        }
+        if ((unsigned)e < p_n) put(e, *ovf_at((unsigned)(e - DEPTH)), MODE == DCTZHIP_QT ? *ovfj_at((unsigned)(e - DEPTH)) : (unsigned char)0);
       }
     }
     // bin ids: 64 bytes per lane -> (through the strip, now free) 1 KiB rows of 16 consecutive blocks
-    const int f2 = (lane >> 1) & 3;
+    int lo = lane;
+    asm volatile("" : "+v"(lo));                     // (re-derived per trip, see tile_map below)
+    const int f2 = (lo >> 1) & 3;
 #pragma unroll
     for (int i = 0; i < 4; i++)
-      *reinterpret_cast<u32x4*>(excbuf + (lane * 4 + (i ^ f2)) * 16) = u32x4{pw[4 * i], pw[4 * i + 1], pw[4 * i + 2], pw[4 * i + 3]};
-    const int bin_goff = (lane >> 2) * 64 + (((lane & 3) ^ ((lane >> 3) & 3)) * 16);
+      *reinterpret_cast<u32x4*>(excbuf + (lo * 4 + (i ^ f2)) * 16) = u32x4{pw[4 * i], pw[4 * i + 1], pw[4 * i + 2], pw[4 * i + 3]};
+    const int bin_goff = (lo >> 2) * 64 + (((lo & 3) ^ ((lo >> 3) & 3)) * 16);
     const int voff = (int)(p_rel * (unsigned)TILE_ELEMS) + bin_goff;
 #pragma unroll
     for (int i = 0; i < 4; i++) {
-      const u32x4 v = *reinterpret_cast<const u32x4*>(excbuf + i * 1024 + lane * 16);
+      const u32x4 v = *reinterpret_cast<const u32x4*>(excbuf + i * 1024 + lo * 16);
       __builtin_amdgcn_raw_buffer_store_b128(v, r_bin, voff + i * 1024, 0, 0);
     }
-    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, p_dc), r_dc, (int)(p_rel * 64u + (unsigned)lane) * 4, 0, 0);   // :350-351 USE_TRUNCATE
+    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, p_dc), r_dc, (int)(p_rel * 64u + (unsigned)lo) * 4, 0, 0);   // :350-351 USE_TRUNCATE
   };
 
   // one phase of the block in registers: calc_data_stat's max|x| / min|x| over the raw values (util.c:18-25), then the
@@ -585,7 +627,9 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(PH))) void k
 #pragma unroll
         for (int j = J0; j < J1; j++) acc.minmax(x[j]);
       }
-      if (J0 == 0 && first && lane == 0) acc.sum -= (double)x[0];      // util.c:22 starts at i = 1
+      // util.c:22 starts at i = 1: x[0] never enters the sum; here the sum is 8 sf * (sum of the DCs), so x[0] leaves it as
+      // x[0] / (8 sf) DC units (tree-order sum either way: only the decimal digits of the header's `mean` come from it)
+      if (J0 == 0 && first && lane == 0) acc.dcs -= (double)x[0] / (scale ? 8.0 * (double)p.sf : 8.0);
     }
     if (scale) {
       if (p.fast_sf == 2) {
@@ -611,33 +655,57 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(PH))) void k
     return tm;
   };
 
-  if (tr.lo < tr.hi) issue_phase_dma<T, PH>(r_in, 0u, 0, tilebuf, tile_map());
+  // PH = 2: the first half of the NEXT tile is taken out of LDS in the middle of the binning of this one (the registers
+  // of the coefficients already binned are free by then), so that the DMA of its second half can start early and
+  // land under the rest of the tile; only what is left of that latency is exposed at the top of the loop
+  T xn[64];
+  if (tr.lo < tr.hi) {
+    const TileMap<T, PH> tm0 = tile_map();
+    issue_phase_dma<T, PH>(r_in, 0u, 0, tilebuf, tm0);
+    if (PH == 2) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      read_phase<T, PH, 0>(xn, tilebuf, tm0);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      issue_phase_dma<T, PH>(r_in, 0u, 1, tilebuf, tm0);
+      stats_scale(xn, std::integral_constant<int, 0>{}, (unsigned)lane < min((unsigned)TILE_BLKS, p.nfull - tr.lo * TILE_BLKS), tr.lo == 0);
+    }
+  }
+  STAMP_DECL;
   for (unsigned tile = tr.lo; tile < tr.hi; tile++) {
     const unsigned rel = tile - tr.lo;
     const unsigned blks_here = min((unsigned)TILE_BLKS, p.nfull - tile * TILE_BLKS);
     const bool active = (unsigned)lane < blks_here;
     const TileMap<T, PH> tm = tile_map();
     T x[64];
-    // phase 0: landed while the previous tile was being computed
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // the DMA has landed (and everything older is done)
-    read_phase<T, PH, 0>(x, tilebuf, tm);
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          // ... and is in registers: the buffer is free
-    if (PH == 2) issue_phase_dma<T, PH>(r_in, rel, 1, tilebuf, tm);
-    else if (tile + 1 < tr.hi) issue_phase_dma<T, PH>(r_in, rel + 1, 0, tilebuf, tm);
-    if (DEFER && pend) flush();
-    stats_scale(x, std::integral_constant<int, 0>{}, active, tile == 0);
-    if (PH == 2) {                                   // phase 1: the wait is covered by the SIMD's other wave
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (PH == 2) {
+#pragma unroll
+      for (int j = 0; j < 32; j++) x[j] = xn[j];
+      STAMP(0);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // the second half has landed (and everything older is done)
+      STAMP(1);
       read_phase<T, PH, PH - 1>(x, tilebuf, tm);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");        // ... and is in registers: the buffer is free
+      STAMP(2);
+      if (tile + 1 < tr.hi) issue_phase_dma<T, PH>(r_in, rel + 1, 0, tilebuf, tm);
+      STAMP(3);
+      if (pend) flush();
+      STAMP(4);
+      stats_scale(x, std::integral_constant<int, PH - 1>{}, active, false);
+      STAMP(5);
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // the DMA has landed (and everything older is done)
+      read_phase<T, PH, 0>(x, tilebuf, tm);
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       if (tile + 1 < tr.hi) issue_phase_dma<T, PH>(r_in, rel + 1, 0, tilebuf, tm);
-      stats_scale(x, std::integral_constant<int, PH - 1>{}, active, false);
+      if (pend) flush();
+      stats_scale(x, std::integral_constant<int, 0>{}, active, tile == 0);
     }
 #if defined(DCTZ_CUT) && DCTZ_CUT == 2
     { T sx = x[0]; for (int j = 1; j < 64; j++) sx += x[j]; if (sx == T(1.2345e300)) p.dc[0] = (float)sx; pend = false; continue; }
 #endif
     __builtin_amdgcn_sched_barrier(0);
     dct64_fwd<T, CTab<T>, (PH > 1)>(x, tab);
+    STAMP(6);
 #if defined(DCTZ_CUT) && DCTZ_CUT == 3
     { T sx = x[0]; for (int j = 1; j < 64; j++) sx += x[j]; if (sx == T(1.2345e300)) p.dc[0] = (float)sx; pend = false; continue; }
 #endif
@@ -653,13 +721,14 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(PH))) void k
     unsigned w[16];
     unsigned n = 0;
     __builtin_amdgcn_sched_barrier(0);               // the binning phase is scheduled on its own (the transform before it peaks in registers)
-    auto bin_loop = [&](auto fast, auto safe) {
+    auto bin_loop = [&](auto fast, auto safe, auto half) {
       // four coefficients = one dword of bin ids at a time, stage by stage, so that the four dependent chains
       // (subtract, divide, floor, map, convert, pack) interleave; the coefficients of a group are only parked in the
       // lane's strip when SOME lane of the wave has an exception in that group (the high-frequency groups of a
       // smooth field never do)
+      constexpr int G0 = decltype(half)::value * 8;
 #pragma unroll
-      for (int g = 0; g < 16; g++) {
+      for (int g = G0; g < G0 + 8; g++) {
         float h[4];
 #pragma unroll
         for (int i = 0; i < 4; i++) {
@@ -677,48 +746,66 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(PH))) void k
         const bool any = (h[0] >= 255.0f) | (h[1] >= 255.0f) | (h[2] >= 255.0f) | (h[3] >= 255.0f);
 #if !(defined(DCTZ_CUT) && DCTZ_CUT == 4)
         if (__builtin_amdgcn_ballot_w64(any)) {
+          // park the coefficients at the lane's current slot whether they are exceptions or not: the slot only
+          // advances when they are, so the next one overwrites it
+          if (!__builtin_amdgcn_ballot_w64(n + 4u > (unsigned)DEPTH)) {          // the usual case: every lane has room for 4 more
 #pragma unroll
-          for (int i = 0; i < 4; i++) {
-            const int j = 4 * g + i;
-            if (j == 0) continue;
-            // park the coefficient at the lane's current slot whether it is an exception or not: the slot only
-            // advances when it is, so the next one overwrites it
-            reinterpret_cast<Item*>(excbuf)[lane * STRIDE + n] = (Item)x[j];
-            if (MODE == DCTZHIP_QT) jbuf[lane * STRIDE + n] = (unsigned char)j;
-            n += (h[i] >= 255.0f) ? 1u : 0u;
+            for (int i = 0; i < 4; i++) {
+              const int j = 4 * g + i;
+              if (j == 0) continue;
+              reinterpret_cast<Item*>(excbuf)[lane * STRIDE + n] = (Item)x[j];
+              if (MODE == DCTZHIP_QT) jbuf[lane * STRIDE + n] = (unsigned char)j;
+              n += (h[i] >= 255.0f) ? 1u : 0u;
+            }
+          } else {                                     // some strip is (nearly) full: the surplus goes to the overflow strips
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+              const int j = 4 * g + i;
+              if (j == 0) continue;
+              const unsigned slot = min(n, (unsigned)DEPTH);
+              reinterpret_cast<Item*>(excbuf)[lane * STRIDE + slot] = (Item)x[j];
+              if (MODE == DCTZHIP_QT) jbuf[lane * STRIDE + slot] = (unsigned char)j;
+              if (n >= (unsigned)DEPTH) { *ovf_at(n - DEPTH) = (Item)x[j]; if (MODE == DCTZHIP_QT) *ovfj_at(n - DEPTH) = (unsigned char)j; }
+              n += (h[i] >= 255.0f) ? 1u : 0u;
+            }
           }
         }
 #endif
         __builtin_amdgcn_sched_barrier(0);           // keep the groups apart: hoisting all 64 quotients first costs 128 registers
       }
     };
-    if (bwd.ok) { if (p.fast_bw & 2u) bin_loop(std::true_type{}, std::false_type{}); else bin_loop(std::true_type{}, std::true_type{}); }
-    else bin_loop(std::false_type{}, std::true_type{});
+    auto bin_half = [&](auto half) {
+      if (bwd.ok) { if (p.fast_bw & 2u) bin_loop(std::true_type{}, std::false_type{}, half); else bin_loop(std::true_type{}, std::true_type{}, half); }
+      else bin_loop(std::false_type{}, std::true_type{}, half);
+    };
+    bin_half(std::integral_constant<int, 0>{});
+    STAMP(7);
+    if (PH == 2 && tile + 1 < tr.hi) {               // the next tile's first half (see above)
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      STAMP(8);
+      read_phase<T, PH, 0>(xn, tilebuf, tm);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      issue_phase_dma<T, PH>(r_in, rel + 1, 1, tilebuf, tm);
+      stats_scale(xn, std::integral_constant<int, 0>{}, (unsigned)lane < min((unsigned)TILE_BLKS, p.nfull - (tile + 1) * TILE_BLKS), false);
+      STAMP(9);
+    }
+    bin_half(std::integral_constant<int, 1>{});
+    STAMP(10);
     w[0] |= 0xFFu;                                   // :361 DC slot
     if (!active) n = 0;
 
     const unsigned incl = wave_incl_scan(n);
     const unsigned total = (unsigned)__builtin_amdgcn_readlane((int)incl, 63);
-    const unsigned dst = list_base + run + (incl - n);
+    const unsigned dst = run + (incl - n);            // index inside the workgroup's list
     run += total;
-    const bool staged = !__builtin_amdgcn_ballot_w64(n > (unsigned)DEPTH);
-    if (!staged && n) {                              // a crowded tile: straight to the list
-      unsigned m = dst;
-#pragma unroll
-      for (int j = 1; j < 64; j++) {
-        if (((w[j >> 2] >> (8 * (j & 3))) & 255u) == 255u) {
-          if (MODE == DCTZHIP_EC) p.ac_tmp[m] = (float)x[j];
-          else { p.qt_item[m] = x[j]; p.qt_j[m] = (unsigned char)j; }
-          m++;
-        }
-      }
-    }
-    pend = true; p_staged = staged; p_rel = rel; p_n = n; p_dst = dst; p_dc = (float)x[0];
+    pend = true; p_rel = rel; p_n = n; p_dst = dst; p_dc = (float)x[0];
 #pragma unroll
     for (int i = 0; i < 16; i++) pw[i] = w[i];
     if (!DEFER) { flush(); pend = false; }
   }
   if (pend) flush();
+  STAMP(11);
+  STAMP_FLUSH(p.ovf_j);
   if (lane == 0) p.tile_cnt[blockIdx.x] = run;
   if (STATS) {
     __syncthreads();

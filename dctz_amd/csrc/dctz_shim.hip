@@ -46,6 +46,8 @@ struct dctzhip_ctx {
   unsigned* tile_cnt = nullptr;     // list lengths (compress) / per-tile flag counts (decode) and their exclusive prefix
   unsigned* tile_off = nullptr;
   size_t tile_cap = 0;              // entries
+  void* ovf = nullptr;              // k_compress overflow strips (dctz_device.h: FwdParams::ovf), sized for the largest grid
+  uint8_t* ovf_j = nullptr;
   void* qt_item = nullptr;
   uint8_t* qt_j = nullptr;
   size_t qt_cap = 0;                // bytes of qt_item
@@ -167,7 +169,7 @@ extern "C" void dctzhip_ctx_destroy(dctzhip_ctx* c) {
   (void)dctzhip_comm_destroy(c);
   (void)hipStreamSynchronize(c->stream);
   if (c->side_stream) { (void)hipStreamSynchronize(c->side_stream); (void)hipStreamDestroy(c->side_stream); }
-  void* bufs[] = {c->ac_tmp, c->tile_cnt, c->tile_off, c->serial_out, c->tab_f64, c->tab_f32, c->rtab, c->qtab, c->ctl, c->part, c->stats_out, c->qt_item, c->qt_j};
+  void* bufs[] = {c->ovf, c->ovf_j, c->ac_tmp, c->tile_cnt, c->tile_off, c->serial_out, c->tab_f64, c->tab_f32, c->rtab, c->qtab, c->ctl, c->part, c->stats_out, c->qt_item, c->qt_j};
   for (void* b : bufs) if (b) (void)hipFree(b);
   if (c->h_pin) (void)hipHostFree(c->h_pin);
   if (c->box) (void)hipHostFree(c->box);
@@ -277,6 +279,11 @@ static int ensure_scratch(dctzhip_ctx* c, size_t n, int dtype, int mode, bool co
     if ((rc = regrow(c, &c->tile_off, &c->tile_cap, entries, sizeof(unsigned)))) return rc;
   }
   if (!compress) return DCTZHIP_OK;
+  if (!c->ovf) {                                       // 64 x 64 items per workgroup, 8 workgroups per CU at most
+    const size_t items = (size_t)c->num_cu * 8 * 64 * 64;
+    HIPCHK(c, hipMalloc(&c->ovf, items * sizeof(double)));
+    HIPCHK(c, hipMalloc(&c->ovf_j, items));
+  }
   const size_t slots = (ntiles + 1) * TILE_ELEMS;      // list of workgroup b at the slot of its first tile; the remainder block's behind them
   if (mode == DCTZHIP_QT) {
     size_t cap_b = c->qt_cap;
@@ -399,6 +406,7 @@ static int compress_pass(dctzhip_ctx* c, const T* d_in, size_t n, double eb, int
   FwdParams<T> p;
   p.x = d_in; p.bin = d_bin; p.dc = d_dc; p.ac = d_ac; p.coef = d_coef;
   p.qt_item = reinterpret_cast<T*>(c->qt_item); p.qt_j = c->qt_j;
+  p.ovf = c->ovf; p.ovf_j = c->ovf_j;
   p.ac_tmp = c->ac_tmp;
   p.tile_cnt = c->tile_cnt;
   p.tile_off = c->tile_off;
@@ -936,3 +944,13 @@ extern "C" int dctzhip_comm_gather(dctzhip_ctx* c, int root, const void* d_bin, 
   HIPCHK(c, hipStreamSynchronize(s));
   return DCTZHIP_OK;
 }
+
+#ifdef DCTZ_STAMP
+// diagnostic builds only: the 12 phase-cycle sums of k_compress (dctz_kernels.hip, STAMP), read and reset
+extern "C" int dctzhip_debug_stamps(dctzhip_ctx* c, unsigned long long* out12) {
+  if (!c || !c->ovf_j) return DCTZHIP_E_ARG;
+  HIPCHK(c, hipMemcpy(out12, c->ovf_j, 96, hipMemcpyDeviceToHost));
+  HIPCHK(c, hipMemset(c->ovf_j, 0, 96));
+  return DCTZHIP_OK;
+}
+#endif
