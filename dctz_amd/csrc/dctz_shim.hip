@@ -105,6 +105,11 @@ extern "C" const char* dctzhip_version(void) { return "0.1.0"; }
 
 extern "C" const char* dctzhip_last_error(const dctzhip_ctx* ctx) { return ctx ? ctx->err : g_create_err; }
 
+extern "C" int dctzhip_device_count(void) {
+  int n = 0;
+  return hipGetDeviceCount(&n) == hipSuccess ? n : 0;
+}
+
 extern "C" int dctzhip_ctx_create(dctzhip_ctx** out, int device) {
   if (!out) return fail(nullptr, DCTZHIP_E_ARG, "dctzhip_ctx_create: out is NULL");
   *out = nullptr;
@@ -232,6 +237,17 @@ extern "C" int dctzhip_memcpy_d2h(dctzhip_ctx* c, void* dst, const void* src, si
   if (!c) return DCTZHIP_E_ARG;
   HIPCHK(c, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
+  return DCTZHIP_OK;
+}
+extern "C" int dctzhip_host_register(dctzhip_ctx* c, void* ptr, size_t bytes) {
+  if (!c || !ptr || !bytes) return DCTZHIP_E_ARG;
+  HIPCHK(c, hipSetDevice(c->device));
+  HIPCHK(c, hipHostRegister(ptr, bytes, hipHostRegisterDefault));
+  return DCTZHIP_OK;
+}
+extern "C" int dctzhip_host_unregister(dctzhip_ctx* c, void* ptr) {
+  if (!c || !ptr) return DCTZHIP_E_ARG;
+  HIPCHK(c, hipHostUnregister(ptr));
   return DCTZHIP_OK;
 }
 extern "C" int dctzhip_sync(dctzhip_ctx* c) {

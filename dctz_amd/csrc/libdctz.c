@@ -80,10 +80,23 @@ static void die(const char *what) {
   exit(1);
 }
 
+/* Which GPU: DCTZ_DEVICE (an index), else the process's rank on its node -- DCTZ_RANK, or what the usual launchers export
+ * (LOCAL_RANK, OMPI_COMM_WORLD_LOCAL_RANK, SLURM_LOCALID) -- modulo the GPUs visible: one process per GPU, every process
+ * compresses its own shards (they are independent dctz_compress calls), see INTEGRATION.md section D. */
+static int pick_device(void) {
+  const char *d = getenv("DCTZ_DEVICE");
+  if (d) return atoi(d);
+  const char *names[] = {"DCTZ_RANK", "LOCAL_RANK", "OMPI_COMM_WORLD_LOCAL_RANK", "SLURM_LOCALID"};
+  for (int i = 0; i < 4; i++) {
+    const char *r = getenv(names[i]);
+    if (r && *r) { const int n = dctzhip_device_count(); return n > 0 ? atoi(r) % n : -1; }
+  }
+  return -1;                                   /* the current HIP device */
+}
+
 static dctzhip_ctx *ctx(void) {
   if (!g_ctx) {
-    const char *d = getenv("DCTZ_DEVICE");
-    if (dctzhip_ctx_create(&g_ctx, d ? atoi(d) : -1) != DCTZHIP_OK) {
+    if (dctzhip_ctx_create(&g_ctx, pick_device()) != DCTZHIP_OK) {
       fprintf(stderr, "libdctz: no usable MI355X context: %s\n", dctzhip_last_error(NULL));
       exit(1);
     }
@@ -113,27 +126,59 @@ void *compress_thread(void *arg) {
   pthread_exit((void *)produced);
 }
 
+/* Our own section jobs feed zlib in pieces of at most 1 GiB: avail_in / avail_out are 32-bit (uInt), and a section can
+ * be larger (AC_exact: 4 bytes x up to 2^31 - 1 exceptions).  Same stream as one deflate(Z_FINISH) call of the whole. */
+static size_t z_piece(void) {                /* DCTZ_ZLIB_PIECE: test hook (tiny pieces exercise the refill loops) */
+  static size_t v = 0;
+  if (!v) { const char *e = getenv("DCTZ_ZLIB_PIECE"); long long x = e ? atoll(e) : 0; v = (x >= 64 && x <= (1ll << 30)) ? (size_t)x : ((size_t)1 << 30); }
+  return v;
+}
+#define Z_PIECE z_piece()
 typedef struct {
   z_stream zs;
   pthread_t th;
   Bytef *dst;
   uLong bound;
+  const Bytef *src;
+  size_t left;
+  int rc;
 } zjob;
 
-static void zjob_start(zjob *j, const void *src, uLong nbytes, pthread_attr_t *attr) {
-  j->bound = compressBound(nbytes);
+static void *zjob_main(void *arg) {
+  zjob *j = (zjob *)arg;
+  z_stream *zs = &j->zs;
+  size_t out_left = j->bound;
+  zs->next_in = (Bytef *)j->src; zs->avail_in = 0;
+  zs->next_out = j->dst; zs->avail_out = 0;
+  for (;;) {
+    if (zs->avail_in == 0 && j->left) {
+      const size_t piece = j->left < Z_PIECE ? j->left : Z_PIECE;
+      zs->avail_in = (uInt)piece; j->left -= piece;                /* next_in already points behind the previous piece */
+    }
+    if (zs->avail_out == 0 && out_left) {
+      const size_t piece = out_left < Z_PIECE ? out_left : Z_PIECE;
+      zs->avail_out = (uInt)piece; out_left -= piece;
+    }
+    const int rc = deflate(zs, j->left ? Z_NO_FLUSH : Z_FINISH);
+    if (rc == Z_STREAM_END) break;
+    if (rc != Z_OK && !(rc == Z_BUF_ERROR && (zs->avail_in == 0 || zs->avail_out == 0) && (j->left || out_left))) { j->rc = rc ? rc : -1; break; }
+  }
+  uLong produced = zs->total_out;
+  deflateEnd(zs);
+  return (void *)produced;
+}
+
+static void zjob_start(zjob *j, const void *src, size_t nbytes, pthread_attr_t *attr) {
+  j->bound = (nbytes <= 0xffffffffu) ? compressBound((uLong)nbytes) : (uLong)(nbytes + nbytes / 1000 + (nbytes >> 25) * 16 + 4096);
   j->dst = (Bytef *)malloc(j->bound ? j->bound : 1);
   if (!j->dst) { fprintf(stderr, "Out of memory: zlib buffer\n"); exit(1); }
   memset(&j->zs, 0, sizeof(j->zs));
   j->zs.zalloc = Z_NULL; j->zs.zfree = Z_NULL; j->zs.opaque = Z_NULL;
   /* dctz-comp-lib.c:642-643: default level, 32K window, memLevel 8, default strategy */
   deflateInit2(&j->zs, Z_DEFAULT_COMPRESSION, Z_DEFLATED, 15, DEF_MEM_LEVEL, Z_DEFAULT_STRATEGY);
-  j->zs.avail_in = (uInt)nbytes;
-  j->zs.next_in = (Bytef *)src;
-  j->zs.avail_out = (uInt)j->bound;
-  j->zs.next_out = j->dst;
   j->zs.data_type = Z_UNKNOWN;
-  if (pthread_create(&j->th, attr, compress_thread, &j->zs)) {
+  j->src = (const Bytef *)src; j->left = nbytes; j->rc = 0;
+  if (pthread_create(&j->th, attr, zjob_main, j)) {
     fprintf(stderr, "Error creating thread\n");
     exit(0); /* dctz-comp-lib.c:651-654 */
   }
@@ -142,19 +187,27 @@ static void zjob_start(zjob *j, const void *src, uLong nbytes, pthread_attr_t *a
 static uLong zjob_join(zjob *j) {
   void *ret = NULL;
   pthread_join(j->th, &ret);
+  if (j->rc) { fprintf(stderr, "libdctz: deflate failed (%d)\n", j->rc); exit(1); }
   return (uLong)ret;
 }
 
-static uLong inflate_into(const Bytef *src, uLong src_len, void *dst, uLong dst_len) {
+static uLong inflate_into(const Bytef *src, uLong src_len, void *dst, size_t dst_len) {
   z_stream zs;
   memset(&zs, 0, sizeof(zs));
   zs.zalloc = Z_NULL; zs.zfree = Z_NULL; zs.opaque = Z_NULL;
   inflateInit(&zs); /* dctz-decomp-lib.c:250 */
-  zs.avail_in = (uInt)src_len;
+  zs.avail_in = (uInt)src_len;                                       /* a section's compressed size is a uint32 of the header */
   zs.next_in = (Bytef *)src;
-  zs.avail_out = (uInt)dst_len;
   zs.next_out = (Bytef *)dst;
-  inflate(&zs, Z_NO_FLUSH);
+  size_t out_left = dst_len;
+  for (;;) {                                                         /* the inflated size may exceed 4 GiB */
+    if (zs.avail_out == 0 && out_left) {
+      const size_t piece = out_left < Z_PIECE ? out_left : Z_PIECE;
+      zs.avail_out = (uInt)piece; out_left -= piece;
+    }
+    const int rc = inflate(&zs, Z_NO_FLUSH);
+    if (rc != Z_OK || (zs.avail_out != 0) || !out_left) break;
+  }
   uLong produced = zs.total_out;
   inflateEnd(&zs);
   return produced;
@@ -300,7 +353,7 @@ int dctz_compress(t_var *var, int N, size_t *outSize, t_var *var_z, double error
     { const char *e = getenv("DCTZ_ZLIB_LEVEL"); dctz_pdeflate_set_level(e ? atoi(e) : -1); }
     if (pthread_create(&pd_thread, &attr, pd_main, &pda)) { fprintf(stderr, "Error creating thread\n"); exit(0); }
   } else {
-    for (int i = 0; i < 3; i++) zjob_start(&jb[i], sec_src[i], (uLong)sec_bytes[i], &attr);
+    for (int i = 0; i < 3; i++) zjob_start(&jb[i], sec_src[i], sec_bytes[i], &attr);
   }
 
   /* while zlib runs: write x/sf back over the caller's buffer (:193-216) and
@@ -321,6 +374,8 @@ int dctz_compress(t_var *var, int N, size_t *outSize, t_var *var_z, double error
   } else {
     for (int i = 0; i < 3; i++) zsz[i] = zjob_join(&jb[i]);
   }
+  for (int i = 0; i < 3; i++)
+    if (zsz[i] > 0xffffffffu) { fprintf(stderr, "libdctz: compressed section %d is %lu bytes; the header holds 32-bit sizes (dctz.h:104-113): shard the array\n", i, zsz[i]); exit(1); }
   pthread_attr_destroy(&attr);
   double t4 = now_s();
 
@@ -447,11 +502,11 @@ int dctz_decompress(t_var *var_z, t_var *var_r) {
     got = ij[0].produced;
     cur += h.bindex_sz_compressed + h.DC_sz_compressed + h.AC_exact_sz_compressed;
   } else {
-    got = inflate_into(cur, h.bindex_sz_compressed, bin_index, (uLong)n);
+    got = inflate_into(cur, h.bindex_sz_compressed, bin_index, (size_t)n);
     cur += h.bindex_sz_compressed;
-    inflate_into(cur, h.DC_sz_compressed, DC, (uLong)(nblk * sizeof(float)));
+    inflate_into(cur, h.DC_sz_compressed, DC, nblk * sizeof(float));
     cur += h.DC_sz_compressed;
-    inflate_into(cur, h.AC_exact_sz_compressed, AC_exact, (uLong)((size_t)cnt * sizeof(float)));
+    inflate_into(cur, h.AC_exact_sz_compressed, AC_exact, (size_t)cnt * sizeof(float));
     cur += h.AC_exact_sz_compressed;
   }
   if (!quiet()) printf("uncompressed bin_index size is: %lu\n", got); /* :260-262 */
@@ -583,8 +638,17 @@ static void blocks(void *a, void *b, size_t n, int is_d, int inverse) {
 void dctz_dct_blocks(double *a, double *b, size_t n, int inverse) { blocks(a, b, n, 1, inverse); }
 void dctz_dct_blocks_f(float *a, float *b, size_t n, int inverse) { blocks(a, b, n, 0, inverse); }
 
-/* one block of length dn <= 64 per call, like the reference (dct.c:55, :115) */
-void dct_fftw(double *a, double *b, int dn, int nblk) { (void)nblk; blocks(a, b, (size_t)dn, 1, 0); }
-void dct_fftw_f(float *a, float *b, int dn, int nblk) { (void)nblk; blocks(a, b, (size_t)dn, 0, 0); }
-void ifft_idct(int dn, double *a, double *data) { blocks(a, data, (size_t)dn, 1, 1); }
-void ifft_idct_f(int dn, float *a, float *data) { blocks(a, data, (size_t)dn, 0, 1); }
+/* one block of length dn per call, like the reference (dct.c:55, :115).  The reference transforms ANY length with one
+ * length-dn plan; the codec only ever uses dn <= BLK_SZ = 64 (dctz.h:28), which is what the GPU tables cover: a longer
+ * block is refused loudly instead of being cut into 64-element blocks (a different transform). */
+static void one_block(void *a, void *b, int dn, int is_d, int inverse) {
+  if (dn < 1 || dn > BLK_SZ) {
+    fprintf(stderr, "libdctz: %s with dn = %d: only block lengths 1..%d are supported\n", inverse ? "ifft_idct" : "dct_fftw", dn, BLK_SZ);
+    exit(1);
+  }
+  blocks(a, b, (size_t)dn, is_d, inverse);
+}
+void dct_fftw(double *a, double *b, int dn, int nblk) { (void)nblk; one_block(a, b, dn, 1, 0); }
+void dct_fftw_f(float *a, float *b, int dn, int nblk) { (void)nblk; one_block(a, b, dn, 0, 0); }
+void ifft_idct(int dn, double *a, double *data) { one_block(a, data, dn, 1, 1); }
+void ifft_idct_f(int dn, float *a, float *data) { one_block(a, data, dn, 0, 1); }

@@ -40,6 +40,7 @@ class Timings(C.Structure):
 _lib = None
 
 _PROTOS = {
+    "dctzhip_device_count": (C.c_int, []),
     "dctzhip_ctx_create": (C.c_int, [C.POINTER(C.c_void_p), C.c_int]),
     "dctzhip_ctx_destroy": (None, [C.c_void_p]),
     "dctzhip_last_error": (C.c_char_p, [C.c_void_p]),
@@ -55,6 +56,8 @@ _PROTOS = {
     "dctzhip_memcpy_h2d": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
     "dctzhip_memcpy_d2h": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
     "dctzhip_sync": (C.c_int, [C.c_void_p]),
+    "dctzhip_host_register": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t]),
+    "dctzhip_host_unregister": (C.c_int, [C.c_void_p, C.c_void_p]),
     "dctzhip_compress": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_double, C.c_int,
                                    C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                    C.POINTER(CompressInfo)]),

@@ -80,6 +80,7 @@ typedef struct {
  * so that later calls do no allocation).  One context per GPU per thread of
  * control; a context is not re-entrant (neither is the reference: file-static
  * FFTW plan, dct.c:18-22). */
+int dctzhip_device_count(void);                            /* GPUs visible to this process (0 if none) */
 int dctzhip_ctx_create(dctzhip_ctx **out, int device);
 void dctzhip_ctx_destroy(dctzhip_ctx *ctx);
 const char *dctzhip_last_error(const dctzhip_ctx *ctx);   /* ctx may be NULL: last create error */
@@ -105,6 +106,11 @@ int dctzhip_free(dctzhip_ctx *ctx, void *dptr);
 int dctzhip_memcpy_h2d(dctzhip_ctx *ctx, void *dst, const void *src, size_t bytes);
 int dctzhip_memcpy_d2h(dctzhip_ctx *ctx, void *dst, const void *src, size_t bytes);
 int dctzhip_sync(dctzhip_ctx *ctx);
+/* Page-lock a caller-owned host buffer for the copies above (hipHostRegister): pageable copies run at about 24 GB/s,
+ * pinned ones at PCIe speed.  Pinning itself costs about as much as one pageable copy of the buffer, so it pays for
+ * buffers that are reused across calls; the buffer must be unregistered before it is freed. */
+int dctzhip_host_register(dctzhip_ctx *ctx, void *ptr, size_t bytes);
+int dctzhip_host_unregister(dctzhip_ctx *ctx, void *ptr);
 
 /* ---- compress stage ------------------------------------------------------ */
 /* Replaces dctz-comp-lib.c:186-217 (calc_data_stat + scale, util.c:12-44),

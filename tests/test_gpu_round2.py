@@ -215,3 +215,22 @@ def test_dump_taps_of_the_dropin(mode, tmp_path, monkeypatch):
         for f in ("bin_index.bin", "AC_exact.bin", "qtable.bin"):
             if (tmp_path / f).exists():
                 (tmp_path / f).unlink()
+
+
+def test_c_program_drives_the_gather_through_the_c_abi(tmp_path):
+    """tests/c/multi_gpu_gather.c (the code INTEGRATION.md section D shows): built with gcc against include/dctz_hip.h,
+    run as ONE rank here (a one-GPU box); the same binary with DCTZ_RANK / DCTZ_WORLD / DCTZ_COMM_ID_FILE set is what
+    eight processes on an eight-GPU node run."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    libdir = os.path.join(root, "dctz_amd", "lib")
+    exe = str(tmp_path / "mgg")
+    subprocess.check_call(["gcc", "-std=gnu99", "-O1", os.path.join(root, "tests", "c", "multi_gpu_gather.c"), "-I", os.path.join(root, "include"),
+                           "-L", libdir, "-ldctzhip", f"-Wl,-rpath,{libdir}", "-lm", "-o", exe])
+    n = 64 * 4000 + 17
+    out = subprocess.check_output([exe, str(n), "1e-3"], text=True, env=dict(os.environ, DCTZ_RANK="0", DCTZ_WORLD="1"))
+    f = [l for l in out.splitlines() if l.startswith("GATHER")][0].split()
+    i = np.arange(n, dtype=np.float64)
+    x = 37.0 * np.sin(i / 97.0) + 0.5 * np.cos(i * 0.37)
+    c = O.compress(x, 1e-3, O.EC, O.FAST)
+    assert [int(v) for v in f[1:]] == [0, 1, n, c.cnt, int(c.bin_index.astype(np.uint64).sum())]

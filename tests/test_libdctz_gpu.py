@@ -174,6 +174,36 @@ def test_plain_c_caller_links_and_runs(mode, tmp_path):
         psnr, maxerr = float(line[4]), float(line[5])
         assert int(line[1]) == n and float(line[3]) > 1.0
         assert psnr > 60.0 and maxerr <= 8.5 * eb * 10.0      # sf = 10 for |x| up to ~50
+        # the zlib sections are fed / drained in pieces (sections beyond 4 GiB need it: avail_in / avail_out are 32-bit);
+        # tiny pieces must give the very same container and reconstruction as one call per section
+        out2 = subprocess.check_output([exe, str(n), str(eb), str(f32)], env=dict(os.environ, DCTZ_QUIET="1", DCTZ_ZLIB_PIECE="4099"), text=True)
+        assert [l for l in out2.splitlines() if l.startswith("RESULT")] == [l for l in out.splitlines() if l.startswith("RESULT")]
+
+
+def test_block_length_beyond_64_is_refused(tmp_path):
+    """dct_fftw / ifft_idct take ANY dn in the reference (one length-dn plan, dct.c:55 / :115); the drop-in covers the
+    codec's 1..64 and says so for anything longer instead of silently transforming 64-element pieces."""
+    import subprocess, textwrap
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = tmp_path / "dn.c"
+    src.write_text(textwrap.dedent("""
+        #include <stdio.h>
+        #include "dctz.h"
+        void dct_fftw(double *a, double *b, int dn, int nblk);
+        int main(int argc, char **argv) {
+          static double a[200], b[200];
+          for (int i = 0; i < 200; i++) a[i] = i * 0.25;
+          dct_fftw(a, b, argc > 1 ? 128 : 40, 1);
+          puts(b[0] == b[0] ? "OK" : "NAN");
+          return 0;
+        }"""))
+    exe = str(tmp_path / "dn")
+    subprocess.check_call(["gcc", "-std=gnu99", str(src), "-I", os.path.join(root, "include"), "-L", LIBDIR, "-ldctz-ec",
+                           f"-Wl,-rpath,{LIBDIR}", "-lm", "-o", exe, "-DUSE_TRUNCATE"])
+    ok = subprocess.run([exe], capture_output=True, text=True, env=dict(os.environ, DCTZ_QUIET="1"))
+    assert ok.returncode == 0 and ok.stdout.startswith("OK")
+    bad = subprocess.run([exe, "long"], capture_output=True, text=True, env=dict(os.environ, DCTZ_QUIET="1"))
+    assert bad.returncode == 1 and "dn = 128" in bad.stderr
 
 
 # ---- fuzz of the drop-in boundary: host buffers in, container out, both zlib tails ------------------
