@@ -581,6 +581,9 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(PH))) void k
     // purpose: one loop that picks the LDS strip or the global overflow strip per trip turns into FLAT loads, and a
     // flat access waits for vmcnt(0) -- i.e. for the tile DMA that has just been issued
     auto put = [&](int e, Item v, unsigned char jj) {
+#if defined(DCTZ_CUT) && (DCTZ_CUT == 5 || DCTZ_CUT == 7)
+      if (p.nfull != 0xffffffffu) return;
+#endif
       const int at = (int)(p_dst + (unsigned)e);                                        // index inside the workgroup's list
       if (MODE == DCTZHIP_EC) {
         __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, (float)v), r_list, at * 4, 0, 0);   // :535-537
@@ -613,6 +616,9 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(PH))) void k
 #pragma unroll
     for (int i = 0; i < 4; i++) {
       const u32x4 v = *reinterpret_cast<const u32x4*>(excbuf + i * 1024 + lo * 16);
+#if defined(DCTZ_CUT) && (DCTZ_CUT == 6 || DCTZ_CUT == 7)
+      if (p.nfull == 0xffffffffu)
+#endif
       __builtin_amdgcn_raw_buffer_store_b128(v, r_bin, voff + i * 1024, 0, 0);
     }
     __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, p_dc), r_dc, (int)(p_rel * 64u + (unsigned)lo) * 4, 0, 0);   // :350-351 USE_TRUNCATE
