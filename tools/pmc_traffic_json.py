@@ -1,0 +1,24 @@
+#!/usr/bin/env python3
+"""pmc_traffic.txt (tools/pmc_summary.py over the FETCH_SIZE and the WRITE_SIZE pass) -> the JSON record bench.py
+quotes as roofline.traffic:  {kernel: {workload key: {hbm_bytes_per_launch, fetch_kib, write_kib}}}.
+
+gfx950 correction (MI355X_MICROARCH.md, HBM / rocprofv3 section): both counters are in KiB, and FETCH_SIZE counts
+half of what a 16-byte-per-lane stream reads, so bytes = (2 * FETCH_SIZE + WRITE_SIZE) * 1024 -- cross-checked on
+k_count_tiles, which reads exactly N bytes (134 217 728) and reports FETCH_SIZE = 65 552 KiB."""
+import json
+import re
+import sys
+
+txt, key = sys.argv[1], sys.argv[2]
+vals = {}
+for line in open(txt):
+    m = re.match(r"(?:void )?dctz::(k_\w+).*dispatches \d+ \{'(FETCH_SIZE|WRITE_SIZE)': (\d+)\}", line)
+    if m:
+        vals.setdefault(m.group(1), {})[m.group(2)] = int(m.group(3))
+out = {}
+for k, v in vals.items():
+    if "FETCH_SIZE" in v and "WRITE_SIZE" in v:
+        out[k] = {key: {"hbm_bytes_per_launch": (2 * v["FETCH_SIZE"] + v["WRITE_SIZE"]) * 1024,
+                        "fetch_size_kib": v["FETCH_SIZE"], "write_size_kib": v["WRITE_SIZE"]}}
+json.dump(out, sys.stdout, indent=1, sort_keys=True)
+print()

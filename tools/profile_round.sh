@@ -4,7 +4,8 @@
 # 2. separate --pmc passes (never combined with trace domains other than kernel-trace): instruction mix / wave
 #    time split / LDS, and the two HBM traffic counters (FETCH_SIZE, WRITE_SIZE) each in a pass of its own
 # 3. the plain bench line                                                 -> gpurun_out/<tag>/bench.json
-# The summaries (not the raw databases) are then copied into profiles/ by hand.
+# The traffic record is placed where bench.py looks for it before the plain bench line is taken; the summaries
+# (not the raw databases) are then copied into profiles/ by hand.
 set -u
 TAG=${1:-r02}
 cd /tmp && export TMPDIR=/tmp
@@ -22,5 +23,6 @@ rocprofv3 --pmc WRITE_SIZE -d $O/pw -o pw -- $BENCH --steps 5 --warmup 2 > /dev/
 python3 tools/pmc_summary.py $O/kt > $O/kernel_stats.csv 2>&1
 python3 tools/pmc_summary.py $O/p1 $O/p2 $O/p3 > $O/pmc.txt 2>&1
 python3 tools/pmc_summary.py $O/pf $O/pw > $O/pmc_traffic.txt 2>&1
+python3 tools/pmc_traffic_json.py $O/pmc_traffic.txt f64_512_ec_0.001 > $O/pmc_traffic.json && cp $O/pmc_traffic.json profiles/${TAG}_pmc_traffic.json
 timeout -k 10 600 python3 bench.py > $O/bench.json 2> $O/bench.err
 cat $O/kernel_stats.csv; cat $O/pmc_traffic.txt | cut -c1-300
