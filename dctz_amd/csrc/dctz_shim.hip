@@ -838,8 +838,6 @@ extern "C" int dctzhip_psnr_terms(dctzhip_ctx* c, const void* d_x, const void* d
 // ---- multi-GPU gather over RCCL -----------------------------------------------------------------------------------
 // The few RCCL entry points used, resolved with dlopen so that libdctzhip.so itself has no RCCL dependency.
 namespace {
-typedef int (*fn_get_id)(void*);
-typedef int (*fn_init_rank)(void**, int, struct rccl_id, int);
 struct rccl_id { char internal[DCTZHIP_COMM_ID_BYTES]; };
 struct Rccl {
   void* h = nullptr;

@@ -587,10 +587,26 @@ void gen_bins_f(float min, float max, float *bin_center, int nbins, float error_
 
 /* ------------------------------------------------------------- calc_psnr --- */
 /* util.c:54-104 (harness metric; not part of the codec). */
+/* Arrays of at least this many elements take the GPU reductions (dctzhip_psnr_terms: min, max and max |e| exact,
+ * the sum of squares in tree order, 1e-15 relative to the serial loop); DCTZ_PSNR_HOST=1 keeps the loop below. */
+#define PSNR_GPU_MIN (1 << 16)
 double calc_psnr(t_var *var, t_var *var_r, int N, double error_bound) {
   (void)error_bound;
   double lo, hi, worst = 0.0, sq = 0.0;
-  if (var->datatype == DOUBLE) {
+  if (N >= PSNR_GPU_MIN && !getenv("DCTZ_PSNR_HOST")) {
+    const int is_d = var->datatype == DOUBLE;
+    const size_t bytes = (size_t)N * (is_d ? sizeof(double) : sizeof(float));
+    dctzhip_ctx *c = ctx();
+    double t[4];
+    grow(&g_dev.in, &g_dev.in_cap, bytes);
+    grow(&g_dev.out, &g_dev.out_cap, bytes);
+    if (dctzhip_memcpy_h2d(c, g_dev.in, is_d ? (void *)var->buf.d : (void *)var->buf.f, bytes) != DCTZHIP_OK ||
+        dctzhip_memcpy_h2d(c, g_dev.out, is_d ? (void *)var_r->buf.d : (void *)var_r->buf.f, bytes) != DCTZHIP_OK)
+      die("H2D");
+    if (dctzhip_psnr_terms(c, g_dev.in, g_dev.out, (size_t)N, is_d ? DCTZHIP_F64 : DCTZHIP_F32, t) != DCTZHIP_OK)
+      die("dctzhip_psnr_terms");
+    lo = t[0]; hi = t[1]; worst = t[2]; sq = t[3];
+  } else if (var->datatype == DOUBLE) {
     const double *x = var->buf.d, *r = var_r->buf.d;
     lo = hi = x[0];
     for (int i = 1; i < N; i++) { if (x[i] > hi) hi = x[i]; if (x[i] < lo) lo = x[i]; }

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """One-off stress of the HIP path against the oracle: many random configurations with arrays large enough
 for multi-tile workgroup ranges (the regime the per-commit tests touch only in a few fixed cases).
-  python tools/stress_parity.py [--cases 150] [--max-n 6000000] [--seed 1]
+  python tests/stress_parity.py [--cases 150] [--max-n 6000000] [--seed 1]
 Exits non-zero at the first mismatch."""
 import argparse
 import os

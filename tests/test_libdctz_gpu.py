@@ -247,3 +247,33 @@ def test_dropin_fuzz(seed, n, log_amp, eb, mode, dtype, zthreads):
     finally:
         os.environ.pop("DCTZ_ZLIB_THREADS", None)
         os.environ.pop("DCTZ_ZLIB_CHUNK", None)
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_calc_psnr_on_the_gpu_agrees_with_its_host_loop(dtype, capfd):
+    """calc_psnr (util.c:54-104) of the drop-in: arrays of 2^16 elements and more take the GPU reductions; the
+    returned PSNR agrees with the host loop (DCTZ_PSNR_HOST=1, the reference's serial order) to 1e-12 relative and
+    the 'Max relative error' line (util.c:95) is the same text."""
+    lib = _lib("ec")
+    lib.calc_psnr.argtypes = [C.POINTER(TVar), C.POINTER(TVar), C.c_int, C.c_double]
+    rng = np.random.default_rng(77)
+    n = (1 << 20) + 37
+    x = (10 * np.sin(np.arange(n) / 311.0) + rng.normal(0, 0.3, n)).astype(dtype)
+    r = (x.astype(np.float64) + rng.uniform(-1e-3, 1e-3, n)).astype(dtype)
+    vx, vr = _tvar(x), _tvar(r)
+    capfd.readouterr()
+    os.environ.pop("DCTZ_PSNR_HOST", None)
+    p_gpu = lib.calc_psnr(C.byref(vx), C.byref(vr), n, 1e-3)
+    out_gpu = capfd.readouterr().out
+    os.environ["DCTZ_PSNR_HOST"] = "1"
+    try:
+        p_host = lib.calc_psnr(C.byref(vx), C.byref(vr), n, 1e-3)
+    finally:
+        os.environ.pop("DCTZ_PSNR_HOST", None)
+    out_host = capfd.readouterr().out
+    assert abs(p_gpu - p_host) <= 1e-12 * abs(p_host)
+    assert "Max relative error" in out_gpu and out_gpu == out_host
+    # and against numpy in the data type
+    e = x - r
+    want = 20 * np.log10((float(x.max()) - float(x.min())) / np.sqrt(float(np.sum((e * e).astype(np.float64))) / n))
+    assert abs(p_gpu - want) <= 1e-9 * abs(want)

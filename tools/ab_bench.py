@@ -1,8 +1,8 @@
 #!/usr/bin/env python3
 """A/B of kernel variants in ONE process, interleaved rounds (cdna guide rule 24).
-Variants are selected through the shim's environment knobs at context creation:
-DCTZHIP_FEAT (0 = two-level scheme, 1 = single-pass look-back, +2 grouped tickets,
-+4 phase stamps), DCTZHIP_FASTDIV, DCTZHIP_WG_PER_CU, DCTZHIP_STATS_GRID.  Prints median kernel times (HIP events) per variant."""
+Variants are selected through the shim's environment knobs at context creation: DCTZHIP_FASTDIV (fd),
+DCTZHIP_WG_PER_CU (wg), DCTZHIP_STATS_GRID (sg).  Different BUILDS are compared by running this tool once per
+library (DCTZHIP_LIBRARY=<path>) inside one gpurun call, alternating.  Prints median kernel times (HIP events)."""
 import argparse
 import json
 import os
@@ -20,7 +20,7 @@ def main():
     ap.add_argument("--dtype", default="f64")
     ap.add_argument("--mode", default="ec")
     ap.add_argument("--eb", type=float, default=1e-3)
-    ap.add_argument("--variants", default="feat=0;feat=1;feat=3;feat=0,fd=0")
+    ap.add_argument("--variants", default="fd=2;fd=1;fd=0;fd=2,wg=4")
     a = ap.parse_args()
     import numpy as np
     import torch
@@ -35,7 +35,6 @@ def main():
     ctxs = []
     for spec in a.variants.split(";"):
         kv = dict(s.split("=") for s in spec.split(","))
-        os.environ["DCTZHIP_FEAT"] = kv.get("feat", "0")
         os.environ["DCTZHIP_FASTDIV"] = kv.get("fd", "2")
         os.environ["DCTZHIP_WG_PER_CU"] = kv.get("wg", "0")
         os.environ["DCTZHIP_STATS_GRID"] = kv.get("sg", "2048")
