@@ -101,6 +101,15 @@ struct HostBox {
   double psnr[6];                          // calc_psnr reduction: min, max, sum e^2, max |e|, max |e/x| (k_psnr_final)
 };
 
+// What k_finish, the last kernel of a call, needs for the hand-off to the host.
+struct FinArgs {
+  Ctl* ctl;
+  const double* part;              // fused statistics partials ({max|x|, min|x|, sum} per slot), nparts of them (0: none)
+  int nparts;
+  HostBox* box;
+  unsigned long long seq;
+};
+
 template <typename T>
 struct FwdParams {
   const T* x;                      // input
@@ -110,7 +119,6 @@ struct FwdParams {
   T* coef;                         // optional coefficient tap (tests)
   float* ac_tmp;                   // workgroup-local AC_exact lists, list of workgroup b starts at the slot of its first tile
   unsigned* tile_cnt;              // list lengths, one per workgroup (+1 for the remainder block)
-  const unsigned* tile_off;        // exclusive prefix of tile_cnt (k_scan_tiles)
   T* qt_item;                      // QT scratch: flagged coefficients, full precision (same list layout as ac_tmp)
   uint8_t* qt_j;                   // QT scratch: their position j
   void* ovf;                       // overflow strips: 64 items per lane of every workgroup (blocks with more exceptions than a strip holds)
@@ -136,9 +144,11 @@ struct InvParams {
   const T* tab;
   const T* rtab;
   const T* qtab;                   // QT: clamped table (device)
-  const unsigned* tile_off;        // exclusive prefix of the per-TILE counts of "stored exactly" flags; [ntiles] = the remainder block's start
+  const unsigned* tile_cnt;        // per-TILE counts of "stored exactly" flags (k_count_tiles)
+  const unsigned* wg_cnt;          // the same summed over the tile range of every workgroup of k_decompress (nwg entries)
   Ctl* ctl;
   unsigned nfull, ntiles, ac_count;
+  unsigned nwg;                    // grid of k_decompress
   T sf, bin_width, range_min, range_max;
   double eb;
 };
@@ -156,8 +166,7 @@ template <typename T> void launch_compress(const FwdParams<T>& p, int mode, bool
 template <typename T> void launch_compress_rem(const FwdParams<T>& p, int mode, bool scale, int l, hipStream_t s);
 template <typename T> void launch_qt_max(const FwdParams<T>& p, unsigned nlists, int grid, hipStream_t s);
 template <typename T> void launch_compact_ac(const FwdParams<T>& p, int mode, double eb, unsigned nlists, int grid, hipStream_t s);
-void launch_scan_tiles(const unsigned* cnt, unsigned* off, unsigned n, Ctl* ctl, hipStream_t s);
-void launch_count_tiles(const uint8_t* bin, unsigned nfull, unsigned ntiles, unsigned* tile_cnt, int grid, hipStream_t s);
+void launch_count_tiles(const uint8_t* bin, unsigned nfull, unsigned ntiles, unsigned nwg, unsigned* tile_cnt, unsigned* wg_cnt, hipStream_t s);
 template <typename T> void launch_decompress(const InvParams<T>& p, int mode, int grid, hipStream_t s);
 template <typename T> void launch_decompress_rem(const InvParams<T>& p, int mode, bool scale, int l, hipStream_t s);
 template <typename T> void launch_dct_blocks(const T* x, T* out, const T* gtab, const T* rtab, size_t n,

@@ -360,10 +360,10 @@ __global__ __launch_bounds__(SWG) void k_stats(const T* __restrict__ x, size_t n
   }
 }
 
-// reduction of {max, min, sum} partials by one workgroup; thread 0 returns with the result
+// reduction of {max, min, sum} partials by one workgroup (any size up to 256 threads); thread 0 returns with the result
 __device__ __forceinline__ void reduce_parts(const double* __restrict__ part, int nparts, double& dmx, double& dmn, double& sum) {
   dmx = 0.0; dmn = 1.79769313486231570815e308; sum = 0.0;
-  for (int i = threadIdx.x; i < nparts; i += SWG) {
+  for (int i = threadIdx.x; i < nparts; i += (int)blockDim.x) {
     dmx = fmax(dmx, part[3 * i]); dmn = fmin(dmn, part[3 * i + 1]); sum += part[3 * i + 2];
   }
 #pragma unroll
@@ -373,15 +373,15 @@ __device__ __forceinline__ void reduce_parts(const double* __restrict__ part, in
     sum += __shfl_down(sum, d);
   }
   __shared__ double s[3][SWG / 64];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = (int)blockDim.x >> 6;
   if (lane == 0) { s[0][wave] = dmx; s[1][wave] = dmn; s[2][wave] = sum; }
   __syncthreads();
   if (threadIdx.x == 0)
-    for (int w = 1; w < SWG / 64; w++) { dmx = fmax(dmx, s[0][w]); dmn = fmin(dmn, s[1][w]); sum += s[2][w]; }
+    for (int w = 1; w < nw; w++) { dmx = fmax(dmx, s[0][w]); dmn = fmin(dmn, s[1][w]); sum += s[2][w]; }
 }
 
-__global__ __launch_bounds__(SWG) void k_stats_final(const double* __restrict__ part, int nparts, double* __restrict__ out,
-                                                    HostBox* box, unsigned long long seq) {
+// final reduction of the statistics partials -> device words + (optionally) the host mailbox; one workgroup
+__device__ __forceinline__ void stats_final_body(const double* part, int nparts, double* out, HostBox* box, unsigned long long seq) {
   double dmx, dmn, sum;
   reduce_parts(part, nparts, dmx, dmn, sum);
   if (threadIdx.x == 0) {
@@ -393,24 +393,35 @@ __global__ __launch_bounds__(SWG) void k_stats_final(const double* __restrict__ 
   }
 }
 
-// Last kernel of a compress / decompress call: final reduction of the fused statistics (nparts > 0),
-// results -> host box, control block back to all-zero for the next call, then the sequence number.
-__global__ __launch_bounds__(SWG) void k_finish(Ctl* ctl, const double* __restrict__ part, int nparts, HostBox* box,
-                                               unsigned long long seq) {
+__global__ __launch_bounds__(SWG) void k_stats_final(const double* part, int nparts, double* out,
+                                                    HostBox* box, unsigned long long seq) {
+  stats_final_body(part, nparts, out, box, seq);
+}
+
+// Last kernel of a compress / decompress call (one workgroup): final reduction of the fused statistics (nparts > 0),
+// results -> host box, control block back to all-zero for the next call, then the sequence number.  (Folding this
+// into the last workgroup of the preceding kernel to finish was measured and dropped: the agent-scope release fence
+// every workgroup then needs writes back the whole L2 of its XCD -- k_decompress 0.214 -> 0.272 ms, DESIGN.md.)
+template <bool WITH_STATS>
+__device__ __forceinline__ void finish_body(const FinArgs& f) {
   const int t = threadIdx.x;
-  if (nparts > 0) {
+  Ctl* ctl = f.ctl;
+  HostBox* box = f.box;
+  if (WITH_STATS && f.nparts > 0) {
     double dmx, dmn, sum;
-    reduce_parts(part, nparts, dmx, dmn, sum);
+    reduce_parts(f.part, f.nparts, dmx, dmn, sum);
     if (t == 0) { box->fstats[0] = dmx; box->fstats[1] = dmn; box->fstats[2] = sum; }
   }
-  if (t < 64) box->qraw[t] = ctl->qraw[t];
+  for (int i = t; i < 64; i += (int)blockDim.x) box->qraw[i] = ctl->qraw[i];
   if (t == 0) { box->cnt_total = ctl->cnt_total; box->error = ctl->error; box->q0 = ctl->q0; }
   __threadfence_system();
   __syncthreads();                                   // all box writes issued and fenced; all ctl reads done
   unsigned long long* w = reinterpret_cast<unsigned long long*>(ctl);
-  for (int i = t; i < (int)(sizeof(Ctl) / 8); i += SWG) w[i] = 0ull;
-  if (t == 0) box_publish(&box->seq_done, seq);
+  for (int i = t; i < (int)(sizeof(Ctl) / 8); i += (int)blockDim.x) w[i] = 0ull;
+  if (t == 0) box_publish(&box->seq_done, f.seq);
 }
+
+__global__ __launch_bounds__(SWG) void k_finish(FinArgs f) { finish_body<true>(f); }
 
 // Sampled statistics for the speculative path: one 4 KiB chunk out of every group of
 // `group` chunks, at a hashed position inside the group (a fixed stride would alias with
@@ -908,59 +919,30 @@ __global__ __launch_bounds__(SWG) void k_qt_max(FwdParams<T> p, unsigned nlists)
   if (threadIdx.x < 64 && qmax[threadIdx.x] != 0) atomicMax(&p.ctl->qraw[threadIdx.x], (unsigned long long)qmax[threadIdx.x]);
 }
 
-// Exclusive prefix over the list lengths / per-tile flag counts
-// (one workgroup; n <= 2^19 + 1 entries for the largest legal input).  off[n] = total.
-__global__ __launch_bounds__(1024) void k_scan_tiles(const unsigned* __restrict__ cnt, unsigned* __restrict__ off,
-                                                     unsigned n, Ctl* ctl) {
-  // Segments of 8192 entries go through LDS so that global accesses are coalesced
-  // (a strided walk through one CU's address path took 34 us for 32 Ki entries);
-  // in LDS thread t owns 8 consecutive entries at pitch 9 (conflict-free).
-  constexpr unsigned SEG = 8192, PER = SEG / 1024;
-  __shared__ unsigned buf[SEG + SEG / PER];
-  __shared__ unsigned part[1024 / 64];
-  __shared__ unsigned carry_s;
-  const unsigned t = threadIdx.x, lane = t & 63u, wave = t >> 6;
-  if (t == 0) carry_s = 0;
-  for (unsigned base = 0; base < n; base += SEG) {
-    const unsigned m = min(SEG, n - base);
-    for (unsigned i = t; i < m; i += 1024) buf[i + i / PER] = cnt[base + i];
-    __syncthreads();
-    unsigned vals[PER], sum = 0;
+// Sum over a workgroup of one unsigned per thread (every thread gets the total); `sh`: one word per wave
+__device__ __forceinline__ unsigned block_sum(unsigned v, unsigned* sh) {
 #pragma unroll
-    for (unsigned k = 0; k < PER; k++) {
-      vals[k] = (t * PER + k < m) ? buf[t * (PER + 1) + k] : 0u;
-      sum += vals[k];
-    }
-    unsigned incl = sum;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-      unsigned o = __shfl_up(incl, d);
-      if (lane >= (unsigned)d) incl += o;
-    }
-    if (lane == 63) part[wave] = incl;
-    __syncthreads();
-    unsigned run = carry_s + incl - sum;
-    for (unsigned w = 0; w < wave; w++) run += part[w];
-#pragma unroll
-    for (unsigned k = 0; k < PER; k++) {
-      buf[t * (PER + 1) + k] = run;
-      run += vals[k];
-    }
-    __syncthreads();
-    for (unsigned i = t; i < m; i += 1024) off[base + i] = buf[i + i / PER];
-    if (t == 1023) carry_s = run;                   // inclusive total through this segment
-    __syncthreads();
-  }
-  if (t == 0) { off[n] = carry_s; ctl->cnt_total = carry_s; }
+  for (int d = 32; d > 0; d >>= 1) v += __shfl_xor(v, d);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = (int)blockDim.x >> 6;
+  __syncthreads();                                   // sh[] of an earlier call is consumed
+  if (lane == 0) sh[wave] = v;
+  __syncthreads();
+  unsigned tot = 0;
+  for (int w = 0; w < nw; w++) tot += sh[w];
+  return tot;
 }
 
 // Move every workgroup-local list to its place in AC_exact[]
 // (dctz-comp-lib.c:478-544 order: lists are already block-major, j ascending).
 // QT: clamp the table (:450-461) and normalise on the way (:488-518).
+// The place of list l -- the running tot_AC_exact_count of :478-544 in front of it -- is the sum of the lengths of the
+// lists before it: at most 2049 of them, summed by the workgroup itself (no scan kernel); the workgroup of the last
+// list leaves the total.
 template <typename T, int MODE>
 __global__ __launch_bounds__(SWG) void k_compact_ac(FwdParams<T> p, double eb, unsigned nlists) {
   using Bits = typename Traits<T>::Bits;
   __shared__ T q[64];
+  __shared__ unsigned sh[SWG / 64];
   if (MODE == DCTZHIP_QT) {
     if (threadIdx.x < 64) {
       T v = Traits<T>::from_bits((Bits)p.ctl->qraw[threadIdx.x]);
@@ -971,7 +953,11 @@ __global__ __launch_bounds__(SWG) void k_compact_ac(FwdParams<T> p, double eb, u
   }
   const unsigned G = p.nlists_main;
   for (unsigned l = blockIdx.x; l < nlists; l += gridDim.x) {
-    const unsigned n = p.tile_cnt[l], dst = p.tile_off[l];
+    unsigned before = 0;
+    for (unsigned i = threadIdx.x; i < l; i += SWG) before += p.tile_cnt[i];
+    const unsigned dst = block_sum(before, sh);
+    const unsigned n = p.tile_cnt[l];
+    if (l == nlists - 1 && threadIdx.x == 0) p.ctl->cnt_total = dst + n;
     const size_t src = list_slot(l, G, p.ntiles);
     for (unsigned i = threadIdx.x; i < n; i += SWG) {
       if (MODE == DCTZHIP_EC) p.ac[dst + i] = p.ac_tmp[src + i];
@@ -984,32 +970,50 @@ __global__ __launch_bounds__(SWG) void k_compact_ac(FwdParams<T> p, double eb, u
 
 // =============================================================== decompress ==
 // Decode side, step 1: per-TILE count of "stored exactly" flags (bin id 255 at j != 0,
-// dctz-decomp-lib.c:400 / :446), 1 byte per element read.  One 256-thread workgroup per tile and trip.
-__global__ __launch_bounds__(SWG) void k_count_tiles(const uint8_t* __restrict__ bin, unsigned nfull, unsigned ntiles,
-                                                     unsigned* __restrict__ tile_cnt) {
+// dctz-decomp-lib.c:400 / :446), 1 byte per element read, and the sum of the counts over the tile range of
+// every workgroup of k_decompress (same partition: workgroup b here <-> workgroup b there), so that
+// k_decompress finds the start of its piece of AC_exact by adding up at most a thousand words -- no scan kernel.
+// A wave takes whole tiles (4 x 1 KiB coalesced rows, plain loads: k_decompress re-reads these lines from the
+// Infinity Cache); no workgroup barrier per tile.
+__global__ __launch_bounds__(SWG) void k_count_tiles(const uint8_t* __restrict__ bin, unsigned nfull, unsigned ntiles, unsigned nwg,
+                                                     unsigned* __restrict__ tile_cnt, unsigned* __restrict__ wg_cnt) {
   __shared__ unsigned part[SWG / 64];
-  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-  for (unsigned tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-    const size_t o = (size_t)tile * TILE_ELEMS + (size_t)t * 16;       // thread t: 16 bytes of block t / 4
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const TileRange tr = tile_range(blockIdx.x, nwg, ntiles);
+  const size_t end = (size_t)nfull * 64;
+  unsigned acc = 0;                                                    // this wave's share of the workgroup's count (uniform)
+  for (unsigned tile = tr.lo + (unsigned)wave; tile < tr.hi; tile += SWG / 64) {
+    const size_t o = (size_t)tile * TILE_ELEMS + (size_t)lane * 16;
     unsigned c = 0;
-    if (o < (size_t)nfull * 64) {
-      const uint4 wv = *reinterpret_cast<const uint4*>(bin + o);      // plain loads: k_decompress re-reads these lines from the Infinity Cache
-      const unsigned w[4] = {wv.x, wv.y, wv.z, wv.w};
+    uint4 wv[4];
 #pragma unroll
-      for (int i = 0; i < 16; i++)
-        if (((w[i >> 2] >> (8 * (i & 3))) & 255u) == 255u && !((t & 3) == 0 && i == 0)) c++;
+    for (int i = 0; i < 4; i++) {
+      wv[i] = make_uint4(0u, 0u, 0u, 0u);                              // (a zero word has no 255 byte)
+      if (o + (size_t)i * 1024 < end) wv[i] = *reinterpret_cast<const uint4*>(bin + o + (size_t)i * 1024);
     }
 #pragma unroll
-    for (int d = 32; d > 0; d >>= 1) c += __shfl_down(c, d);
-    __syncthreads();                                                   // part[] of the previous trip is consumed
-    if (lane == 0) part[wave] = c;
-    __syncthreads();
-    if (t == 0) {
-      unsigned sum = 0;
+    for (int i = 0; i < 4; i++) {
+      const unsigned w[4] = {wv[i].x, wv[i].y, wv[i].z, wv[i].w};
 #pragma unroll
-      for (int w = 0; w < SWG / 64; w++) sum += part[w];
-      tile_cnt[tile] = sum;
+      for (int k = 0; k < 4; k++) {
+        const unsigned v = ~w[k];                                      // a zero byte of v <=> bin id 255
+        const unsigned z = ((v & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | v;      // bit 7 of a byte set <=> that byte of v is non-zero
+        unsigned m = ~z & 0x80808080u;
+        if (k == 0 && (lane & 3) == 0) m &= ~0x80u;                    // byte 0 of every 64: j = 0, the DC slot (:392 / :438)
+        c += (unsigned)__popc(m);
+      }
     }
+    const unsigned tot = (unsigned)__builtin_amdgcn_readlane((int)wave_incl_scan(c), 63);
+    if (lane == 0) tile_cnt[tile] = tot;
+    acc += tot;
+  }
+  if (lane == 0) part[wave] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    unsigned sum = 0;
+#pragma unroll
+    for (int w = 0; w < SWG / 64; w++) sum += part[w];
+    wg_cnt[blockIdx.x] = sum;
   }
 }
 
@@ -1035,8 +1039,11 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(PH))) void k
   const __amdgpu_buffer_rsrc_t r_out = __builtin_amdgcn_make_buffer_rsrc(p.out + first_el, 0, range_el * (int)sizeof(T), 0x00020000);
   const __amdgpu_buffer_rsrc_t r_bin = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(p.bin + first_el), 0, range_el, 0x00020000);
   const __amdgpu_buffer_rsrc_t r_dc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.dc + first_el / 64), 0, range_el / 64 * 4, 0x00020000);
-  // AC_exact behind a descriptor based at this workgroup's first exact coefficient (32-bit offsets stay small for any N)
-  const unsigned S_wg = tr.lo < tr.hi ? p.tile_off[tr.lo] : 0u;
+  // AC_exact behind a descriptor based at this workgroup's first exact coefficient (32-bit offsets stay small for any N):
+  // the running pos of dctz-decomp-lib.c:402-412 at the workgroup's first tile = the counts of all workgroups before it
+  unsigned before = 0;
+  for (unsigned i = (unsigned)lane; i < blockIdx.x; i += WG) before += p.wg_cnt[i];
+  const unsigned S_wg = (unsigned)__builtin_amdgcn_readlane((int)wave_incl_scan(before), 63);
   const size_t ac_left = S_wg < p.ac_count ? (size_t)(p.ac_count - S_wg) * 4 : 0;
   const __amdgpu_buffer_rsrc_t r_ac = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.ac + (ac_left ? S_wg : 0u)), 0, (int)min(ac_left, (size_t)0x7ffffffc), 0x00020000);
   TileMap<T, PH> tm;
@@ -1056,14 +1063,16 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(PH))) void k
   u32x4 bw[4];
   float dcv = 0.f;
   unsigned S = 0, total = 0;                          // first exact coefficient of the tile / how many (uniform)
+  unsigned S_next = S_wg;                             // ... of the tile to be prefetched next
   auto prefetch = [&](unsigned tile) {
     const unsigned rel = tile - tr.lo;
     const int vo = (int)(rel * (unsigned)TILE_ELEMS) + lane * 64;
 #pragma unroll
     for (int i = 0; i < 4; i++) bw[i] = __builtin_amdgcn_raw_buffer_load_b128(r_bin, vo + i * 16, 0, 0);
     dcv = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r_dc, (int)(rel * 64u + (unsigned)lane) * 4, 0, 0));
-    S = __builtin_amdgcn_readfirstlane(p.tile_off[tile]);
-    total = __builtin_amdgcn_readfirstlane(p.tile_off[tile + 1]) - S;
+    S = S_next;
+    total = __builtin_amdgcn_readfirstlane(p.tile_cnt[tile]);
+    S_next = S + total;
     if (total <= (unsigned)DEC_EXC_CAP) {
 #pragma unroll
       for (int i = 0; i < DEC_EXC_CAP / 256; i++)
@@ -1158,7 +1167,9 @@ __global__ __launch_bounds__(64) void k_decompress_rem(InvParams<T> p, int l) {
   const bool exc = (k < l) && (k != 0) && (b == 255u);
   const unsigned long long m = __ballot(exc);
   const unsigned rank = (unsigned)__popcll(m & ((1ull << k) - 1ull));
-  const unsigned start = p.tile_off[p.ntiles];
+  unsigned before = 0;                                             // everything the full blocks consumed
+  for (unsigned i = (unsigned)k; i < p.nwg; i += 64) before += p.wg_cnt[i];
+  const unsigned start = (unsigned)__builtin_amdgcn_readlane((int)wave_incl_scan(before), 63);
   cr[k] = T(0); ci[k] = T(0); cr[k + 64] = T(0); ci[k + 64] = T(0);
   if (k < l) {
     T val;
@@ -1340,7 +1351,8 @@ void launch_stats_final(const double* part, int nparts, double* out, hipStream_t
   hipLaunchKernelGGL(k_stats_final, dim3(1), dim3(SWG), 0, s, part, nparts, out, (HostBox*)nullptr, 0ull);
 }
 void launch_finish(Ctl* ctl, const double* part, int nparts, HostBox* box, unsigned long long seq, hipStream_t s) {
-  hipLaunchKernelGGL(k_finish, dim3(1), dim3(SWG), 0, s, ctl, part, nparts, box, seq);
+  const FinArgs f = {ctl, part, nparts, box, seq};
+  hipLaunchKernelGGL(k_finish, dim3(1), dim3(SWG), 0, s, f);
 }
 
 template <typename T>
@@ -1385,12 +1397,8 @@ void launch_qt_max(const FwdParams<T>& p, unsigned nlists, int grid, hipStream_t
   hipLaunchKernelGGL(k_qt_max<T>, dim3(grid), dim3(SWG), 0, s, p, nlists);
 }
 
-void launch_scan_tiles(const unsigned* cnt, unsigned* off, unsigned n, Ctl* ctl, hipStream_t s) {
-  hipLaunchKernelGGL(k_scan_tiles, dim3(1), dim3(1024), 0, s, cnt, off, n, ctl);
-}
-
-void launch_count_tiles(const uint8_t* bin, unsigned nfull, unsigned ntiles, unsigned* tile_cnt, int grid, hipStream_t s) {
-  hipLaunchKernelGGL(k_count_tiles, dim3(grid), dim3(SWG), 0, s, bin, nfull, ntiles, tile_cnt);
+void launch_count_tiles(const uint8_t* bin, unsigned nfull, unsigned ntiles, unsigned nwg, unsigned* tile_cnt, unsigned* wg_cnt, hipStream_t s) {
+  hipLaunchKernelGGL(k_count_tiles, dim3(nwg), dim3(SWG), 0, s, bin, nfull, ntiles, nwg, tile_cnt, wg_cnt);
 }
 
 template <typename T>

@@ -44,7 +44,7 @@ struct dctzhip_ctx {
   float* ac_tmp = nullptr;          // workgroup-local AC_exact lists (list of workgroup b at the slot of its first tile)
   size_t ac_tmp_cap = 0;            // floats
   unsigned* tile_cnt = nullptr;     // list lengths (compress) / per-tile flag counts (decode) and their exclusive prefix
-  unsigned* tile_off = nullptr;
+  unsigned* wg_cnt = nullptr;       // decode: flag counts per workgroup of k_decompress
   size_t tile_cap = 0;              // entries
   void* ovf = nullptr;              // k_compress overflow strips (dctz_device.h: FwdParams::ovf), sized for the largest grid
   uint8_t* ovf_j = nullptr;
@@ -174,7 +174,7 @@ extern "C" void dctzhip_ctx_destroy(dctzhip_ctx* c) {
   (void)dctzhip_comm_destroy(c);
   (void)hipStreamSynchronize(c->stream);
   if (c->side_stream) { (void)hipStreamSynchronize(c->side_stream); (void)hipStreamDestroy(c->side_stream); }
-  void* bufs[] = {c->ovf, c->ovf_j, c->ac_tmp, c->tile_cnt, c->tile_off, c->serial_out, c->tab_f64, c->tab_f32, c->rtab, c->qtab, c->ctl, c->part, c->stats_out, c->qt_item, c->qt_j};
+  void* bufs[] = {c->ovf, c->ovf_j, c->ac_tmp, c->tile_cnt, c->wg_cnt, c->serial_out, c->tab_f64, c->tab_f32, c->rtab, c->qtab, c->ctl, c->part, c->stats_out, c->qt_item, c->qt_j};
   for (void* b : bufs) if (b) (void)hipFree(b);
   if (c->h_pin) (void)hipHostFree(c->h_pin);
   if (c->box) (void)hipHostFree(c->box);
@@ -292,7 +292,7 @@ static int ensure_scratch(dctzhip_ctx* c, size_t n, int dtype, int mode, bool co
   {
     size_t cap = c->tile_cap;
     if ((rc = regrow(c, &c->tile_cnt, &cap, entries, sizeof(unsigned)))) return rc;
-    if ((rc = regrow(c, &c->tile_off, &c->tile_cap, entries, sizeof(unsigned)))) return rc;
+    if ((rc = regrow(c, &c->wg_cnt, &c->tile_cap, entries, sizeof(unsigned)))) return rc;
   }
   if (!compress) return DCTZHIP_OK;
   if (!c->ovf) {                                       // 64 x 64 items per workgroup, 8 workgroups per CU at most
@@ -425,7 +425,6 @@ static int compress_pass(dctzhip_ctx* c, const T* d_in, size_t n, double eb, int
   p.ovf = c->ovf; p.ovf_j = c->ovf_j;
   p.ac_tmp = c->ac_tmp;
   p.tile_cnt = c->tile_cnt;
-  p.tile_off = c->tile_off;
   p.tab = tab_of<T>(c); p.rtab = reinterpret_cast<const T*>(c->rtab);
   p.ctl = c->ctl;
   p.stat_part = fused ? c->part : nullptr;
@@ -461,8 +460,7 @@ static int compress_pass(dctzhip_ctx* c, const T* d_in, size_t n, double eb, int
   // stitch the workgroup-local lists into AC_exact[]
   const unsigned nlists = (unsigned)grid + (rem ? 1u : 0u);
   if (mode == DCTZHIP_QT) launch_qt_max<T>(p, nlists, (int)(nlists < 1024u ? nlists : 1024u), s);   // :371-372 over the lists
-  launch_scan_tiles(c->tile_cnt, c->tile_off, nlists, c->ctl, s);
-  launch_compact_ac<T>(p, mode, eb, nlists, (int)nlists, s);
+  launch_compact_ac<T>(p, mode, eb, nlists, (int)nlists, s);    // (finds the place of every list itself: no scan kernel)
   if (seq) launch_finish(c->ctl, c->part, fused ? (int)nlists : 0, c->box_dev, seq, s);   // results -> host box, Ctl -> 0
   else if (fused) launch_stats_final(c->part, (int)nlists, c->stats_out, s);
   if (c->profiling) HIPCHK(c, hipEventRecord(c->ev[4], s));
@@ -737,7 +735,7 @@ static int decompress_impl(dctzhip_ctx* c, const uint8_t* d_bin, const float* d_
   p.bin = d_bin; p.dc = d_dc; p.ac = d_ac; p.out = d_out;
   p.tab = tab_of<T>(c); p.rtab = reinterpret_cast<const T*>(c->rtab); p.qtab = reinterpret_cast<const T*>(c->qtab);
   p.ctl = c->ctl;
-  p.tile_off = c->tile_off;
+  p.tile_cnt = c->tile_cnt; p.wg_cnt = c->wg_cnt;
   p.nfull = nfull; p.ntiles = ntiles; p.ac_count = ac_count;
   p.sf = (T)sf;
   // gen_bins / gen_bins_f (binning.c:17 / :37): bin_width = error_bound*2*BRSF in
@@ -750,10 +748,10 @@ static int decompress_impl(dctzhip_ctx* c, const uint8_t* d_bin, const float* d_
 
   const unsigned cap = (unsigned)(c->num_cu * wg_per_cu<T>(c, true, mode));
   const int grid = (int)(cap < ntiles ? cap : ntiles);
+  p.nwg = (unsigned)grid;
   if (c->profiling) HIPCHK(c, hipEventRecord(c->ev[0], s));
-  // per-tile counts of "stored exactly" flags -> exclusive prefix: where every tile's piece of AC_exact starts
-  if (ntiles) launch_count_tiles(d_bin, nfull, ntiles, c->tile_cnt, (int)(ntiles < (unsigned)(c->num_cu * 8) ? ntiles : (unsigned)(c->num_cu * 8)), s);
-  launch_scan_tiles(c->tile_cnt, c->tile_off, ntiles, c->ctl, s);
+  // counts of "stored exactly" flags per tile and per workgroup of k_decompress: where every piece of AC_exact starts
+  if (ntiles) launch_count_tiles(d_bin, nfull, ntiles, p.nwg, c->tile_cnt, c->wg_cnt, s);
   if (c->profiling) { HIPCHK(c, hipEventRecord(c->ev[1], s)); HIPCHK(c, hipEventRecord(c->ev[2], s)); }
   if (ntiles) launch_decompress<T>(p, mode, grid, s);
   if (c->profiling) HIPCHK(c, hipEventRecord(c->ev[3], s));

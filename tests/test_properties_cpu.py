@@ -13,7 +13,9 @@ from dctz_amd import shard
 from tests.noise import classify_flips
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-SET = dict(max_examples=40, deadline=None, suppress_health_check=[HealthCheck.too_slow])
+# derandomize: the same examples on every run (a CPU suite that is red one run in ten tells nobody anything);
+# widen with HYPOTHESIS_SEED-style exploration by flipping it locally
+SET = dict(max_examples=60, deadline=None, derandomize=True, suppress_health_check=[HealthCheck.too_slow])
 
 
 def _field(seed, n, amp, noise):
@@ -37,10 +39,20 @@ def test_oracle_stream_invariants_and_error_bound(seed, n, log_amp, noise, eb, m
     m = np.abs(x).max()
     if m > 0 and np.isfinite(c.sf) and c.sf > 0:
         assert 0.99 <= np.abs(c.scaled).max() <= 10.0 * (1 + 1e-6)
-    # round trip: orthonormal transform, so the l2 error per block is bounded by the bin width
+    # round trip: orthonormal transform, so an element's error is at most the l2 norm of the block's coefficient
+    # errors: <= eb for each of the 63 binned coefficients, plus what USE_TRUNCATE costs -- DC and AC_exact are stored
+    # as float (dctz-comp-lib.c:350-351, :535-537): 2^-24 relative, in l2 at most 2^-24 * ||block|| <= 2^-24 * 8 *
+    # max|scaled|.  That term does not shrink with eb (at eb = 1e-6 it is the larger one).  QT stores an out-of-range
+    # coefficient as (item / q) * 10 eb + range_max in float (:488-518), so the float's rounding (2^-24 * 265 eb) comes
+    # back multiplied by q / (10 eb): 2^-24 * 26.5 * q per coefficient -- the reference's QT mode does not keep the
+    # user's bound at small eb, and neither does a faithful restatement.
     r = O.decompress(c, O.FAST)
     err = np.abs(r.astype(np.float64) - c.scaled.astype(np.float64) * c.sf)
-    tol = 8.5 * eb * c.sf * (1.0 if dtype == np.float64 else 1.5) + (0 if dtype == np.float64 else 2e-6 * m * 64)
+    smax = float(np.abs(c.scaled).max()) if n else 0.0
+    trunc = 2.0 ** -24 * 8.0 * smax
+    if mode == O.QT:
+        trunc += 2.0 ** -24 * 26.5 * float(np.linalg.norm(np.asarray(c.qtable, dtype=np.float64)[1:]))
+    tol = (np.sqrt(63.0) * eb * 1.07 + trunc) * c.sf * (1.0 if dtype == np.float64 else 1.5) + (0 if dtype == np.float64 else 2e-6 * m * 64)
     assert err.max() <= tol, (err.max(), tol)
     # the fast flow and the definition-order flow agree to rounding: coefficients within the noise bound, and a bin
     # id may differ only where that noise reaches a bin edge or the range limit (tests/noise.py).  How MANY flip is
