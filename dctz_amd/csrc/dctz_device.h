@@ -75,7 +75,8 @@ template <typename T, int PHASES = 1> struct Geo {
 template <typename T> struct Phases { static constexpr int C = 1, D = 1; };
 template <> struct Phases<double> { static constexpr int C = DCTZ_PHC64, D = DCTZ_PHD64; };
 
-// Per-call control block in device memory; left all-zero by the last kernel of every call.
+// Per-call control block in device memory; zeroed by the first kernel of every compress call (k_stats_final) --
+// a decode call only ever sets `error`, and the host clears the block after a failed call.
 struct Ctl {
   unsigned pad_ticket;
   unsigned cnt_total;              // exceptions emitted / consumed so far
@@ -101,7 +102,8 @@ struct HostBox {
   double psnr[6];                          // calc_psnr reduction: min, max, sum e^2, max |e|, max |e/x| (k_psnr_final)
 };
 
-// What k_finish, the last kernel of a call, needs for the hand-off to the host.
+// What the hand-off of a call's results to the host needs (k_finish, or the first workgroup of k_compact_ac /
+// k_decompress; box == NULL there: no hand-off in that kernel).
 struct FinArgs {
   Ctl* ctl;
   const double* part;              // fused statistics partials ({max|x|, min|x|, sum} per slot), nparts of them (0: none)
@@ -154,9 +156,9 @@ struct InvParams {
 };
 
 template <typename T> void launch_stats(const T* x, size_t n, double* part, int nparts, double* out, hipStream_t s,
-                                        HostBox* box = nullptr, unsigned long long seq = 0);
+                                        HostBox* box = nullptr, unsigned long long seq = 0, Ctl* zero = nullptr);
 template <typename T> void launch_stats_sample(const T* x, size_t n, unsigned group, double* part, int nparts, double* out, hipStream_t s,
-                                               HostBox* box = nullptr, unsigned long long seq = 0);
+                                               HostBox* box = nullptr, unsigned long long seq = 0, Ctl* zero = nullptr);
 void launch_stats_final(const double* part, int nparts, double* out, hipStream_t s);
 void launch_finish(Ctl* ctl, const double* part, int nparts, HostBox* box, unsigned long long seq, hipStream_t s);
 template <typename T> void launch_debug_divide(const T* x, size_t n, T d, int ok, T* fast, T* ref, hipStream_t s);
@@ -165,9 +167,9 @@ template <typename T> void launch_scale(const T* x, T* out, size_t n, T sf, int 
 template <typename T> void launch_compress(const FwdParams<T>& p, int mode, bool stats, int grid, hipStream_t s);
 template <typename T> void launch_compress_rem(const FwdParams<T>& p, int mode, bool scale, int l, hipStream_t s);
 template <typename T> void launch_qt_max(const FwdParams<T>& p, unsigned nlists, int grid, hipStream_t s);
-template <typename T> void launch_compact_ac(const FwdParams<T>& p, int mode, double eb, unsigned nlists, int grid, hipStream_t s);
+template <typename T> void launch_compact_ac(const FwdParams<T>& p, int mode, double eb, unsigned nlists, int grid, const FinArgs& fin, hipStream_t s);
 void launch_count_tiles(const uint8_t* bin, unsigned nfull, unsigned ntiles, unsigned nwg, unsigned* tile_cnt, unsigned* wg_cnt, hipStream_t s);
-template <typename T> void launch_decompress(const InvParams<T>& p, int mode, int grid, hipStream_t s);
+template <typename T> void launch_decompress(const InvParams<T>& p, int mode, int grid, const FinArgs& fin, hipStream_t s);
 template <typename T> void launch_decompress_rem(const InvParams<T>& p, int mode, bool scale, int l, hipStream_t s);
 template <typename T> void launch_dct_blocks(const T* x, T* out, const T* gtab, const T* rtab, size_t n,
                                              bool inverse, int grid, hipStream_t s);

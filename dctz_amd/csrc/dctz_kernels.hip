@@ -393,17 +393,31 @@ __device__ __forceinline__ void stats_final_body(const double* part, int nparts,
   }
 }
 
+// zero != NULL: also the first kernel-side act of a compress call -- the control block back to all-zero (the
+// per-position maxima of the QT table accumulate with atomicMax, :371-372)
 __global__ __launch_bounds__(SWG) void k_stats_final(const double* part, int nparts, double* out,
-                                                    HostBox* box, unsigned long long seq) {
+                                                    HostBox* box, unsigned long long seq, Ctl* zero) {
+  if (zero != nullptr) {
+    unsigned long long* w = reinterpret_cast<unsigned long long*>(zero);
+    for (int i = threadIdx.x; i < (int)(sizeof(Ctl) / 8); i += SWG) w[i] = 0ull;
+  }
   stats_final_body(part, nparts, out, box, seq);
 }
 
-// Last kernel of a compress / decompress call (one workgroup): final reduction of the fused statistics (nparts > 0),
-// results -> host box, control block back to all-zero for the next call, then the sequence number.  (Folding this
-// into the last workgroup of the preceding kernel to finish was measured and dropped: the agent-scope release fence
-// every workgroup then needs writes back the whole L2 of its XCD -- k_decompress 0.214 -> 0.272 ms, DESIGN.md.)
+// Hand-off of a call's results to the host, by ONE workgroup: final reduction of the fused statistics (nparts > 0),
+// results -> host box, then the sequence number.  Everything it reads was written by EARLIER kernels of the call, so it
+// runs in the first workgroup of the call's last big kernel (k_compact_ac / k_decompress) as soon as that kernel
+// starts: the host gets its few words while the GPU is still busy and has the next call's launches queued by the time
+// the stream drains (results are complete in STREAM order, as with any asynchronous launch).  k_finish is the same
+// hand-off as a kernel of its own, for the calls whose last kernel is a different one (remainder block on decode).
+// (Folding it into the workgroup that FINISHES last was measured and dropped: the agent-scope release fence every
+// workgroup then needs writes back the whole L2 of its XCD -- k_decompress 0.214 -> 0.272 ms, DESIGN.md.)
+struct FinBody : FinArgs {
+  bool cnt_known, err_known;       // the caller has computed tot_AC_exact_count / the error flag itself (else: from the control block)
+  unsigned cnt_total, error;
+};
 template <bool WITH_STATS>
-__device__ __forceinline__ void finish_body(const FinArgs& f) {
+__device__ __forceinline__ void finish_body(const FinBody& f) {
   const int t = threadIdx.x;
   Ctl* ctl = f.ctl;
   HostBox* box = f.box;
@@ -412,16 +426,22 @@ __device__ __forceinline__ void finish_body(const FinArgs& f) {
     reduce_parts(f.part, f.nparts, dmx, dmn, sum);
     if (t == 0) { box->fstats[0] = dmx; box->fstats[1] = dmn; box->fstats[2] = sum; }
   }
-  for (int i = t; i < 64; i += (int)blockDim.x) box->qraw[i] = ctl->qraw[i];
-  if (t == 0) { box->cnt_total = ctl->cnt_total; box->error = ctl->error; box->q0 = ctl->q0; }
+  if (WITH_STATS) {                                  // (compress side: the QT table's raw maxima, the last block's DC)
+    for (int i = t; i < 64; i += (int)blockDim.x) box->qraw[i] = ctl->qraw[i];
+    if (t == 0) box->q0 = ctl->q0;
+  }
+  if (t == 0) { box->cnt_total = f.cnt_known ? f.cnt_total : ctl->cnt_total; box->error = f.err_known ? f.error : ctl->error; }
   __threadfence_system();
-  __syncthreads();                                   // all box writes issued and fenced; all ctl reads done
-  unsigned long long* w = reinterpret_cast<unsigned long long*>(ctl);
-  for (int i = t; i < (int)(sizeof(Ctl) / 8); i += (int)blockDim.x) w[i] = 0ull;
+  __syncthreads();                                   // all box writes issued and fenced
   if (t == 0) box_publish(&box->seq_done, f.seq);
 }
 
-__global__ __launch_bounds__(SWG) void k_finish(FinArgs f) { finish_body<true>(f); }
+__global__ __launch_bounds__(SWG) void k_finish(FinArgs a) {
+  FinBody f;
+  f.ctl = a.ctl; f.part = a.part; f.nparts = a.nparts; f.box = a.box; f.seq = a.seq;
+  f.cnt_known = false; f.err_known = false; f.cnt_total = 0; f.error = 0;
+  finish_body<true>(f);
+}
 
 // Sampled statistics for the speculative path: one 4 KiB chunk out of every group of
 // `group` chunks, at a hashed position inside the group (a fixed stride would alias with
@@ -937,9 +957,9 @@ __device__ __forceinline__ unsigned block_sum(unsigned v, unsigned* sh) {
 // QT: clamp the table (:450-461) and normalise on the way (:488-518).
 // The place of list l -- the running tot_AC_exact_count of :478-544 in front of it -- is the sum of the lengths of the
 // lists before it: at most 2049 of them, summed by the workgroup itself (no scan kernel); the workgroup of the last
-// list leaves the total.
+// list leaves the total.  fin.box set: workgroup 0 hands the call's results to the host first (finish_body).
 template <typename T, int MODE>
-__global__ __launch_bounds__(SWG) void k_compact_ac(FwdParams<T> p, double eb, unsigned nlists) {
+__global__ __launch_bounds__(SWG) void k_compact_ac(FwdParams<T> p, double eb, unsigned nlists, FinArgs fin) {
   using Bits = typename Traits<T>::Bits;
   __shared__ T q[64];
   __shared__ unsigned sh[SWG / 64];
@@ -950,6 +970,15 @@ __global__ __launch_bounds__(SWG) void k_compact_ac(FwdParams<T> p, double eb, u
       q[threadIdx.x] = v;
     }
     __syncthreads();
+  }
+  if (fin.box != nullptr && blockIdx.x == 0) {
+    unsigned all = 0;
+    for (unsigned i = threadIdx.x; i < nlists; i += SWG) all += p.tile_cnt[i];
+    FinBody f;
+    f.ctl = fin.ctl; f.part = fin.part; f.nparts = fin.nparts; f.box = fin.box; f.seq = fin.seq;
+    f.cnt_known = true; f.cnt_total = block_sum(all, sh);                // tot_AC_exact_count (:478-544)
+    f.err_known = true; f.error = 0;
+    finish_body<true>(f);
   }
   const unsigned G = p.nlists_main;
   for (unsigned l = blockIdx.x; l < nlists; l += gridDim.x) {
@@ -1025,7 +1054,7 @@ template <typename T>
 size_t decompress_lds_bytes() { return (size_t)Geo<T, Phases<T>::D>::PHB + 256 * sizeof(T) + DEC_EXC_CAP * 4 + 64 * sizeof(T); }
 
 template <typename T, int MODE, int PH>
-__global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(PH))) void k_decompress(InvParams<T> p) {
+__global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(PH))) void k_decompress(InvParams<T> p, FinArgs fin) {
   using G = Geo<T, PH>;
   __shared__ __attribute__((aligned(1024))) unsigned char outbuf[G::PHB];
   __shared__ __attribute__((aligned(16))) T bctab[256];               // bin_center[] of gen_bins
@@ -1044,6 +1073,18 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(PH))) void k
   unsigned before = 0;
   for (unsigned i = (unsigned)lane; i < blockIdx.x; i += WG) before += p.wg_cnt[i];
   const unsigned S_wg = (unsigned)__builtin_amdgcn_readlane((int)wave_incl_scan(before), 63);
+  if (fin.box != nullptr && blockIdx.x == 0) {
+    // the one thing the host waits for on decode: does the stream promise more exact coefficients than the caller
+    // provides (all counts are in: k_count_tiles)?  Known before the first block is rebuilt -> hand it over now.
+    unsigned all = 0;
+    for (unsigned i = (unsigned)lane; i < p.nwg; i += WG) all += p.wg_cnt[i];
+    all = (unsigned)__builtin_amdgcn_readlane((int)wave_incl_scan(all), 63);
+    FinBody f;
+    f.ctl = fin.ctl; f.part = nullptr; f.nparts = 0; f.box = fin.box; f.seq = fin.seq;
+    f.cnt_known = true; f.cnt_total = all;
+    f.err_known = true; f.error = all > p.ac_count ? 2u : 0u;
+    finish_body<false>(f);
+  }
   const size_t ac_left = S_wg < p.ac_count ? (size_t)(p.ac_count - S_wg) * 4 : 0;
   const __amdgpu_buffer_rsrc_t r_ac = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.ac + (ac_left ? S_wg : 0u)), 0, (int)min(ac_left, (size_t)0x7ffffffc), 0x00020000);
   TileMap<T, PH> tm;
@@ -1336,19 +1377,19 @@ __global__ __launch_bounds__(SWG) void k_psnr_final(const double* __restrict__ p
 
 // ================================================================= launchers ==
 template <typename T>
-void launch_stats(const T* x, size_t n, double* part, int nparts, double* out, hipStream_t s, HostBox* box, unsigned long long seq) {
+void launch_stats(const T* x, size_t n, double* part, int nparts, double* out, hipStream_t s, HostBox* box, unsigned long long seq, Ctl* zero) {
   hipLaunchKernelGGL(k_stats<T>, dim3(nparts), dim3(SWG), 0, s, x, n, part);
-  hipLaunchKernelGGL(k_stats_final, dim3(1), dim3(SWG), 0, s, (const double*)part, nparts, out, box, seq);
+  hipLaunchKernelGGL(k_stats_final, dim3(1), dim3(SWG), 0, s, (const double*)part, nparts, out, box, seq, zero);
 }
 
 template <typename T>
 void launch_stats_sample(const T* x, size_t n, unsigned group, double* part, int nparts, double* out, hipStream_t s,
-                         HostBox* box, unsigned long long seq) {
+                         HostBox* box, unsigned long long seq, Ctl* zero) {
   hipLaunchKernelGGL(k_stats_sample<T>, dim3(nparts), dim3(SWG), 0, s, x, n, group, part);
-  hipLaunchKernelGGL(k_stats_final, dim3(1), dim3(SWG), 0, s, (const double*)part, nparts, out, box, seq);
+  hipLaunchKernelGGL(k_stats_final, dim3(1), dim3(SWG), 0, s, (const double*)part, nparts, out, box, seq, zero);
 }
 void launch_stats_final(const double* part, int nparts, double* out, hipStream_t s) {
-  hipLaunchKernelGGL(k_stats_final, dim3(1), dim3(SWG), 0, s, part, nparts, out, (HostBox*)nullptr, 0ull);
+  hipLaunchKernelGGL(k_stats_final, dim3(1), dim3(SWG), 0, s, part, nparts, out, (HostBox*)nullptr, 0ull, (Ctl*)nullptr);
 }
 void launch_finish(Ctl* ctl, const double* part, int nparts, HostBox* box, unsigned long long seq, hipStream_t s) {
   const FinArgs f = {ctl, part, nparts, box, seq};
@@ -1402,15 +1443,15 @@ void launch_count_tiles(const uint8_t* bin, unsigned nfull, unsigned ntiles, uns
 }
 
 template <typename T>
-void launch_compact_ac(const FwdParams<T>& p, int mode, double eb, unsigned nlists, int grid, hipStream_t s) {
-  if (mode == DCTZHIP_EC) hipLaunchKernelGGL((k_compact_ac<T, DCTZHIP_EC>), dim3(grid), dim3(SWG), 0, s, p, eb, nlists);
-  else hipLaunchKernelGGL((k_compact_ac<T, DCTZHIP_QT>), dim3(grid), dim3(SWG), 0, s, p, eb, nlists);
+void launch_compact_ac(const FwdParams<T>& p, int mode, double eb, unsigned nlists, int grid, const FinArgs& fin, hipStream_t s) {
+  if (mode == DCTZHIP_EC) hipLaunchKernelGGL((k_compact_ac<T, DCTZHIP_EC>), dim3(grid), dim3(SWG), 0, s, p, eb, nlists, fin);
+  else hipLaunchKernelGGL((k_compact_ac<T, DCTZHIP_QT>), dim3(grid), dim3(SWG), 0, s, p, eb, nlists, fin);
 }
 
 template <typename T>
-void launch_decompress(const InvParams<T>& p, int mode, int grid, hipStream_t s) {
-  if (mode == DCTZHIP_EC) hipLaunchKernelGGL((k_decompress<T, DCTZHIP_EC, Phases<T>::D>), dim3(grid), dim3(WG), 0, s, p);
-  else hipLaunchKernelGGL((k_decompress<T, DCTZHIP_QT, Phases<T>::D>), dim3(grid), dim3(WG), 0, s, p);
+void launch_decompress(const InvParams<T>& p, int mode, int grid, const FinArgs& fin, hipStream_t s) {
+  if (mode == DCTZHIP_EC) hipLaunchKernelGGL((k_decompress<T, DCTZHIP_EC, Phases<T>::D>), dim3(grid), dim3(WG), 0, s, p, fin);
+  else hipLaunchKernelGGL((k_decompress<T, DCTZHIP_QT, Phases<T>::D>), dim3(grid), dim3(WG), 0, s, p, fin);
 }
 
 template <typename T>
@@ -1450,16 +1491,16 @@ void launch_psnr(const T* x, const T* r, size_t n, double* part, int nparts, dou
 
 // explicit instantiations used by dctz_shim.hip
 #define INST(T)                                                                                         \
-  template void launch_stats<T>(const T*, size_t, double*, int, double*, hipStream_t, HostBox*, unsigned long long); \
-  template void launch_stats_sample<T>(const T*, size_t, unsigned, double*, int, double*, hipStream_t, HostBox*, unsigned long long); \
+  template void launch_stats<T>(const T*, size_t, double*, int, double*, hipStream_t, HostBox*, unsigned long long, Ctl*); \
+  template void launch_stats_sample<T>(const T*, size_t, unsigned, double*, int, double*, hipStream_t, HostBox*, unsigned long long, Ctl*); \
   template void launch_debug_divide<T>(const T*, size_t, T, int, T*, T*, hipStream_t);                  \
   template void launch_serial_sum<T>(const T*, size_t, double*, hipStream_t);                           \
   template void launch_scale<T>(const T*, T*, size_t, T, int, hipStream_t);                             \
   template void launch_compress<T>(const FwdParams<T>&, int, bool, int, hipStream_t);                   \
   template void launch_compress_rem<T>(const FwdParams<T>&, int, bool, int, hipStream_t);               \
   template void launch_qt_max<T>(const FwdParams<T>&, unsigned, int, hipStream_t);                      \
-  template void launch_compact_ac<T>(const FwdParams<T>&, int, double, unsigned, int, hipStream_t);     \
-  template void launch_decompress<T>(const InvParams<T>&, int, int, hipStream_t);                       \
+  template void launch_compact_ac<T>(const FwdParams<T>&, int, double, unsigned, int, const FinArgs&, hipStream_t); \
+  template void launch_decompress<T>(const InvParams<T>&, int, int, const FinArgs&, hipStream_t);       \
   template void launch_decompress_rem<T>(const InvParams<T>&, int, bool, int, hipStream_t);             \
   template void launch_dct_blocks<T>(const T*, T*, const T*, const T*, size_t, bool, int, hipStream_t); \
   template void launch_psnr<T>(const T*, const T*, size_t, double*, int, double*, hipStream_t);         \

@@ -460,9 +460,12 @@ static int compress_pass(dctzhip_ctx* c, const T* d_in, size_t n, double eb, int
   // stitch the workgroup-local lists into AC_exact[]
   const unsigned nlists = (unsigned)grid + (rem ? 1u : 0u);
   if (mode == DCTZHIP_QT) launch_qt_max<T>(p, nlists, (int)(nlists < 1024u ? nlists : 1024u), s);   // :371-372 over the lists
-  launch_compact_ac<T>(p, mode, eb, nlists, (int)nlists, s);    // (finds the place of every list itself: no scan kernel)
-  if (seq) launch_finish(c->ctl, c->part, fused ? (int)nlists : 0, c->box_dev, seq, s);   // results -> host box, Ctl -> 0
-  else if (fused) launch_stats_final(c->part, (int)nlists, c->stats_out, s);
+  // (k_compact_ac finds the place of every list itself: no scan kernel.)  With the mailbox its first workgroup hands
+  // the call's results to the host as soon as the kernel starts -- all of them are in by then -- so the host is back in
+  // the caller, queueing the next call's launches, while the lists are still being moved
+  const FinArgs fin = {c->ctl, c->part, fused ? (int)nlists : 0, seq ? c->box_dev : nullptr, seq};
+  launch_compact_ac<T>(p, mode, eb, nlists, (int)nlists, fin, s);
+  if (!seq && fused) launch_stats_final(c->part, (int)nlists, c->stats_out, s);
   if (c->profiling) HIPCHK(c, hipEventRecord(c->ev[4], s));
   HIPCHK(c, hipGetLastError());
   return DCTZHIP_OK;
@@ -493,7 +496,7 @@ static int compress_impl(dctzhip_ctx* c, const T* d_in, size_t n, double eb, int
   const bool box = c->handoff != 0;
   HostBox* hb = c->box;
   auto reset = [&]() -> int {
-    if (!box || c->ctl_dirty) HIPCHK(c, hipMemsetAsync(c->ctl, 0, sizeof(Ctl), s));   // (k_finish leaves it zeroed)
+    if (!box || c->ctl_dirty) HIPCHK(c, hipMemsetAsync(c->ctl, 0, sizeof(Ctl), s));   // (else: k_stats_final zeroes it)
     c->ctl_dirty = 1;                               // until this call's k_finish has been seen
     return DCTZHIP_OK;
   };
@@ -505,13 +508,13 @@ static int compress_impl(dctzhip_ctx* c, const T* d_in, size_t n, double eb, int
   if (spec) {
     const size_t ngroups = n / chunk / c->spec_group;
     const int sgrid = (int)(ngroups < (size_t)c->stats_grid ? ngroups : (size_t)c->stats_grid);
-    launch_stats_sample<T>(d_in, n, c->spec_group, c->part, sgrid, c->stats_out, s, box ? c->box_dev : nullptr, seq);
+    launch_stats_sample<T>(d_in, n, c->spec_group, c->part, sgrid, c->stats_out, s, box ? c->box_dev : nullptr, seq, box ? c->ctl : nullptr);
   } else {
     const size_t nvec = n / Traits<T>::EPV;
     int sgrid = (int)((nvec + SWG * 4 - 1) / (SWG * 4));
     if (sgrid < 1) sgrid = 1;
     if (sgrid > c->stats_grid) sgrid = c->stats_grid;
-    launch_stats<T>(d_in, n, c->part, sgrid, c->stats_out, s, box ? c->box_dev : nullptr, seq);
+    launch_stats<T>(d_in, n, c->part, sgrid, c->stats_out, s, box ? c->box_dev : nullptr, seq, box ? c->ctl : nullptr);
   }
   if (c->profiling) HIPCHK(c, hipEventRecord(c->ev[1], s));
   HostStats st;
@@ -565,6 +568,7 @@ static int compress_impl(dctzhip_ctx* c, const T* d_in, size_t n, double eb, int
       c->spec_misses++;
       c->spec_cooldown = SPEC_COOLDOWN;
       flags |= DCTZHIP_INFO_RESPUN;
+      c->ctl_dirty = 1;                             // the first pass left its QT maxima behind
       int rc = reset();
       if (rc) return rc;
       if (box) seq = ++c->seq;
@@ -720,7 +724,7 @@ static int decompress_impl(dctzhip_ctx* c, const uint8_t* d_bin, const float* d_
   const int rem = (int)(n % 64);
   const unsigned ntiles = (nfull + TILE_BLKS - 1) / TILE_BLKS;
   const bool box = c->handoff != 0;                 // mailbox + spin instead of D2H copy + stream sync
-  if (!box || c->ctl_dirty) HIPCHK(c, hipMemsetAsync(c->ctl, 0, sizeof(Ctl), s));      // (k_finish leaves it zeroed)
+  if (!box || c->ctl_dirty) HIPCHK(c, hipMemsetAsync(c->ctl, 0, sizeof(Ctl), s));      // (a good call leaves `error` at zero)
   c->ctl_dirty = 1;
   if (mode == DCTZHIP_QT) {
     // staged through pinned memory that the NEXT call may rewrite: safe because every call ends with a host
@@ -753,11 +757,16 @@ static int decompress_impl(dctzhip_ctx* c, const uint8_t* d_bin, const float* d_
   // counts of "stored exactly" flags per tile and per workgroup of k_decompress: where every piece of AC_exact starts
   if (ntiles) launch_count_tiles(d_bin, nfull, ntiles, p.nwg, c->tile_cnt, c->wg_cnt, s);
   if (c->profiling) { HIPCHK(c, hipEventRecord(c->ev[1], s)); HIPCHK(c, hipEventRecord(c->ev[2], s)); }
-  if (ntiles) launch_decompress<T>(p, mode, grid, s);
+  const unsigned long long seq = box ? ++c->seq : 0ull;
+  // With the mailbox and no remainder block, the first workgroup of k_decompress tells the host at once whether the
+  // stream under-runs the caller's AC_exact (the counts are all in): the host is back in the caller while the
+  // reconstruction is being written -- complete in stream order, like any launch.  Otherwise k_finish does it.
+  const bool early = box && ntiles && !rem;
+  const FinArgs fin = {c->ctl, nullptr, 0, early ? c->box_dev : nullptr, seq};
+  if (ntiles) launch_decompress<T>(p, mode, grid, fin, s);
   if (c->profiling) HIPCHK(c, hipEventRecord(c->ev[3], s));
   if (rem) launch_decompress_rem<T>(p, mode, scale, rem, s);
-  const unsigned long long seq = box ? ++c->seq : 0ull;
-  if (box) launch_finish(c->ctl, nullptr, 0, c->box_dev, seq, s);
+  if (box && !early) launch_finish(c->ctl, nullptr, 0, c->box_dev, seq, s);
   if (c->profiling) HIPCHK(c, hipEventRecord(c->ev[4], s));
   HIPCHK(c, hipGetLastError());
   Ctl* hc = reinterpret_cast<Ctl*>(c->h_pin + PIN_CTL);
