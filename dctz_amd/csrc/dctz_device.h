@@ -8,6 +8,7 @@
 
 #include "../../include/dctz_hip.h"
 #include "dct64_block.h"
+#include "dct_nd_block.h"
 
 namespace dctz {
 
@@ -112,6 +113,14 @@ struct FinArgs {
   unsigned long long seq;
 };
 
+// A multi-dimensional array and its tile grid (dct_nd_block.h): nd = 2 -> 8 x 8 tiles, nd = 3 -> 4 x 4 x 4 tiles.
+struct NdShape {
+  int nd;
+  size_t d[3];                     // extents, last axis fastest
+  size_t nb[3];                    // tiles per axis = ceil(d / edge)
+  size_t nblk;                     // number of blocks = product of nb
+};
+
 template <typename T>
 struct FwdParams {
   const T* x;                      // input
@@ -159,17 +168,20 @@ template <typename T> void launch_stats(const T* x, size_t n, double* part, int 
                                         HostBox* box = nullptr, unsigned long long seq = 0, Ctl* zero = nullptr);
 template <typename T> void launch_stats_sample(const T* x, size_t n, unsigned group, double* part, int nparts, double* out, hipStream_t s,
                                                HostBox* box = nullptr, unsigned long long seq = 0, Ctl* zero = nullptr);
-void launch_stats_final(const double* part, int nparts, double* out, hipStream_t s);
+void launch_stats_final(const double* part, int nparts, double* out, hipStream_t s, HostBox* box = nullptr,
+                        unsigned long long seq = 0, Ctl* zero = nullptr);
 void launch_finish(Ctl* ctl, const double* part, int nparts, HostBox* box, unsigned long long seq, hipStream_t s);
 template <typename T> void launch_debug_divide(const T* x, size_t n, T d, int ok, T* fast, T* ref, hipStream_t s);
 template <typename T> void launch_serial_sum(const T* x, size_t n, double* out, hipStream_t s);
 template <typename T> void launch_scale(const T* x, T* out, size_t n, T sf, int grid, hipStream_t s);
-template <typename T> void launch_compress(const FwdParams<T>& p, int mode, bool stats, int grid, hipStream_t s);
+template <typename T> void launch_compress(const FwdParams<T>& p, int mode, bool stats, int grid, int geom, hipStream_t s);
+template <typename T> void launch_gather_nd(const T* x, T* lin, const NdShape& sh, double* part, int nparts, hipStream_t s);
+template <typename T> void launch_scatter_nd(const T* lin, T* out, const NdShape& sh, int grid, hipStream_t s);
 template <typename T> void launch_compress_rem(const FwdParams<T>& p, int mode, bool scale, int l, hipStream_t s);
 template <typename T> void launch_qt_max(const FwdParams<T>& p, unsigned nlists, int grid, hipStream_t s);
 template <typename T> void launch_compact_ac(const FwdParams<T>& p, int mode, double eb, unsigned nlists, int grid, const FinArgs& fin, hipStream_t s);
 void launch_count_tiles(const uint8_t* bin, unsigned nfull, unsigned ntiles, unsigned nwg, unsigned* tile_cnt, unsigned* wg_cnt, hipStream_t s);
-template <typename T> void launch_decompress(const InvParams<T>& p, int mode, int grid, const FinArgs& fin, hipStream_t s);
+template <typename T> void launch_decompress(const InvParams<T>& p, int mode, int grid, const FinArgs& fin, int geom, hipStream_t s);
 template <typename T> void launch_decompress_rem(const InvParams<T>& p, int mode, bool scale, int l, hipStream_t s);
 template <typename T> void launch_dct_blocks(const T* x, T* out, const T* gtab, const T* rtab, size_t n,
                                              bool inverse, int grid, hipStream_t s);

@@ -36,6 +36,7 @@
 #include <type_traits>
 
 #include "dct64_block.h"
+#include "dct_nd_block.h"
 #include "dctz_device.h"
 
 namespace dctz {
@@ -556,7 +557,10 @@ size_t compress_lds_bytes(int mode) {              // tile image + strips (+ pos
 // workgroups per CU = two waves per SIMD that cover each other's waits.  Either way the outputs of tile k are flushed
 // only after the next DMA of tile k + 1 has been issued, so that the wait for tile k + 1's first phase never sits
 // behind tile k's stores.
-template <typename T, int MODE, bool STATS, int PH>
+// GEOM: what the 64 values of a block are -- the reference's 64 consecutive elements (GEOM_1D), or an 8 x 8 / 4 x 4 x 4
+// tile of a multi-dimensional array that k_gather_nd has laid out block after block (dct_nd_block.h); only the
+// transform differs.
+template <typename T, int MODE, bool STATS, int PH, int GEOM>
 __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(PH))) void k_compress(FwdParams<T> p) {
   using G = Geo<T, PH>;
   constexpr bool DEFER = true;
@@ -741,7 +745,7 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(PH))) void k
     { T sx = x[0]; for (int j = 1; j < 64; j++) sx += x[j]; if (sx == T(1.2345e300)) p.dc[0] = (float)sx; pend = false; continue; }
 #endif
     __builtin_amdgcn_sched_barrier(0);
-    dct64_fwd<T, CTab<T>, (PH > 1)>(x, tab);
+    block_fwd<T, CTab<T>, GEOM, (PH > 1)>(x, tab);
     STAMP(6);
 #if defined(DCTZ_CUT) && DCTZ_CUT == 3
     { T sx = x[0]; for (int j = 1; j < 64; j++) sx += x[j]; if (sx == T(1.2345e300)) p.dc[0] = (float)sx; pend = false; continue; }
@@ -1053,7 +1057,7 @@ __global__ __launch_bounds__(SWG) void k_count_tiles(const uint8_t* __restrict__
 template <typename T>
 size_t decompress_lds_bytes() { return (size_t)Geo<T, Phases<T>::D>::PHB + 256 * sizeof(T) + DEC_EXC_CAP * 4 + 64 * sizeof(T); }
 
-template <typename T, int MODE, int PH>
+template <typename T, int MODE, int PH, int GEOM>
 __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(PH))) void k_decompress(InvParams<T> p, FinArgs fin) {
   using G = Geo<T, PH>;
   __shared__ __attribute__((aligned(1024))) unsigned char outbuf[G::PHB];
@@ -1166,7 +1170,7 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(PH))) void k
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                  // the staged coefficients are consumed: the strip is free
     if (tile + 1 < tr.hi) prefetch(tile + 1);
-    dct64_inv<T, CTab<T>, (PH > 1)>(x, tab);
+    block_inv<T, CTab<T>, GEOM, (PH > 1)>(x, tab);
     if (scale) {
 #pragma unroll
       for (int j = 0; j < 64; j++) x[j] = x[j] * p.sf;                 // dctz-decomp-lib.c:494-511
@@ -1327,6 +1331,97 @@ __global__ __launch_bounds__(64) void k_dct_rem(const T* __restrict__ x, T* __re
   }
 }
 
+// ==================================================== multi-dimensional blocks ==
+// SURVEY section 8 f4 (not in the reference's library; the hint is dct-fftw-test.c:74-97).  A 2-D array is cut into
+// 8 x 8 tiles, a 3-D array into 4 x 4 x 4 tiles (last axis fastest; edge tiles repeat the last sample), and
+// k_gather_nd lays the tiles out block after block -- row-major over the tile grid, row-major inside a tile -- so that
+// the 1-D pipeline above runs on them unchanged with the separable block transform (GEOM).  One thread moves one
+// 16-byte piece of the block-linear side: fully coalesced there, whole rows of a tile (32 / 64 bytes) on the array side.
+// The same pass takes calc_data_stat's reductions over the ORIGINAL elements (util.c:12-44; a repeated edge sample
+// changes neither max nor min and stays out of the sum; x[0] never enters the sum, util.c:22).
+template <typename T>
+__device__ __forceinline__ void nd_locate(const NdShape& sh, size_t q, size_t (&src)[Traits<T>::EPV], bool (&real)[Traits<T>::EPV]) {
+  constexpr int EPV = Traits<T>::EPV;
+  const size_t blk = q / (64 / EPV);
+  const int j0 = (int)(q % (64 / EPV)) * EPV;                       // first element of the piece inside its block
+  if (sh.nd == 2) {
+    const size_t b0 = blk / sh.nb[1], b1 = blk % sh.nb[1];
+    const size_t r = b0 * 8 + (size_t)(j0 >> 3);
+    const bool rin = r < sh.d[0];
+    const size_t rr = rin ? r : sh.d[0] - 1;
+#pragma unroll
+    for (int k = 0; k < EPV; k++) {
+      const size_t c = b1 * 8 + (size_t)((j0 & 7) + k);
+      const bool cin = c < sh.d[1];
+      src[k] = rr * sh.d[1] + (cin ? c : sh.d[1] - 1);
+      real[k] = rin && cin;
+    }
+  } else {
+    const size_t b2 = blk % sh.nb[2], t = blk / sh.nb[2], b1 = t % sh.nb[1], b0 = t / sh.nb[1];
+    const size_t z = b0 * 4 + (size_t)(j0 >> 4), y = b1 * 4 + (size_t)((j0 >> 2) & 3);
+    const bool zin = z < sh.d[0], yin = y < sh.d[1];
+    const size_t base = ((zin ? z : sh.d[0] - 1) * sh.d[1] + (yin ? y : sh.d[1] - 1)) * sh.d[2];
+#pragma unroll
+    for (int k = 0; k < EPV; k++) {
+      const size_t xx = b2 * 4 + (size_t)((j0 & 3) + k);
+      const bool xin = xx < sh.d[2];
+      src[k] = base + (xin ? xx : sh.d[2] - 1);
+      real[k] = zin && yin && xin;
+    }
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(SWG) void k_gather_nd(const T* __restrict__ x, T* __restrict__ lin, NdShape sh, double* __restrict__ part) {
+  using Vec = typename Traits<T>::Vec;
+  constexpr int EPV = Traits<T>::EPV;
+  const size_t nq = sh.nblk * (64 / EPV);
+  StatAcc<T> acc;
+  acc.init();
+  for (size_t q = (size_t)blockIdx.x * SWG + threadIdx.x; q < nq; q += (size_t)gridDim.x * SWG) {
+    size_t src[EPV];
+    bool real[EPV];
+    nd_locate<T>(sh, q, src, real);
+    T e[EPV];
+#pragma unroll
+    for (int k = 0; k < EPV; k++) {
+      e[k] = x[src[k]];
+      acc.minmax(e[k]);
+      if (real[k] && src[k] != 0) acc.sum += (double)e[k];
+    }
+    reinterpret_cast<Vec*>(lin)[q] = Traits<T>::pack(e);
+  }
+  __shared__ double ss[3 * (SWG / 64)];
+  acc.flush(part, blockIdx.x, ss, SWG / 64);
+}
+
+// block-linear reconstruction -> the array (the padding of edge tiles is dropped)
+template <typename T>
+__global__ __launch_bounds__(SWG) void k_scatter_nd(const T* __restrict__ lin, T* __restrict__ out, NdShape sh) {
+  using Vec = typename Traits<T>::Vec;
+  constexpr int EPV = Traits<T>::EPV;
+  const size_t nq = sh.nblk * (64 / EPV);
+  for (size_t q = (size_t)blockIdx.x * SWG + threadIdx.x; q < nq; q += (size_t)gridDim.x * SWG) {
+    size_t dst[EPV];
+    bool real[EPV];
+    nd_locate<T>(sh, q, dst, real);
+    T e[EPV];
+    Traits<T>::unpack(reinterpret_cast<const Vec*>(lin)[q], e);
+#pragma unroll
+    for (int k = 0; k < EPV; k++)
+      if (real[k]) out[dst[k]] = e[k];
+  }
+}
+
+template <typename T>
+void launch_gather_nd(const T* x, T* lin, const NdShape& sh, double* part, int nparts, hipStream_t s) {
+  hipLaunchKernelGGL(k_gather_nd<T>, dim3(nparts), dim3(SWG), 0, s, x, lin, sh, part);
+}
+template <typename T>
+void launch_scatter_nd(const T* lin, T* out, const NdShape& sh, int grid, hipStream_t s) {
+  hipLaunchKernelGGL(k_scatter_nd<T>, dim3(grid), dim3(SWG), 0, s, lin, out, sh);
+}
+
 // ===================================================================== PSNR ==
 // calc_psnr's reductions (util.c:54-104): min / max of the original, max |x - r|, sum of (x - r)^2 with the
 // difference and its square taken in the data type (util.c:72-73 / :88-89), summed in double -- in tree order,
@@ -1388,8 +1483,8 @@ void launch_stats_sample(const T* x, size_t n, unsigned group, double* part, int
   hipLaunchKernelGGL(k_stats_sample<T>, dim3(nparts), dim3(SWG), 0, s, x, n, group, part);
   hipLaunchKernelGGL(k_stats_final, dim3(1), dim3(SWG), 0, s, (const double*)part, nparts, out, box, seq, zero);
 }
-void launch_stats_final(const double* part, int nparts, double* out, hipStream_t s) {
-  hipLaunchKernelGGL(k_stats_final, dim3(1), dim3(SWG), 0, s, part, nparts, out, (HostBox*)nullptr, 0ull, (Ctl*)nullptr);
+void launch_stats_final(const double* part, int nparts, double* out, hipStream_t s, HostBox* box, unsigned long long seq, Ctl* zero) {
+  hipLaunchKernelGGL(k_stats_final, dim3(1), dim3(SWG), 0, s, part, nparts, out, box, seq, zero);
 }
 void launch_finish(Ctl* ctl, const double* part, int nparts, HostBox* box, unsigned long long seq, hipStream_t s) {
   const FinArgs f = {ctl, part, nparts, box, seq};
@@ -1412,13 +1507,21 @@ void launch_scale(const T* x, T* out, size_t n, T sf, int grid, hipStream_t s) {
 }
 
 template <typename T>
-void launch_compress(const FwdParams<T>& p, int mode, bool stats, int grid, hipStream_t s) {
-  if (mode == DCTZHIP_EC) {
-    if (stats) hipLaunchKernelGGL((k_compress<T, DCTZHIP_EC, true, Phases<T>::C>), dim3(grid), dim3(WG), 0, s, p);
-    else hipLaunchKernelGGL((k_compress<T, DCTZHIP_EC, false, Phases<T>::C>), dim3(grid), dim3(WG), 0, s, p);
+void launch_compress(const FwdParams<T>& p, int mode, bool stats, int grid, int geom, hipStream_t s) {
+  if (geom == GEOM_1D) {
+    if (mode == DCTZHIP_EC) {
+      if (stats) hipLaunchKernelGGL((k_compress<T, DCTZHIP_EC, true, Phases<T>::C, GEOM_1D>), dim3(grid), dim3(WG), 0, s, p);
+      else hipLaunchKernelGGL((k_compress<T, DCTZHIP_EC, false, Phases<T>::C, GEOM_1D>), dim3(grid), dim3(WG), 0, s, p);
+    } else {
+      if (stats) hipLaunchKernelGGL((k_compress<T, DCTZHIP_QT, true, Phases<T>::C, GEOM_1D>), dim3(grid), dim3(WG), 0, s, p);
+      else hipLaunchKernelGGL((k_compress<T, DCTZHIP_QT, false, Phases<T>::C, GEOM_1D>), dim3(grid), dim3(WG), 0, s, p);
+    }
+  } else if (geom == GEOM_2D) {            // (the statistics of a multi-dimensional array come from k_gather_nd)
+    if (mode == DCTZHIP_EC) hipLaunchKernelGGL((k_compress<T, DCTZHIP_EC, false, Phases<T>::C, GEOM_2D>), dim3(grid), dim3(WG), 0, s, p);
+    else hipLaunchKernelGGL((k_compress<T, DCTZHIP_QT, false, Phases<T>::C, GEOM_2D>), dim3(grid), dim3(WG), 0, s, p);
   } else {
-    if (stats) hipLaunchKernelGGL((k_compress<T, DCTZHIP_QT, true, Phases<T>::C>), dim3(grid), dim3(WG), 0, s, p);
-    else hipLaunchKernelGGL((k_compress<T, DCTZHIP_QT, false, Phases<T>::C>), dim3(grid), dim3(WG), 0, s, p);
+    if (mode == DCTZHIP_EC) hipLaunchKernelGGL((k_compress<T, DCTZHIP_EC, false, Phases<T>::C, GEOM_3D>), dim3(grid), dim3(WG), 0, s, p);
+    else hipLaunchKernelGGL((k_compress<T, DCTZHIP_QT, false, Phases<T>::C, GEOM_3D>), dim3(grid), dim3(WG), 0, s, p);
   }
 }
 
@@ -1449,9 +1552,17 @@ void launch_compact_ac(const FwdParams<T>& p, int mode, double eb, unsigned nlis
 }
 
 template <typename T>
-void launch_decompress(const InvParams<T>& p, int mode, int grid, const FinArgs& fin, hipStream_t s) {
-  if (mode == DCTZHIP_EC) hipLaunchKernelGGL((k_decompress<T, DCTZHIP_EC, Phases<T>::D>), dim3(grid), dim3(WG), 0, s, p, fin);
-  else hipLaunchKernelGGL((k_decompress<T, DCTZHIP_QT, Phases<T>::D>), dim3(grid), dim3(WG), 0, s, p, fin);
+void launch_decompress(const InvParams<T>& p, int mode, int grid, const FinArgs& fin, int geom, hipStream_t s) {
+  if (geom == GEOM_1D) {
+    if (mode == DCTZHIP_EC) hipLaunchKernelGGL((k_decompress<T, DCTZHIP_EC, Phases<T>::D, GEOM_1D>), dim3(grid), dim3(WG), 0, s, p, fin);
+    else hipLaunchKernelGGL((k_decompress<T, DCTZHIP_QT, Phases<T>::D, GEOM_1D>), dim3(grid), dim3(WG), 0, s, p, fin);
+  } else if (geom == GEOM_2D) {
+    if (mode == DCTZHIP_EC) hipLaunchKernelGGL((k_decompress<T, DCTZHIP_EC, Phases<T>::D, GEOM_2D>), dim3(grid), dim3(WG), 0, s, p, fin);
+    else hipLaunchKernelGGL((k_decompress<T, DCTZHIP_QT, Phases<T>::D, GEOM_2D>), dim3(grid), dim3(WG), 0, s, p, fin);
+  } else {
+    if (mode == DCTZHIP_EC) hipLaunchKernelGGL((k_decompress<T, DCTZHIP_EC, Phases<T>::D, GEOM_3D>), dim3(grid), dim3(WG), 0, s, p, fin);
+    else hipLaunchKernelGGL((k_decompress<T, DCTZHIP_QT, Phases<T>::D, GEOM_3D>), dim3(grid), dim3(WG), 0, s, p, fin);
+  }
 }
 
 template <typename T>
@@ -1496,11 +1607,13 @@ void launch_psnr(const T* x, const T* r, size_t n, double* part, int nparts, dou
   template void launch_debug_divide<T>(const T*, size_t, T, int, T*, T*, hipStream_t);                  \
   template void launch_serial_sum<T>(const T*, size_t, double*, hipStream_t);                           \
   template void launch_scale<T>(const T*, T*, size_t, T, int, hipStream_t);                             \
-  template void launch_compress<T>(const FwdParams<T>&, int, bool, int, hipStream_t);                   \
+  template void launch_compress<T>(const FwdParams<T>&, int, bool, int, int, hipStream_t);              \
+  template void launch_gather_nd<T>(const T*, T*, const NdShape&, double*, int, hipStream_t);           \
+  template void launch_scatter_nd<T>(const T*, T*, const NdShape&, int, hipStream_t);                   \
   template void launch_compress_rem<T>(const FwdParams<T>&, int, bool, int, hipStream_t);               \
   template void launch_qt_max<T>(const FwdParams<T>&, unsigned, int, hipStream_t);                      \
   template void launch_compact_ac<T>(const FwdParams<T>&, int, double, unsigned, int, const FinArgs&, hipStream_t); \
-  template void launch_decompress<T>(const InvParams<T>&, int, int, const FinArgs&, hipStream_t);       \
+  template void launch_decompress<T>(const InvParams<T>&, int, int, const FinArgs&, int, hipStream_t);  \
   template void launch_decompress_rem<T>(const InvParams<T>&, int, bool, int, hipStream_t);             \
   template void launch_dct_blocks<T>(const T*, T*, const T*, const T*, size_t, bool, int, hipStream_t); \
   template void launch_psnr<T>(const T*, const T*, size_t, double*, int, double*, hipStream_t);         \

@@ -52,6 +52,8 @@ struct dctzhip_ctx {
   uint8_t* qt_j = nullptr;
   size_t qt_cap = 0;                // bytes of qt_item
   size_t qtj_cap = 0;
+  void* nd_buf = nullptr;           // multi-dimensional blocks: the array laid out block after block (k_gather_nd / k_scatter_nd)
+  size_t nd_cap = 0;                // bytes
   // pinned host staging
   unsigned char* h_pin = nullptr;   // [0,64): stats, [64, 64+sizeof(Ctl)): ctl, then tables
   HostBox* box = nullptr;           // result mailbox, fine-grained pinned host memory (kernels write, host spins)
@@ -134,8 +136,8 @@ extern "C" int dctzhip_ctx_create(dctzhip_ctx** out, int device) {
   c->stream = c->own_stream;
   HIPCHK(nullptr, hipStreamCreateWithFlags(&c->side_stream, hipStreamNonBlocking));
   HIPCHK(nullptr, hipMalloc(&c->serial_out, 16));
-  HIPCHK(nullptr, hipMalloc(&c->tab_f64, sizeof(double) * TB_SIZE));
-  HIPCHK(nullptr, hipMalloc(&c->tab_f32, sizeof(float) * TB_SIZE));
+  HIPCHK(nullptr, hipMalloc(&c->tab_f64, sizeof(double) * TB_TOTAL));
+  HIPCHK(nullptr, hipMalloc(&c->tab_f32, sizeof(float) * TB_TOTAL));
   HIPCHK(nullptr, hipMalloc(&c->rtab, sizeof(double) * RTAB_SIZE));
   HIPCHK(nullptr, hipMalloc(&c->qtab, sizeof(double) * 64));
   HIPCHK(nullptr, hipMalloc(&c->ctl, sizeof(Ctl)));
@@ -155,8 +157,8 @@ extern "C" int dctzhip_ctx_create(dctzhip_ctx** out, int device) {
   }
   if (const char* e = getenv("DCTZHIP_HANDOFF")) c->handoff = (atoi(e) != 0) && c->box != nullptr;
   {
-    double t64[TB_SIZE];
-    float t32[TB_SIZE];
+    double t64[TB_TOTAL];
+    float t32[TB_TOTAL];
     fill_tab_block<double>(t64);
     fill_tab_block<float>(t32);
     HIPCHK(nullptr, hipMemcpy(c->tab_f64, t64, sizeof(t64), hipMemcpyHostToDevice));
@@ -174,7 +176,7 @@ extern "C" void dctzhip_ctx_destroy(dctzhip_ctx* c) {
   (void)dctzhip_comm_destroy(c);
   (void)hipStreamSynchronize(c->stream);
   if (c->side_stream) { (void)hipStreamSynchronize(c->side_stream); (void)hipStreamDestroy(c->side_stream); }
-  void* bufs[] = {c->ovf, c->ovf_j, c->ac_tmp, c->tile_cnt, c->wg_cnt, c->serial_out, c->tab_f64, c->tab_f32, c->rtab, c->qtab, c->ctl, c->part, c->stats_out, c->qt_item, c->qt_j};
+  void* bufs[] = {c->ovf, c->ovf_j, c->ac_tmp, c->tile_cnt, c->wg_cnt, c->serial_out, c->tab_f64, c->tab_f32, c->rtab, c->qtab, c->ctl, c->part, c->stats_out, c->qt_item, c->qt_j, c->nd_buf};
   for (void* b : bufs) if (b) (void)hipFree(b);
   if (c->h_pin) (void)hipHostFree(c->h_pin);
   if (c->box) (void)hipHostFree(c->box);
@@ -408,7 +410,7 @@ static int wg_per_cu(dctzhip_ctx* c, bool decode, int mode) {
 template <typename T>
 static int compress_pass(dctzhip_ctx* c, const T* d_in, size_t n, double eb, int mode, uint8_t* d_bin, float* d_dc,
                          float* d_ac, T* d_coef, const HostStats& st, bool fused, double* sf_out, T* sf_t_out,
-                         unsigned* fast_sf_out, unsigned long long seq) {
+                         unsigned* fast_sf_out, unsigned long long seq, int geom) {
   const int dtype = sizeof(T) == 8 ? DCTZHIP_F64 : DCTZHIP_F32;
   hipStream_t s = c->stream;
   const unsigned nfull = (unsigned)(n / 64);
@@ -454,7 +456,7 @@ static int compress_pass(dctzhip_ctx* c, const T* d_in, size_t n, double eb, int
   const unsigned cap = (unsigned)(c->num_cu * wg_per_cu<T>(c, false, mode));
   const int grid = (int)(cap < ntiles ? cap : ntiles);
   p.nlists_main = (unsigned)grid;
-  if (ntiles) launch_compress<T>(p, mode, fused, grid, s);
+  if (ntiles) launch_compress<T>(p, mode, fused, grid, geom, s);
   if (c->profiling) HIPCHK(c, hipEventRecord(c->ev[3], s));
   if (rem) launch_compress_rem<T>(p, mode, scale, rem, s);
   // stitch the workgroup-local lists into AC_exact[]
@@ -471,9 +473,12 @@ static int compress_pass(dctzhip_ctx* c, const T* d_in, size_t n, double eb, int
   return DCTZHIP_OK;
 }
 
+// geom != GEOM_1D: d_in is the block-linear layout of a multi-dimensional array (n = nblk * 64) and the statistics
+// partials of the ORIGINAL array (n_orig elements) are already in c->part[0 .. pre_parts) -- k_gather_nd.
 template <typename T>
 static int compress_impl(dctzhip_ctx* c, const T* d_in, size_t n, double eb, int mode, uint8_t* d_bin, float* d_dc,
-                         float* d_ac, T* d_scaled, T* d_coef, dctzhip_cinfo* info) {
+                         float* d_ac, T* d_scaled, T* d_coef, dctzhip_cinfo* info, int geom = GEOM_1D, int pre_parts = 0,
+                         size_t n_orig = 0) {
   const int dtype = sizeof(T) == 8 ? DCTZHIP_F64 : DCTZHIP_F32;
   hipStream_t s = c->stream;
   const unsigned nfull = (unsigned)(n / 64);
@@ -489,7 +494,7 @@ static int compress_impl(dctzhip_ctx* c, const T* d_in, size_t n, double eb, int
   // guess afterwards; a wrong guess costs one re-run with the true values.  (The scaled copy the
   // reference's in-place semantics ask for is written at the very end, with the verified sf.)
   constexpr size_t chunk = (size_t)SWG * Traits<T>::EPV;
-  bool spec = c->speculate && ntiles && n >= c->spec_min && n >= 4 * chunk * c->spec_group;
+  bool spec = geom == GEOM_1D && c->speculate && ntiles && n >= c->spec_min && n >= 4 * chunk * c->spec_group;
   if (spec && c->spec_cooldown > 0) { c->spec_cooldown--; spec = false; }
 
   // Host hand-off: mailbox + spin, or D2H copy + stream sync
@@ -505,7 +510,9 @@ static int compress_impl(dctzhip_ctx* c, const T* d_in, size_t n, double eb, int
   // ---- calc_data_stat (util.c:12-44): the full pass, or the sample -------------
   unsigned long long seq = box ? ++c->seq : 0ull;
   if (c->profiling) HIPCHK(c, hipEventRecord(c->ev[0], s));
-  if (spec) {
+  if (geom != GEOM_1D) {
+    launch_stats_final(c->part, pre_parts, c->stats_out, s, box ? c->box_dev : nullptr, seq, box ? c->ctl : nullptr);
+  } else if (spec) {
     const size_t ngroups = n / chunk / c->spec_group;
     const int sgrid = (int)(ngroups < (size_t)c->stats_grid ? ngroups : (size_t)c->stats_grid);
     launch_stats_sample<T>(d_in, n, c->spec_group, c->part, sgrid, c->stats_out, s, box ? c->box_dev : nullptr, seq, box ? c->ctl : nullptr);
@@ -534,7 +541,7 @@ static int compress_impl(dctzhip_ctx* c, const T* d_in, size_t n, double eb, int
   unsigned flags = 0;
   // one pass of the kernels + the hand-off of its results into *hc / hs[4..6]
   auto run = [&](const HostStats& stats, bool fused) -> int {
-    int rc = compress_pass<T>(c, d_in, n, eb, mode, d_bin, d_dc, d_ac, d_coef, stats, fused, &sf, &sf_t, &fast_sf, seq);
+    int rc = compress_pass<T>(c, d_in, n, eb, mode, d_bin, d_dc, d_ac, d_coef, stats, fused, &sf, &sf_t, &fast_sf, seq, geom);
     if (rc) return rc;
     if (box) {
       rc = wait_seq(c, &hb->seq_done, seq, "compress");
@@ -587,7 +594,8 @@ static int compress_impl(dctzhip_ctx* c, const T* d_in, size_t n, double eb, int
   if (info) {
     memset(info, 0, sizeof(*info));
     info->sf = sf;
-    info->mean = (dtype == DCTZHIP_F64) ? st.sum / (double)(int)n : (double)((float)st.sum / (float)(int)n);
+    const size_t nm = n_orig ? n_orig : n;          // util.c:28 / :41: sum / N over the caller's array
+    info->mean = (dtype == DCTZHIP_F64) ? st.sum / (double)(int)nm : (double)((float)st.sum / (float)(int)nm);
     info->max_abs = st.max_abs; info->min_abs = st.min_abs;
     info->cnt = hc->cnt_total; info->nblk = nblk;
     info->flags = flags;
@@ -718,7 +726,7 @@ extern "C" int dctzhip_compress(dctzhip_ctx* c, const void* d_in, size_t n, int 
 template <typename T>
 static int decompress_impl(dctzhip_ctx* c, const uint8_t* d_bin, const float* d_dc, const float* d_ac,
                            uint32_t ac_count, const void* qtable_host, size_t n, double eb, double sf, int mode,
-                           T* d_out) {
+                           T* d_out, int geom = GEOM_1D) {
   hipStream_t s = c->stream;
   const unsigned nfull = (unsigned)(n / 64);
   const int rem = (int)(n % 64);
@@ -763,7 +771,7 @@ static int decompress_impl(dctzhip_ctx* c, const uint8_t* d_bin, const float* d_
   // reconstruction is being written -- complete in stream order, like any launch.  Otherwise k_finish does it.
   const bool early = box && ntiles && !rem;
   const FinArgs fin = {c->ctl, nullptr, 0, early ? c->box_dev : nullptr, seq};
-  if (ntiles) launch_decompress<T>(p, mode, grid, fin, s);
+  if (ntiles) launch_decompress<T>(p, mode, grid, fin, geom, s);
   if (c->profiling) HIPCHK(c, hipEventRecord(c->ev[3], s));
   if (rem) launch_decompress_rem<T>(p, mode, scale, rem, s);
   if (box && !early) launch_finish(c->ctl, nullptr, 0, c->box_dev, seq, s);
@@ -800,6 +808,114 @@ extern "C" int dctzhip_decompress(dctzhip_ctx* c, const void* d_bin, const float
   if (dtype == DCTZHIP_F64)
     return decompress_impl<double>(c, (const uint8_t*)d_bin, d_dc, d_ac, ac_count, qtable_host, n, eb, sf, mode, (double*)d_out);
   return decompress_impl<float>(c, (const uint8_t*)d_bin, d_dc, d_ac, ac_count, qtable_host, n, eb, sf, mode, (float*)d_out);
+}
+
+// ---- multi-dimensional blocks (include/dctz_hip.h) -------------------------------------------------
+static bool nd_shape(int ndims, const size_t* dims, NdShape* sh) {
+  if ((ndims != 2 && ndims != 3) || !dims) return false;
+  const size_t edge = ndims == 2 ? 8 : 4;
+  sh->nd = ndims;
+  sh->nblk = 1;
+  for (int i = 0; i < 3; i++) { sh->d[i] = 1; sh->nb[i] = 1; }
+  for (int i = 0; i < ndims; i++) {
+    if (dims[i] == 0 || dims[i] > (size_t)INT_MAX) return false;
+    sh->d[i] = dims[i];
+    sh->nb[i] = (dims[i] + edge - 1) / edge;
+    if (sh->nblk > (size_t)INT_MAX / 64 / sh->nb[i]) return false;        // nblk * 64 must stay an int (dctz.h:126)
+    sh->nblk *= sh->nb[i];
+  }
+  return true;
+}
+
+extern "C" size_t dctzhip_nd_blocks(int ndims, const size_t* dims) {
+  NdShape sh;
+  return nd_shape(ndims, dims, &sh) ? sh.nblk : 0;
+}
+
+static int ensure_nd(dctzhip_ctx* c, size_t bytes) {
+  char* b = (char*)c->nd_buf;
+  int rc = regrow(c, &b, &c->nd_cap, bytes, 1);
+  c->nd_buf = b;
+  return rc;
+}
+
+template <typename T>
+static int compress_nd_impl(dctzhip_ctx* c, const T* d_in, const NdShape& sh, double eb, int mode, uint8_t* d_bin,
+                            float* d_dc, float* d_ac, T* d_scaled, dctzhip_cinfo* info) {
+  const size_t n_lin = sh.nblk * 64, n_orig = sh.d[0] * sh.d[1] * sh.d[2];
+  int rc = ensure_nd(c, n_lin * sizeof(T));
+  if (rc) return rc;
+  T* lin = reinterpret_cast<T*>(c->nd_buf);
+  // tiles -> block after block, with calc_data_stat's reductions over the original elements on the way
+  const size_t nq = n_lin / Traits<T>::EPV;
+  int grid = (int)((nq + SWG * 4 - 1) / (SWG * 4));
+  if (grid < 1) grid = 1;
+  if (grid > c->stats_grid) grid = c->stats_grid;
+  launch_gather_nd<T>(d_in, lin, sh, c->part, grid, c->stream);
+  HIPCHK(c, hipGetLastError());
+  dctzhip_cinfo local;
+  rc = compress_impl<T>(c, lin, n_lin, eb, mode, d_bin, d_dc, d_ac, (T*)nullptr, (T*)nullptr, &local, sh.nd == 2 ? GEOM_2D : GEOM_3D,
+                        grid, n_orig);
+  if (rc) return rc;
+  if (d_scaled) {                                   // dctz-comp-lib.c:193-216 on the caller's array
+    const T sf_t = (T)local.sf;
+    if (sf_t != (T)1.0) launch_scale<T>(d_in, d_scaled, n_orig, sf_t, c->num_cu * 8, c->stream);
+    else if ((const void*)d_scaled != (const void*)d_in) HIPCHK(c, hipMemcpyAsync(d_scaled, d_in, n_orig * sizeof(T), hipMemcpyDeviceToDevice, c->stream));
+    HIPCHK(c, hipGetLastError());
+  }
+  if (info) *info = local;
+  return DCTZHIP_OK;
+}
+
+extern "C" int dctzhip_compress_nd(dctzhip_ctx* c, const void* d_in, int ndims, const size_t* dims, int dtype, double eb,
+                                   int mode, void* d_bin, float* d_dc, float* d_ac, void* d_scaled, dctzhip_cinfo* info) {
+  if (!c) return DCTZHIP_E_ARG;
+  NdShape sh;
+  if (!nd_shape(ndims, dims, &sh)) return fail(c, DCTZHIP_E_ARG, "multi-dimensional blocks: 2 or 3 non-zero extents whose tile count fits an int");
+  int rc = check_common(c, sh.nblk * 64, dtype, mode);
+  if (rc) return rc;
+  if (!d_in || !d_bin || !d_dc || !d_ac) return fail(c, DCTZHIP_E_ARG, "null device buffer");
+  if (!aligned16(d_in) || !aligned16(d_bin) || !aligned16(d_dc) || !aligned16(d_ac) || (d_scaled && !aligned16(d_scaled)))
+    return fail(c, DCTZHIP_E_ARG, "device buffers must be 16-byte aligned");
+  if (eb < 1E-6) return fail(c, DCTZHIP_E_BOUND, "ERROR BOUND is not acceptable");   // dctz-comp-lib.c:135-138
+  HIPCHK(c, hipSetDevice(c->device));
+  rc = ensure_scratch(c, sh.nblk * 64, dtype, mode);
+  if (rc) return rc;
+  if (dtype == DCTZHIP_F64)
+    return compress_nd_impl<double>(c, (const double*)d_in, sh, eb, mode, (uint8_t*)d_bin, d_dc, d_ac, (double*)d_scaled, info);
+  return compress_nd_impl<float>(c, (const float*)d_in, sh, eb, mode, (uint8_t*)d_bin, d_dc, d_ac, (float*)d_scaled, info);
+}
+
+extern "C" int dctzhip_decompress_nd(dctzhip_ctx* c, const void* d_bin, const float* d_dc, const float* d_ac, uint32_t ac_count,
+                                     const void* qtable_host, int ndims, const size_t* dims, int dtype, double eb, double sf,
+                                     int mode, void* d_out) {
+  if (!c) return DCTZHIP_E_ARG;
+  NdShape sh;
+  if (!nd_shape(ndims, dims, &sh)) return fail(c, DCTZHIP_E_ARG, "multi-dimensional blocks: 2 or 3 non-zero extents whose tile count fits an int");
+  const size_t n_lin = sh.nblk * 64;
+  int rc = check_common(c, n_lin, dtype, mode);
+  if (rc) return rc;
+  if (!d_bin || !d_dc || !d_out || (ac_count && !d_ac)) return fail(c, DCTZHIP_E_ARG, "null device buffer");
+  if (!aligned16(d_bin) || !aligned16(d_out)) return fail(c, DCTZHIP_E_ARG, "device buffers must be 16-byte aligned");
+  if (mode == DCTZHIP_QT && !qtable_host) return fail(c, DCTZHIP_E_ARG, "QT mode needs the 64-entry table");
+  HIPCHK(c, hipSetDevice(c->device));
+  rc = ensure_scratch(c, n_lin, dtype, DCTZHIP_EC, false);
+  if (rc) return rc;
+  rc = ensure_nd(c, n_lin * elem_size(dtype));
+  if (rc) return rc;
+  const int geom = ndims == 2 ? GEOM_2D : GEOM_3D;
+  const int grid = c->num_cu * 8;
+  if (dtype == DCTZHIP_F64) {
+    rc = decompress_impl<double>(c, (const uint8_t*)d_bin, d_dc, d_ac, ac_count, qtable_host, n_lin, eb, sf, mode, (double*)c->nd_buf, geom);
+    if (rc) return rc;
+    launch_scatter_nd<double>((const double*)c->nd_buf, (double*)d_out, sh, grid, c->stream);
+  } else {
+    rc = decompress_impl<float>(c, (const uint8_t*)d_bin, d_dc, d_ac, ac_count, qtable_host, n_lin, eb, sf, mode, (float*)c->nd_buf, geom);
+    if (rc) return rc;
+    launch_scatter_nd<float>((const float*)c->nd_buf, (float*)d_out, sh, grid, c->stream);
+  }
+  HIPCHK(c, hipGetLastError());
+  return DCTZHIP_OK;
 }
 
 extern "C" int dctzhip_dct_blocks(dctzhip_ctx* c, const void* d_in, void* d_out, size_t n, int dtype, int inverse) {

@@ -12,6 +12,7 @@
 #include <type_traits>
 
 #include "dct64_block.h"
+#include "dct_nd_block.h"
 
 #ifndef M_PI
 #define M_PI 3.14159265358979323846 /* dct.h:13-15 */
@@ -55,7 +56,7 @@ inline void reference_twiddles(int n, T* as, T* ax, T* ias, T* iax) {
 template <typename T>
 inline T sqrt2() { return std::is_same<T, double>::value ? (T)sqrt(2.0) : (T)sqrtf(2.0); }
 
-// The TB_* block of dct64_block.h for the 64-point fast path.  Exact definitions (theta_j = j pi / 128,
+// The TB_* block of dct64_block.h for the 64-point fast path (TB_TOTAL elements: the constants of dct_nd_block.h follow it).  Exact definitions (theta_j = j pi / 128,
 // cw = cos(2 pi k / 64), sw = sin(2 pi k / 64)):
 //   forward:  alpha_j = cos(theta_j) / sqrt(128) = as[j] / 2,  beta_j = sin(theta_j) / sqrt(128) = -ax[j] / 2   (dct.c:37-47)
 //   inverse:  C_j = sqrt(128) cos(theta_j) = ias[j],           S_j = sqrt(128) sin(theta_j) = iax[j]            (dct.c:130-134)
@@ -65,8 +66,14 @@ inline T sqrt2() { return std::is_same<T, double>::value ? (T)sqrt(2.0) : (T)sqr
 template <typename T>
 inline void fill_tab_block(T* tab) {
   typedef long double L;
-  std::memset(tab, 0, sizeof(T) * TB_SIZE);
+  std::memset(tab, 0, sizeof(T) * TB_TOTAL);
   const L pi = 3.141592653589793238462643383279502884L;
+  // multi-dimensional blocks (dct_nd_block.h): the 8- and 4-point orthonormal DCT constants, rounded once
+  tab[TB_ND_R8] = (T)sqrtl((L)0.125);
+  tab[TB_ND_G1] = (T)(cosl(pi / 8) / 2);      tab[TB_ND_G3] = (T)(cosl(3 * pi / 8) / 2);
+  tab[TB_ND_C1] = (T)(cosl(pi / 16) / 2);     tab[TB_ND_C3] = (T)(cosl(3 * pi / 16) / 2);
+  tab[TB_ND_C5] = (T)(cosl(5 * pi / 16) / 2); tab[TB_ND_C7] = (T)(cosl(7 * pi / 16) / 2);
+  tab[TB_ND_H1] = (T)(sqrtl((L)0.5) * cosl(pi / 8)); tab[TB_ND_H3] = (T)(sqrtl((L)0.5) * cosl(3 * pi / 8));
   const L rt128 = sqrtl((L)128);
   auto al = [&](int j) { return cosl(j * pi / 128) / rt128; };
   auto be = [&](int j) { return sinl(j * pi / 128) / rt128; };

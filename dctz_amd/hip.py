@@ -64,6 +64,11 @@ _PROTOS = {
     "dctzhip_decompress": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32,
                                      C.c_void_p, C.c_size_t, C.c_int, C.c_double, C.c_double, C.c_int,
                                      C.c_void_p]),
+    "dctzhip_nd_blocks": (C.c_size_t, [C.c_int, C.POINTER(C.c_size_t)]),
+    "dctzhip_compress_nd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_size_t), C.c_int, C.c_double, C.c_int,
+                                      C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(CompressInfo)]),
+    "dctzhip_decompress_nd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_int,
+                                        C.POINTER(C.c_size_t), C.c_int, C.c_double, C.c_double, C.c_int, C.c_void_p]),
     "dctzhip_dct_blocks": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_int]),
     "dctzhip_stats": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.POINTER(CompressInfo)]),
     "dctzhip_serial_mean_begin": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]),
@@ -205,6 +210,48 @@ class Context:
             int(cnt), q.ctypes.data_as(C.c_void_p) if q is not None else None, n, _dt(dtype),
             float(eb), float(sf), mode, dst.data_ptr())
         self._check(rc, "dctzhip_decompress")
+        return dst
+
+    # ---- multi-dimensional blocks (include/dctz_hip.h: 8 x 8 tiles of a 2-D array, 4 x 4 x 4 tiles of a 3-D array) ----
+    def nd_blocks(self, shape):
+        dims = (C.c_size_t * len(shape))(*shape)
+        nblk = self.lib.dctzhip_nd_blocks(len(shape), dims)
+        if nblk == 0:
+            raise DctzHipError(f"multi-dimensional blocks: bad shape {tuple(shape)}")
+        return nblk
+
+    def compress_nd(self, x, eb, mode=EC, out=None, scaled=None):
+        """x: contiguous 2-D or 3-D CUDA tensor.  The streams cover nblk * 64 positions (edge tiles are padded)."""
+        assert x.is_cuda and x.is_contiguous() and x.dim() in (2, 3)
+        self._bind_stream()
+        shape = tuple(x.shape)
+        if out is None:
+            out = self.alloc_outputs(self.nd_blocks(shape) * 64, x.dtype)
+        dims = (C.c_size_t * len(shape))(*shape)
+        info = CompressInfo()
+        rc = self.lib.dctzhip_compress_nd(
+            self.h, x.data_ptr(), len(shape), dims, _dt(x.dtype), float(eb), mode, out["bin_index"].data_ptr(),
+            out["dc"].data_ptr(), out["ac_exact"].data_ptr(), scaled.data_ptr() if scaled is not None else None,
+            C.byref(info))
+        self._check(rc, "dctzhip_compress_nd")
+        return out, info
+
+    def decompress_nd(self, out, cnt, shape, dtype, eb, sf, mode=EC, qtable=None, dst=None):
+        t = self.torch
+        self._bind_stream()
+        shape = tuple(shape)
+        if dst is None:
+            dst = t.empty(shape, dtype=dtype, device=self.device)
+        q = None
+        if mode == QT:
+            q = np.ascontiguousarray(qtable, dtype=np.float64 if dtype == t.float64 else np.float32)
+            assert q.size == 64
+        dims = (C.c_size_t * len(shape))(*shape)
+        rc = self.lib.dctzhip_decompress_nd(
+            self.h, out["bin_index"].data_ptr(), out["dc"].data_ptr(), out["ac_exact"].data_ptr(), int(cnt),
+            q.ctypes.data_as(C.c_void_p) if q is not None else None, len(shape), dims, _dt(dtype), float(eb), float(sf),
+            mode, dst.data_ptr())
+        self._check(rc, "dctzhip_decompress_nd")
         return dst
 
     def psnr_terms(self, x, r):

@@ -125,7 +125,9 @@ int dctzhip_host_unregister(dctzhip_ctx *ctx, void *ptr);
  *               caller's buffer, :193-216); may be NULL, may alias d_in
  *   d_coef      optional debug tap: the DCT coefficients a_x after pass 1
  *               (= dct_result.bin under -DDCT_FILE_DEBUG, :422-428); may be NULL
- * Synchronous with respect to the host on return (info is filled). */
+ * On return *info is filled (the host has waited for it); the last kernels of the
+ * call may still be running: the output buffers are complete in STREAM order --
+ * for any later call or copy on the context's stream, or after dctzhip_sync(). */
 int dctzhip_compress(dctzhip_ctx *ctx, const void *d_in, size_t n, int dtype,
                      double error_bound, int mode, void *d_bin_index, float *d_dc,
                      float *d_ac_exact, void *d_scaled, void *d_coef,
@@ -157,11 +159,38 @@ int dctzhip_scale_inplace(dctzhip_ctx *ctx, void *d_x, size_t n, int dtype, doub
  *                from the stream tail, dctz-decomp-lib.c:193-199); EC: NULL
  *   sf           header scaling factor (scaling_factor.d, or .f widened)
  *   d_out        n elements out
- * Synchronous with respect to the host on return. */
+ * Returns once the stream is known to be consistent with ac_count (the only thing the
+ * host has to learn); the reconstruction itself is complete in STREAM order -- for
+ * any later call or copy on the context's stream, or after dctzhip_sync(). */
 int dctzhip_decompress(dctzhip_ctx *ctx, const void *d_bin_index, const float *d_dc,
                        const float *d_ac_exact, uint32_t ac_count,
                        const void *qtable_host, size_t n, int dtype,
                        double error_bound, double sf, int mode, void *d_out);
+
+/* ---- multi-dimensional blocks (optional mode) ------------------------------ */
+/* SURVEY section 8 f4.  NOT a path of the reference's library, which treats every array as flat
+ * (dctz-test.c:77-91); the hint is its stand-alone experiment dct-fftw-test.c:74-97 (FFTW_REDFT10 /
+ * FFTW_REDFT01 along every axis of a 2-D / 3-D array).  Here the 64 values of a block are an 8 x 8 tile
+ * (ndims = 2) or a 4 x 4 x 4 tile (ndims = 3) of the array -- dims[] row-major, last axis fastest, edge tiles
+ * padded by repeating the last sample -- transformed with the separable orthonormal DCT-II / DCT-III; tiles
+ * are numbered row-major over the tile grid and coefficients row-major inside a tile (position 0 = DC).
+ * Everything after the transform is the 1-D pipeline (DC, bins, AC_exact order, QT table per position), so the
+ * three streams have the reference's meaning over nblk = prod ceil(dims[i] / edge) blocks:
+ *   d_bin_index  nblk * 64 bytes,  d_dc  nblk floats,  d_ac_exact  capacity nblk * 64 floats.
+ * Statistics (sf, mean) are those of the original array.  Round 2 implementation: a gather pass lays the tiles
+ * out block after block (+2 element sizes of HBM traffic per element and direction), then the 1-D kernels run
+ * with the block transform swapped.  dctzhip_nd_blocks returns nblk (0 for bad arguments). */
+#define DCTZHIP_GEOM_1D 0
+#define DCTZHIP_GEOM_2D 1
+#define DCTZHIP_GEOM_3D 2
+size_t dctzhip_nd_blocks(int ndims, const size_t *dims);
+int dctzhip_compress_nd(dctzhip_ctx *ctx, const void *d_in, int ndims, const size_t *dims, int dtype,
+                        double error_bound, int mode, void *d_bin_index, float *d_dc,
+                        float *d_ac_exact, void *d_scaled, dctzhip_cinfo *info);
+int dctzhip_decompress_nd(dctzhip_ctx *ctx, const void *d_bin_index, const float *d_dc,
+                          const float *d_ac_exact, uint32_t ac_count, const void *qtable_host,
+                          int ndims, const size_t *dims, int dtype, double error_bound, double sf,
+                          int mode, void *d_out);
 
 /* ---- transform only ------------------------------------------------------ */
 /* Batched drop-in for dct_init + per-block dct_fftw / ifft_idct (+ the

@@ -46,6 +46,10 @@ extern "C" {
 enum { ORC_F32 = 0, ORC_F64 = 1 };          /* dctz.h:44-47 t_datatype */
 enum { ORC_EC = 0, ORC_QT = 1 };            /* Makefile:12-17 build variants */
 enum { ORC_DCT_NAIVE = 0, ORC_DCT_FAST = 1 };
+/* `impl` arguments: engine | (geometry << 4).  Geometry 0 = the reference's 1-D blocks of 64 consecutive
+ * elements; 1 = 8 x 8 and 2 = 4 x 4 x 4 tiles with the separable orthonormal DCT (not a path of the
+ * reference's library -- pinned on the definition, scipy.fft.dctn(norm="ortho"), only). */
+#define ORC_GEOM(g) ((g) << 4)
 
 /* Statistics + scaling factor (util.c:12-44).  `sum` accumulates in the data
  * type (float for f32, util.c:31).  Outputs are written as doubles; for f32

@@ -147,3 +147,54 @@ def psnr(x, r):
     p = getattr(lib(), "orc_psnr_" + _suf(x.dtype))(
         _p(x), _p(r), C.c_size_t(x.size), C.byref(md), C.byref(rm), C.byref(rg))
     return {"psnr": p, "maxdiff": md.value, "rmse": rm.value, "range": rg.value}
+
+
+# ---- multi-dimensional blocks (dctz_amd/csrc/dct_nd_block.h) ---------------------------------
+# Not a path of the reference's library: the blocks are 8 x 8 tiles of a 2-D array / 4 x 4 x 4 tiles of a 3-D array
+# (edge tiles padded by repeating the last sample), laid out block after block (row-major over the tile grid,
+# row-major inside a tile); everything after the per-block transform is the reference's 1-D pipeline on that layout.
+GEOM_EDGE = {2: 8, 3: 4}
+
+
+def geom_impl(ndim, impl=FAST):
+    return impl | ((ndim - 1) << 4)
+
+
+def nd_gather(x):
+    """dims-aware array (2-D or 3-D) -> block-linear 1-D array of nblk * 64 elements."""
+    x = np.asarray(x)
+    e = GEOM_EDGE[x.ndim]
+    pad = [(0, (-d) % e) for d in x.shape]
+    xp = np.pad(x, pad, mode="edge")
+    nb = [d // e for d in xp.shape]
+    if x.ndim == 2:
+        t = xp.reshape(nb[0], e, nb[1], e).transpose(0, 2, 1, 3)
+    else:
+        t = xp.reshape(nb[0], e, nb[1], e, nb[2], e).transpose(0, 2, 4, 1, 3, 5)
+    return np.ascontiguousarray(t).reshape(-1)
+
+
+def nd_scatter(lin, shape):
+    """inverse of nd_gather: block-linear -> array of `shape` (the padding is dropped)."""
+    nd = len(shape)
+    e = GEOM_EDGE[nd]
+    nb = [(d + e - 1) // e for d in shape]
+    if nd == 2:
+        t = np.asarray(lin).reshape(nb[0], nb[1], e, e).transpose(0, 2, 1, 3).reshape(nb[0] * e, nb[1] * e)
+    else:
+        t = np.asarray(lin).reshape(nb[0], nb[1], nb[2], e, e, e).transpose(0, 3, 1, 4, 2, 5).reshape(nb[0] * e, nb[1] * e, nb[2] * e)
+    return np.ascontiguousarray(t[tuple(slice(0, d) for d in shape)])
+
+
+def compress_nd(x, eb, mode=EC, impl=FAST, want_coef=False):
+    """x: 2-D or 3-D array.  Streams over the block-linear layout; statistics (sf, mean) over the ORIGINAL array."""
+    x = np.asarray(x)
+    c = compress(nd_gather(x), eb, mode, geom_impl(x.ndim, impl), want_coef)
+    st = stats(np.ascontiguousarray(x).reshape(-1))
+    assert st.sf == c.sf                      # the padding repeats samples: max|x| is unchanged
+    c.stats, c.mean = st, st.mean
+    return c
+
+
+def decompress_nd(c, shape, impl=FAST):
+    return nd_scatter(decompress(c, geom_impl(len(shape), impl)), shape)

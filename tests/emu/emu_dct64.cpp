@@ -3,18 +3,21 @@
 // arithmetic can be checked bit-for-bit against the oracle without a GPU.
 // Build: g++ -O1 -ffp-contract=off -mfma -shared -fPIC (tests/test_lane_emulation.py).
 #include "../../dctz_amd/csrc/dct64_block.h"
+#include "../../dctz_amd/csrc/dct_nd_block.h"
 #include "../../dctz_amd/csrc/dctz_tables.h"
 
 using namespace dctz;
 
 template <typename T>
-static void emu(const T* a, T* b, bool inverse) {
-  static T tab[TB_SIZE];
+static void emu(const T* a, T* b, bool inverse, int geom = 0) {
+  static T tab[TB_TOTAL];
   static bool ready = false;
   if (!ready) { fill_tab_block<T>(tab); ready = true; }
   T x[64];
   for (int i = 0; i < 64; i++) x[i] = a[i];
-  if (inverse) dct64_inv<T, const T*>(x, tab); else dct64_fwd<T, const T*>(x, tab);
+  if (geom == GEOM_2D) { if (inverse) dct8x8_inv<T, const T*>(x, tab); else dct8x8_fwd<T, const T*>(x, tab); }
+  else if (geom == GEOM_3D) { if (inverse) dct4x4x4_inv<T, const T*>(x, tab); else dct4x4x4_fwd<T, const T*>(x, tab); }
+  else if (inverse) dct64_inv<T, const T*>(x, tab); else dct64_fwd<T, const T*>(x, tab);
   for (int i = 0; i < 64; i++) b[i] = x[i];
 }
 
@@ -26,6 +29,9 @@ void emu_inv_f32(const float* a, float* b) { emu<float>(a, b, true); }
 void emu_tab_f64(double* tab) { fill_tab_block<double>(tab); }
 void emu_tab_f32(float* tab) { fill_tab_block<float>(tab); }
 int emu_tab_size(void) { return TB_SIZE; }
+// multi-dimensional blocks (dct_nd_block.h): geom 1 = 8 x 8, 2 = 4 x 4 x 4
+void emu_nd_f64(const double* a, double* b, int geom, int inverse) { emu<double>(a, b, inverse != 0, geom); }
+void emu_nd_f32(const float* a, float* b, int geom, int inverse) { emu<float>(a, b, inverse != 0, geom); }
 void emu_rem_tab_f64(int l, double* tab) { fill_rem_tab<double>(l, tab); }
 void emu_rem_tab_f32(int l, float* tab) { fill_rem_tab<float>(l, tab); }
 }
