@@ -104,6 +104,17 @@ int main(int argc, char *argv[]) {
   set_buf(&var_r, dt, recon);
   set_buf(&var_z, dt, comp);
 
+  /* extension (not in the reference, whose library ignores the extents, dctz-test.c:77-91): with DCTZ_ND_BLOCKS set
+   * and 2 or 3 extents on the command line the blocks are 8 x 8 / 4 x 4 x 4 tiles (dctz.h: dctz_set_block_dims).  The
+   * command line lists the FASTEST extent first, as the reference's data lists do (tests/list-CESM-ATM-tylor.txt:1:
+   * a 1800 x 3600 field is "3600 1800"); the library wants row-major order. */
+  if (getenv("DCTZ_ND_BLOCKS") && dim[1] && !dim[3]) {
+    size_t rm[3];
+    const int nd = dim[2] ? 3 : 2;
+    for (int i = 0; i < nd; i++) rm[i] = dim[nd - 1 - i];
+    if (dctz_set_block_dims(nd, rm) != 0) { printf("bad dimension sizes for multi-dimensional blocks\n"); exit(1); }
+    printf("multi-dimensional blocks: %s tiles\n", nd == 2 ? "8 x 8" : "4 x 4 x 4");
+  }
   size_t out_size = 0;
   dctz_compress(&var, N, &out_size, &var_z, eb);
   printf("oriFilePath = %s, outputFilePath = %s, datatype = %s, error = %s, dim1 = %zu, dim2 = %zu, dim3 = %zu, dim4 = %zu\n",

@@ -39,6 +39,8 @@ int main(int argc, char *argv[]) {
     return 1;
   }
   printf("File Name=%s\n", path);
+  const unsigned geom = DCTZ_GEOM_OF(h.datatype);          /* 0: the reference's flat blocks; 2, 3: tiles (dctz.h) */
+  h.datatype = DCTZ_TYPE_OF(h.datatype);
   printf("data type=%s\n", (h.datatype == DOUBLE) ? "double" : "float");
   printf("N=%d\n", h.num_elements);
   printf("error_bound=%f\n", h.error_bound);
@@ -50,21 +52,38 @@ int main(int argc, char *argv[]) {
     fseek(fp, 0, SEEK_END);
     const long fsz = ftell(fp);
     const size_t ts = h.datatype == DOUBLE ? sizeof(double) : sizeof(float);
-    const size_t nblk = ((size_t)h.num_elements + BLK_SZ - 1) / BLK_SZ;
-    const size_t o0 = sizeof(h), o1 = o0 + h.bindex_sz_compressed, o2 = o1 + h.DC_sz_compressed,
-                 end = o2 + h.AC_exact_sz_compressed;
+    size_t nblk = ((size_t)h.num_elements + BLK_SZ - 1) / BLK_SZ;
+    const size_t o0 = sizeof(h), o1 = o0 + h.bindex_sz_compressed, o2 = o1 + h.DC_sz_compressed;
+    size_t end = o2 + h.AC_exact_sz_compressed;
+    size_t npos = h.num_elements;
+    if (geom) {                                             /* "DZND" + three extents close the file */
+      unsigned int tr[4] = {0, 0, 0, 0};
+      if (fsz >= 16 && fseek(fp, fsz - 16, SEEK_SET) == 0 && fread(tr, sizeof(tr), 1, fp) == 1 && tr[0] == DCTZ_ND_MAGIC) {
+        const size_t e = geom == 2 ? 8 : 4;
+        nblk = 1;
+        for (unsigned i = 0; i < geom; i++) nblk *= (tr[1 + i] + e - 1) / e;
+        npos = nblk * BLK_SZ;
+        if (geom == 2) printf("multi-dimensional blocks: %u x %u array, 8 x 8 tiles\n", tr[1], tr[2]);
+        else printf("multi-dimensional blocks: %u x %u x %u array, 4 x 4 x 4 tiles\n", tr[1], tr[2], tr[3]);
+      } else {
+        printf("LAYOUT MISMATCH: geometry %u in the header but no extents at the end of the file\n", geom);
+        rc = 2;
+      }
+    }
     printf("mean=%.17g\n", h.datatype == DOUBLE ? h.mean.d : (double)h.mean.f);
-    printf("blocks=%zu (last one %zu elements)\n", nblk, h.num_elements % BLK_SZ ? (size_t)(h.num_elements % BLK_SZ) : (size_t)BLK_SZ);
-    printf("bin_index: offset %zu, %u bytes deflated (%u raw)\n", o0, h.bindex_sz_compressed, h.num_elements);
+    printf("blocks=%zu (last one %zu elements)\n", nblk, (!geom && h.num_elements % BLK_SZ) ? (size_t)(h.num_elements % BLK_SZ) : (size_t)BLK_SZ);
+    printf("bin_index: offset %zu, %u bytes deflated (%zu raw)\n", o0, h.bindex_sz_compressed, npos);
     printf("DC:        offset %zu, %u bytes deflated (%zu raw)\n", o1, h.DC_sz_compressed, nblk * sizeof(float));
     printf("AC_exact:  offset %zu, %u bytes deflated (%zu raw)\n", o2, h.AC_exact_sz_compressed,
            (size_t)h.tot_AC_exact_count * sizeof(float));
+    const size_t trailer = geom ? 16 : 0;
+    end += trailer;
     if ((size_t)fsz == end) {
       printf("variant=ec (no table), file size %ld = layout\n", fsz);
     } else if ((size_t)fsz == end + BLK_SZ * ts) {
-      printf("variant=qt, bindex_count=%u, table at offset %zu, file size %ld = layout\n", h.bindex_count, end, fsz);
+      printf("variant=qt, bindex_count=%u, table at offset %zu, file size %ld = layout\n", h.bindex_count, end - trailer, fsz);
       unsigned char q[BLK_SZ * sizeof(double)];
-      fseek(fp, (long)end, SEEK_SET);
+      fseek(fp, (long)(end - trailer), SEEK_SET);
       if (fread(q, ts, BLK_SZ, fp) == BLK_SZ) {
         printf("qtable[1..4]=");
         for (int j = 1; j <= 4; j++) {

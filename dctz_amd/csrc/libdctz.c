@@ -54,6 +54,9 @@ static struct {
   size_t in_cap, bin_cap, dc_cap, ac_cap, out_cap;
 } g_dev;
 static dctz_stage_times g_times;
+/* multi-dimensional blocks requested for the next dctz_compress call (dctz.h: dctz_set_block_dims) */
+static int g_nd = 0;
+static size_t g_dims[3] = {0, 0, 0};
 
 static double now_s(void) {
   struct timeval tv;
@@ -270,6 +273,43 @@ static void dump_file(const char *name, const void *p, size_t bytes) {
   fclose(fp);
 }
 
+/* ------------------------------------------------- multi-dimensional blocks --- */
+int dctz_set_block_dims(int ndims, const size_t *dims) {
+  g_nd = 0;
+  if (ndims <= 1) return 0;
+  if (ndims > 3 || !dims) return -1;
+  for (int i = 0; i < ndims; i++) if (dims[i] == 0 || dims[i] > 0x7FFFFFFFu) return -1;
+  for (int i = 0; i < 3; i++) g_dims[i] = i < ndims ? dims[i] : 1;
+  g_nd = ndims;
+  return 0;
+}
+
+/* geometry of this call: the explicit request (one call only), else DCTZ_BLOCK_DIMS when its product is N */
+static int take_block_dims(size_t n, size_t dims[3]) {
+  int nd = g_nd;
+  if (nd) { for (int i = 0; i < 3; i++) dims[i] = g_dims[i]; g_nd = 0; }
+  else {
+    const char *e = getenv("DCTZ_BLOCK_DIMS");
+    if (!e || !*e) return 0;
+    char *end = NULL;
+    while (nd < 3) {
+      const unsigned long long v = strtoull(e, &end, 10);
+      if (end == e || v == 0 || v > 0x7FFFFFFFull) return 0;
+      dims[nd++] = (size_t)v;
+      if (*end != 'x' && *end != 'X') break;
+      e = end + 1;
+    }
+    if (*end != 0 || nd < 2) return 0;
+  }
+  size_t prod = 1;
+  for (int i = 0; i < nd; i++) prod *= dims[i];
+  if (prod != n) {
+    if (nd && !getenv("DCTZ_BLOCK_DIMS")) { fprintf(stderr, "libdctz: block dims do not multiply to N\n"); exit(1); }
+    return 0;                                    /* the environment describes some other array of the run */
+  }
+  return nd;
+}
+
 /* -------------------------------------------------------------- compress --- */
 int dctz_compress(t_var *var, int N, size_t *outSize, t_var *var_z, double error_bound) {
   const double t_begin = now_s();
@@ -284,13 +324,20 @@ int dctz_compress(t_var *var, int N, size_t *outSize, t_var *var_z, double error
   }
   if (N <= 0) { fprintf(stderr, "libdctz: N must be positive\n"); exit(1); }
   const size_t n = (size_t)N;
-  const size_t nblk = CEIL(n, BLK_SZ);
+  size_t dims[3] = {0, 0, 0};
+  const int nd = take_block_dims(n, dims);      /* 0: the reference's flat blocks */
+  size_t nblk = CEIL(n, BLK_SZ);
+  if (nd) {
+    nblk = dctzhip_nd_blocks(nd, dims);
+    if (!nblk) { fprintf(stderr, "libdctz: array too large for multi-dimensional blocks\n"); exit(1); }
+  }
+  const size_t npos = nd ? nblk * BLK_SZ : n;   /* positions the streams cover (edge tiles are padded) */
 
   dctzhip_ctx *c = ctx();
   grow(&g_dev.in, &g_dev.in_cap, n * ts);
-  grow(&g_dev.bin, &g_dev.bin_cap, n);
+  grow(&g_dev.bin, &g_dev.bin_cap, npos);
   grow(&g_dev.dc, &g_dev.dc_cap, nblk * sizeof(float));
-  grow(&g_dev.ac, &g_dev.ac_cap, n * sizeof(float));
+  grow(&g_dev.ac, &g_dev.ac_cap, npos * sizeof(float));
 
   double t0 = now_s();
   if (dctzhip_memcpy_h2d(c, g_dev.in, host_in, n * ts) != DCTZHIP_OK) die("H2D");
@@ -305,23 +352,26 @@ int dctz_compress(t_var *var, int N, size_t *outSize, t_var *var_z, double error
   int mean_on_host = 0;
   if (fast_tail && pthread_create(&mean_thread, NULL, host_mean_main, &mj) == 0) mean_on_host = 1;
   if (!mean_on_host && dctzhip_serial_mean_begin(c, g_dev.in, n, dtype) != DCTZHIP_OK) die("serial mean");
-  int rc = dctzhip_compress(c, g_dev.in, n, dtype, error_bound, DCTZ_MODE, g_dev.bin, (float *)g_dev.dc,
-                            (float *)g_dev.ac, NULL, NULL, &info);
+  int rc = nd ? dctzhip_compress_nd(c, g_dev.in, nd, dims, dtype, error_bound, DCTZ_MODE, g_dev.bin, (float *)g_dev.dc,
+                                    (float *)g_dev.ac, NULL, &info)
+              : dctzhip_compress(c, g_dev.in, n, dtype, error_bound, DCTZ_MODE, g_dev.bin, (float *)g_dev.dc,
+                                 (float *)g_dev.ac, NULL, NULL, &info);
   if (rc != DCTZHIP_OK) die("dctzhip_compress");
+  if (dctzhip_sync(c) != DCTZHIP_OK) die("sync");   /* (the call returns while its last kernels drain: keep the stage timers honest) */
   double t2 = now_s();
 
-  t_bin_id *bin_index = (t_bin_id *)malloc(n);
+  t_bin_id *bin_index = (t_bin_id *)malloc(npos);
   float *DC = (float *)malloc(nblk * sizeof(float));
   float *AC_exact = (float *)malloc((info.cnt ? info.cnt : 1) * sizeof(float));
   if (!bin_index || !DC || !AC_exact) { fprintf(stderr, "Out of memory: streams\n"); exit(1); }
-  if (dctzhip_memcpy_d2h(c, bin_index, g_dev.bin, n) != DCTZHIP_OK) die("D2H bin_index");
+  if (dctzhip_memcpy_d2h(c, bin_index, g_dev.bin, npos) != DCTZHIP_OK) die("D2H bin_index");
   if (dctzhip_memcpy_d2h(c, DC, g_dev.dc, nblk * sizeof(float)) != DCTZHIP_OK) die("D2H DC");
   if (info.cnt && dctzhip_memcpy_d2h(c, AC_exact, g_dev.ac, (size_t)info.cnt * sizeof(float)) != DCTZHIP_OK)
     die("D2H AC_exact");
   double t3 = now_s();
 
   if (getenv("DCTZ_DUMP_STREAMS")) { /* dctz-comp-lib.c:583-595, :443-448 */
-    dump_file("bin_index.bin", bin_index, n);
+    dump_file("bin_index.bin", bin_index, npos);
     dump_file("AC_exact.bin", AC_exact, (size_t)info.cnt * sizeof(float));
 #ifdef USE_QTABLE
     if (is_d) dump_file("qtable.bin", info.qtable_raw, BLK_SZ * sizeof(double));
@@ -331,7 +381,7 @@ int dctz_compress(t_var *var, int N, size_t *outSize, t_var *var_z, double error
 
   /* zlib tail: three streams on three threads (dctz-comp-lib.c:620-732) */
   const int zthreads = zlib_threads();
-  const size_t sec_bytes[3] = {n * sizeof(t_bin_id), nblk * sizeof(float), (size_t)info.cnt * sizeof(float)};
+  const size_t sec_bytes[3] = {npos * sizeof(t_bin_id), nblk * sizeof(float), (size_t)info.cnt * sizeof(float)};
   const void *sec_src[3] = {bin_index, DC, AC_exact};
   pthread_attr_t attr;
   pthread_attr_init(&attr);
@@ -382,7 +432,7 @@ int dctz_compress(t_var *var, int N, size_t *outSize, t_var *var_z, double error
   /* container: header | bin_indexz | DCz | AC_exactz | [qtable]  (:775-820) */
   struct header h;
   memset(&h, 0, sizeof(h));
-  h.datatype = var->datatype;
+  h.datatype = (t_datatype)((unsigned)var->datatype | ((unsigned)nd << DCTZ_GEOM_SHIFT));
   h.num_elements = (unsigned int)N;
   h.error_bound = error_bound;
   h.tot_AC_exact_count = info.cnt;
@@ -392,12 +442,13 @@ int dctz_compress(t_var *var, int N, size_t *outSize, t_var *var_z, double error
   h.DC_sz_compressed = (unsigned int)zsz[1];
   h.AC_exact_sz_compressed = (unsigned int)zsz[2];
 #ifdef USE_QTABLE
-  h.bindex_count = (unsigned int)N;
+  h.bindex_count = (unsigned int)npos;
 #endif
   *outSize = sizeof(struct header) + zsz[0] + zsz[1] + zsz[2];
 #ifdef USE_QTABLE
   *outSize += BLK_SZ * ts;
 #endif
+  if (nd) *outSize += 16;                      /* "DZND" + the extents */
   unsigned char *cur = is_d ? (unsigned char *)var_z->buf.d : (unsigned char *)var_z->buf.f;
   memcpy(cur, &h, sizeof(h)); cur += sizeof(h);
   memcpy(cur, jb[0].dst, zsz[0]); cur += zsz[0];
@@ -406,7 +457,12 @@ int dctz_compress(t_var *var, int N, size_t *outSize, t_var *var_z, double error
 #ifdef USE_QTABLE
   if (is_d) memcpy(cur, info.qtable, BLK_SZ * sizeof(double));
   else { float q[BLK_SZ]; for (int j = 0; j < BLK_SZ; j++) q[j] = (float)info.qtable[j]; memcpy(cur, q, sizeof(q)); }
+  cur += BLK_SZ * ts;
 #endif
+  if (nd) {
+    const unsigned int tr[4] = {DCTZ_ND_MAGIC, (unsigned int)dims[0], (unsigned int)dims[1], (unsigned int)(nd == 3 ? dims[2] : 0)};
+    memcpy(cur, tr, sizeof(tr));
+  }
   for (int i = 0; i < 3; i++) free(jb[i].dst);
   free(bin_index); free(DC); free(AC_exact);
 
@@ -426,24 +482,42 @@ int dctz_check_container(const void *z, size_t zbytes, int max_elements, int dee
   struct header h;
   if (!z || zbytes < sizeof(h)) return DCTZ_CHECK_TRUNCATED;
   memcpy(&h, z, sizeof(h));
-  if (h.datatype != FLOAT && h.datatype != DOUBLE) return DCTZ_CHECK_BAD_HEADER;
+  const t_datatype base = DCTZ_TYPE_OF(h.datatype);
+  const unsigned geom = DCTZ_GEOM_OF(h.datatype);
+  if ((base != FLOAT && base != DOUBLE) || ((unsigned)h.datatype >> 16) || (geom != 0 && geom != 2 && geom != 3)) return DCTZ_CHECK_BAD_HEADER;
   if (h.num_elements == 0 || h.num_elements > 0x7FFFFFFFu) return DCTZ_CHECK_BAD_HEADER;     /* N is an int, dctz.h:126 */
   if (max_elements > 0 && h.num_elements > (unsigned int)max_elements) return DCTZ_CHECK_TOO_LARGE;
   if (!(h.error_bound >= 1E-6) || h.error_bound != h.error_bound) return DCTZ_CHECK_BAD_HEADER;   /* :135-138 */
-  const size_t n = h.num_elements, nblk = CEIL(n, BLK_SZ), ts = h.datatype == DOUBLE ? sizeof(double) : sizeof(float);
-  if ((size_t)h.tot_AC_exact_count > n - nblk) return DCTZ_CHECK_BAD_HEADER;                   /* at most 63 per block */
+  const size_t n = h.num_elements, ts = base == DOUBLE ? sizeof(double) : sizeof(float);
   const size_t body = (size_t)h.bindex_sz_compressed + h.DC_sz_compressed + h.AC_exact_sz_compressed;
   size_t want = sizeof(h) + body;
 #ifdef USE_QTABLE
   want += BLK_SZ * ts;
-  if (h.bindex_count != h.num_elements) return DCTZ_CHECK_BAD_HEADER;                           /* :798 */
 #else
   (void)ts;
+#endif
+  size_t nblk = CEIL(n, BLK_SZ), npos = n;
+  if (geom) {                                           /* multi-dimensional blocks: the extents follow the last section */
+    if (zbytes < want + 16) return DCTZ_CHECK_TRUNCATED;
+    unsigned int tr[4];
+    memcpy(tr, (const unsigned char *)z + want, sizeof(tr));
+    want += 16;
+    size_t dims[3] = {tr[1], tr[2], tr[3]};
+    if (tr[0] != DCTZ_ND_MAGIC || (geom == 2 && tr[3] != 0)) return DCTZ_CHECK_BAD_HEADER;
+    nblk = dctzhip_nd_blocks((int)geom, dims);
+    size_t prod = 1;
+    for (unsigned i = 0; i < geom; i++) prod *= dims[i];
+    if (!nblk || prod != n) return DCTZ_CHECK_BAD_HEADER;
+    npos = nblk * BLK_SZ;
+  }
+  if ((size_t)h.tot_AC_exact_count > npos - nblk) return DCTZ_CHECK_BAD_HEADER;                /* at most 63 per block */
+#ifdef USE_QTABLE
+  if (h.bindex_count != npos) return DCTZ_CHECK_BAD_HEADER;                                     /* :798 */
 #endif
   if (zbytes < want) return DCTZ_CHECK_TRUNCATED;
   if (!deep) return DCTZ_CHECK_OK;
   const unsigned char *cur = (const unsigned char *)z + sizeof(h);
-  const size_t raw[3] = {n, nblk * sizeof(float), (size_t)h.tot_AC_exact_count * sizeof(float)};
+  const size_t raw[3] = {npos, nblk * sizeof(float), (size_t)h.tot_AC_exact_count * sizeof(float)};
   const unsigned int zs[3] = {h.bindex_sz_compressed, h.DC_sz_compressed, h.AC_exact_sz_compressed};
   for (int i = 0; i < 3; i++) {
     /* inflate into a small window, counting: the section must end exactly at `raw[i]` bytes */
@@ -477,11 +551,26 @@ int dctz_decompress(t_var *var_z, t_var *var_r) {
   memcpy(&h, cur, sizeof(h)); /* dctz-decomp-lib.c:84-94 */
   cur += sizeof(h);
   const size_t n = h.num_elements;
-  const size_t nblk = CEIL(n, BLK_SZ);
   const unsigned int cnt = h.tot_AC_exact_count;
   if (n == 0) { fprintf(stderr, "libdctz: empty stream\n"); exit(1); }
+  /* multi-dimensional blocks (dctz.h: dctz_set_block_dims): the extents sit behind the last section */
+  const int nd = (int)DCTZ_GEOM_OF(h.datatype);
+  size_t dims[3] = {0, 0, 0};
+  size_t nblk = CEIL(n, BLK_SZ);
+  if (nd) {
+    size_t off = (size_t)h.bindex_sz_compressed + h.DC_sz_compressed + h.AC_exact_sz_compressed;
+#ifdef USE_QTABLE
+    off += BLK_SZ * ts;
+#endif
+    unsigned int tr[4];
+    memcpy(tr, cur + off, sizeof(tr));
+    dims[0] = tr[1]; dims[1] = tr[2]; dims[2] = tr[3];
+    nblk = (tr[0] == DCTZ_ND_MAGIC && (nd == 2 || nd == 3)) ? dctzhip_nd_blocks(nd, dims) : 0;
+    if (!nblk || dims[0] * dims[1] * (nd == 3 ? dims[2] : 1) != n) { fprintf(stderr, "libdctz: bad multi-dimensional container\n"); exit(1); }
+  }
+  const size_t npos = nd ? nblk * BLK_SZ : n;
 
-  t_bin_id *bin_index = (t_bin_id *)malloc(n);
+  t_bin_id *bin_index = (t_bin_id *)malloc(npos);
   float *DC = (float *)malloc(nblk * sizeof(float));
   float *AC_exact = (float *)malloc((cnt ? cnt : 1) * sizeof(float));
   if (!bin_index || !DC || !AC_exact) { fprintf(stderr, "Out of memory: streams\n"); exit(1); }
@@ -490,7 +579,7 @@ int dctz_decompress(t_var *var_z, t_var *var_r) {
   /* three inflates, in order (dctz-decomp-lib.c:244-322) */
   uLong got;
   if (zlib_threads() > 3) {                 /* the sections are independent streams: inflate them side by side */
-    inflate_job ij[3] = {{cur, h.bindex_sz_compressed, (uLong)n, 0, bin_index},
+    inflate_job ij[3] = {{cur, h.bindex_sz_compressed, (uLong)npos, 0, bin_index},
                          {cur + h.bindex_sz_compressed, h.DC_sz_compressed, (uLong)(nblk * sizeof(float)), 0, DC},
                          {cur + h.bindex_sz_compressed + h.DC_sz_compressed, h.AC_exact_sz_compressed,
                           (uLong)((size_t)cnt * sizeof(float)), 0, AC_exact}};
@@ -502,7 +591,7 @@ int dctz_decompress(t_var *var_z, t_var *var_r) {
     got = ij[0].produced;
     cur += h.bindex_sz_compressed + h.DC_sz_compressed + h.AC_exact_sz_compressed;
   } else {
-    got = inflate_into(cur, h.bindex_sz_compressed, bin_index, (size_t)n);
+    got = inflate_into(cur, h.bindex_sz_compressed, bin_index, npos);
     cur += h.bindex_sz_compressed;
     inflate_into(cur, h.DC_sz_compressed, DC, nblk * sizeof(float));
     cur += h.DC_sz_compressed;
@@ -520,19 +609,22 @@ int dctz_decompress(t_var *var_z, t_var *var_r) {
   double t1 = now_s();
 
   dctzhip_ctx *c = ctx();
-  grow(&g_dev.bin, &g_dev.bin_cap, n);
+  grow(&g_dev.bin, &g_dev.bin_cap, npos);
   grow(&g_dev.dc, &g_dev.dc_cap, nblk * sizeof(float));
   grow(&g_dev.ac, &g_dev.ac_cap, (cnt ? cnt : 4) * sizeof(float));
   grow(&g_dev.out, &g_dev.out_cap, n * ts);
-  if (dctzhip_memcpy_h2d(c, g_dev.bin, bin_index, n) != DCTZHIP_OK) die("H2D bin_index");
+  if (dctzhip_memcpy_h2d(c, g_dev.bin, bin_index, npos) != DCTZHIP_OK) die("H2D bin_index");
   if (dctzhip_memcpy_h2d(c, g_dev.dc, DC, nblk * sizeof(float)) != DCTZHIP_OK) die("H2D DC");
   if (cnt && dctzhip_memcpy_h2d(c, g_dev.ac, AC_exact, (size_t)cnt * sizeof(float)) != DCTZHIP_OK) die("H2D AC_exact");
   double t2 = now_s();
 
   const double sf = is_d ? h.scaling_factor.d : (double)h.scaling_factor.f;
-  int rc = dctzhip_decompress(c, g_dev.bin, (const float *)g_dev.dc, (const float *)g_dev.ac, cnt, qtable, n, dtype,
-                              h.error_bound, sf, DCTZ_MODE, g_dev.out);
+  int rc = nd ? dctzhip_decompress_nd(c, g_dev.bin, (const float *)g_dev.dc, (const float *)g_dev.ac, cnt, qtable, nd, dims,
+                                      dtype, h.error_bound, sf, DCTZ_MODE, g_dev.out)
+              : dctzhip_decompress(c, g_dev.bin, (const float *)g_dev.dc, (const float *)g_dev.ac, cnt, qtable, n, dtype,
+                                   h.error_bound, sf, DCTZ_MODE, g_dev.out);
   if (rc != DCTZHIP_OK) die("dctzhip_decompress");
+  if (dctzhip_sync(c) != DCTZHIP_OK) die("sync");   /* (stage timers: the call returns while the reconstruction is being written) */
   double t3 = now_s();
   void *host_out = is_d ? (void *)var_r->buf.d : (void *)var_r->buf.f;
   if (dctzhip_memcpy_d2h(c, host_out, g_dev.out, n * ts) != DCTZHIP_OK) die("D2H output");

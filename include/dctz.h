@@ -122,6 +122,21 @@ void idct_finish_f(void);
  * compute with a loop. */
 void dctz_dct_blocks(double *a, double *b, size_t n, int inverse);
 void dctz_dct_blocks_f(float *a, float *b, size_t n, int inverse);
+/* Multi-dimensional blocks (optional; SURVEY section 8 f4 -- NOT in the reference, whose library flattens every
+ * array, dctz-test.c:77-91; the hint is its FFTW r2r experiment dct-fftw-test.c:74-97).  The NEXT dctz_compress call
+ * treats var->buf as a row-major ndims-dimensional array (ndims = 2: 8 x 8 tiles, ndims = 3: 4 x 4 x 4 tiles, last
+ * extent fastest, product = N) and transforms tiles with the separable orthonormal DCT instead of runs of 64
+ * consecutive elements; the call after that is flat again.  Environment DCTZ_BLOCK_DIMS="1800x3600" does the same
+ * for every call whose N matches (callers that cannot be changed).  ndims <= 1 cancels.  Returns 0, or -1 for
+ * bad arguments.
+ * Container of such a call: header.datatype carries the geometry in bits 8..15 (DCTZ_GEOM_OF), the three
+ * sections cover nblk * 64 positions (edge tiles are padded), and 16 bytes follow the last section:
+ * "DZND" + three 32-bit extents.  The reference's decoder cannot read it; dctz_decompress here reads both. */
+int dctz_set_block_dims(int ndims, const size_t *dims);
+#define DCTZ_GEOM_SHIFT 8
+#define DCTZ_GEOM_OF(datatype) (((unsigned)(datatype) >> DCTZ_GEOM_SHIFT) & 0xffu)   /* 0: flat; 2, 3: number of axes */
+#define DCTZ_TYPE_OF(datatype) ((t_datatype)((unsigned)(datatype) & 0xffu))
+#define DCTZ_ND_MAGIC 0x444E5A44u   /* "DZND" little-endian */
 /* Stage timers of the last dctz_compress / dctz_decompress call, seconds
  * (the reference's -DTIME_DEBUG split, dctz-comp-lib.c:762-773). */
 typedef struct {

@@ -168,3 +168,146 @@ def test_hip_nd_rejects_bad_shapes(ctx):
         ctx.nd_blocks((5,))
     with pytest.raises(dctz_amd.hip.DctzHipError):
         ctx.nd_blocks((4, 0, 4))
+
+
+# ------------------------------------------------------------------------- drop-in library, container, CLI --
+ROOT = os.path.dirname(HERE)
+LIBDIR = os.path.join(ROOT, "dctz_amd", "lib")
+BIN = os.path.join(ROOT, "dctz_amd", "bin")
+
+
+def _nd_container(x, eb, mode):
+    """A multi-dimensional .z assembled from the oracle's streams: the reference's layout (dctz-comp-lib.c:775-820)
+    with the geometry in bits 8..15 of `datatype` and "DZND" + three extents behind the last section (include/dctz.h)."""
+    import struct
+    import zlib
+    c = O.compress_nd(x, eb, mode, O.FAST)
+    z = [zlib.compress(c.bin_index.tobytes()), zlib.compress(c.dc.tobytes()), zlib.compress(c.ac_exact.tobytes())]
+    is_d = x.dtype == np.float64
+    h = bytearray(56)
+    struct.pack_into("<II", h, 0, (1 if is_d else 0) | (x.ndim << 8), x.size)
+    struct.pack_into("<d", h, 8, eb)
+    struct.pack_into("<I", h, 16, c.cnt)
+    struct.pack_into("<d" if is_d else "<f", h, 24, c.sf)
+    struct.pack_into("<d" if is_d else "<f", h, 32, c.mean)
+    struct.pack_into("<III", h, 40, len(z[0]), len(z[1]), len(z[2]))
+    if mode == O.QT:
+        struct.pack_into("<I", h, 52, c.bin_index.size)
+    blob = bytes(h) + b"".join(z)
+    if mode == O.QT:
+        blob += c.qtable.tobytes()
+    dims = list(x.shape) + [0] * (3 - x.ndim)
+    blob += struct.pack("<IIII", 0x444E5A44, *dims)
+    return blob, c
+
+
+@pytest.mark.parametrize("mode,variant", [(O.EC, "ec"), (O.QT, "qt")])
+def test_nd_container_check_and_dump(tmp_path, mode, variant):
+    """Host only: dctz_check_container (shallow + deep) and dctz-dump -v on oracle-built multi-dimensional containers."""
+    if not os.path.exists(os.path.join(BIN, "dctz-dump")):
+        import __graft_entry__ as g
+        g.build()
+    lib = C.CDLL(os.path.join(LIBDIR, f"libdctz-{variant}.so"))
+    lib.dctz_check_container.argtypes = [C.c_void_p, C.c_size_t, C.c_int, C.c_int]
+    for x in (field((45, 77), np.float64), field((13, 22, 35), np.float32)):
+        blob, c = _nd_container(x, 1e-3, mode)
+        buf = np.frombuffer(blob, np.uint8).copy()
+        assert lib.dctz_check_container(buf.ctypes.data, buf.size, 0, 1) == 0
+        assert lib.dctz_check_container(buf.ctypes.data, buf.size - 1, 0, 0) == -1           # truncated
+        bad = buf.copy(); bad[-4] ^= 1                                                        # an extent that no longer multiplies to N
+        assert lib.dctz_check_container(bad.ctypes.data, bad.size, 0, 0) == -2
+        f = tmp_path / f"nd{x.ndim}.z"
+        f.write_bytes(blob)
+        r = subprocess.run([os.path.join(BIN, "dctz-dump"), "-v", str(f)], capture_output=True, text=True)
+        assert r.returncode == 0, r.stdout
+        assert f"N={x.size}" in r.stdout and "multi-dimensional blocks: " + " x ".join(str(d) for d in x.shape) in r.stdout
+        assert f"({c.bin_index.size} raw)" in r.stdout and "= layout" in r.stdout
+
+
+class _TVarBuf(C.Union):
+    _fields_ = [("f", C.POINTER(C.c_float)), ("d", C.POINTER(C.c_double))]
+
+
+class _TVar(C.Structure):   # dctz.h:49-59
+    _fields_ = [("datatype", C.c_int), ("err_bound", C.c_double), ("var_name", C.c_char_p), ("buf", _TVarBuf)]
+
+
+def _tvar(arr):
+    v = _TVar()
+    v.datatype = 1 if arr.dtype == np.float64 else 0
+    if arr.dtype == np.float64:
+        v.buf.d = arr.ctypes.data_as(C.POINTER(C.c_double))
+    else:
+        v.buf.f = arr.ctypes.data_as(C.POINTER(C.c_float))
+    return v
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("variant", ["ec", "qt"])
+@pytest.mark.parametrize("shape,dtype", [((90, 130), np.float32), ((13, 22, 35), np.float64)])
+@pytest.mark.parametrize("how", ["call", "env"])
+def test_dropin_nd_container_equals_oracle(variant, shape, dtype, how):
+    """dctz_set_block_dims / DCTZ_BLOCK_DIMS + dctz_compress: the container is byte for byte the one assembled from the
+    oracle's streams (same zlib), the caller's buffer holds x / sf, dctz_decompress gives the oracle's reconstruction,
+    and the next call is flat again."""
+    os.environ["DCTZ_QUIET"] = "1"
+    lib = C.CDLL(os.path.join(LIBDIR, f"libdctz-{variant}.so"))
+    lib.dctz_compress.argtypes = [C.POINTER(_TVar), C.c_int, C.POINTER(C.c_size_t), C.POINTER(_TVar), C.c_double]
+    lib.dctz_decompress.argtypes = [C.POINTER(_TVar), C.POINTER(_TVar)]
+    lib.dctz_set_block_dims.argtypes = [C.c_int, C.POINTER(C.c_size_t)]
+    mode = O.QT if variant == "qt" else O.EC
+    x = field(shape, dtype, seed=23)
+    want, c = _nd_container(x, 1e-3, mode)
+    work = x.copy()
+    n = x.size
+    zbuf = np.zeros(n * x.itemsize + 65536, np.uint8)
+    rec = np.zeros(n, dtype)
+    var, var_z, var_r = _tvar(work.reshape(-1)), _TVar(), _tvar(rec)
+    var_z.datatype = var.datatype
+    var_z.buf.d = zbuf.ctypes.data_as(C.POINTER(C.c_double))
+    out_size = C.c_size_t(0)
+    try:
+        if how == "call":
+            assert lib.dctz_set_block_dims(len(shape), (C.c_size_t * len(shape))(*shape)) == 0
+        else:
+            os.environ["DCTZ_BLOCK_DIMS"] = "x".join(str(d) for d in shape)
+        assert lib.dctz_compress(C.byref(var), n, C.byref(out_size), C.byref(var_z), 1e-3) == 1
+    finally:
+        os.environ.pop("DCTZ_BLOCK_DIMS", None)
+    got = bytes(zbuf[:out_size.value])
+    assert len(got) == len(want)
+    assert got[:32] == want[:32] and got[40:] == want[40:]            # everything but the header's mean (below)
+    mean = np.frombuffer(got[32:40], dtype)[0]
+    assert mean == dtype(c.mean)                                     # serial-order mean of the original array: bit-exact
+    scaled = (x / dtype(c.sf)) if c.sf != 1 else x
+    assert np.array_equal(work, scaled)
+    assert lib.dctz_decompress(C.byref(var_z), C.byref(var_r)) == 1
+    assert np.array_equal(rec.reshape(shape), O.decompress_nd(c, shape, O.FAST))
+    # the request was for one call: the same array again is compressed flat
+    work2 = x.copy().reshape(-1)
+    var2 = _tvar(work2)
+    assert lib.dctz_compress(C.byref(var2), n, C.byref(out_size), C.byref(var_z), 1e-3) == 1
+    assert (int(np.frombuffer(bytes(zbuf[:4]), np.uint32)[0]) >> 8) == 0
+
+
+@pytest.mark.gpu
+def test_cli_nd_blocks(tmp_path):
+    """dctz-ec-test with DCTZ_ND_BLOCKS: the reference's argv (fastest extent first) -> tiles; CR improves on a smooth field."""
+    x = field((180, 360), np.float32, seed=2, noise=0.0)
+    src = tmp_path / "f.dat"
+    x.tofile(src)
+    env = dict(os.environ, DCTZ_QUIET="1")
+    outs = {}
+    for nd in (False, True):
+        e = dict(env, DCTZ_ND_BLOCKS="1") if nd else env
+        r = subprocess.run([os.path.join(BIN, "dctz-ec-test"), "-f", "1E-3", "var", str(src), "360", "180"], capture_output=True,
+                           text=True, env=e, cwd=tmp_path)
+        assert r.returncode == 0, r.stdout + r.stderr
+        assert ("multi-dimensional blocks: 8 x 8 tiles" in r.stdout) == nd
+        cr = float(r.stdout.split("CR = ")[1].split(",")[0]); psnr = float(r.stdout.split("PSNR = ")[1].split()[0])
+        outs[nd] = (cr, psnr)
+        rec = np.fromfile(str(src) + ".ec.1E-3.z.r", np.float32).reshape(x.shape)
+        assert np.abs(rec - x).max() <= np.sqrt(63.0) * 1e-3 * 1.1 * 100 + 1e-3
+    assert outs[True][0] > outs[False][0], outs
+    d = subprocess.run([os.path.join(BIN, "dctz-dump"), "-v", str(src) + ".ec.1E-3.z"], capture_output=True, text=True)
+    assert "multi-dimensional blocks: 180 x 360 array, 8 x 8 tiles" in d.stdout and "= layout" in d.stdout
