@@ -45,8 +45,8 @@ HBM_PEAK_GBPS = 8000.0      # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=200, help="timed steps (0.5 ms each: the default is a tenth of a second of GPU time)")
+    ap.add_argument("--warmup", type=int, default=20, help="untimed steps first (clocks and caches settle over the first dozens of steps)")
     ap.add_argument("--n", type=int, default=512, help="volume edge (512 -> 1 GiB fp64 shard)")
     ap.add_argument("--eb", type=float, default=1e-3)
     ap.add_argument("--mode", choices=["ec", "qt"], default="ec")

@@ -99,8 +99,29 @@ struct HostBox {
   unsigned cnt_total, error;
   unsigned long long q0;
   unsigned long long qraw[64];
+  double sf_used;                          // scaling factor / FastDiv level the device chose for this call (SfGuess)
+  unsigned fast_used, pad_used;
   double fstats[3];                        // statistics fused into k_compress
   double psnr[6];                          // calc_psnr reduction: min, max, sum e^2, max |e|, max |e/x| (k_psnr_final)
+};
+
+// The scaling factor of a speculative compress call, chosen ON THE DEVICE from the sampled statistics (k_stats_final)
+// so that the host need not be asked between the sample and k_compress; the host checks it afterwards against the true
+// statistics with its own libm (util.c:29 / :43), exactly as it checks its own guesses.
+struct SfGuess {
+  double sf;                       // value of the data type (exactly representable in a double)
+  unsigned fast_sf;                // FastDiv level the kernel may assume for x / sf (FwdParams::fast_sf)
+  unsigned pad;
+};
+// Decade tables built by the host with ITS log10 / pow (so that the device's choice is the host's, by construction):
+// thr[i] = largest value m of the data type with ceil(log10(m)) <= kmin + i,  pw[i] = 10^(kmin - 1 + i) in the data
+// type; both widened to double.  sf(max) = pw[#{i : thr[i] < max}].
+struct SfTable {
+  const double* thr;
+  const double* pw;
+  int nk;
+  int fastdiv;                     // the context's DCTZHIP_FASTDIV level
+  int dtype;
 };
 
 // What the hand-off of a call's results to the host needs (k_finish, or the first workgroup of k_compact_ac /
@@ -111,6 +132,7 @@ struct FinArgs {
   int nparts;
   HostBox* box;
   unsigned long long seq;
+  const SfGuess* guess;            // device-chosen scaling factor of this call, reported with the results (NULL: the host chose it)
 };
 
 // A multi-dimensional array and its tile grid (dct_nd_block.h): nd = 2 -> 8 x 8 tiles, nd = 3 -> 4 x 4 x 4 tiles.
@@ -137,6 +159,7 @@ struct FwdParams {
   const T* tab;                    // TB_* block (device)
   const T* rtab;                   // RTAB_* block (device), remainder block only
   Ctl* ctl;
+  const SfGuess* guess;            // speculative call: sf / fast_sf chosen on the device (k_stats_final); NULL: the two fields below
   double* stat_part;               // fused statistics: {max|x|, min|x|, sum} per workgroup (+1 slot for the remainder block), else NULL
   unsigned nfull;                  // number of full 64-element blocks
   unsigned ntiles;
@@ -167,7 +190,8 @@ struct InvParams {
 template <typename T> void launch_stats(const T* x, size_t n, double* part, int nparts, double* out, hipStream_t s,
                                         HostBox* box = nullptr, unsigned long long seq = 0, Ctl* zero = nullptr);
 template <typename T> void launch_stats_sample(const T* x, size_t n, unsigned group, double* part, int nparts, double* out, hipStream_t s,
-                                               HostBox* box = nullptr, unsigned long long seq = 0, Ctl* zero = nullptr);
+                                               HostBox* box = nullptr, unsigned long long seq = 0, Ctl* zero = nullptr,
+                                               const SfTable* tab = nullptr, SfGuess* guess = nullptr);
 void launch_stats_final(const double* part, int nparts, double* out, hipStream_t s, HostBox* box = nullptr,
                         unsigned long long seq = 0, Ctl* zero = nullptr);
 void launch_finish(Ctl* ctl, const double* part, int nparts, HostBox* box, unsigned long long seq, hipStream_t s);
@@ -177,7 +201,7 @@ template <typename T> void launch_scale(const T* x, T* out, size_t n, T sf, int 
 template <typename T> void launch_compress(const FwdParams<T>& p, int mode, bool stats, int grid, int geom, hipStream_t s);
 template <typename T> void launch_gather_nd(const T* x, T* lin, const NdShape& sh, double* part, int nparts, hipStream_t s);
 template <typename T> void launch_scatter_nd(const T* lin, T* out, const NdShape& sh, int grid, hipStream_t s);
-template <typename T> void launch_compress_rem(const FwdParams<T>& p, int mode, bool scale, int l, hipStream_t s);
+template <typename T> void launch_compress_rem(const FwdParams<T>& p, int mode, int l, hipStream_t s);
 template <typename T> void launch_qt_max(const FwdParams<T>& p, unsigned nlists, int grid, hipStream_t s);
 template <typename T> void launch_compact_ac(const FwdParams<T>& p, int mode, double eb, unsigned nlists, int grid, const FinArgs& fin, hipStream_t s);
 void launch_count_tiles(const uint8_t* bin, unsigned nfull, unsigned ntiles, unsigned nwg, unsigned* tile_cnt, unsigned* wg_cnt, hipStream_t s);

@@ -364,8 +364,16 @@ __global__ __launch_bounds__(SWG) void k_stats(const T* __restrict__ x, size_t n
 // reduction of {max, min, sum} partials by one workgroup (any size up to 256 threads); thread 0 returns with the result
 __device__ __forceinline__ void reduce_parts(const double* __restrict__ part, int nparts, double& dmx, double& dmn, double& sum) {
   dmx = 0.0; dmn = 1.79769313486231570815e308; sum = 0.0;
-  for (int i = threadIdx.x; i < nparts; i += (int)blockDim.x) {
-    dmx = fmax(dmx, part[3 * i]); dmn = fmin(dmn, part[3 * i + 1]); sum += part[3 * i + 2];
+  for (int i0 = threadIdx.x; i0 < nparts; i0 += 4 * (int)blockDim.x) {      // four entries in flight per thread
+    double a[4], b[4], c[4];
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      const int i = i0 + u * (int)blockDim.x;
+      const bool in = i < nparts;
+      a[u] = in ? part[3 * i] : 0.0; b[u] = in ? part[3 * i + 1] : 1.79769313486231570815e308; c[u] = in ? part[3 * i + 2] : 0.0;
+    }
+#pragma unroll
+    for (int u = 0; u < 4; u++) { dmx = fmax(dmx, a[u]); dmn = fmin(dmn, b[u]); sum += c[u]; }
   }
 #pragma unroll
   for (int d = 32; d > 0; d >>= 1) {
@@ -396,6 +404,15 @@ __device__ __forceinline__ void stats_final_body(const double* part, int nparts,
 
 // zero != NULL: also the first kernel-side act of a compress call -- the control block back to all-zero (the
 // per-position maxima of the QT table accumulate with atomicMax, :371-372)
+__device__ __forceinline__ unsigned block_sum(unsigned v, unsigned* sh);
+
+// FastDiv's windows on the host's terms (dctz_shim.hip: divisor_in_window / value_in_window): unbiased exponent of a
+// finite non-zero double in [lo, hi)
+__device__ __forceinline__ bool exp_in(double v, int lo, int hi) {
+  const int e = (int)(((unsigned)__double2hiint(v) >> 20) & 0x7ffu) - 1023;     // subnormal / zero: -1023, inf / NaN: 1024
+  return e >= lo && e < hi;
+}
+
 __global__ __launch_bounds__(SWG) void k_stats_final(const double* part, int nparts, double* out,
                                                     HostBox* box, unsigned long long seq, Ctl* zero) {
   if (zero != nullptr) {
@@ -403,6 +420,35 @@ __global__ __launch_bounds__(SWG) void k_stats_final(const double* part, int npa
     for (int i = threadIdx.x; i < (int)(sizeof(Ctl) / 8); i += SWG) w[i] = 0ull;
   }
   stats_final_body(part, nparts, out, box, seq);
+}
+
+// The same, for a speculative compress call: the scaling factor of util.c:29 / :43 for the SAMPLED max|x| is chosen
+// here, with the host's own decade tables (SfTable), and left in device memory for k_compress -- no host round trip
+// between the sample and the main launch (the host verifies the choice against the true statistics afterwards).
+__global__ __launch_bounds__(SWG) void k_stats_final_sf(const double* part, int nparts, double* out, Ctl* zero, SfTable tab,
+                                                       SfGuess* guess) {
+  if (zero != nullptr) {
+    unsigned long long* w = reinterpret_cast<unsigned long long*>(zero);
+    for (int i = threadIdx.x; i < (int)(sizeof(Ctl) / 8); i += SWG) w[i] = 0ull;
+  }
+  __shared__ double smax, smin;
+  __shared__ unsigned cnt_s[SWG / 64];
+  double dmx, dmn, sum;
+  reduce_parts(part, nparts, dmx, dmn, sum);
+  if (threadIdx.x == 0) { out[0] = dmx; out[1] = dmn; out[2] = sum; smax = dmx; smin = dmn; }
+  __syncthreads();
+  const double mx = smax, mn = smin;
+  unsigned below = 0;                                  // decades whose upper end lies below max|x|
+  for (int i = threadIdx.x; i < tab.nk; i += SWG) below += (tab.thr[i] < mx) ? 1u : 0u;
+  const unsigned k = block_sum(below, cnt_s);
+  if (threadIdx.x == 0) {
+    double sf = (mx == 0.0) ? 1.0 : tab.pw[k < (unsigned)tab.nk ? k : (unsigned)tab.nk];   // all-zero input: sf = 1
+    const bool f64 = tab.dtype == DCTZHIP_F64;
+    unsigned fast = (tab.fastdiv && (f64 ? exp_in(sf, -250, 250) : exp_in(sf, -30, 30))) ? 1u : 0u;
+    if (fast && tab.fastdiv >= 2 && (f64 ? (exp_in(mn, -500, 500) && exp_in(mx, -500, 500)) : (exp_in(mn, -63, 63) && exp_in(mx, -63, 63)))) fast = 2u;
+    guess->sf = sf;
+    guess->fast_sf = fast;
+  }
 }
 
 // Hand-off of a call's results to the host, by ONE workgroup: final reduction of the fused statistics (nparts > 0),
@@ -430,6 +476,7 @@ __device__ __forceinline__ void finish_body(const FinBody& f) {
   if (WITH_STATS) {                                  // (compress side: the QT table's raw maxima, the last block's DC)
     for (int i = t; i < 64; i += (int)blockDim.x) box->qraw[i] = ctl->qraw[i];
     if (t == 0) box->q0 = ctl->q0;
+    if (t == 0 && f.guess != nullptr) { box->sf_used = f.guess->sf; box->fast_used = f.guess->fast_sf; }
   }
   if (t == 0) { box->cnt_total = f.cnt_known ? f.cnt_total : ctl->cnt_total; box->error = f.err_known ? f.error : ctl->error; }
   __threadfence_system();
@@ -439,7 +486,7 @@ __device__ __forceinline__ void finish_body(const FinBody& f) {
 
 __global__ __launch_bounds__(SWG) void k_finish(FinArgs a) {
   FinBody f;
-  f.ctl = a.ctl; f.part = a.part; f.nparts = a.nparts; f.box = a.box; f.seq = a.seq;
+  f.ctl = a.ctl; f.part = a.part; f.nparts = a.nparts; f.box = a.box; f.seq = a.seq; f.guess = a.guess;
   f.cnt_known = false; f.err_known = false; f.cnt_total = 0; f.error = 0;
   finish_body<true>(f);
 }
@@ -457,13 +504,25 @@ __global__ __launch_bounds__(SWG) void k_stats_sample(const T* __restrict__ x, s
   const Vec* src = reinterpret_cast<const Vec*>(x);
   StatAcc<T> acc;
   acc.init();
-  for (size_t g = blockIdx.x; g < ngroups; g += gridDim.x) {
-    const unsigned h = ((unsigned)g * 2654435761u) >> 8;
-    const size_t chunk = g * group + h % group;
-    T e[EPV];
-    Traits<T>::unpack(load_stream(&src[chunk * SWG + threadIdx.x]), e);
+  // up to four chunks of a workgroup in flight at once (the kernel is a handful of dependent round trips otherwise)
+  for (size_t g0 = blockIdx.x; g0 < ngroups; g0 += (size_t)gridDim.x * 4) {
+    Vec v[4];
 #pragma unroll
-    for (int k = 0; k < EPV; k++) acc.add(e[k], true);
+    for (int u = 0; u < 4; u++) {
+      const size_t g = g0 + (size_t)u * gridDim.x;
+      const size_t gg = g < ngroups ? g : g0;                    // (a repeated chunk changes neither max nor min; its sum is skipped)
+      const unsigned h = ((unsigned)gg * 2654435761u) >> 8;
+      const size_t chunk = gg * group + h % group;
+      v[u] = load_stream(&src[chunk * SWG + threadIdx.x]);
+    }
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      const bool real = g0 + (size_t)u * gridDim.x < ngroups;
+      T e[EPV];
+      Traits<T>::unpack(v[u], e);
+#pragma unroll
+      for (int k = 0; k < EPV; k++) acc.add(e[k], real);
+    }
   }
   __shared__ double ss[3 * (SWG / 64)];
   acc.flush(part, blockIdx.x, ss, SWG / 64);
@@ -595,10 +654,13 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(PH))) void k
       ? __builtin_amdgcn_make_buffer_rsrc(p.ac_tmp + list_base, 0, list_slots * 4, 0x00020000)
       : __builtin_amdgcn_make_buffer_rsrc(p.qt_item + list_base, 0, list_slots * (int)sizeof(T), 0x00020000);
   const __amdgpu_buffer_rsrc_t r_listj = __builtin_amdgcn_make_buffer_rsrc(p.qt_j + (MODE == DCTZHIP_QT ? list_base : 0u), 0, MODE == DCTZHIP_QT ? list_slots : 0, 0x00020000);
+  // the scaling factor: the host's, or (speculative call) the one k_stats_final_sf chose on the device
+  const T sf = p.guess ? (T)p.guess->sf : p.sf;
+  const unsigned fast_sf = p.guess ? p.guess->fast_sf : p.fast_sf;
   FastDiv<T> sfd, bwd;
-  sfd.init(p.sf, p.fast_sf != 0);
+  sfd.init(sf, fast_sf != 0);
   bwd.init(p.bin_width, (p.fast_bw & 1u) != 0);
-  const bool scale = (p.sf != T(1));                 // dctz-comp-lib.c:193 / :208
+  const bool scale = (sf != T(1));                   // dctz-comp-lib.c:193 / :208
   const T rmin = p.range_min, rmax = p.range_max;
   const CTab<T> tab = as_ctab<T>(p.tab);
   StatAcc<T> acc;
@@ -670,13 +732,13 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(PH))) void k
       }
       // util.c:22 starts at i = 1: x[0] never enters the sum; here the sum is 8 sf * (sum of the DCs), so x[0] leaves it as
       // x[0] / (8 sf) DC units (tree-order sum either way: only the decimal digits of the header's `mean` come from it)
-      if (J0 == 0 && first && lane == 0) acc.dcs -= (double)x[0] / (scale ? 8.0 * (double)p.sf : 8.0);
+      if (J0 == 0 && first && lane == 0) acc.dcs -= (double)x[0] / (scale ? 8.0 * (double)sf : 8.0);
     }
     if (scale) {
-      if (p.fast_sf == 2) {
+      if (fast_sf == 2) {
 #pragma unroll
         for (int j = J0; j < J1; j++) x[j] = sfd.core(x[j]);
-      } else if (p.fast_sf == 1) {
+      } else if (fast_sf == 1) {
 #pragma unroll
         for (int j = J0; j < J1; j++) x[j] = sfd.div(x[j]);
       } else {
@@ -850,22 +912,24 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(PH))) void k
   if (lane == 0) p.tile_cnt[blockIdx.x] = run;
   if (STATS) {
     __syncthreads();
-    acc.flush(p.stat_part, blockIdx.x, reinterpret_cast<double*>(tilebuf), 1, scale ? 8.0 * (double)p.sf : 8.0);
+    acc.flush(p.stat_part, blockIdx.x, reinterpret_cast<double*>(tilebuf), 1, scale ? 8.0 * (double)sf : 8.0);
   }
 }
 
 // The last, short block (length l = N % 64): the reference re-plans a length-l
 // (l even) or 2l (l odd) FFT for it (dctz-comp-lib.c:326-336, dct.c:59-72).
 // One wavefront, definition-order DFT with host-built roots.
-template <typename T, int MODE, bool SCALE>
+template <typename T, int MODE>
 __global__ __launch_bounds__(64) void k_compress_rem(FwdParams<T> p, int l) {
   __shared__ T v[128];
   const int k = threadIdx.x;
   const size_t base = (size_t)p.nfull * 64;
   const T* rt = p.rtab;
   const int N = (l & 1) ? 2 * l : l;
+  const T sf = p.guess ? (T)p.guess->sf : p.sf;
+  const bool SCALE = (sf != T(1));                                 // dctz-comp-lib.c:193 / :208
   FastDiv<T> sfd, bwd;
-  sfd.init(p.sf, p.fast_sf != 0);
+  sfd.init(sf, (p.guess ? p.guess->fast_sf : p.fast_sf) != 0);
   bwd.init(p.bin_width, (p.fast_bw & 1u) != 0);
   if (p.stat_part != nullptr) {                                    // speculative launch: raw-input statistics of this block
     __shared__ double ss[3];
@@ -979,7 +1043,7 @@ __global__ __launch_bounds__(SWG) void k_compact_ac(FwdParams<T> p, double eb, u
     unsigned all = 0;
     for (unsigned i = threadIdx.x; i < nlists; i += SWG) all += p.tile_cnt[i];
     FinBody f;
-    f.ctl = fin.ctl; f.part = fin.part; f.nparts = fin.nparts; f.box = fin.box; f.seq = fin.seq;
+    f.ctl = fin.ctl; f.part = fin.part; f.nparts = fin.nparts; f.box = fin.box; f.seq = fin.seq; f.guess = fin.guess;
     f.cnt_known = true; f.cnt_total = block_sum(all, sh);                // tot_AC_exact_count (:478-544)
     f.err_known = true; f.error = 0;
     finish_body<true>(f);
@@ -992,11 +1056,25 @@ __global__ __launch_bounds__(SWG) void k_compact_ac(FwdParams<T> p, double eb, u
     const unsigned n = p.tile_cnt[l];
     if (l == nlists - 1 && threadIdx.x == 0) p.ctl->cnt_total = dst + n;
     const size_t src = list_slot(l, G, p.ntiles);
-    for (unsigned i = threadIdx.x; i < n; i += SWG) {
-      if (MODE == DCTZHIP_EC) p.ac[dst + i] = p.ac_tmp[src + i];
-      // The in-range else-branch of :502-506 cannot fire for finite data and stores nothing; every flagged
-      // coefficient is appended.
-      else p.ac[dst + i] = (float)qt_normalise(p.qt_item[src + i], q[p.qt_j[src + i]], eb, T(10), p.range_min, p.range_max);
+    // four independent loads in flight per thread (a list is ~3 K items: the copy is latency-bound)
+    for (unsigned i0 = threadIdx.x; i0 < n; i0 += 4 * SWG) {
+      float v[4];
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+        const unsigned i = i0 + (unsigned)u * SWG;
+        v[u] = 0.f;
+        if (i < n) {
+          if (MODE == DCTZHIP_EC) v[u] = p.ac_tmp[src + i];
+          // The in-range else-branch of :502-506 cannot fire for finite data and stores nothing; every flagged
+          // coefficient is appended.
+          else v[u] = (float)qt_normalise(p.qt_item[src + i], q[p.qt_j[src + i]], eb, T(10), p.range_min, p.range_max);
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+        const unsigned i = i0 + (unsigned)u * SWG;
+        if (i < n) p.ac[dst + i] = v[u];
+      }
     }
   }
 }
@@ -1084,7 +1162,7 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(PH))) void k
     for (unsigned i = (unsigned)lane; i < p.nwg; i += WG) all += p.wg_cnt[i];
     all = (unsigned)__builtin_amdgcn_readlane((int)wave_incl_scan(all), 63);
     FinBody f;
-    f.ctl = fin.ctl; f.part = nullptr; f.nparts = 0; f.box = fin.box; f.seq = fin.seq;
+    f.ctl = fin.ctl; f.part = nullptr; f.nparts = 0; f.box = fin.box; f.seq = fin.seq; f.guess = nullptr;
     f.cnt_known = true; f.cnt_total = all;
     f.err_known = true; f.error = all > p.ac_count ? 2u : 0u;
     finish_body<false>(f);
@@ -1479,15 +1557,16 @@ void launch_stats(const T* x, size_t n, double* part, int nparts, double* out, h
 
 template <typename T>
 void launch_stats_sample(const T* x, size_t n, unsigned group, double* part, int nparts, double* out, hipStream_t s,
-                         HostBox* box, unsigned long long seq, Ctl* zero) {
+                         HostBox* box, unsigned long long seq, Ctl* zero, const SfTable* tab, SfGuess* guess) {
   hipLaunchKernelGGL(k_stats_sample<T>, dim3(nparts), dim3(SWG), 0, s, x, n, group, part);
-  hipLaunchKernelGGL(k_stats_final, dim3(1), dim3(SWG), 0, s, (const double*)part, nparts, out, box, seq, zero);
+  if (tab != nullptr) hipLaunchKernelGGL(k_stats_final_sf, dim3(1), dim3(SWG), 0, s, (const double*)part, nparts, out, zero, *tab, guess);
+  else hipLaunchKernelGGL(k_stats_final, dim3(1), dim3(SWG), 0, s, (const double*)part, nparts, out, box, seq, zero);
 }
 void launch_stats_final(const double* part, int nparts, double* out, hipStream_t s, HostBox* box, unsigned long long seq, Ctl* zero) {
   hipLaunchKernelGGL(k_stats_final, dim3(1), dim3(SWG), 0, s, part, nparts, out, box, seq, zero);
 }
 void launch_finish(Ctl* ctl, const double* part, int nparts, HostBox* box, unsigned long long seq, hipStream_t s) {
-  const FinArgs f = {ctl, part, nparts, box, seq};
+  const FinArgs f = {ctl, part, nparts, box, seq, nullptr};
   hipLaunchKernelGGL(k_finish, dim3(1), dim3(SWG), 0, s, f);
 }
 
@@ -1526,14 +1605,9 @@ void launch_compress(const FwdParams<T>& p, int mode, bool stats, int grid, int 
 }
 
 template <typename T>
-void launch_compress_rem(const FwdParams<T>& p, int mode, bool scale, int l, hipStream_t s) {
-  if (mode == DCTZHIP_EC) {
-    if (scale) hipLaunchKernelGGL((k_compress_rem<T, DCTZHIP_EC, true>), dim3(1), dim3(64), 0, s, p, l);
-    else hipLaunchKernelGGL((k_compress_rem<T, DCTZHIP_EC, false>), dim3(1), dim3(64), 0, s, p, l);
-  } else {
-    if (scale) hipLaunchKernelGGL((k_compress_rem<T, DCTZHIP_QT, true>), dim3(1), dim3(64), 0, s, p, l);
-    else hipLaunchKernelGGL((k_compress_rem<T, DCTZHIP_QT, false>), dim3(1), dim3(64), 0, s, p, l);
-  }
+void launch_compress_rem(const FwdParams<T>& p, int mode, int l, hipStream_t s) {
+  if (mode == DCTZHIP_EC) hipLaunchKernelGGL((k_compress_rem<T, DCTZHIP_EC>), dim3(1), dim3(64), 0, s, p, l);
+  else hipLaunchKernelGGL((k_compress_rem<T, DCTZHIP_QT>), dim3(1), dim3(64), 0, s, p, l);
 }
 
 template <typename T>
@@ -1603,14 +1677,14 @@ void launch_psnr(const T* x, const T* r, size_t n, double* part, int nparts, dou
 // explicit instantiations used by dctz_shim.hip
 #define INST(T)                                                                                         \
   template void launch_stats<T>(const T*, size_t, double*, int, double*, hipStream_t, HostBox*, unsigned long long, Ctl*); \
-  template void launch_stats_sample<T>(const T*, size_t, unsigned, double*, int, double*, hipStream_t, HostBox*, unsigned long long, Ctl*); \
+  template void launch_stats_sample<T>(const T*, size_t, unsigned, double*, int, double*, hipStream_t, HostBox*, unsigned long long, Ctl*, const SfTable*, SfGuess*); \
   template void launch_debug_divide<T>(const T*, size_t, T, int, T*, T*, hipStream_t);                  \
   template void launch_serial_sum<T>(const T*, size_t, double*, hipStream_t);                           \
   template void launch_scale<T>(const T*, T*, size_t, T, int, hipStream_t);                             \
   template void launch_compress<T>(const FwdParams<T>&, int, bool, int, int, hipStream_t);              \
   template void launch_gather_nd<T>(const T*, T*, const NdShape&, double*, int, hipStream_t);           \
   template void launch_scatter_nd<T>(const T*, T*, const NdShape&, int, hipStream_t);                   \
-  template void launch_compress_rem<T>(const FwdParams<T>&, int, bool, int, hipStream_t);               \
+  template void launch_compress_rem<T>(const FwdParams<T>&, int, int, hipStream_t);                     \
   template void launch_qt_max<T>(const FwdParams<T>&, unsigned, int, hipStream_t);                      \
   template void launch_compact_ac<T>(const FwdParams<T>&, int, double, unsigned, int, const FinArgs&, hipStream_t); \
   template void launch_decompress<T>(const InvParams<T>&, int, int, const FinArgs&, int, hipStream_t);  \

@@ -52,6 +52,12 @@ struct dctzhip_ctx {
   uint8_t* qt_j = nullptr;
   size_t qt_cap = 0;                // bytes of qt_item
   size_t qtj_cap = 0;
+  // device-side choice of the scaling factor for speculative calls (dctz_device.h: SfGuess / SfTable)
+  double* sf_thr[2] = {nullptr, nullptr};   // [DCTZHIP_F32], [DCTZHIP_F64]
+  double* sf_pw[2] = {nullptr, nullptr};
+  int sf_nk[2] = {0, 0};
+  SfGuess* sf_guess = nullptr;
+  int dev_sf = 1;                   // 0: the host chooses sf between the sample and k_compress (DCTZHIP_DEVICE_SF)
   void* nd_buf = nullptr;           // multi-dimensional blocks: the array laid out block after block (k_gather_nd / k_scatter_nd)
   size_t nd_cap = 0;                // bytes
   // pinned host staging
@@ -82,6 +88,7 @@ struct dctzhip_ctx {
 };
 
 static char g_create_err[512] = "";
+static int build_sf_tables(dctzhip_ctx* c);
 static constexpr int STATS_GRID_MAX = 2048;
 static constexpr int PART_SLOTS = 256 * 16 + 64;       // >= largest k_compress grid + 1 (fused statistics partials), >= 4/3 of the PSNR grid
 static constexpr int SPEC_COOLDOWN = 8;
@@ -165,6 +172,8 @@ extern "C" int dctzhip_ctx_create(dctzhip_ctx** out, int device) {
     HIPCHK(nullptr, hipMemcpy(c->tab_f32, t32, sizeof(t32), hipMemcpyHostToDevice));
   }
   for (int i = 0; i < 6; i++) HIPCHK(nullptr, hipEventCreate(&c->ev[i]));
+  if (const char* e = getenv("DCTZHIP_DEVICE_SF")) c->dev_sf = atoi(e) != 0;
+  if (int rc = build_sf_tables(c)) return rc;
   *out = c;
   return DCTZHIP_OK;
 }
@@ -176,7 +185,7 @@ extern "C" void dctzhip_ctx_destroy(dctzhip_ctx* c) {
   (void)dctzhip_comm_destroy(c);
   (void)hipStreamSynchronize(c->stream);
   if (c->side_stream) { (void)hipStreamSynchronize(c->side_stream); (void)hipStreamDestroy(c->side_stream); }
-  void* bufs[] = {c->ovf, c->ovf_j, c->ac_tmp, c->tile_cnt, c->wg_cnt, c->serial_out, c->tab_f64, c->tab_f32, c->rtab, c->qtab, c->ctl, c->part, c->stats_out, c->qt_item, c->qt_j, c->nd_buf};
+  void* bufs[] = {c->ovf, c->ovf_j, c->ac_tmp, c->tile_cnt, c->wg_cnt, c->serial_out, c->tab_f64, c->tab_f32, c->rtab, c->qtab, c->ctl, c->part, c->stats_out, c->qt_item, c->qt_j, c->nd_buf, c->sf_thr[0], c->sf_thr[1], c->sf_pw[0], c->sf_pw[1], c->sf_guess};
   for (void* b : bufs) if (b) (void)hipFree(b);
   if (c->h_pin) (void)hipHostFree(c->h_pin);
   if (c->box) (void)hipHostFree(c->box);
@@ -374,11 +383,38 @@ static int wait_seq(dctzhip_ctx* c, volatile unsigned long long* word, unsigned 
   }
 }
 
-// util.c:29 / util.c:43, with the host libm exactly like the reference
-static double scaling_factor(int dtype, double max_abs) {
-  if (max_abs == 0.0) return 1.0;               // documented deviation: reference divides by 0
-  if (dtype == DCTZHIP_F64) return pow(10, ceil(log10(max_abs)) - 1);
-  return (double)powf(10, ceil(log10f((float)max_abs)) - 1);
+static int build_sf_tables(dctzhip_ctx* c) {
+  const int kmin[2] = {-46, -324}, kmax[2] = {39, 309};          // decades of float / double, subnormals included
+  for (int dt = 0; dt < 2; dt++) {
+    const int nk = kmax[dt] - kmin[dt] + 1;
+    double* thr = new double[nk];
+    double* pw = new double[nk + 1];
+    if (dt == DCTZHIP_F64) decade_tables<double>(kmin[dt], kmax[dt], thr, pw); else decade_tables<float>(kmin[dt], kmax[dt], thr, pw);
+    // self-check against scaling_factor() on both sides of every boundary: a table that disagrees with the host's own
+    // expression anywhere switches the device-side choice off (the host then chooses, as before)
+    bool ok = true;
+    for (int i = 0; i < nk && ok; i++) {
+      const double probes[2] = {thr[i], dt == DCTZHIP_F64 ? nextafter(thr[i], INFINITY) : (double)nextafterf((float)thr[i], INFINITY)};
+      for (double v : probes) {
+        if (!(v > 0) || std::isinf(v)) continue;
+        int below = 0;
+        for (int j = 0; j < nk; j++) below += thr[j] < v;
+        const double want = scaling_factor(dt, v);
+        if (!(pw[below] == want)) ok = false;
+      }
+    }
+    if (!ok) c->dev_sf = 0;
+    hipError_t e1 = hipMalloc(&c->sf_thr[dt], sizeof(double) * nk), e2 = hipMalloc(&c->sf_pw[dt], sizeof(double) * (nk + 1));
+    if (e1 == hipSuccess && e2 == hipSuccess) {
+      e1 = hipMemcpy(c->sf_thr[dt], thr, sizeof(double) * nk, hipMemcpyHostToDevice);
+      e2 = hipMemcpy(c->sf_pw[dt], pw, sizeof(double) * (nk + 1), hipMemcpyHostToDevice);
+    }
+    delete[] thr; delete[] pw;
+    if (e1 != hipSuccess || e2 != hipSuccess) return fail(nullptr, DCTZHIP_E_HIP, "decade tables: %s", hipGetErrorString(e1 != hipSuccess ? e1 : e2));
+    c->sf_nk[dt] = nk;
+  }
+  HIPCHK(nullptr, hipMalloc(&c->sf_guess, sizeof(SfGuess)));
+  return DCTZHIP_OK;
 }
 
 static int read_timings(dctzhip_ctx* c, int nev_main_start) {
@@ -410,13 +446,13 @@ static int wg_per_cu(dctzhip_ctx* c, bool decode, int mode) {
 template <typename T>
 static int compress_pass(dctzhip_ctx* c, const T* d_in, size_t n, double eb, int mode, uint8_t* d_bin, float* d_dc,
                          float* d_ac, T* d_coef, const HostStats& st, bool fused, double* sf_out, T* sf_t_out,
-                         unsigned* fast_sf_out, unsigned long long seq, int geom) {
+                         unsigned* fast_sf_out, unsigned long long seq, int geom, bool device_sf = false) {
   const int dtype = sizeof(T) == 8 ? DCTZHIP_F64 : DCTZHIP_F32;
   hipStream_t s = c->stream;
   const unsigned nfull = (unsigned)(n / 64);
   const int rem = (int)(n % 64);
   const unsigned ntiles = (nfull + TILE_BLKS - 1) / TILE_BLKS;
-  const double sf = scaling_factor(dtype, st.max_abs);
+  const double sf = device_sf ? 1.0 : scaling_factor(dtype, st.max_abs);   // (device_sf: k_stats_final_sf has chosen it; read back after the call)
   *sf_out = sf;
 
   // ---- bin ranges, dctz-comp-lib.c:271-281 (computed in double, stored in T) --
@@ -429,6 +465,7 @@ static int compress_pass(dctzhip_ctx* c, const T* d_in, size_t n, double eb, int
   p.tile_cnt = c->tile_cnt;
   p.tab = tab_of<T>(c); p.rtab = reinterpret_cast<const T*>(c->rtab);
   p.ctl = c->ctl;
+  p.guess = device_sf ? c->sf_guess : nullptr;       // (then p.sf / p.fast_sf below are placeholders)
   p.stat_part = fused ? c->part : nullptr;
   p.nfull = nfull; p.ntiles = ntiles; p.last_is_full = rem ? 0u : 1u;
   p.sf = (T)sf;
@@ -437,7 +474,7 @@ static int compress_pass(dctzhip_ctx* c, const T* d_in, size_t n, double eb, int
   p.range_max = (T)((half * 2 + 1) * (eb * 1.0));
   // 2: every element is inside FastDiv's window (min|x| and max|x| are there) -> no per-element test
   p.fast_sf = c->fastdiv ? divisor_in_window(dtype, (double)p.sf) : 0u;
-  if (p.fast_sf && c->fastdiv >= 2 && value_in_window(dtype, st.min_abs) && value_in_window(dtype, st.max_abs)) p.fast_sf = 2;
+  if (!device_sf && p.fast_sf && c->fastdiv >= 2 && value_in_window(dtype, st.min_abs) && value_in_window(dtype, st.max_abs)) p.fast_sf = 2;
   p.fast_bw = c->fastdiv ? divisor_in_window(dtype, (double)p.bin_width) : 0u;
   {
     // bit 1: "item > range_max  =>  (item - range_min) / bin_width >= 255" holds for these launch constants, in T
@@ -448,8 +485,6 @@ static int compress_pass(dctzhip_ctx* c, const T* d_in, size_t n, double eb, int
     if (p.fast_bw && c->fastdiv >= 2 && q >= (T)255) p.fast_bw |= 2u;
   }
   *sf_t_out = p.sf; *fast_sf_out = p.fast_sf;
-  const bool scale = (p.sf != (T)1.0);              // :193 / :208
-
   if (rem) { int rc = upload_rtab<T>(c, rem); if (rc) return rc; }
 
   if (c->profiling) HIPCHK(c, hipEventRecord(c->ev[2], s));
@@ -458,14 +493,14 @@ static int compress_pass(dctzhip_ctx* c, const T* d_in, size_t n, double eb, int
   p.nlists_main = (unsigned)grid;
   if (ntiles) launch_compress<T>(p, mode, fused, grid, geom, s);
   if (c->profiling) HIPCHK(c, hipEventRecord(c->ev[3], s));
-  if (rem) launch_compress_rem<T>(p, mode, scale, rem, s);
+  if (rem) launch_compress_rem<T>(p, mode, rem, s);
   // stitch the workgroup-local lists into AC_exact[]
   const unsigned nlists = (unsigned)grid + (rem ? 1u : 0u);
   if (mode == DCTZHIP_QT) launch_qt_max<T>(p, nlists, (int)(nlists < 1024u ? nlists : 1024u), s);   // :371-372 over the lists
   // (k_compact_ac finds the place of every list itself: no scan kernel.)  With the mailbox its first workgroup hands
   // the call's results to the host as soon as the kernel starts -- all of them are in by then -- so the host is back in
   // the caller, queueing the next call's launches, while the lists are still being moved
-  const FinArgs fin = {c->ctl, c->part, fused ? (int)nlists : 0, seq ? c->box_dev : nullptr, seq};
+  const FinArgs fin = {c->ctl, c->part, fused ? (int)nlists : 0, seq ? c->box_dev : nullptr, seq, p.guess};
   launch_compact_ac<T>(p, mode, eb, nlists, (int)nlists, fin, s);
   if (!seq && fused) launch_stats_final(c->part, (int)nlists, c->stats_out, s);
   if (c->profiling) HIPCHK(c, hipEventRecord(c->ev[4], s));
@@ -496,6 +531,7 @@ static int compress_impl(dctzhip_ctx* c, const T* d_in, size_t n, double eb, int
   constexpr size_t chunk = (size_t)SWG * Traits<T>::EPV;
   bool spec = geom == GEOM_1D && c->speculate && ntiles && n >= c->spec_min && n >= 4 * chunk * c->spec_group;
   if (spec && c->spec_cooldown > 0) { c->spec_cooldown--; spec = false; }
+  const bool dsf = spec && c->handoff != 0 && c->dev_sf && c->sf_nk[dtype] > 0;   // scaling factor of the guess chosen on the device
 
   // Host hand-off: mailbox + spin, or D2H copy + stream sync
   const bool box = c->handoff != 0;
@@ -515,7 +551,9 @@ static int compress_impl(dctzhip_ctx* c, const T* d_in, size_t n, double eb, int
   } else if (spec) {
     const size_t ngroups = n / chunk / c->spec_group;
     const int sgrid = (int)(ngroups < (size_t)c->stats_grid ? ngroups : (size_t)c->stats_grid);
-    launch_stats_sample<T>(d_in, n, c->spec_group, c->part, sgrid, c->stats_out, s, box ? c->box_dev : nullptr, seq, box ? c->ctl : nullptr);
+    const SfTable tab = {c->sf_thr[dtype], c->sf_pw[dtype], c->sf_nk[dtype], c->fastdiv, dtype};
+    launch_stats_sample<T>(d_in, n, c->spec_group, c->part, sgrid, c->stats_out, s, box ? c->box_dev : nullptr, seq, box ? c->ctl : nullptr,
+                           dsf ? &tab : nullptr, c->sf_guess);
   } else {
     const size_t nvec = n / Traits<T>::EPV;
     int sgrid = (int)((nvec + SWG * 4 - 1) / (SWG * 4));
@@ -524,8 +562,11 @@ static int compress_impl(dctzhip_ctx* c, const T* d_in, size_t n, double eb, int
     launch_stats<T>(d_in, n, c->part, sgrid, c->stats_out, s, box ? c->box_dev : nullptr, seq, box ? c->ctl : nullptr);
   }
   if (c->profiling) HIPCHK(c, hipEventRecord(c->ev[1], s));
-  HostStats st;
-  if (box) {
+  HostStats st = {0.0, 0.0, 0.0};
+  if (dsf) {
+    // nothing to wait for: the scaling factor of the sampled max|x| is chosen on the device (k_stats_final_sf) and the
+    // main launch follows at once; the choice comes back with the call's results and is verified below like a guess
+  } else if (box) {
     int rc = wait_seq(c, &hb->seq_stats, seq, "statistics");
     if (rc) return rc;
     st = {hb->stats[0], hb->stats[1], hb->stats[2]};
@@ -541,12 +582,14 @@ static int compress_impl(dctzhip_ctx* c, const T* d_in, size_t n, double eb, int
   unsigned flags = 0;
   // one pass of the kernels + the hand-off of its results into *hc / hs[4..6]
   auto run = [&](const HostStats& stats, bool fused) -> int {
-    int rc = compress_pass<T>(c, d_in, n, eb, mode, d_bin, d_dc, d_ac, d_coef, stats, fused, &sf, &sf_t, &fast_sf, seq, geom);
+    const bool dev = fused && dsf;
+    int rc = compress_pass<T>(c, d_in, n, eb, mode, d_bin, d_dc, d_ac, d_coef, stats, fused, &sf, &sf_t, &fast_sf, seq, geom, dev);
     if (rc) return rc;
     if (box) {
       rc = wait_seq(c, &hb->seq_done, seq, "compress");
       if (rc) return rc;
       c->ctl_dirty = 0;
+      if (dev) { sf = hb->sf_used; sf_t = (T)sf; fast_sf = hb->fast_used; }
       hc->cnt_total = hb->cnt_total; hc->error = hb->error; hc->q0 = hb->q0;
       for (int j = 0; j < 64; j++) hc->qraw[j] = hb->qraw[j];
       hs[4] = hb->fstats[0]; hs[5] = hb->fstats[1]; hs[6] = hb->fstats[2];
@@ -770,7 +813,7 @@ static int decompress_impl(dctzhip_ctx* c, const uint8_t* d_bin, const float* d_
   // stream under-runs the caller's AC_exact (the counts are all in): the host is back in the caller while the
   // reconstruction is being written -- complete in stream order, like any launch.  Otherwise k_finish does it.
   const bool early = box && ntiles && !rem;
-  const FinArgs fin = {c->ctl, nullptr, 0, early ? c->box_dev : nullptr, seq};
+  const FinArgs fin = {c->ctl, nullptr, 0, early ? c->box_dev : nullptr, seq, nullptr};
   if (ntiles) launch_decompress<T>(p, mode, grid, fin, geom, s);
   if (c->profiling) HIPCHK(c, hipEventRecord(c->ev[3], s));
   if (rem) launch_decompress_rem<T>(p, mode, scale, rem, s);

@@ -123,6 +123,42 @@ inline void fill_tab_block(T* tab) {
   tab[TB_IS16 + 2] = (T)(-2 * Ss(16)); tab[TB_IS16 + 3] = (T)(2 * Ss(48));     // Im Zb[16]
 }
 
+// util.c:29 / util.c:43, with the host libm exactly like the reference
+inline double scaling_factor(int dtype, double max_abs) {
+  if (max_abs == 0.0) return 1.0;               // documented deviation: reference divides by 0
+  if (dtype == 1 /* DCTZHIP_F64 */) return pow(10, ceil(log10(max_abs)) - 1);
+  return (double)powf(10, ceil(log10f((float)max_abs)) - 1);
+}
+
+
+// Decade tables for the device-side choice of sf (SfTable): for every decade k, the LARGEST value m of the data type
+// with ceil(log10(m)) <= k under THIS host's log10 / log10f, and 10^(k-1) under its pow / powf -- so that
+// pw[#{k : thr[k] < max}] is what scaling_factor(max) returns, by construction, rounding quirks of libm included.
+template <typename T>
+inline void decade_tables(int kmin, int kmax, double* thr, double* pw) {
+  const bool f64 = sizeof(T) == 8;
+  typedef typename std::conditional<sizeof(T) == 8, unsigned long long, unsigned int>::type Bits;
+  auto cl = [&](T m) -> double { return f64 ? ceil(log10((double)m)) : ceil((double)log10f((float)m)); };
+  auto p10 = [&](int k) -> T { return f64 ? (T)pow(10, (double)k) : (T)powf(10, (float)k); };
+  auto bits = [](T v) { Bits b; std::memcpy(&b, &v, sizeof(T)); return b; };
+  auto val = [](Bits b) { T v; std::memcpy(&v, &b, sizeof(T)); return v; };
+  const T big = f64 ? (T)1.79769313486231570815e308 : (T)3.40282346638528859812e38f;
+  const Bits bmin = 1, bmax = bits(big);               // smallest subnormal .. largest finite (positive values order like their bits)
+  for (int k = kmin; k <= kmax; k++) {
+    pw[k - kmin] = (double)p10(k - 1);
+    // largest m with ceil(log10(m)) <= k: bisection over the bit patterns (log10 is monotonic)
+    if (cl(val(bmin)) > (double)k) { thr[k - kmin] = 0.0; continue; }               // the decade lies below the smallest subnormal
+    if (cl(val(bmax)) <= (double)k) { thr[k - kmin] = (double)INFINITY; continue; } // ... reaches past the largest finite value
+    Bits lo = bmin, hi = bmax;                         // invariant: cl(lo) <= k < cl(hi)
+    while (hi - lo > 1) {
+      const Bits mid = lo + (hi - lo) / 2;
+      if (cl(val(mid)) <= (double)k) lo = mid; else hi = mid;
+    }
+    thr[k - kmin] = (double)val(lo);
+  }
+  pw[kmax - kmin + 1] = (double)p10(kmax);
+}
+
 // Tables for the remainder block (length l = 1..63, transformed with an l- or
 // 2l-point DFT exactly like dct.c:59-72 / 144-164 do through FFTW).
 // Layout (elements of T): as[64] ax[64] ias[64] iax[64] wr[128] wi[128];

@@ -32,6 +32,11 @@ int emu_tab_size(void) { return TB_SIZE; }
 // multi-dimensional blocks (dct_nd_block.h): geom 1 = 8 x 8, 2 = 4 x 4 x 4
 void emu_nd_f64(const double* a, double* b, int geom, int inverse) { emu<double>(a, b, inverse != 0, geom); }
 void emu_nd_f32(const float* a, float* b, int geom, int inverse) { emu<float>(a, b, inverse != 0, geom); }
+// scaling factor of util.c:29 / :43 and the decade tables the device chooses it from (dctz_tables.h)
+double emu_scaling_factor(int dtype, double max_abs) { return scaling_factor(dtype, max_abs); }
+void emu_decades(int dtype, int kmin, int kmax, double* thr, double* pw) {
+  if (dtype == 1) decade_tables<double>(kmin, kmax, thr, pw); else decade_tables<float>(kmin, kmax, thr, pw);
+}
 void emu_rem_tab_f64(int l, double* tab) { fill_rem_tab<double>(l, tab); }
 void emu_rem_tab_f32(int l, float* tab) { fill_rem_tab<float>(l, tab); }
 }

@@ -48,3 +48,39 @@ def test_remainder_tables_identical_to_oracle(emu, dtype, suf):
         as_, ax, ias, iax = O.dct_tables(l, dtype)
         assert np.array_equal(tab[0:l], as_) and np.array_equal(tab[64:64 + l], ax)
         assert np.array_equal(tab[192:192 + l], iax) and np.array_equal(tab[129:128 + l], ias[1:])
+
+
+@pytest.mark.parametrize("dtype,code,kmin,kmax", [(np.float64, 1, -324, 309), (np.float32, 0, -46, 39)])
+def test_decade_tables_reproduce_the_host_scaling_factor(emu, dtype, code, kmin, kmax):
+    """The device chooses the scaling factor of a speculative call as pw[#{k : thr[k] < max}] from tables the host
+    builds with its own log10 / pow (dctz_tables.h: decade_tables).  That must be scaling_factor() -- util.c:29 / :43 --
+    for every value: checked at both sides of every decade boundary, at exact powers of ten, and on random values; and
+    against the oracle's calc_data_stat restatement."""
+    nk = kmax - kmin + 1
+    thr = np.zeros(nk)
+    pw = np.zeros(nk + 1)
+    emu.emu_decades.argtypes = [C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+    emu.emu_scaling_factor.restype = C.c_double
+    emu.emu_scaling_factor.argtypes = [C.c_int, C.c_double]
+    emu.emu_decades(code, kmin, kmax, thr.ctypes.data_as(C.c_void_p), pw.ctypes.data_as(C.c_void_p))
+    assert np.all(np.diff(thr) >= 0)
+
+    def dev(v):
+        return pw[int((thr < v).sum())]
+
+    probes = []
+    for t in thr:
+        if 0 < t < np.inf:
+            probes += [t, float(np.nextafter(dtype(t), dtype(np.inf))), float(np.nextafter(dtype(t), dtype(0)))]
+    probes += [float(dtype(10.0) ** k) for k in range(-20, 21)] + [1.0, 0.1, 0.5, 37.5, 999.9999, 1000.0, 1000.0001]
+    rng = np.random.default_rng(9)
+    probes += list((10.0 ** rng.uniform(-30, 30, 4000)).astype(dtype).astype(np.float64))
+    fin = np.finfo(dtype)
+    for v in probes:
+        v = float(dtype(v))
+        if not (0 < v <= fin.max):
+            continue
+        assert dev(v) == emu.emu_scaling_factor(code, v), v
+    # ... and scaling_factor() itself is the oracle's (util.c:29 / :43 through the same libm)
+    for v in (0.37, 1.0, 9.99, 10.0, 10.01, 37.5, 1e-7, 123456.0):
+        assert emu.emu_scaling_factor(code, float(dtype(v))) == O.stats(np.array([0.0, v], dtype)).sf
