@@ -51,6 +51,9 @@ template <> struct Traits<float> {
 // Geometry of a tile in bytes for element type T, moved through LDS in PH phases (elements [64 p / PH, 64 (p + 1) / PH)
 // of every block per phase).  PH = 2 halves a wave's LDS footprint (fp64: 16 KiB), which leaves room for two waves per
 // SIMD: one issues instructions while the other waits.
+#ifndef DCTZ_EC_DEPTH
+#define DCTZ_EC_DEPTH 12   /* 14 measured: -3 % at p = 17 %, +1 % at p = 5 % */
+#endif
 template <typename T, int PHASES = 1> struct Geo {
   static constexpr int BLKB = 64 * (int)sizeof(T);      // bytes per block (512 / 256)
   static constexpr int NSEG = BLKB / 128;               // 128-byte segments per block (4 / 2)
@@ -63,7 +66,7 @@ template <typename T, int PHASES = 1> struct Geo {
   static constexpr int PHB = TILEB / PH;                 // bytes of a phase image
   static_assert(NSEG % PH == 0, "a phase is a whole number of 128-byte segments");
   // exceptions of a block that a lane parks in its LDS strip (DEPTH + 1 items); the rest goes to global overflow strips
-  static constexpr int EC_DEPTH = 12;                                  // floats:  64 * 13 * 4 = 3328 bytes per wave
+  static constexpr int EC_DEPTH = DCTZ_EC_DEPTH;                                  // floats:  64 * 13 * 4 = 3328 bytes per wave
   static constexpr int QT_DEPTH = sizeof(T) == 8 ? 14 : 12;            // full-precision items: 64 * 15 * 8 = 7680 bytes
 };
 // phases of k_compress / k_decompress per element type (build knobs for A/B runs)
@@ -73,7 +76,13 @@ template <typename T, int PHASES = 1> struct Geo {
 #ifndef DCTZ_PHD64
 #define DCTZ_PHD64 1
 #endif
-template <typename T> struct Phases { static constexpr int C = 1, D = 1; };
+#ifndef DCTZ_PHC32
+#define DCTZ_PHC32 1
+#endif
+#ifndef DCTZ_PHD32
+#define DCTZ_PHD32 1
+#endif
+template <typename T> struct Phases { static constexpr int C = DCTZ_PHC32, D = DCTZ_PHD32; };
 template <> struct Phases<double> { static constexpr int C = DCTZ_PHC64, D = DCTZ_PHD64; };
 
 // Per-call control block in device memory; zeroed by the first kernel of every compress call (k_stats_final) --

@@ -619,8 +619,11 @@ size_t compress_lds_bytes(int mode) {              // tile image + strips (+ pos
 // GEOM: what the 64 values of a block are -- the reference's 64 consecutive elements (GEOM_1D), or an 8 x 8 / 4 x 4 x 4
 // tile of a multi-dimensional array that k_gather_nd has laid out block after block (dct_nd_block.h); only the
 // transform differs.
+#ifndef DCTZ_WPE32
+#define DCTZ_WPE32 0
+#endif
 template <typename T, int MODE, bool STATS, int PH, int GEOM>
-__global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(PH))) void k_compress(FwdParams<T> p) {
+__global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu((sizeof(T) == 4 && DCTZ_WPE32) ? DCTZ_WPE32 : PH))) void k_compress(FwdParams<T> p) {
   using G = Geo<T, PH>;
   constexpr bool DEFER = true;
   constexpr int DEPTH = (MODE == DCTZHIP_EC) ? G::EC_DEPTH : G::QT_DEPTH;
@@ -637,8 +640,10 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(PH))) void k
   __shared__ __attribute__((aligned(16))) unsigned char jbuf[MODE == DCTZHIP_QT ? 1024 : 16];   // QT: position j of every parked item
   static_assert(MODE != DCTZHIP_QT || 64 * STRIDE <= (int)sizeof(jbuf), "positions strip");
   // (the addresses are formed where they are used: kept in registers across the loop they cost four VGPRs for a rare path)
-  auto ovf_at = [&](unsigned k) -> Item* { return reinterpret_cast<Item*>(p.ovf) + ((size_t)blockIdx.x * 64 + threadIdx.x) * 64 + k; };
-  auto ovfj_at = [&](unsigned k) -> unsigned char* { return p.ovf_j + ((size_t)blockIdx.x * 64 + threadIdx.x) * 64 + k; };
+  // (item k of all 64 lanes side by side: the flush reads whole rows, and the lanes of a store -- all within a few items
+  // of each other -- touch a handful of lines instead of 64)
+  auto ovf_at = [&](unsigned k) -> Item* { return reinterpret_cast<Item*>(p.ovf) + ((size_t)blockIdx.x * 64 + k) * 64 + threadIdx.x; };
+  auto ovfj_at = [&](unsigned k) -> unsigned char* { return p.ovf_j + ((size_t)blockIdx.x * 64 + k) * 64 + threadIdx.x; };
   const int lane = threadIdx.x;
   const TileRange tr = tile_range(blockIdx.x, gridDim.x, p.ntiles);
   const unsigned list_base = tr.lo * TILE_ELEMS;     // this workgroup's exception list lives in its tiles' slots
@@ -1231,6 +1236,48 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(PH))) void k
     unsigned ptr = wave_incl_scan(n) - n;                              // index inside the tile's piece of AC_exact
     if (S_t + total_t > p.ac_count) underrun = true;                  // the stream promises more than the caller provides
     T x[64];
+    if constexpr (sizeof(T) == 8) {
+    // Four coefficients = one dword of bin ids at a time: the (up to four) exact coefficients of the group are fetched
+    // together -- their places follow from the flag bits alone -- so that a tile pays one LDS round trip per GROUP that
+    // has a flag somewhere in the wave (16 at most), not one per flagged POSITION (63 on noisy data: at p = 17 % the
+    // serialised round trips were a third of the kernel; 512^3 fp64: 0.33 -> 0.28 ms there, 0.245 -> 0.235 at p = 5 %).
+#pragma unroll
+    for (int g = 0; g < 16; g++) {
+      const unsigned wg = w[g];
+      const unsigned nv = ~wg;                                         // a zero byte of nv <=> bin id 255
+      unsigned m = ~(((nv & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | nv) & 0x80808080u;
+      if (g == 0) m &= ~0x80u;                                         // j = 0 is the DC slot (:392 / :438)
+      float e[4] = {0.f, 0.f, 0.f, 0.f};
+      if (__builtin_amdgcn_ballot_w64(m != 0u)) {                      // :400 / :446 somewhere in the wave
+        unsigned at[4];
+        at[0] = ptr;
+        at[1] = at[0] + ((m >> 7) & 1u);
+        at[2] = at[1] + ((m >> 15) & 1u);
+        at[3] = at[2] + ((m >> 23) & 1u);
+        ptr = at[3] + (m >> 31);
+        if (in_lds) {                                                  // (all lanes read: predicating the reads on the flag measured slower)
+#pragma unroll
+          for (int i = 0; i < 4; i++) e[i] = excbuf[min(at[i], (unsigned)DEC_EXC_CAP - 1u)];
+        } else {
+#pragma unroll
+          for (int i = 0; i < 4; i++) e[i] = (((m >> (8 * i + 7)) & 1u) && S_t + at[i] < p.ac_count) ? p.ac[S_t + at[i]] : 0.f;
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < 4; i++) {
+        const int j = 4 * g + i;
+        if (j == 0) { x[0] = (T)dc_t; continue; }                      // :392 / :438
+        const unsigned b = (wg >> (8 * i)) & 255u;
+        T v = bctab[b];                                                // :416 / :462
+        if ((m >> (8 * i + 7)) & 1u) {
+          v = (T)e[i];
+          if (MODE == DCTZHIP_QT) v = qt_restore(v, qt[j], p.eb, T(10), p.range_min, p.range_max);
+        }
+        x[j] = v;
+      }
+    }
+    } else {
+    // fp32 (seven waves per CU hide the round trips; the grouped form measured 10 % slower here): position by position
     x[0] = (T)dc_t;                                                    // :392 / :438
 #pragma unroll
     for (int j = 1; j < 64; j++) {
@@ -1245,6 +1292,7 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(PH))) void k
         if (MODE == DCTZHIP_QT) v = qt_restore(v, qt[j], p.eb, T(10), p.range_min, p.range_max);
       }
       x[j] = v;
+    }
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                  // the staged coefficients are consumed: the strip is free
     if (tile + 1 < tr.hi) prefetch(tile + 1);

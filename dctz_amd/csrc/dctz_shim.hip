@@ -437,7 +437,11 @@ static int wg_per_cu(dctzhip_ctx* c, bool decode, int mode) {
   if (c->wg_per_cu) return c->wg_per_cu;
   const size_t lds = decode ? decompress_lds_bytes<T>() : compress_lds_bytes<T>(mode);
   const int v = (int)((size_t)160 * 1024 / lds);
+#ifdef DCTZ_WGCAP
+  return v < 1 ? 1 : (v > DCTZ_WGCAP ? DCTZ_WGCAP : v);
+#else
   return v < 1 ? 1 : (v > 8 ? 8 : v);
+#endif
 }
 
 // One pass of the compress kernels for a given set of statistics.  `fused`: the
