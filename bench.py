@@ -323,6 +323,9 @@ def run_rank(a, rank, local_rank, world):
                         "k_decompress": {"ms": acc["d_main"], "GBps": ach_d, "frac": ach_d / HBM_PEAK_GBPS},
                         "compress_tail_ms": acc["c_tail"], "decompress_count_scan_ms": acc["d_pre"], "decompress_tail_ms": acc["d_tail"],
                         "sum_ms": kern_sum},
+            # step time minus the event spans.  The spans come from a SEPARATE, profiled run of the same K steps and carry the
+            # event markers' own cost (about 4 us per span); since the host returns from a call while its last kernel is still
+            # running (early hand-off) the unprofiled step can be SHORTER than their sum -- the difference is then negative
             "host_gap_ms": ms_per_step - kern_sum,
             "host_call_ms": {"compress": t_c, "decompress": t_d},
             "compress_GBps_input": n * es / (t_c * 1e-3) / 1e9,

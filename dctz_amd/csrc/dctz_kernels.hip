@@ -1003,9 +1003,20 @@ __global__ __launch_bounds__(SWG) void k_qt_max(FwdParams<T> p, unsigned nlists)
   for (unsigned l = blockIdx.x; l < nlists; l += gridDim.x) {
     const unsigned n = p.tile_cnt[l];
     const size_t src = list_slot(l, G, p.ntiles);
-    for (unsigned i = threadIdx.x; i < n; i += SWG) {
-      const T a = fabs(p.qt_item[src + i]);
-      if (a > p.range_max) atomicMax(&qmax[p.qt_j[src + i]], to_bits(a));   // positive values order like their bits
+    // eight items per thread in flight (a list of some thousand items is a chain of dependent round trips otherwise:
+    // 93 us for 22 M items before, fp32 512^3 at p = 17 %)
+    for (unsigned i0 = threadIdx.x; i0 < n; i0 += 8 * SWG) {
+      T a[8];
+      unsigned jj[8];
+#pragma unroll
+      for (int u = 0; u < 8; u++) {
+        const unsigned i = i0 + (unsigned)u * SWG;
+        a[u] = T(0); jj[u] = 0;
+        if (i < n) { a[u] = fabs(p.qt_item[src + i]); jj[u] = p.qt_j[src + i]; }
+      }
+#pragma unroll
+      for (int u = 0; u < 8; u++)
+        if (a[u] > p.range_max) atomicMax(&qmax[jj[u]], to_bits(a[u]));   // positive values order like their bits
     }
   }
   __syncthreads();
