@@ -197,12 +197,13 @@ struct InvParams {
 };
 
 template <typename T> void launch_stats(const T* x, size_t n, double* part, int nparts, double* out, hipStream_t s,
-                                        HostBox* box = nullptr, unsigned long long seq = 0, Ctl* zero = nullptr);
+                                        HostBox* box = nullptr, unsigned long long seq = 0, Ctl* zero = nullptr,
+                                        const SfTable* tab = nullptr, SfGuess* guess = nullptr);
 template <typename T> void launch_stats_sample(const T* x, size_t n, unsigned group, double* part, int nparts, double* out, hipStream_t s,
                                                HostBox* box = nullptr, unsigned long long seq = 0, Ctl* zero = nullptr,
                                                const SfTable* tab = nullptr, SfGuess* guess = nullptr);
 void launch_stats_final(const double* part, int nparts, double* out, hipStream_t s, HostBox* box = nullptr,
-                        unsigned long long seq = 0, Ctl* zero = nullptr);
+                        unsigned long long seq = 0, Ctl* zero = nullptr, const SfTable* tab = nullptr, SfGuess* guess = nullptr);
 void launch_finish(Ctl* ctl, const double* part, int nparts, HostBox* box, unsigned long long seq, hipStream_t s);
 template <typename T> void launch_debug_divide(const T* x, size_t n, T d, int ok, T* fast, T* ref, hipStream_t s);
 template <typename T> void launch_serial_sum(const T* x, size_t n, double* out, hipStream_t s);

@@ -426,7 +426,7 @@ __global__ __launch_bounds__(SWG) void k_stats_final(const double* part, int npa
 // here, with the host's own decade tables (SfTable), and left in device memory for k_compress -- no host round trip
 // between the sample and the main launch (the host verifies the choice against the true statistics afterwards).
 __global__ __launch_bounds__(SWG) void k_stats_final_sf(const double* part, int nparts, double* out, Ctl* zero, SfTable tab,
-                                                       SfGuess* guess) {
+                                                       SfGuess* guess, HostBox* box) {
   if (zero != nullptr) {
     unsigned long long* w = reinterpret_cast<unsigned long long*>(zero);
     for (int i = threadIdx.x; i < (int)(sizeof(Ctl) / 8); i += SWG) w[i] = 0ull;
@@ -435,7 +435,11 @@ __global__ __launch_bounds__(SWG) void k_stats_final_sf(const double* part, int 
   __shared__ unsigned cnt_s[SWG / 64];
   double dmx, dmn, sum;
   reduce_parts(part, nparts, dmx, dmn, sum);
-  if (threadIdx.x == 0) { out[0] = dmx; out[1] = dmn; out[2] = sum; smax = dmx; smin = dmn; }
+  if (threadIdx.x == 0) {
+    out[0] = dmx; out[1] = dmn; out[2] = sum; smax = dmx; smin = dmn;
+    // (no sequence number here: the host reads these after the call's hand-off, which is a later kernel's)
+    if (box != nullptr) { box->stats[0] = dmx; box->stats[1] = dmn; box->stats[2] = sum; }
+  }
   __syncthreads();
   const double mx = smax, mn = smin;
   unsigned below = 0;                                  // decades whose upper end lies below max|x|
@@ -1609,20 +1613,24 @@ __global__ __launch_bounds__(SWG) void k_psnr_final(const double* __restrict__ p
 
 // ================================================================= launchers ==
 template <typename T>
-void launch_stats(const T* x, size_t n, double* part, int nparts, double* out, hipStream_t s, HostBox* box, unsigned long long seq, Ctl* zero) {
+void launch_stats(const T* x, size_t n, double* part, int nparts, double* out, hipStream_t s, HostBox* box, unsigned long long seq, Ctl* zero,
+                  const SfTable* tab, SfGuess* guess) {
   hipLaunchKernelGGL(k_stats<T>, dim3(nparts), dim3(SWG), 0, s, x, n, part);
-  hipLaunchKernelGGL(k_stats_final, dim3(1), dim3(SWG), 0, s, (const double*)part, nparts, out, box, seq, zero);
+  if (tab != nullptr) hipLaunchKernelGGL(k_stats_final_sf, dim3(1), dim3(SWG), 0, s, (const double*)part, nparts, out, zero, *tab, guess, box);
+  else hipLaunchKernelGGL(k_stats_final, dim3(1), dim3(SWG), 0, s, (const double*)part, nparts, out, box, seq, zero);
 }
 
 template <typename T>
 void launch_stats_sample(const T* x, size_t n, unsigned group, double* part, int nparts, double* out, hipStream_t s,
                          HostBox* box, unsigned long long seq, Ctl* zero, const SfTable* tab, SfGuess* guess) {
   hipLaunchKernelGGL(k_stats_sample<T>, dim3(nparts), dim3(SWG), 0, s, x, n, group, part);
-  if (tab != nullptr) hipLaunchKernelGGL(k_stats_final_sf, dim3(1), dim3(SWG), 0, s, (const double*)part, nparts, out, zero, *tab, guess);
+  if (tab != nullptr) hipLaunchKernelGGL(k_stats_final_sf, dim3(1), dim3(SWG), 0, s, (const double*)part, nparts, out, zero, *tab, guess, box);
   else hipLaunchKernelGGL(k_stats_final, dim3(1), dim3(SWG), 0, s, (const double*)part, nparts, out, box, seq, zero);
 }
-void launch_stats_final(const double* part, int nparts, double* out, hipStream_t s, HostBox* box, unsigned long long seq, Ctl* zero) {
-  hipLaunchKernelGGL(k_stats_final, dim3(1), dim3(SWG), 0, s, part, nparts, out, box, seq, zero);
+void launch_stats_final(const double* part, int nparts, double* out, hipStream_t s, HostBox* box, unsigned long long seq, Ctl* zero,
+                        const SfTable* tab, SfGuess* guess) {
+  if (tab != nullptr) hipLaunchKernelGGL(k_stats_final_sf, dim3(1), dim3(SWG), 0, s, part, nparts, out, zero, *tab, guess, box);
+  else hipLaunchKernelGGL(k_stats_final, dim3(1), dim3(SWG), 0, s, part, nparts, out, box, seq, zero);
 }
 void launch_finish(Ctl* ctl, const double* part, int nparts, HostBox* box, unsigned long long seq, hipStream_t s) {
   const FinArgs f = {ctl, part, nparts, box, seq, nullptr};
@@ -1735,7 +1743,7 @@ void launch_psnr(const T* x, const T* r, size_t n, double* part, int nparts, dou
 
 // explicit instantiations used by dctz_shim.hip
 #define INST(T)                                                                                         \
-  template void launch_stats<T>(const T*, size_t, double*, int, double*, hipStream_t, HostBox*, unsigned long long, Ctl*); \
+  template void launch_stats<T>(const T*, size_t, double*, int, double*, hipStream_t, HostBox*, unsigned long long, Ctl*, const SfTable*, SfGuess*); \
   template void launch_stats_sample<T>(const T*, size_t, unsigned, double*, int, double*, hipStream_t, HostBox*, unsigned long long, Ctl*, const SfTable*, SfGuess*); \
   template void launch_debug_divide<T>(const T*, size_t, T, int, T*, T*, hipStream_t);                  \
   template void launch_serial_sum<T>(const T*, size_t, double*, hipStream_t);                           \

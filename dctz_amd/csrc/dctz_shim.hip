@@ -535,7 +535,9 @@ static int compress_impl(dctzhip_ctx* c, const T* d_in, size_t n, double eb, int
   constexpr size_t chunk = (size_t)SWG * Traits<T>::EPV;
   bool spec = geom == GEOM_1D && c->speculate && ntiles && n >= c->spec_min && n >= 4 * chunk * c->spec_group;
   if (spec && c->spec_cooldown > 0) { c->spec_cooldown--; spec = false; }
-  const bool dsf = spec && c->handoff != 0 && c->dev_sf && c->sf_nk[dtype] > 0;   // scaling factor of the guess chosen on the device
+  // the scaling factor is chosen on the device (k_stats_final_sf: from the sample of a speculative call, else from the
+  // full statistics) and the main launch follows without asking the host; the host verifies it when the call is over
+  const bool dsf = c->handoff != 0 && c->dev_sf && c->sf_nk[dtype] > 0;
 
   // Host hand-off: mailbox + spin, or D2H copy + stream sync
   const bool box = c->handoff != 0;
@@ -550,12 +552,13 @@ static int compress_impl(dctzhip_ctx* c, const T* d_in, size_t n, double eb, int
   // ---- calc_data_stat (util.c:12-44): the full pass, or the sample -------------
   unsigned long long seq = box ? ++c->seq : 0ull;
   if (c->profiling) HIPCHK(c, hipEventRecord(c->ev[0], s));
+  const SfTable tab = {c->sf_thr[dtype], c->sf_pw[dtype], c->sf_nk[dtype], c->fastdiv, dtype};
   if (geom != GEOM_1D) {
-    launch_stats_final(c->part, pre_parts, c->stats_out, s, box ? c->box_dev : nullptr, seq, box ? c->ctl : nullptr);
+    launch_stats_final(c->part, pre_parts, c->stats_out, s, box ? c->box_dev : nullptr, seq, box ? c->ctl : nullptr,
+                       dsf ? &tab : nullptr, c->sf_guess);
   } else if (spec) {
     const size_t ngroups = n / chunk / c->spec_group;
     const int sgrid = (int)(ngroups < (size_t)c->stats_grid ? ngroups : (size_t)c->stats_grid);
-    const SfTable tab = {c->sf_thr[dtype], c->sf_pw[dtype], c->sf_nk[dtype], c->fastdiv, dtype};
     launch_stats_sample<T>(d_in, n, c->spec_group, c->part, sgrid, c->stats_out, s, box ? c->box_dev : nullptr, seq, box ? c->ctl : nullptr,
                            dsf ? &tab : nullptr, c->sf_guess);
   } else {
@@ -563,13 +566,14 @@ static int compress_impl(dctzhip_ctx* c, const T* d_in, size_t n, double eb, int
     int sgrid = (int)((nvec + SWG * 4 - 1) / (SWG * 4));
     if (sgrid < 1) sgrid = 1;
     if (sgrid > c->stats_grid) sgrid = c->stats_grid;
-    launch_stats<T>(d_in, n, c->part, sgrid, c->stats_out, s, box ? c->box_dev : nullptr, seq, box ? c->ctl : nullptr);
+    launch_stats<T>(d_in, n, c->part, sgrid, c->stats_out, s, box ? c->box_dev : nullptr, seq, box ? c->ctl : nullptr,
+                    dsf ? &tab : nullptr, c->sf_guess);
   }
   if (c->profiling) HIPCHK(c, hipEventRecord(c->ev[1], s));
   HostStats st = {0.0, 0.0, 0.0};
   if (dsf) {
-    // nothing to wait for: the scaling factor of the sampled max|x| is chosen on the device (k_stats_final_sf) and the
-    // main launch follows at once; the choice comes back with the call's results and is verified below like a guess
+    // nothing to wait for: the scaling factor is chosen on the device (k_stats_final_sf) and the main launch follows at
+    // once; the choice comes back with the call's results and is verified below
   } else if (box) {
     int rc = wait_seq(c, &hb->seq_stats, seq, "statistics");
     if (rc) return rc;
@@ -584,9 +588,10 @@ static int compress_impl(dctzhip_ctx* c, const T* d_in, size_t n, double eb, int
   T sf_t = T(1);
   unsigned fast_sf = 0;
   unsigned flags = 0;
+  bool respin = false;                              // second pass of a call: the host's own statistics and scaling factor
   // one pass of the kernels + the hand-off of its results into *hc / hs[4..6]
   auto run = [&](const HostStats& stats, bool fused) -> int {
-    const bool dev = fused && dsf;
+    const bool dev = dsf && !respin;
     int rc = compress_pass<T>(c, d_in, n, eb, mode, d_bin, d_dc, d_ac, d_coef, stats, fused, &sf, &sf_t, &fast_sf, seq, geom, dev);
     if (rc) return rc;
     if (box) {
@@ -609,18 +614,19 @@ static int compress_impl(dctzhip_ctx* c, const T* d_in, size_t n, double eb, int
   };
   { int rc = run(st, spec); if (rc) return rc; }
 
-  if (spec) {
-    const HostStats truth = {hs[4], hs[5], hs[6]};
+  if (spec || dsf) {
+    // what the kernels used against what the TRUE statistics ask for (the fused ones of a speculative call; else the
+    // full pass's own, which the device has turned into sf by the host's tables: a mismatch there would be a table bug)
+    const HostStats truth = spec ? HostStats{hs[4], hs[5], hs[6]} : HostStats{hb->stats[0], hb->stats[1], hb->stats[2]};
     const double true_sf = scaling_factor(dtype, truth.max_abs);
     const bool window_ok = fast_sf != 2 || (value_in_window(dtype, truth.min_abs) && value_in_window(dtype, truth.max_abs));
     st = truth;
     if ((T)true_sf == sf_t && window_ok) {
       sf = true_sf;
-      flags |= DCTZHIP_INFO_STATS_FUSED;
-      c->spec_hits++;
+      if (spec) { flags |= DCTZHIP_INFO_STATS_FUSED; c->spec_hits++; }
     } else {                                        // wrong guess: everything again with the true statistics
-      c->spec_misses++;
-      c->spec_cooldown = SPEC_COOLDOWN;
+      if (spec) { c->spec_misses++; c->spec_cooldown = SPEC_COOLDOWN; }
+      respin = true;
       flags |= DCTZHIP_INFO_RESPUN;
       c->ctl_dirty = 1;                             // the first pass left its QT maxima behind
       int rc = reset();
