@@ -152,6 +152,20 @@ struct NdShape {
   size_t nblk;                     // number of blocks = product of nb
 };
 
+// Direct addressing of a multi-dimensional array by the big kernels (no gather / scatter pass): possible when every
+// extent is a multiple of the tile edge (no padding) and the array is below 4 GiB (one buffer descriptor covers it).
+// Block B of the tile grid -> its origin in the array needs one or two divisions by launch constants (multiply-high +
+// one correction step).
+struct NdDirect {
+  unsigned on;                     // 0: the kernels read / write the block-after-block layout
+  unsigned nd;                     // 2 | 3
+  unsigned dx, dy;                 // extents (elements): dx = last (fastest) axis; dy = middle axis (3-D only)
+  unsigned nbx, nby;               // tiles along x / y
+  unsigned mx, my;                 // floor(2^32 / nbx), floor(2^32 / nby)
+  unsigned nblk;
+  unsigned bytes;                  // size of the array (buffer descriptor range)
+};
+
 template <typename T>
 struct FwdParams {
   const T* x;                      // input
@@ -176,6 +190,7 @@ struct FwdParams {
   unsigned fast_sf, fast_bw;       // divisor inside FastDiv's exponent window (host check); fast_sf == 2: every element too
   unsigned nlists_main;            // number of workgroup lists = grid of k_compress
   T sf, bin_width, range_min, range_max;
+  NdDirect nd;                     // multi-dimensional blocks straight from the array (GEOM != GEOM_1D only)
 };
 
 template <typename T>
@@ -192,6 +207,7 @@ struct InvParams {
   Ctl* ctl;
   unsigned nfull, ntiles, ac_count;
   unsigned nwg;                    // grid of k_decompress
+  NdDirect nd;                     // multi-dimensional blocks straight into the array (GEOM != GEOM_1D only)
   T sf, bin_width, range_min, range_max;
   double eb;
 };

@@ -202,6 +202,54 @@ __device__ __forceinline__ void issue_phase_dma(__amdgpu_buffer_rsrc_t rsrc, uns
       DMA16(rsrc, tilebuf + (jg * G::SEGP + s) * 1024, (jg & 1) ? tm.g_odd : tm.g_even, base + jg * 8 * G::BLKB + s * 128, 2 /* nt */);
 }
 
+// ---- multi-dimensional blocks straight from / to the array (NdDirect) ----
+// Byte offset of the origin of block B of the tile grid, or an offset beyond any descriptor range for B >= nblk
+// (loads return zeros there, stores are dropped).
+template <typename T>
+__device__ __forceinline__ unsigned nd_block_origin(const NdDirect& nd, unsigned B) {
+  auto divmod = [](unsigned a, unsigned d, unsigned m, unsigned& r) {
+    unsigned q = __umulhi(a, m);                     // m = floor(2^32 / d): q is the quotient or one short of it
+    r = a - q * d;
+    if (r >= d) { q++; r -= d; }
+    return q;
+  };
+  unsigned bx, elem;
+  const unsigned t = divmod(B, nd.nbx, nd.mx, bx);
+  if (nd.nd == 2) {
+    elem = t * 8u * nd.dx + bx * 8u;
+  } else {
+    unsigned by;
+    const unsigned bz = divmod(t, nd.nby, nd.my, by);
+    elem = (bz * 4u * nd.dy + by * 4u) * nd.dx + bx * 4u;
+  }
+  return B < nd.nblk ? elem * (unsigned)sizeof(T) : 0xFFFFFFF0u;
+}
+// Byte offset, inside its block's footprint in the array, of 16-byte chunk ch of the block (chunk ch = elements
+// [ch * EPV, ch * EPV + EPV) of the row-major tile: always inside one row of the tile)
+template <typename T>
+__device__ __forceinline__ unsigned nd_chunk_offset(const NdDirect& nd, int ch) {
+  const unsigned j0 = (unsigned)ch * (unsigned)Traits<T>::EPV;
+  if (nd.nd == 2) return ((j0 >> 3) * nd.dx + (j0 & 7u)) * (unsigned)sizeof(T);
+  return (((j0 >> 4) * nd.dy + ((j0 >> 2) & 3u)) * nd.dx + (j0 & 3u)) * (unsigned)sizeof(T);
+}
+// HBM -> LDS, one phase of a tile of a multi-dimensional array: same image in LDS as issue_phase_dma builds for the
+// flat layout (row (jg, s) = segment s of blocks 8 jg .. 8 jg + 7, chunks XOR-swizzled), other addresses in HBM.
+template <typename T, int PH>
+__device__ __forceinline__ void issue_phase_dma_nd(__amdgpu_buffer_rsrc_t rsrc, const NdDirect& nd, unsigned tile, int phase, unsigned char* tilebuf, int lane) {
+  using G = Geo<T, PH>;
+  const int beta = lane >> 3, gam = lane & 7;
+#pragma unroll
+  for (int jg = 0; jg < 8; jg++) {
+    const unsigned org = nd_block_origin<T>(nd, tile * (unsigned)TILE_BLKS + (unsigned)(8 * jg + beta));
+    const int cg = gam ^ (beta >> 1) ^ ((jg & 1) << 2);                // chunk of the segment this lane moves (TileMap's swizzle)
+#pragma unroll
+    for (int s = 0; s < G::SEGP; s++) {
+      const unsigned off = org + nd_chunk_offset<T>(nd, 8 * (phase * G::SEGP + s) + cg);
+      DMA16(rsrc, tilebuf + (jg * G::SEGP + s) * 1024, (int)(org >= 0xFFFFFFF0u ? org : off), 0, 2 /* nt */);
+    }
+  }
+}
+
 // LDS image of phase PHASE -> this lane's elements [PHASE * 64 / PH, (PHASE + 1) * 64 / PH) of its block
 template <typename T, int PH, int PHASE>
 __device__ __forceinline__ void read_phase(T (&x)[64], const unsigned char* tilebuf, const TileMap<T, PH>& tm) {
@@ -654,7 +702,21 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu((sizeof(T) =
   const size_t first_el = (size_t)tr.lo * TILE_ELEMS;
   const size_t end_el = min((size_t)p.nfull * 64, (size_t)tr.hi * TILE_ELEMS);
   const int range_el = tr.lo < tr.hi ? (int)(end_el - first_el) : 0;                  // whole blocks only
-  const __amdgpu_buffer_rsrc_t r_in = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(p.x + first_el), 0, range_el * (int)sizeof(T), 0x00020000);
+  // input: the workgroup's own range of the flat / block-after-block layout -- or, for multi-dimensional blocks read in
+  // place (p.nd.on), the whole array
+  const bool nd_direct = (GEOM != GEOM_1D) && p.nd.on != 0u;
+  const __amdgpu_buffer_rsrc_t r_in = nd_direct
+      ? __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(p.x), 0, (int)p.nd.bytes, 0x00020000)
+      : __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(p.x + first_el), 0, range_el * (int)sizeof(T), 0x00020000);
+  auto issue_dma = [&](unsigned rel, int phase, const TileMap<T, PH>& tmx) {
+    if (GEOM != GEOM_1D && nd_direct) {
+      int l = lane;
+      asm volatile("" : "+v"(l));                      // (re-derived per issue, like tile_map)
+      issue_phase_dma_nd<T, PH>(r_in, p.nd, tr.lo + rel, phase, tilebuf, l);
+    } else {
+      issue_phase_dma<T, PH>(r_in, rel, phase, tilebuf, tmx);
+    }
+  };
   const __amdgpu_buffer_rsrc_t r_bin = __builtin_amdgcn_make_buffer_rsrc(p.bin + first_el, 0, range_el, 0x00020000);
   const __amdgpu_buffer_rsrc_t r_dc = __builtin_amdgcn_make_buffer_rsrc(p.dc + first_el / 64, 0, range_el / 64 * 4, 0x00020000);
   // the workgroup's exception list(s) behind descriptors too: 32-bit offsets, no 64-bit pointers to keep alive (or spill)
@@ -773,12 +835,12 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu((sizeof(T) =
   T xn[64];
   if (tr.lo < tr.hi) {
     const TileMap<T, PH> tm0 = tile_map();
-    issue_phase_dma<T, PH>(r_in, 0u, 0, tilebuf, tm0);
+    issue_dma(0u, 0, tm0);
     if (PH == 2) {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       read_phase<T, PH, 0>(xn, tilebuf, tm0);
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      issue_phase_dma<T, PH>(r_in, 0u, 1, tilebuf, tm0);
+      issue_dma(0u, 1, tm0);
       stats_scale(xn, std::integral_constant<int, 0>{}, (unsigned)lane < min((unsigned)TILE_BLKS, p.nfull - tr.lo * TILE_BLKS), tr.lo == 0);
     }
   }
@@ -798,7 +860,7 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu((sizeof(T) =
       read_phase<T, PH, PH - 1>(x, tilebuf, tm);
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");        // ... and is in registers: the buffer is free
       STAMP(2);
-      if (tile + 1 < tr.hi) issue_phase_dma<T, PH>(r_in, rel + 1, 0, tilebuf, tm);
+      if (tile + 1 < tr.hi) issue_dma(rel + 1, 0, tm);
       STAMP(3);
       if (pend) flush();
       STAMP(4);
@@ -808,7 +870,7 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu((sizeof(T) =
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // the DMA has landed (and everything older is done)
       read_phase<T, PH, 0>(x, tilebuf, tm);
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      if (tile + 1 < tr.hi) issue_phase_dma<T, PH>(r_in, rel + 1, 0, tilebuf, tm);
+      if (tile + 1 < tr.hi) issue_dma(rel + 1, 0, tm);
       if (pend) flush();
       stats_scale(x, std::integral_constant<int, 0>{}, active, tile == 0);
     }
@@ -897,7 +959,7 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu((sizeof(T) =
       STAMP(8);
       read_phase<T, PH, 0>(xn, tilebuf, tm);
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      issue_phase_dma<T, PH>(r_in, rel + 1, 1, tilebuf, tm);
+      issue_dma(rel + 1, 1, tm);
       stats_scale(xn, std::integral_constant<int, 0>{}, (unsigned)lane < min((unsigned)TILE_BLKS, p.nfull - (tile + 1) * TILE_BLKS), false);
       STAMP(9);
     }
@@ -1167,7 +1229,10 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(PH))) void k
   const size_t first_el = (size_t)tr.lo * TILE_ELEMS;
   const size_t end_el = min((size_t)p.nfull * 64, (size_t)tr.hi * TILE_ELEMS);
   const int range_el = tr.lo < tr.hi ? (int)(end_el - first_el) : 0;
-  const __amdgpu_buffer_rsrc_t r_out = __builtin_amdgcn_make_buffer_rsrc(p.out + first_el, 0, range_el * (int)sizeof(T), 0x00020000);
+  const bool nd_direct = (GEOM != GEOM_1D) && p.nd.on != 0u;           // multi-dimensional blocks written in place: the whole array
+  const __amdgpu_buffer_rsrc_t r_out = nd_direct
+      ? __builtin_amdgcn_make_buffer_rsrc(p.out, 0, (int)p.nd.bytes, 0x00020000)
+      : __builtin_amdgcn_make_buffer_rsrc(p.out + first_el, 0, range_el * (int)sizeof(T), 0x00020000);
   const __amdgpu_buffer_rsrc_t r_bin = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(p.bin + first_el), 0, range_el, 0x00020000);
   const __amdgpu_buffer_rsrc_t r_dc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.dc + first_el / 64), 0, range_el / 64 * 4, 0x00020000);
   // AC_exact behind a descriptor based at this workgroup's first exact coefficient (32-bit offsets stay small for any N):
@@ -1324,11 +1389,20 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(PH))) void k
       write_phase<T, PH, PHASE>(x, outbuf, tm);
 #pragma unroll
       for (int jg = 0; jg < 8; jg++) {
+        unsigned org = 0;
+        int cg = 0;
+        if (GEOM != GEOM_1D && nd_direct) {            // this lane's piece of row (jg, s): a chunk of block 8 jg + beta of the tile
+          const int beta = lane >> 3, gam = lane & 7;
+          org = nd_block_origin<T>(p.nd, tile * (unsigned)TILE_BLKS + (unsigned)(8 * jg + beta));
+          cg = gam ^ (beta >> 1) ^ ((jg & 1) << 2);
+        }
         const int vo = vbase + jg * 8 * G::BLKB + ((jg & 1) ? tm.g_odd : tm.g_even);
 #pragma unroll
         for (int s = 0; s < G::SEGP; s++) {
           const u32x4 v = *reinterpret_cast<const u32x4*>(outbuf + (jg * G::SEGP + s) * 1024 + lane * 16);
-          __builtin_amdgcn_raw_buffer_store_b128(v, r_out, vo + (PHASE * G::SEGP + s) * 128, 0, 2 /* nt */);
+          int at = vo + (PHASE * G::SEGP + s) * 128;
+          if (GEOM != GEOM_1D && nd_direct) at = (int)(org >= 0xFFFFFFF0u ? org : org + nd_chunk_offset<T>(p.nd, 8 * (PHASE * G::SEGP + s) + cg));
+          __builtin_amdgcn_raw_buffer_store_b128(v, r_out, at, 0, 2 /* nt */);
         }
       }
     };
@@ -1662,12 +1736,22 @@ void launch_compress(const FwdParams<T>& p, int mode, bool stats, int grid, int 
       if (stats) hipLaunchKernelGGL((k_compress<T, DCTZHIP_QT, true, Phases<T>::C, GEOM_1D>), dim3(grid), dim3(WG), 0, s, p);
       else hipLaunchKernelGGL((k_compress<T, DCTZHIP_QT, false, Phases<T>::C, GEOM_1D>), dim3(grid), dim3(WG), 0, s, p);
     }
-  } else if (geom == GEOM_2D) {            // (the statistics of a multi-dimensional array come from k_gather_nd)
-    if (mode == DCTZHIP_EC) hipLaunchKernelGGL((k_compress<T, DCTZHIP_EC, false, Phases<T>::C, GEOM_2D>), dim3(grid), dim3(WG), 0, s, p);
-    else hipLaunchKernelGGL((k_compress<T, DCTZHIP_QT, false, Phases<T>::C, GEOM_2D>), dim3(grid), dim3(WG), 0, s, p);
+  } else if (geom == GEOM_2D) {
+    if (mode == DCTZHIP_EC) {
+      if (stats) hipLaunchKernelGGL((k_compress<T, DCTZHIP_EC, true, Phases<T>::C, GEOM_2D>), dim3(grid), dim3(WG), 0, s, p);
+      else hipLaunchKernelGGL((k_compress<T, DCTZHIP_EC, false, Phases<T>::C, GEOM_2D>), dim3(grid), dim3(WG), 0, s, p);
+    } else {
+      if (stats) hipLaunchKernelGGL((k_compress<T, DCTZHIP_QT, true, Phases<T>::C, GEOM_2D>), dim3(grid), dim3(WG), 0, s, p);
+      else hipLaunchKernelGGL((k_compress<T, DCTZHIP_QT, false, Phases<T>::C, GEOM_2D>), dim3(grid), dim3(WG), 0, s, p);
+    }
   } else {
-    if (mode == DCTZHIP_EC) hipLaunchKernelGGL((k_compress<T, DCTZHIP_EC, false, Phases<T>::C, GEOM_3D>), dim3(grid), dim3(WG), 0, s, p);
-    else hipLaunchKernelGGL((k_compress<T, DCTZHIP_QT, false, Phases<T>::C, GEOM_3D>), dim3(grid), dim3(WG), 0, s, p);
+    if (mode == DCTZHIP_EC) {
+      if (stats) hipLaunchKernelGGL((k_compress<T, DCTZHIP_EC, true, Phases<T>::C, GEOM_3D>), dim3(grid), dim3(WG), 0, s, p);
+      else hipLaunchKernelGGL((k_compress<T, DCTZHIP_EC, false, Phases<T>::C, GEOM_3D>), dim3(grid), dim3(WG), 0, s, p);
+    } else {
+      if (stats) hipLaunchKernelGGL((k_compress<T, DCTZHIP_QT, true, Phases<T>::C, GEOM_3D>), dim3(grid), dim3(WG), 0, s, p);
+      else hipLaunchKernelGGL((k_compress<T, DCTZHIP_QT, false, Phases<T>::C, GEOM_3D>), dim3(grid), dim3(WG), 0, s, p);
+    }
   }
 }
 

@@ -58,6 +58,7 @@ struct dctzhip_ctx {
   int sf_nk[2] = {0, 0};
   SfGuess* sf_guess = nullptr;
   int dev_sf = 1;                   // 0: the host chooses sf between the sample and k_compress (DCTZHIP_DEVICE_SF)
+  int nd_direct = 1;                // multi-dimensional blocks read / written in place where the shape allows (DCTZHIP_ND_DIRECT)
   void* nd_buf = nullptr;           // multi-dimensional blocks: the array laid out block after block (k_gather_nd / k_scatter_nd)
   size_t nd_cap = 0;                // bytes
   // pinned host staging
@@ -173,6 +174,7 @@ extern "C" int dctzhip_ctx_create(dctzhip_ctx** out, int device) {
   }
   for (int i = 0; i < 6; i++) HIPCHK(nullptr, hipEventCreate(&c->ev[i]));
   if (const char* e = getenv("DCTZHIP_DEVICE_SF")) c->dev_sf = atoi(e) != 0;
+  if (const char* e = getenv("DCTZHIP_ND_DIRECT")) c->nd_direct = atoi(e) != 0;
   if (int rc = build_sf_tables(c)) return rc;
   *out = c;
   return DCTZHIP_OK;
@@ -450,7 +452,8 @@ static int wg_per_cu(dctzhip_ctx* c, bool decode, int mode) {
 template <typename T>
 static int compress_pass(dctzhip_ctx* c, const T* d_in, size_t n, double eb, int mode, uint8_t* d_bin, float* d_dc,
                          float* d_ac, T* d_coef, const HostStats& st, bool fused, double* sf_out, T* sf_t_out,
-                         unsigned* fast_sf_out, unsigned long long seq, int geom, bool device_sf = false) {
+                         unsigned* fast_sf_out, unsigned long long seq, int geom, bool device_sf = false,
+                         const NdDirect* nd = nullptr) {
   const int dtype = sizeof(T) == 8 ? DCTZHIP_F64 : DCTZHIP_F32;
   hipStream_t s = c->stream;
   const unsigned nfull = (unsigned)(n / 64);
@@ -470,6 +473,7 @@ static int compress_pass(dctzhip_ctx* c, const T* d_in, size_t n, double eb, int
   p.tab = tab_of<T>(c); p.rtab = reinterpret_cast<const T*>(c->rtab);
   p.ctl = c->ctl;
   p.guess = device_sf ? c->sf_guess : nullptr;       // (then p.sf / p.fast_sf below are placeholders)
+  if (nd) p.nd = *nd; else memset(&p.nd, 0, sizeof(p.nd));
   p.stat_part = fused ? c->part : nullptr;
   p.nfull = nfull; p.ntiles = ntiles; p.last_is_full = rem ? 0u : 1u;
   p.sf = (T)sf;
@@ -512,12 +516,13 @@ static int compress_pass(dctzhip_ctx* c, const T* d_in, size_t n, double eb, int
   return DCTZHIP_OK;
 }
 
-// geom != GEOM_1D: d_in is the block-linear layout of a multi-dimensional array (n = nblk * 64) and the statistics
-// partials of the ORIGINAL array (n_orig elements) are already in c->part[0 .. pre_parts) -- k_gather_nd.
+// geom != GEOM_1D, nd == NULL: d_in is the block-linear layout of a multi-dimensional array (n = nblk * 64) and the
+// statistics partials of the ORIGINAL array (n_orig elements) are already in c->part[0 .. pre_parts) -- k_gather_nd.
+// geom != GEOM_1D, nd != NULL: d_in is the array itself, read in place by k_compress (no padding: n = nblk * 64 = N).
 template <typename T>
 static int compress_impl(dctzhip_ctx* c, const T* d_in, size_t n, double eb, int mode, uint8_t* d_bin, float* d_dc,
                          float* d_ac, T* d_scaled, T* d_coef, dctzhip_cinfo* info, int geom = GEOM_1D, int pre_parts = 0,
-                         size_t n_orig = 0) {
+                         size_t n_orig = 0, const NdDirect* nd = nullptr) {
   const int dtype = sizeof(T) == 8 ? DCTZHIP_F64 : DCTZHIP_F32;
   hipStream_t s = c->stream;
   const unsigned nfull = (unsigned)(n / 64);
@@ -533,7 +538,8 @@ static int compress_impl(dctzhip_ctx* c, const T* d_in, size_t n, double eb, int
   // guess afterwards; a wrong guess costs one re-run with the true values.  (The scaled copy the
   // reference's in-place semantics ask for is written at the very end, with the verified sf.)
   constexpr size_t chunk = (size_t)SWG * Traits<T>::EPV;
-  bool spec = geom == GEOM_1D && c->speculate && ntiles && n >= c->spec_min && n >= 4 * chunk * c->spec_group;
+  const bool pre = pre_parts > 0;                   // statistics partials already there (k_gather_nd)
+  bool spec = !pre && c->speculate && ntiles && n >= c->spec_min && n >= 4 * chunk * c->spec_group;
   if (spec && c->spec_cooldown > 0) { c->spec_cooldown--; spec = false; }
   // the scaling factor is chosen on the device (k_stats_final_sf: from the sample of a speculative call, else from the
   // full statistics) and the main launch follows without asking the host; the host verifies it when the call is over
@@ -553,7 +559,7 @@ static int compress_impl(dctzhip_ctx* c, const T* d_in, size_t n, double eb, int
   unsigned long long seq = box ? ++c->seq : 0ull;
   if (c->profiling) HIPCHK(c, hipEventRecord(c->ev[0], s));
   const SfTable tab = {c->sf_thr[dtype], c->sf_pw[dtype], c->sf_nk[dtype], c->fastdiv, dtype};
-  if (geom != GEOM_1D) {
+  if (pre) {
     launch_stats_final(c->part, pre_parts, c->stats_out, s, box ? c->box_dev : nullptr, seq, box ? c->ctl : nullptr,
                        dsf ? &tab : nullptr, c->sf_guess);
   } else if (spec) {
@@ -592,7 +598,7 @@ static int compress_impl(dctzhip_ctx* c, const T* d_in, size_t n, double eb, int
   // one pass of the kernels + the hand-off of its results into *hc / hs[4..6]
   auto run = [&](const HostStats& stats, bool fused) -> int {
     const bool dev = dsf && !respin;
-    int rc = compress_pass<T>(c, d_in, n, eb, mode, d_bin, d_dc, d_ac, d_coef, stats, fused, &sf, &sf_t, &fast_sf, seq, geom, dev);
+    int rc = compress_pass<T>(c, d_in, n, eb, mode, d_bin, d_dc, d_ac, d_coef, stats, fused, &sf, &sf_t, &fast_sf, seq, geom, dev, nd);
     if (rc) return rc;
     if (box) {
       rc = wait_seq(c, &hb->seq_done, seq, "compress");
@@ -779,7 +785,7 @@ extern "C" int dctzhip_compress(dctzhip_ctx* c, const void* d_in, size_t n, int 
 template <typename T>
 static int decompress_impl(dctzhip_ctx* c, const uint8_t* d_bin, const float* d_dc, const float* d_ac,
                            uint32_t ac_count, const void* qtable_host, size_t n, double eb, double sf, int mode,
-                           T* d_out, int geom = GEOM_1D) {
+                           T* d_out, int geom = GEOM_1D, const NdDirect* nd = nullptr) {
   hipStream_t s = c->stream;
   const unsigned nfull = (unsigned)(n / 64);
   const int rem = (int)(n % 64);
@@ -801,6 +807,7 @@ static int decompress_impl(dctzhip_ctx* c, const uint8_t* d_bin, const float* d_
   p.tab = tab_of<T>(c); p.rtab = reinterpret_cast<const T*>(c->rtab); p.qtab = reinterpret_cast<const T*>(c->qtab);
   p.ctl = c->ctl;
   p.tile_cnt = c->tile_cnt; p.wg_cnt = c->wg_cnt;
+  if (nd) p.nd = *nd; else memset(&p.nd, 0, sizeof(p.nd));
   p.nfull = nfull; p.ntiles = ntiles; p.ac_count = ac_count;
   p.sf = (T)sf;
   // gen_bins / gen_bins_f (binning.c:17 / :37): bin_width = error_bound*2*BRSF in
@@ -885,6 +892,25 @@ extern "C" size_t dctzhip_nd_blocks(int ndims, const size_t* dims) {
   return nd_shape(ndims, dims, &sh) ? sh.nblk : 0;
 }
 
+// The kernels can read / write the array in place (NdDirect) when no tile is padded and one 32-bit buffer descriptor
+// covers it; DCTZHIP_ND_DIRECT=0 forces the gather / scatter passes (A/B, tests).
+static bool nd_direct(dctzhip_ctx* c, const NdShape& sh, size_t es, NdDirect* d) {
+  memset(d, 0, sizeof(*d));
+  if (!c->nd_direct) return false;
+  const size_t edge = sh.nd == 2 ? 8 : 4;
+  size_t n = 1;
+  for (int i = 0; i < sh.nd; i++) { if (sh.d[i] % edge) return false; n *= sh.d[i]; }
+  if (n * es > (size_t)0xFFFFF000u) return false;
+  d->on = 1; d->nd = (unsigned)sh.nd;
+  d->dx = (unsigned)sh.d[sh.nd - 1]; d->dy = sh.nd == 3 ? (unsigned)sh.d[1] : 1u;
+  d->nbx = (unsigned)sh.nb[sh.nd - 1]; d->nby = sh.nd == 3 ? (unsigned)sh.nb[1] : 1u;
+  d->mx = (unsigned)(((unsigned long long)1 << 32) / d->nbx > 0xFFFFFFFFull ? 0xFFFFFFFFull : ((unsigned long long)1 << 32) / d->nbx);
+  d->my = (unsigned)(((unsigned long long)1 << 32) / d->nby > 0xFFFFFFFFull ? 0xFFFFFFFFull : ((unsigned long long)1 << 32) / d->nby);
+  d->nblk = (unsigned)sh.nblk;
+  d->bytes = (unsigned)(n * es);
+  return true;
+}
+
 static int ensure_nd(dctzhip_ctx* c, size_t bytes) {
   char* b = (char*)c->nd_buf;
   int rc = regrow(c, &b, &c->nd_cap, bytes, 1);
@@ -896,6 +922,10 @@ template <typename T>
 static int compress_nd_impl(dctzhip_ctx* c, const T* d_in, const NdShape& sh, double eb, int mode, uint8_t* d_bin,
                             float* d_dc, float* d_ac, T* d_scaled, dctzhip_cinfo* info) {
   const size_t n_lin = sh.nblk * 64, n_orig = sh.d[0] * sh.d[1] * sh.d[2];
+  NdDirect direct;
+  if (nd_direct(c, sh, sizeof(T), &direct))         // no padding, below 4 GiB: the flat pipeline with other addresses
+    return compress_impl<T>(c, d_in, n_orig, eb, mode, d_bin, d_dc, d_ac, d_scaled, (T*)nullptr, info, sh.nd == 2 ? GEOM_2D : GEOM_3D, 0,
+                            n_orig, &direct);
   int rc = ensure_nd(c, n_lin * sizeof(T));
   if (rc) return rc;
   T* lin = reinterpret_cast<T*>(c->nd_buf);
@@ -954,9 +984,15 @@ extern "C" int dctzhip_decompress_nd(dctzhip_ctx* c, const void* d_bin, const fl
   HIPCHK(c, hipSetDevice(c->device));
   rc = ensure_scratch(c, n_lin, dtype, DCTZHIP_EC, false);
   if (rc) return rc;
+  const int geom = ndims == 2 ? GEOM_2D : GEOM_3D;
+  NdDirect direct;
+  if (nd_direct(c, sh, elem_size(dtype), &direct)) {
+    if (dtype == DCTZHIP_F64)
+      return decompress_impl<double>(c, (const uint8_t*)d_bin, d_dc, d_ac, ac_count, qtable_host, n_lin, eb, sf, mode, (double*)d_out, geom, &direct);
+    return decompress_impl<float>(c, (const uint8_t*)d_bin, d_dc, d_ac, ac_count, qtable_host, n_lin, eb, sf, mode, (float*)d_out, geom, &direct);
+  }
   rc = ensure_nd(c, n_lin * elem_size(dtype));
   if (rc) return rc;
-  const int geom = ndims == 2 ? GEOM_2D : GEOM_3D;
   const int grid = c->num_cu * 8;
   if (dtype == DCTZHIP_F64) {
     rc = decompress_impl<double>(c, (const uint8_t*)d_bin, d_dc, d_ac, ac_count, qtable_host, n_lin, eb, sf, mode, (double*)c->nd_buf, geom);

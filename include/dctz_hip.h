@@ -177,9 +177,10 @@ int dctzhip_decompress(dctzhip_ctx *ctx, const void *d_bin_index, const float *d
  * Everything after the transform is the 1-D pipeline (DC, bins, AC_exact order, QT table per position), so the
  * three streams have the reference's meaning over nblk = prod ceil(dims[i] / edge) blocks:
  *   d_bin_index  nblk * 64 bytes,  d_dc  nblk floats,  d_ac_exact  capacity nblk * 64 floats.
- * Statistics (sf, mean) are those of the original array.  Round 2 implementation: a gather pass lays the tiles
- * out block after block (+2 element sizes of HBM traffic per element and direction), then the 1-D kernels run
- * with the block transform swapped.  dctzhip_nd_blocks returns nblk (0 for bad arguments). */
+ * Statistics (sf, mean) are those of the original array.  Arrays whose extents are multiples of the tile edge (and
+ * below 4 GiB) are read and written in place by the big kernels, at the flat path's speed; ragged ones go through a
+ * gather / scatter pass (+2 element sizes of HBM traffic per element and direction).  dctzhip_nd_blocks returns nblk
+ * (0 for bad arguments). */
 #define DCTZHIP_GEOM_1D 0
 #define DCTZHIP_GEOM_2D 1
 #define DCTZHIP_GEOM_3D 2

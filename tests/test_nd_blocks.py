@@ -109,8 +109,12 @@ def ctx():
     c.close()
 
 
+# ragged shapes go through the gather / scatter passes; shapes whose extents are multiples of the tile edge are read and
+# written in place by the big kernels (NdDirect: partial last tiles, one block per row, many tiles per workgroup)
 CASES = [((45, 77), np.float64), ((360, 720), np.float32), ((64, 8), np.float64), ((13, 22, 35), np.float64),
-         ((64, 64, 64), np.float32), ((4, 4, 260), np.float64), ((100, 7, 9), np.float32)]
+         ((64, 64, 64), np.float32), ((4, 4, 260), np.float64), ((100, 7, 9), np.float32), ((64, 128), np.float64),
+         ((8, 16, 64), np.float64), ((16, 8), np.float32), ((256, 1544), np.float64), ((40, 36, 52), np.float64),
+         ((4, 4, 4), np.float32)]
 
 
 @pytest.mark.gpu
@@ -141,6 +145,38 @@ def test_hip_nd_streams_bit_exact(ctx, shape, dtype, mode):
     tdt = torch.float64 if dtype == np.float64 else torch.float32
     r = ctx.decompress_nd(out, info.cnt, shape, tdt, eb, info.sf, hmode, qtable=np.array(info.qtable[:])).cpu().numpy()
     assert np.array_equal(r, O.decompress_nd(c, shape, O.FAST))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape,dtype,mode", [((1800, 3600), np.float32, O.EC), ((128, 256, 160), np.float64, O.QT)])
+def test_hip_nd_in_place_large_equals_oracle_and_gather_path(shape, dtype, mode):
+    """Large enough for the speculative single pass: the array is read in place (no gather), statistics fused into
+    k_compress behind the device-chosen scaling factor; streams == oracle, and == what the gather / scatter path gives."""
+    import torch
+    import dctz_amd
+    x = field(shape, dtype, seed=31, noise=0.002)
+    c = O.compress_nd(x, 1e-3, mode, O.FAST)
+    hmode = dctz_amd.QT if mode == O.QT else dctz_amd.EC
+    tdt = torch.float64 if dtype == np.float64 else torch.float32
+    res = {}
+    for direct in ("1", "0"):
+        os.environ["DCTZHIP_ND_DIRECT"] = direct
+        try:
+            cx = dctz_amd.Context(0)
+        finally:
+            os.environ.pop("DCTZHIP_ND_DIRECT", None)
+        xd = torch.from_numpy(x).to(cx.device)
+        out, info = cx.compress_nd(xd, 1e-3, hmode)
+        assert info.sf == c.sf and info.cnt == c.cnt
+        if direct == "1":
+            assert info.flags & dctz_amd.hip.INFO_STATS_FUSED
+        assert np.array_equal(out["bin_index"].cpu().numpy(), c.bin_index)
+        assert np.array_equal(out["dc"].cpu().numpy().view(np.uint32), c.dc.view(np.uint32))
+        assert np.array_equal(out["ac_exact"][:c.cnt].cpu().numpy().view(np.uint32), c.ac_exact.view(np.uint32))
+        r = cx.decompress_nd(out, info.cnt, shape, tdt, 1e-3, info.sf, hmode, qtable=np.array(info.qtable[:])).cpu().numpy()
+        res[direct] = r
+        cx.close()
+    assert np.array_equal(res["1"], res["0"]) and np.array_equal(res["1"], O.decompress_nd(c, shape, O.FAST))
 
 
 @pytest.mark.gpu
