@@ -38,6 +38,7 @@ def main():
         os.environ["DCTZHIP_FASTDIV"] = kv.get("fd", "2")
         os.environ["DCTZHIP_WG_PER_CU"] = kv.get("wg", "0")
         os.environ["DCTZHIP_STATS_GRID"] = kv.get("sg", "2048")
+        os.environ["DCTZHIP_GRID_C"] = kv.get("gc", "0")
         c = dctz_amd.Context(0)
         c.set_profiling(True)
         c.reserve(n, tdt, mode)
