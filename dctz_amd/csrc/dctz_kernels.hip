@@ -10,15 +10,23 @@
 //     lane -> global-address map of every DMA row is chosen so that the image in LDS is the transposed,
 //     bank-conflict-free one (TileMap); the reconstruction goes registers -> LDS (same image) -> 1 KiB rows;
 //   * workgroups are single wavefronts, the grid is persistent (as many workgroups per CU as the LDS
-//     admits: 4 for fp64, 7 for fp32) and workgroup b owns the contiguous tile range
+//     admits: k_compress 8, k_decompress 4 for fp64 / 7 for fp32) and workgroup b owns the contiguous tile range
 //     [b*ntiles/G, (b+1)*ntiles/G), so its exceptions form one contiguous piece of AC_exact[];
 //   * the ordered stream of "stored exactly" coefficients (AC_exact) is placed in two levels: a lane
 //     parks the exceptions of its block in a private LDS strip while it bins, a wave scan of the
-//     counts gives every block its place in the workgroup's list, k_scan_tiles turns the list lengths
-//     into offsets and k_compact_ac moves the lists; the big kernels have no inter-workgroup traffic;
-//   * the outputs of tile k are flushed AFTER the DMA of tile k+2 has been issued, so that the wait for
-//     tile k+1's data never sits behind tile k's stores;
-//   * calc_data_stat rides inside k_compress (STATS) behind a sampled, verified guess of sf.
+//     counts gives every block its place in the workgroup's list, and k_compact_ac moves every list to its
+//     place -- the sum of the lengths of the lists before it, added up by the list's own workgroup; on decode
+//     k_count_tiles leaves the counts per tile and per workgroup of k_decompress.  No scan kernels, and the big
+//     kernels have no inter-workgroup traffic;
+//   * k_compress<double> moves a tile through LDS in two phases (two waves per SIMD cover each other); the outputs
+//     of tile k are flushed after the next DMA of tile k+1 has been issued, so that the wait for tile k+1's data
+//     never sits behind tile k's stores;
+//   * calc_data_stat rides inside k_compress (STATS) behind a sampled guess of sf that the DEVICE turns into the
+//     scaling factor (k_stats_final_sf, host-built decade tables) and the host verifies afterwards;
+//   * what the host waits for at the end of a call is handed over by the first workgroup of the call's last big
+//     kernel (finish_body), while the GPU drains;
+//   * multi-dimensional blocks (8 x 8 / 4 x 4 x 4 tiles, dct_nd_block.h): the same kernels with the block transform
+//     swapped (GEOM) and, where no tile is padded, the array addressed in place (NdDirect).
 //
 // Store-data hazard (gfx950, found in round 1 as rare corruption of QT reconstructions, reproduced in
 // tools/ubench/probe_r2.hip): a buffer_store_dwordx4 whose soffset is an SGPR, followed with NO wait

@@ -435,7 +435,7 @@ static int read_timings(dctzhip_ctx* c, int nev_main_start) {
 
 struct HostStats { double max_abs, min_abs, sum; };
 
-// resident single-wave workgroups per CU of the two big kernels (LDS-limited: 4 for fp64, 7 for fp32)
+// resident single-wave workgroups per CU of the two big kernels (LDS-limited: k_compress 8; k_decompress 4 for fp64, 7 for fp32)
 template <typename T>
 static int wg_per_cu(dctzhip_ctx* c, bool decode, int mode) {
   if (c->wg_per_cu) return c->wg_per_cu;
@@ -553,7 +553,7 @@ static int compress_impl(dctzhip_ctx* c, const T* d_in, size_t n, double eb, int
   HostBox* hb = c->box;
   auto reset = [&]() -> int {
     if (!box || c->ctl_dirty) HIPCHK(c, hipMemsetAsync(c->ctl, 0, sizeof(Ctl), s));   // (else: k_stats_final zeroes it)
-    c->ctl_dirty = 1;                               // until this call's k_finish has been seen
+    c->ctl_dirty = 1;                               // until this call's hand-off has been seen
     return DCTZHIP_OK;
   };
   { int rc = reset(); if (rc) return rc; }
