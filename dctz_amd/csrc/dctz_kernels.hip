@@ -51,6 +51,7 @@ namespace dctz {
 
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 #define LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
 // The twiddle block is written once at context creation and never by a kernel: reading it through the constant
 // address space lets the compiler use scalar loads (the table indices are compile-time constants, the base is a
@@ -154,6 +155,16 @@ template <> struct FastDiv<float> {
     const float r2 = fmaf(-d, q2, x);
     return fmaf(r2, y, q2);
   }
+  // two quotients at once with the packed fp32 instructions of gfx950 (v_pk_mul_f32 / v_pk_fma_f32: the same IEEE
+  // operations per component, half the issue slots)
+  __device__ __forceinline__ f32x2 core2(f32x2 x) const {
+    const f32x2 dd = {d, d}, yy = {y, y};
+    const f32x2 q = x * yy;
+    const f32x2 r = __builtin_elementwise_fma(-dd, q, x);
+    const f32x2 q2 = __builtin_elementwise_fma(r, yy, q);
+    const f32x2 r2 = __builtin_elementwise_fma(-dd, q2, x);
+    return __builtin_elementwise_fma(r2, yy, q2);
+  }
   __device__ __forceinline__ float div(float x) const {
     const unsigned ex = (__float_as_uint(x) >> 23) & 0xffu;
     if (ok && (ex - 64u) <= 126u) return core(x);                  // |x| in [2^-63, 2^64)
@@ -161,6 +172,10 @@ template <> struct FastDiv<float> {
     return x / d;
   }
 };
+
+// (call sites shared by the fp64 instantiations, where the packed form does not exist and the branch is compiled out)
+__device__ __forceinline__ f32x2 fastdiv_core2(const FastDiv<float>& d, f32x2 x) { return d.core2(x); }
+__device__ __forceinline__ f32x2 fastdiv_core2(const FastDiv<double>&, f32x2 x) { return x; }
 
 // Workgroup b of G owns the contiguous tiles [lo, hi) -- the same partition in k_compress / k_compact_ac
 // and in k_decompress.
@@ -815,8 +830,16 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu((sizeof(T) =
     }
     if (scale) {
       if (fast_sf == 2) {
+        if constexpr (sizeof(T) == 4) {
 #pragma unroll
-        for (int j = J0; j < J1; j++) x[j] = sfd.core(x[j]);
+          for (int j = J0; j < J1; j += 2) {
+            const f32x2 v = fastdiv_core2(sfd, f32x2{(float)x[j], (float)x[j + 1]});
+            x[j] = v.x; x[j + 1] = v.y;
+          }
+        } else {
+#pragma unroll
+          for (int j = J0; j < J1; j++) x[j] = sfd.core(x[j]);
+        }
       } else if (fast_sf == 1) {
 #pragma unroll
         for (int j = J0; j < J1; j++) x[j] = sfd.div(x[j]);
@@ -912,12 +935,22 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu((sizeof(T) =
 #pragma unroll
       for (int g = G0; g < G0 + 8; g++) {
         float h[4];
+        if constexpr (sizeof(T) == 4 && decltype(fast)::value) {
 #pragma unroll
-        for (int i = 0; i < 4; i++) {
-          const int j = 4 * g + i;
-          const T u = x[j] - rmin;                   // :377 / :402
-          const T q = decltype(fast)::value ? bwd.core(u) : u / bwd.d;
-          h[i] = bin_value<T, decltype(safe)::value>(x[j], q, rmax);
+          for (int i = 0; i < 4; i += 2) {           // fp32: subtract and divide two coefficients per instruction
+            const int j = 4 * g + i;
+            const f32x2 q = fastdiv_core2(bwd, f32x2{(float)x[j], (float)x[j + 1]} - f32x2{(float)rmin, (float)rmin});   // :377 / :402
+            h[i] = bin_value<T, decltype(safe)::value>(x[j], q.x, rmax);
+            h[i + 1] = bin_value<T, decltype(safe)::value>(x[j + 1], q.y, rmax);
+          }
+        } else {
+#pragma unroll
+          for (int i = 0; i < 4; i++) {
+            const int j = 4 * g + i;
+            const T u = x[j] - rmin;                 // :377 / :402
+            const T q = decltype(fast)::value ? bwd.core(u) : u / bwd.d;
+            h[i] = bin_value<T, decltype(safe)::value>(x[j], q, rmax);
+          }
         }
         if (g == 0) h[0] = 0.0f;                     // j = 0 is the DC slot (:361): never an exception, its id is set below
         unsigned wg = 0u;
