@@ -168,7 +168,7 @@ def test_hip_nd_in_place_large_equals_oracle_and_gather_path(shape, dtype, mode)
         xd = torch.from_numpy(x).to(cx.device)
         out, info = cx.compress_nd(xd, 1e-3, hmode)
         assert info.sf == c.sf and info.cnt == c.cnt
-        if direct == "1":
+        if direct == "1" and os.environ.get("DCTZHIP_SPECULATE", "1") != "0":
             assert info.flags & dctz_amd.hip.INFO_STATS_FUSED
         assert np.array_equal(out["bin_index"].cpu().numpy(), c.bin_index)
         assert np.array_equal(out["dc"].cpu().numpy().view(np.uint32), c.dc.view(np.uint32))
