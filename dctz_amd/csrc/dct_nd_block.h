@@ -158,18 +158,4 @@ DCTZ_HD void dct4x4x4_inv(T (&x)[64], TabPtr tab) {
   Lines4<T, 0, 16, 16, 0, 4, 1, false>::run(x, k);
 }
 
-// the block transform of a geometry
-template <typename T, typename TabPtr, int GEOM, bool FENCED>
-DCTZ_HD void block_fwd(T (&x)[64], TabPtr tab) {
-  if (GEOM == GEOM_2D) dct8x8_fwd<T, TabPtr>(x, tab);
-  else if (GEOM == GEOM_3D) dct4x4x4_fwd<T, TabPtr>(x, tab);
-  else dct64_fwd<T, TabPtr, FENCED>(x, tab);
-}
-template <typename T, typename TabPtr, int GEOM, bool FENCED>
-DCTZ_HD void block_inv(T (&x)[64], TabPtr tab) {
-  if (GEOM == GEOM_2D) dct8x8_inv<T, TabPtr>(x, tab);
-  else if (GEOM == GEOM_3D) dct4x4x4_inv<T, TabPtr>(x, tab);
-  else dct64_inv<T, TabPtr, FENCED>(x, tab);
-}
-
 }  // namespace dctz

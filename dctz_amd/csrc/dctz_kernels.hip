@@ -45,6 +45,7 @@
 
 #include "dct64_block.h"
 #include "dct_nd_block.h"
+#include "dct64_block_pk.h"
 #include "dctz_device.h"
 
 namespace dctz {

@@ -145,8 +145,8 @@ extern "C" int dctzhip_ctx_create(dctzhip_ctx** out, int device) {
   c->stream = c->own_stream;
   HIPCHK(nullptr, hipStreamCreateWithFlags(&c->side_stream, hipStreamNonBlocking));
   HIPCHK(nullptr, hipMalloc(&c->serial_out, 16));
-  HIPCHK(nullptr, hipMalloc(&c->tab_f64, sizeof(double) * TB_TOTAL));
-  HIPCHK(nullptr, hipMalloc(&c->tab_f32, sizeof(float) * TB_TOTAL));
+  HIPCHK(nullptr, hipMalloc(&c->tab_f64, sizeof(double) * TBP_TOTAL));
+  HIPCHK(nullptr, hipMalloc(&c->tab_f32, sizeof(float) * TBP_TOTAL));
   HIPCHK(nullptr, hipMalloc(&c->rtab, sizeof(double) * RTAB_SIZE));
   HIPCHK(nullptr, hipMalloc(&c->qtab, sizeof(double) * 64));
   HIPCHK(nullptr, hipMalloc(&c->ctl, sizeof(Ctl)));
@@ -166,8 +166,8 @@ extern "C" int dctzhip_ctx_create(dctzhip_ctx** out, int device) {
   }
   if (const char* e = getenv("DCTZHIP_HANDOFF")) c->handoff = (atoi(e) != 0) && c->box != nullptr;
   {
-    double t64[TB_TOTAL];
-    float t32[TB_TOTAL];
+    double t64[TBP_TOTAL];
+    float t32[TBP_TOTAL];
     fill_tab_block<double>(t64);
     fill_tab_block<float>(t32);
     HIPCHK(nullptr, hipMemcpy(c->tab_f64, t64, sizeof(t64), hipMemcpyHostToDevice));

@@ -13,6 +13,7 @@
 
 #include "dct64_block.h"
 #include "dct_nd_block.h"
+#include "dct64_block_pk.h"
 
 #ifndef M_PI
 #define M_PI 3.14159265358979323846 /* dct.h:13-15 */
@@ -66,7 +67,7 @@ inline T sqrt2() { return std::is_same<T, double>::value ? (T)sqrt(2.0) : (T)sqr
 template <typename T>
 inline void fill_tab_block(T* tab) {
   typedef long double L;
-  std::memset(tab, 0, sizeof(T) * TB_TOTAL);
+  std::memset(tab, 0, sizeof(T) * TBP_TOTAL);
   const L pi = 3.141592653589793238462643383279502884L;
   // multi-dimensional blocks (dct_nd_block.h): the 8- and 4-point orthonormal DCT constants, rounded once
   tab[TB_ND_R8] = (T)sqrtl((L)0.125);
@@ -121,6 +122,18 @@ inline void fill_tab_block(T* tab) {
   tab[TB_FS16 + 2] = (T)(2 * al(48)); tab[TB_FS16 + 3] = (T)(2 * be(48));      // b[48]
   tab[TB_IS16 + 0] = (T)(2 * Cc(16)); tab[TB_IS16 + 1] = (T)(2 * Cc(48));      // Re Zb[16]
   tab[TB_IS16 + 2] = (T)(-2 * Ss(16)); tab[TB_IS16 + 3] = (T)(2 * Ss(48));     // Im Zb[16]
+  // the same numbers once more, two rows side by side, for the packed fp32 transform (dct64_block_pk.h): pair j of a
+  // group = (row 2g, row 2g + 1) x constant j
+  for (int k = 1; k < 16; k++)
+    for (int g = 0; g < 2; g++)
+      for (int j = 0; j < 4; j++) {
+        tab[TBP_FS + 16 * (k - 1) + 8 * g + 2 * j] = tab[TB_FS + 16 * (k - 1) + 8 * g + j];
+        tab[TBP_FS + 16 * (k - 1) + 8 * g + 2 * j + 1] = tab[TB_FS + 16 * (k - 1) + 8 * g + 4 + j];
+        tab[TBP_IS + 16 * (k - 1) + 8 * g + 2 * j] = tab[TB_IS + 16 * (k - 1) + 8 * g + j];
+        tab[TBP_IS + 16 * (k - 1) + 8 * g + 2 * j + 1] = tab[TB_IS + 16 * (k - 1) + 8 * g + 4 + j];
+      }
+  tab[TBP_FS16 + 0] = tab[TB_FS16 + 0]; tab[TBP_FS16 + 1] = tab[TB_FS16 + 2]; tab[TBP_FS16 + 2] = tab[TB_FS16 + 1]; tab[TBP_FS16 + 3] = tab[TB_FS16 + 3];
+  tab[TBP_IS16 + 0] = tab[TB_IS16 + 0]; tab[TBP_IS16 + 1] = tab[TB_IS16 + 2]; tab[TBP_IS16 + 2] = tab[TB_IS16 + 1]; tab[TBP_IS16 + 3] = tab[TB_IS16 + 3];
 }
 
 // util.c:29 / util.c:43, with the host libm exactly like the reference

@@ -10,7 +10,7 @@ using namespace dctz;
 
 template <typename T>
 static void emu(const T* a, T* b, bool inverse, int geom = 0) {
-  static T tab[TB_TOTAL];
+  static T tab[TBP_TOTAL];
   static bool ready = false;
   if (!ready) { fill_tab_block<T>(tab); ready = true; }
   T x[64];
@@ -26,9 +26,19 @@ void emu_fwd_f64(const double* a, double* b) { emu<double>(a, b, false); }
 void emu_inv_f64(const double* a, double* b) { emu<double>(a, b, true); }
 void emu_fwd_f32(const float* a, float* b) { emu<float>(a, b, false); }
 void emu_inv_f32(const float* a, float* b) { emu<float>(a, b, true); }
-void emu_tab_f64(double* tab) { fill_tab_block<double>(tab); }
-void emu_tab_f32(float* tab) { fill_tab_block<float>(tab); }
+void emu_tab_f64(double* tab) { static double t[TBP_TOTAL]; fill_tab_block<double>(t); for (int i = 0; i < TB_SIZE; i++) tab[i] = t[i]; }
+void emu_tab_f32(float* tab) { static float t[TBP_TOTAL]; fill_tab_block<float>(t); for (int i = 0; i < TB_SIZE; i++) tab[i] = t[i]; }
 int emu_tab_size(void) { return TB_SIZE; }
+// the packed fp32 form of the 64-point transform (dct64_block_pk.h)
+void emu_pk_f32(const float* a, float* b, int inverse) {
+  static float tab[TBP_TOTAL];
+  static bool ready = false;
+  if (!ready) { fill_tab_block<float>(tab); ready = true; }
+  float x[64];
+  for (int i = 0; i < 64; i++) x[i] = a[i];
+  if (inverse) dct64_inv_pk<const float*>(x, tab); else dct64_fwd_pk<const float*>(x, tab);
+  for (int i = 0; i < 64; i++) b[i] = x[i];
+}
 // multi-dimensional blocks (dct_nd_block.h): geom 1 = 8 x 8, 2 = 4 x 4 x 4
 void emu_nd_f64(const double* a, double* b, int geom, int inverse) { emu<double>(a, b, inverse != 0, geom); }
 void emu_nd_f32(const float* a, float* b, int geom, int inverse) { emu<float>(a, b, inverse != 0, geom); }

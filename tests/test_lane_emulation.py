@@ -84,3 +84,20 @@ def test_decade_tables_reproduce_the_host_scaling_factor(emu, dtype, code, kmin,
     # ... and scaling_factor() itself is the oracle's (util.c:29 / :43 through the same libm)
     for v in (0.37, 1.0, 9.99, 10.0, 10.01, 37.5, 1e-7, 123456.0):
         assert emu.emu_scaling_factor(code, float(dtype(v))) == O.stats(np.array([0.0, v], dtype)).sf
+
+
+def test_packed_fp32_transform_bit_identical_to_oracle(emu):
+    """dct64_block_pk.h (two fp32 values per instruction on the GPU; GCC vectors here) performs, component for
+    component, the operations of the scalar flow: forward and inverse == the oracle's pinned flow, bit for bit."""
+    rng = np.random.default_rng(23)
+    for i in range(2000):
+        a = (rng.standard_normal(64) * 10 ** rng.uniform(-3, 2)).astype(np.float32)
+        if i == 0:
+            a[:] = 0
+        if i == 1:
+            a[:] = 1
+        b = np.empty_like(a)
+        emu.emu_pk_f32(a.ctypes.data_as(C.c_void_p), b.ctypes.data_as(C.c_void_p), 0)
+        assert np.array_equal(b.view(np.uint32), O.dct_fwd(a, O.FAST).view(np.uint32))
+        emu.emu_pk_f32(a.ctypes.data_as(C.c_void_p), b.ctypes.data_as(C.c_void_p), 1)
+        assert np.array_equal(b.view(np.uint32), O.dct_inv(a, O.FAST).view(np.uint32))
