@@ -58,6 +58,7 @@ struct dctzhip_ctx {
   int sf_nk[2] = {0, 0};
   SfGuess* sf_guess = nullptr;
   int dev_sf = 1;                   // 0: the host chooses sf between the sample and k_compress (DCTZHIP_DEVICE_SF)
+  int blocking = 0;                 // 1: every compress / decompress call ends with a stream synchronisation (DCTZHIP_BLOCKING, dctzhip_set_blocking)
   int grid_c = 0;                   // upper bound of k_compress's grid (DCTZHIP_GRID_C; 0 = what the LDS admits)
   int nd_direct = 1;                // multi-dimensional blocks read / written in place where the shape allows (DCTZHIP_ND_DIRECT)
   void* nd_buf = nullptr;           // multi-dimensional blocks: the array laid out block after block (k_gather_nd / k_scatter_nd)
@@ -177,6 +178,7 @@ extern "C" int dctzhip_ctx_create(dctzhip_ctx** out, int device) {
   if (const char* e = getenv("DCTZHIP_DEVICE_SF")) c->dev_sf = atoi(e) != 0;
   if (const char* e = getenv("DCTZHIP_ND_DIRECT")) c->nd_direct = atoi(e) != 0;
   if (const char* e = getenv("DCTZHIP_GRID_C")) c->grid_c = atoi(e);
+  if (const char* e = getenv("DCTZHIP_BLOCKING")) c->blocking = atoi(e) != 0;
   if (int rc = build_sf_tables(c)) return rc;
   *out = c;
   return DCTZHIP_OK;
@@ -214,6 +216,12 @@ extern "C" void* dctzhip_get_stream(dctzhip_ctx* c) { return c ? (void*)c->strea
 extern "C" int dctzhip_set_profiling(dctzhip_ctx* c, int on) {
   if (!c) return DCTZHIP_E_ARG;
   c->profiling = on ? 1 : 0;
+  return DCTZHIP_OK;
+}
+
+extern "C" int dctzhip_set_blocking(dctzhip_ctx* c, int on) {
+  if (!c) return DCTZHIP_E_ARG;
+  c->blocking = on != 0;
   return DCTZHIP_OK;
 }
 
@@ -781,11 +789,11 @@ extern "C" int dctzhip_compress(dctzhip_ctx* c, const void* d_in, size_t n, int 
   HIPCHK(c, hipSetDevice(c->device));
   rc = ensure_scratch(c, n, dtype, mode);
   if (rc) return rc;
-  if (dtype == DCTZHIP_F64)
-    return compress_impl<double>(c, (const double*)d_in, n, eb, mode, (uint8_t*)d_bin, d_dc, d_ac, (double*)d_scaled,
-                                 (double*)d_coef, info);
-  return compress_impl<float>(c, (const float*)d_in, n, eb, mode, (uint8_t*)d_bin, d_dc, d_ac, (float*)d_scaled,
-                              (float*)d_coef, info);
+  rc = (dtype == DCTZHIP_F64)
+           ? compress_impl<double>(c, (const double*)d_in, n, eb, mode, (uint8_t*)d_bin, d_dc, d_ac, (double*)d_scaled, (double*)d_coef, info)
+           : compress_impl<float>(c, (const float*)d_in, n, eb, mode, (uint8_t*)d_bin, d_dc, d_ac, (float*)d_scaled, (float*)d_coef, info);
+  if (rc == DCTZHIP_OK && c->blocking) HIPCHK(c, hipStreamSynchronize(c->stream));
+  return rc;
 }
 
 template <typename T>
@@ -871,9 +879,11 @@ extern "C" int dctzhip_decompress(dctzhip_ctx* c, const void* d_bin, const float
   HIPCHK(c, hipSetDevice(c->device));
   rc = ensure_scratch(c, n, dtype, DCTZHIP_EC, false);
   if (rc) return rc;
-  if (dtype == DCTZHIP_F64)
-    return decompress_impl<double>(c, (const uint8_t*)d_bin, d_dc, d_ac, ac_count, qtable_host, n, eb, sf, mode, (double*)d_out);
-  return decompress_impl<float>(c, (const uint8_t*)d_bin, d_dc, d_ac, ac_count, qtable_host, n, eb, sf, mode, (float*)d_out);
+  rc = (dtype == DCTZHIP_F64)
+           ? decompress_impl<double>(c, (const uint8_t*)d_bin, d_dc, d_ac, ac_count, qtable_host, n, eb, sf, mode, (double*)d_out)
+           : decompress_impl<float>(c, (const uint8_t*)d_bin, d_dc, d_ac, ac_count, qtable_host, n, eb, sf, mode, (float*)d_out);
+  if (rc == DCTZHIP_OK && c->blocking) HIPCHK(c, hipStreamSynchronize(c->stream));
+  return rc;
 }
 
 // ---- multi-dimensional blocks (include/dctz_hip.h) -------------------------------------------------
@@ -970,9 +980,11 @@ extern "C" int dctzhip_compress_nd(dctzhip_ctx* c, const void* d_in, int ndims, 
   HIPCHK(c, hipSetDevice(c->device));
   rc = ensure_scratch(c, sh.nblk * 64, dtype, mode);
   if (rc) return rc;
-  if (dtype == DCTZHIP_F64)
-    return compress_nd_impl<double>(c, (const double*)d_in, sh, eb, mode, (uint8_t*)d_bin, d_dc, d_ac, (double*)d_scaled, info);
-  return compress_nd_impl<float>(c, (const float*)d_in, sh, eb, mode, (uint8_t*)d_bin, d_dc, d_ac, (float*)d_scaled, info);
+  rc = (dtype == DCTZHIP_F64)
+           ? compress_nd_impl<double>(c, (const double*)d_in, sh, eb, mode, (uint8_t*)d_bin, d_dc, d_ac, (double*)d_scaled, info)
+           : compress_nd_impl<float>(c, (const float*)d_in, sh, eb, mode, (uint8_t*)d_bin, d_dc, d_ac, (float*)d_scaled, info);
+  if (rc == DCTZHIP_OK && c->blocking) HIPCHK(c, hipStreamSynchronize(c->stream));
+  return rc;
 }
 
 extern "C" int dctzhip_decompress_nd(dctzhip_ctx* c, const void* d_bin, const float* d_dc, const float* d_ac, uint32_t ac_count,
@@ -993,9 +1005,11 @@ extern "C" int dctzhip_decompress_nd(dctzhip_ctx* c, const void* d_bin, const fl
   const int geom = ndims == 2 ? GEOM_2D : GEOM_3D;
   NdDirect direct;
   if (nd_direct(c, sh, elem_size(dtype), &direct)) {
-    if (dtype == DCTZHIP_F64)
-      return decompress_impl<double>(c, (const uint8_t*)d_bin, d_dc, d_ac, ac_count, qtable_host, n_lin, eb, sf, mode, (double*)d_out, geom, &direct);
-    return decompress_impl<float>(c, (const uint8_t*)d_bin, d_dc, d_ac, ac_count, qtable_host, n_lin, eb, sf, mode, (float*)d_out, geom, &direct);
+    rc = (dtype == DCTZHIP_F64)
+             ? decompress_impl<double>(c, (const uint8_t*)d_bin, d_dc, d_ac, ac_count, qtable_host, n_lin, eb, sf, mode, (double*)d_out, geom, &direct)
+             : decompress_impl<float>(c, (const uint8_t*)d_bin, d_dc, d_ac, ac_count, qtable_host, n_lin, eb, sf, mode, (float*)d_out, geom, &direct);
+    if (rc == DCTZHIP_OK && c->blocking) HIPCHK(c, hipStreamSynchronize(c->stream));
+    return rc;
   }
   rc = ensure_nd(c, n_lin * elem_size(dtype));
   if (rc) return rc;
@@ -1010,6 +1024,7 @@ extern "C" int dctzhip_decompress_nd(dctzhip_ctx* c, const void* d_bin, const fl
     launch_scatter_nd<float>((const float*)c->nd_buf, (float*)d_out, sh, grid, c->stream);
   }
   HIPCHK(c, hipGetLastError());
+  if (c->blocking) HIPCHK(c, hipStreamSynchronize(c->stream));
   return DCTZHIP_OK;
 }
 

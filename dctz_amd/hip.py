@@ -64,6 +64,7 @@ _PROTOS = {
     "dctzhip_decompress": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32,
                                      C.c_void_p, C.c_size_t, C.c_int, C.c_double, C.c_double, C.c_int,
                                      C.c_void_p]),
+    "dctzhip_set_blocking": (C.c_int, [C.c_void_p, C.c_int]),
     "dctzhip_nd_blocks": (C.c_size_t, [C.c_int, C.POINTER(C.c_size_t)]),
     "dctzhip_compress_nd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_size_t), C.c_int, C.c_double, C.c_int,
                                       C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(CompressInfo)]),
@@ -164,6 +165,10 @@ class Context:
     def set_speculation(self, on=True, min_elements=0):
         """Fused statistics behind a sampled guess of sf (include/dctz_hip.h, DCTZHIP_INFO_*)."""
         self._check(self.lib.dctzhip_set_speculation(self.h, int(on), int(min_elements)), "set_speculation")
+
+    def set_blocking(self, on=True):
+        """Calls return only when their outputs are complete for any observer (default: complete in stream order)."""
+        self._check(self.lib.dctzhip_set_blocking(self.h, int(on)), "set_blocking")
 
     def timings(self):
         t = Timings()

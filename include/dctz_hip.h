@@ -99,6 +99,11 @@ int dctzhip_set_profiling(dctzhip_ctx *ctx, int on);
  * it off).  d_scaled (which may alias d_in) is written last, with the verified sf. */
 int dctzhip_set_speculation(dctzhip_ctx *ctx, int on, size_t min_elements);
 int dctzhip_last_timings(dctzhip_ctx *ctx, dctzhip_timings *t);
+/* on != 0: every compress / decompress call ends with a synchronisation of the context's stream, i.e. its outputs are
+ * complete for ANY observer when it returns (default off: complete in stream order, see the two calls below; env
+ * DCTZHIP_BLOCKING=1 does the same).  For callers that read the buffers from another stream or from the host without
+ * going through the context's stream. */
+int dctzhip_set_blocking(dctzhip_ctx *ctx, int on);
 
 /* ---- device memory helpers (so plain-C hosts need no HIP headers) --------- */
 int dctzhip_malloc(dctzhip_ctx *ctx, void **dptr, size_t bytes);

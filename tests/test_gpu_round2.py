@@ -234,3 +234,33 @@ def test_c_program_drives_the_gather_through_the_c_abi(tmp_path):
     x = 37.0 * np.sin(i / 97.0) + 0.5 * np.cos(i * 0.37)
     c = O.compress(x, 1e-3, O.EC, O.FAST)
     assert [int(v) for v in f[1:]] == [0, 1, n, c.cnt, int(c.bin_index.astype(np.uint64).sum())]
+
+
+def test_completion_semantics_stream_order_and_blocking(ctx):
+    """dctzhip_decompress hands its one result to the host when k_decompress STARTS and returns; the reconstruction is
+    complete in stream order (a consumer on the context's stream, or after a sync), and with set_blocking(True) for
+    any observer at return.  Checked against the oracle both ways, with an observer on ANOTHER stream in the blocking
+    case (a side stream that is not ordered behind the context's stream by anything but the host)."""
+    import torch
+    n = 1 << 25
+    x = W.ragged(n, np.float64, scale=37.0)
+    xd = torch.from_numpy(x).to(ctx.device)
+    out, info = ctx.compress(xd, 1e-3, O.EC)
+    want = O.decompress(O.compress(x, 1e-3, O.EC, O.FAST), O.FAST)
+    rec = torch.zeros(n, dtype=torch.float64, device=ctx.device)
+    torch.cuda.synchronize()
+    ctx.decompress(out, info.cnt, n, torch.float64, 1e-3, info.sf, O.EC, dst=rec)
+    got = rec.clone()                                    # a consumer on the same stream: ordered behind the kernels
+    assert np.array_equal(got.cpu().numpy(), want)
+    side = torch.cuda.Stream(device=ctx.device)
+    ctx.set_blocking(True)
+    try:
+        rec.zero_()
+        torch.cuda.synchronize()
+        ctx.decompress(out, info.cnt, n, torch.float64, 1e-3, info.sf, O.EC, dst=rec)
+        with torch.cuda.stream(side):                    # no event, no sync: only the blocking return orders this read
+            got2 = rec.clone()
+        side.synchronize()
+        assert np.array_equal(got2.cpu().numpy(), want)
+    finally:
+        ctx.set_blocking(False)
