@@ -17,6 +17,7 @@ def main():
     ap.add_argument("--cases", type=int, default=150)
     ap.add_argument("--max-n", type=int, default=6_000_000)
     ap.add_argument("--seed", type=int, default=1)
+    ap.add_argument("--nd-cases", type=int, default=60, help="random 2-D / 3-D shapes through the tile mode (in place and gather paths)")
     a = ap.parse_args()
     import numpy as np
     import torch
@@ -61,6 +62,42 @@ def main():
         if k % 10 == 9:
             print(f"{k + 1} cases ok, {time.time() - t0:.0f} s, flags {flags_seen}", flush=True)
     print(f"all {a.cases} cases bit-exact; statistics paths seen (flags -> count): {flags_seen}")
+    # multi-dimensional blocks: random shapes, a third of them with every extent a multiple of the tile edge (read and
+    # written in place), the rest ragged (gather / scatter passes)
+    nd_seen = {"in_place": 0, "gather": 0}
+    for k in range(a.nd_cases):
+        nd = int(rng.integers(2, 4))
+        e = 8 if nd == 2 else 4
+        cap = 3_000_000
+        while True:
+            shape = tuple(int(rng.integers(1, 2000 if nd == 2 else 200)) for _ in range(nd))
+            if rng.random() < 0.4:
+                shape = tuple(max(e, (d // e) * e) for d in shape)
+            if int(np.prod(shape)) <= cap:
+                break
+        dtype = np.float64 if rng.random() < 0.5 else np.float32
+        mode = O.QT if rng.random() < 0.4 else O.EC
+        eb = float(rng.choice([1e-2, 1e-3, 1e-4, 1e-5]))
+        amp = 10.0 ** rng.uniform(-3, 4)
+        axes = np.meshgrid(*[np.linspace(0, rng.uniform(1, 9), d) for d in shape], indexing="ij")
+        x = amp * (np.sin(axes[0] * 3.1 + 0.2) * np.cos(axes[1] * 2.3) + (0.3 * np.sin(axes[2] * 5.0) if nd == 3 else 0.0)
+                   + float(rng.choice([0.0, 1e-4, 0.02, 0.5])) * rng.standard_normal(shape))
+        x = np.ascontiguousarray(x.astype(dtype))
+        c = O.compress_nd(x, eb, mode, O.FAST)
+        ref = O.decompress_nd(c, shape, O.FAST)
+        out, info = ctx.compress_nd(torch.from_numpy(x).cuda(), eb, mode)
+        nd_seen["in_place" if all(d % e == 0 for d in shape) else "gather"] += 1
+        tdt = torch.float64 if dtype == np.float64 else torch.float32
+        r = ctx.decompress_nd(out, info.cnt, shape, tdt, eb, info.sf, mode, qtable=np.array(info.qtable[:])).cpu().numpy()
+        it = np.uint64 if dtype == np.float64 else np.uint32
+        ok = (info.sf == c.sf and info.cnt == c.cnt and np.array_equal(out["bin_index"].cpu().numpy(), c.bin_index)
+              and np.array_equal(out["dc"].cpu().numpy().view(np.uint32), c.dc.view(np.uint32))
+              and np.array_equal(out["ac_exact"][:c.cnt].cpu().numpy().view(np.uint32), c.ac_exact.view(np.uint32))
+              and np.array_equal(r.view(it), ref.view(it)))
+        if not ok:
+            print(f"MISMATCH nd case {k}: shape={shape} dtype={dtype.__name__} mode={mode} eb={eb} amp={amp:g}")
+            sys.exit(1)
+    print(f"all {a.nd_cases} multi-dimensional cases bit-exact ({nd_seen})")
 
 
 if __name__ == "__main__":
