@@ -680,6 +680,15 @@ __device__ __forceinline__ float bin_value(T item, T q, T range_max) {
 #define STAMP_FLUSH(ptr) ((void)0)
 #endif
 
+#ifdef DCTZ_STAMP
+__device__ unsigned long long g_dec_stamps[12];      // k_decompress's phase timers (diagnostic builds)
+void read_dec_stamps(unsigned long long* out12) {
+  (void)hipMemcpyFromSymbol(out12, HIP_SYMBOL(g_dec_stamps), 96);
+  unsigned long long z[12] = {0};
+  (void)hipMemcpyToSymbol(HIP_SYMBOL(g_dec_stamps), z, 96);
+}
+#endif
+
 template <typename T>
 size_t compress_lds_bytes(int mode) {              // tile image + strips (+ positions, QT); must match k_compress's static arrays
   using G = Geo<T, Phases<T>::C>;
@@ -1332,15 +1341,18 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(PH))) void k
   };
 
   if (tr.lo < tr.hi) prefetch(tr.lo);
+  STAMP_DECL;
   for (unsigned tile = tr.lo; tile < tr.hi; tile++) {
     const unsigned rel = tile - tr.lo;
     const unsigned blks_here = min((unsigned)TILE_BLKS, p.nfull - tile * TILE_BLKS);
     const bool active = (unsigned)lane < blks_here;
     const unsigned S_t = S, total_t = total;
     const bool in_lds = total_t <= (unsigned)DEC_EXC_CAP;
+    STAMP(0);
     // this tile's inputs have landed: everything but the previous tile's row stores (the youngest NROW operations)
     if (tile == tr.lo) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(%0)" :: "n"(G::NROW) : "memory");
+    STAMP(1);
     unsigned w[16] = {bw[0].x, bw[0].y, bw[0].z, bw[0].w, bw[1].x, bw[1].y, bw[1].z, bw[1].w,
                       bw[2].x, bw[2].y, bw[2].z, bw[2].w, bw[3].x, bw[3].y, bw[3].z, bw[3].w};
     const float dc_t = dcv;
@@ -1356,6 +1368,7 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(PH))) void k
     }
     if (!active) n = 0;
     unsigned ptr = wave_incl_scan(n) - n;                              // index inside the tile's piece of AC_exact
+    STAMP(2);
     if (S_t + total_t > p.ac_count) underrun = true;                  // the stream promises more than the caller provides
     T x[64];
     if constexpr (sizeof(T) == 8) {
@@ -1417,12 +1430,16 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(PH))) void k
     }
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                  // the staged coefficients are consumed: the strip is free
+    STAMP(3);
     if (tile + 1 < tr.hi) prefetch(tile + 1);
+    STAMP(4);
     block_inv<T, CTab<T>, GEOM, (PH > 1)>(x, tab);
+    STAMP(5);
     if (scale) {
 #pragma unroll
       for (int j = 0; j < 64; j++) x[j] = x[j] * p.sf;                 // dctz-decomp-lib.c:494-511
     }
+    STAMP(6);
     // registers -> LDS image -> HBM, one 1 KiB row (8 whole 128-byte lines) per instruction, a phase at a time; blocks
     // beyond the end fall outside r_out
     const int vbase = (int)(rel * (unsigned)G::TILEB);
@@ -1450,7 +1467,11 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(PH))) void k
     };
     store_phase(std::integral_constant<int, 0>{});
     if (PH == 2) store_phase(std::integral_constant<int, PH - 1>{});
+    STAMP(7);
   }
+#ifdef DCTZ_STAMP
+  STAMP_FLUSH(g_dec_stamps);
+#endif
   if (underrun) atomicExch(&p.ctl->error, 2u);
 }
 

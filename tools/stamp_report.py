@@ -46,6 +46,27 @@ def main():
         tot += v
         print(f"{i:2d}  {v:9.0f} cycles/tile  {NAMES[i]}")
     print(f"    {tot:9.0f} cycles per tile and wave in all (s_memtime ticks)")
+    # ---- k_decompress<double>: one wave per SIMD ----
+    dn = ["loop head", "wait: bin ids / DC / exact coefficients of this tile landed", "flag counts + wave scan",
+          "de-quantisation (bin centres, exact coefficients)", "prefetch of the next tile (issue)", "inverse transform",
+          "de-scaling", "registers -> LDS image -> 32 row stores"]
+    if hasattr(lib, "dctzhip_debug_stamps_dec"):
+        lib.dctzhip_debug_stamps_dec.argtypes = [C.c_void_p, C.POINTER(C.c_ulonglong)]
+        _, info = ctx.compress(x, 1e-3, dctz_amd.EC, out=out)
+        rec = torch.empty(n, dtype=torch.float64, device=ctx.device)
+        for _ in range(3):
+            ctx.decompress(out, info.cnt, n, torch.float64, 1e-3, info.sf, dctz_amd.EC, dst=rec)
+        lib.dctzhip_debug_stamps_dec(ctx.h, buf)
+        for _ in range(reps):
+            ctx.decompress(out, info.cnt, n, torch.float64, 1e-3, info.sf, dctz_amd.EC, dst=rec)
+        lib.dctzhip_debug_stamps_dec(ctx.h, buf)
+        tot = 0.0
+        print("k_decompress<double>:")
+        for i in range(8):
+            v = buf[i] / tiles
+            tot += v
+            print(f"{i:2d}  {v:9.0f} cycles/tile  {dn[i]}")
+        print(f"    {tot:9.0f} cycles per tile and wave in all")
 
 
 if __name__ == "__main__":
