@@ -54,6 +54,12 @@ template <> struct Traits<float> {
 #ifndef DCTZ_EC_DEPTH
 #define DCTZ_EC_DEPTH 12   /* 14 measured: -3 % at p = 17 %, +1 % at p = 5 % */
 #endif
+#ifndef DCTZ_QT_DEPTH64
+#define DCTZ_QT_DEPTH64 10    /* 64 * 11 * (8 + 1) = 6336 bytes: 7 workgroups per CU (14 items: 6; 6 items reach 8 per CU but spill and overflow more: measured equal) */
+#endif
+#ifndef DCTZ_QT_DEPTH32
+#define DCTZ_QT_DEPTH32 12    /* 64 * 13 * (4 + 1) = 4160 bytes */
+#endif
 template <typename T, int PHASES = 1> struct Geo {
   static constexpr int BLKB = 64 * (int)sizeof(T);      // bytes per block (512 / 256)
   static constexpr int NSEG = BLKB / 128;               // 128-byte segments per block (4 / 2)
@@ -67,7 +73,7 @@ template <typename T, int PHASES = 1> struct Geo {
   static_assert(NSEG % PH == 0, "a phase is a whole number of 128-byte segments");
   // exceptions of a block that a lane parks in its LDS strip (DEPTH + 1 items); the rest goes to global overflow strips
   static constexpr int EC_DEPTH = DCTZ_EC_DEPTH;                                  // floats:  64 * 13 * 4 = 3328 bytes per wave
-  static constexpr int QT_DEPTH = sizeof(T) == 8 ? 14 : 12;            // full-precision items: 64 * 15 * 8 = 7680 bytes
+  static constexpr int QT_DEPTH = sizeof(T) == 8 ? DCTZ_QT_DEPTH64 : DCTZ_QT_DEPTH32;   // full-precision items + their positions
 };
 // phases of k_compress / k_decompress per element type (build knobs for A/B runs)
 #ifndef DCTZ_PHC64

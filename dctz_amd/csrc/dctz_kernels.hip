@@ -693,8 +693,8 @@ template <typename T>
 size_t compress_lds_bytes(int mode) {              // tile image + strips (+ positions, QT); must match k_compress's static arrays
   using G = Geo<T, Phases<T>::C>;
   if (mode != DCTZHIP_QT) return (size_t)G::PHB + EXC_BYTES;
-  const size_t strips = 64 * (size_t)(G::QT_DEPTH + 1) * sizeof(T);
-  return (size_t)G::PHB + (strips > EXC_BYTES ? strips : (size_t)EXC_BYTES) + 1024;
+  const size_t strips = 64 * (size_t)(G::QT_DEPTH + 1) * (sizeof(T) + 1);          // items + their positions, one buffer
+  return (size_t)G::PHB + (strips > EXC_BYTES ? strips : (size_t)EXC_BYTES);
 }
 
 // PH = 1: the whole tile (fp32: 16 KiB) sits in LDS.  PH = 2 (fp64): half a tile at a time (16 KiB), eight single-wave
@@ -720,10 +720,13 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu((sizeof(T) =
   // holds a coefficient parked "in case"; the odd stride in dwords spreads the lanes over the banks); what does not fit
   // (a block with more than DEPTH exceptions: rare on smooth data) goes to the lane's overflow strip in global memory
   constexpr int STRIDE = DEPTH + 1;
-  constexpr int STRIP_BYTES = 64 * STRIDE * (int)sizeof(Item) > EXC_BYTES ? 64 * STRIDE * (int)sizeof(Item) : EXC_BYTES;
+  // QT: the positions j of the parked items sit behind the items in the same buffer (a separate 1 KiB array cost the
+  // eighth workgroup per CU: with 6 / 10 items per lane, fp64 / fp32, everything fits the 4 KiB the bin ids need anyway)
+  constexpr int ITEM_BYTES = 64 * STRIDE * (int)sizeof(Item);
+  constexpr int POS_BYTES = (MODE == DCTZHIP_QT) ? 64 * STRIDE : 0;
+  constexpr int STRIP_BYTES = ITEM_BYTES + POS_BYTES > EXC_BYTES ? ITEM_BYTES + POS_BYTES : EXC_BYTES;
   __shared__ __attribute__((aligned(16))) unsigned char excbuf[STRIP_BYTES];        // also: the tile's bin ids on their way out
-  __shared__ __attribute__((aligned(16))) unsigned char jbuf[MODE == DCTZHIP_QT ? 1024 : 16];   // QT: position j of every parked item
-  static_assert(MODE != DCTZHIP_QT || 64 * STRIDE <= (int)sizeof(jbuf), "positions strip");
+  unsigned char* const jbuf = excbuf + ITEM_BYTES;                                   // QT: position j of every parked item
   // (the addresses are formed where they are used: kept in registers across the loop they cost four VGPRs for a rare path)
   // (item k of all 64 lanes side by side: the flush reads whole rows, and the lanes of a store -- all within a few items
   // of each other -- touch a handful of lines instead of 64)
