@@ -83,7 +83,8 @@ template <typename T, int PHASES = 1> struct Geo {
 #define DCTZ_PHD64 1
 #endif
 #ifndef DCTZ_PHC32
-#define DCTZ_PHC32 1
+#define DCTZ_PHC32 2      /* fp32 compress: 8 KiB half-tile images; with the packed transform the kernel needs 160 VGPRs, so three
+                             waves fit a SIMD (12 workgroups per CU): 0.168 -> 0.148 ms on 512^3 (one phase, 8 per CU: =1) */
 #endif
 #ifndef DCTZ_PHD32
 #define DCTZ_PHD32 1
@@ -242,6 +243,8 @@ template <typename T> void launch_decompress_rem(const InvParams<T>& p, int mode
 template <typename T> void launch_dct_blocks(const T* x, T* out, const T* gtab, const T* rtab, size_t n,
                                              bool inverse, int grid, hipStream_t s);
 template <typename T> void launch_psnr(const T* x, const T* r, size_t n, double* part, int nparts, double* out, hipStream_t s);
+template <typename T> int compress_occupancy(int mode, bool stats, int geom);
+template <typename T> int decompress_occupancy(int mode, int geom);
 template <typename T> size_t compress_lds_bytes(int mode);
 template <typename T> size_t decompress_lds_bytes();
 

@@ -1821,6 +1821,31 @@ void launch_compress(const FwdParams<T>& p, int mode, bool stats, int grid, int 
   }
 }
 
+// Resident workgroups per CU of the k_compress instantiation a launch would pick (registers AND LDS: the persistent
+// grid must not exceed what is resident at once, or its tail runs as a second round)
+template <typename T>
+int compress_occupancy(int mode, bool stats, int geom) {
+  int n = 0;
+  hipError_t e;
+#define OCC(M, S, G) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, (const void*)k_compress<T, M, S, Phases<T>::C, G>, WG, 0)
+  if (geom == GEOM_1D) { if (mode == DCTZHIP_EC) { if (stats) OCC(DCTZHIP_EC, true, GEOM_1D); else OCC(DCTZHIP_EC, false, GEOM_1D); } else { if (stats) OCC(DCTZHIP_QT, true, GEOM_1D); else OCC(DCTZHIP_QT, false, GEOM_1D); } }
+  else if (geom == GEOM_2D) { if (mode == DCTZHIP_EC) { if (stats) OCC(DCTZHIP_EC, true, GEOM_2D); else OCC(DCTZHIP_EC, false, GEOM_2D); } else { if (stats) OCC(DCTZHIP_QT, true, GEOM_2D); else OCC(DCTZHIP_QT, false, GEOM_2D); } }
+  else { if (mode == DCTZHIP_EC) { if (stats) OCC(DCTZHIP_EC, true, GEOM_3D); else OCC(DCTZHIP_EC, false, GEOM_3D); } else { if (stats) OCC(DCTZHIP_QT, true, GEOM_3D); else OCC(DCTZHIP_QT, false, GEOM_3D); } }
+#undef OCC
+  return e == hipSuccess ? n : 0;
+}
+template <typename T>
+int decompress_occupancy(int mode, int geom) {
+  int n = 0;
+  hipError_t e;
+#define OCC(M, G) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, (const void*)k_decompress<T, M, Phases<T>::D, G>, WG, 0)
+  if (geom == GEOM_1D) { if (mode == DCTZHIP_EC) OCC(DCTZHIP_EC, GEOM_1D); else OCC(DCTZHIP_QT, GEOM_1D); }
+  else if (geom == GEOM_2D) { if (mode == DCTZHIP_EC) OCC(DCTZHIP_EC, GEOM_2D); else OCC(DCTZHIP_QT, GEOM_2D); }
+  else { if (mode == DCTZHIP_EC) OCC(DCTZHIP_EC, GEOM_3D); else OCC(DCTZHIP_QT, GEOM_3D); }
+#undef OCC
+  return e == hipSuccess ? n : 0;
+}
+
 template <typename T>
 void launch_compress_rem(const FwdParams<T>& p, int mode, int l, hipStream_t s) {
   if (mode == DCTZHIP_EC) hipLaunchKernelGGL((k_compress_rem<T, DCTZHIP_EC>), dim3(1), dim3(64), 0, s, p, l);
@@ -1908,6 +1933,8 @@ void launch_psnr(const T* x, const T* r, size_t n, double* part, int nparts, dou
   template void launch_decompress_rem<T>(const InvParams<T>&, int, bool, int, hipStream_t);             \
   template void launch_dct_blocks<T>(const T*, T*, const T*, const T*, size_t, bool, int, hipStream_t); \
   template void launch_psnr<T>(const T*, const T*, size_t, double*, int, double*, hipStream_t);         \
+  template int compress_occupancy<T>(int, bool, int);                                                      \
+  template int decompress_occupancy<T>(int, int);                                                          \
   template size_t compress_lds_bytes<T>(int);                                                              \
   template size_t decompress_lds_bytes<T>();
 INST(double)

@@ -59,6 +59,7 @@ struct dctzhip_ctx {
   SfGuess* sf_guess = nullptr;
   int dev_sf = 1;                   // 0: the host chooses sf between the sample and k_compress (DCTZHIP_DEVICE_SF)
   int blocking = 0;                 // 1: every compress / decompress call ends with a stream synchronisation (DCTZHIP_BLOCKING, dctzhip_set_blocking)
+  int occ[2][2][2][2][3] = {};      // resident workgroups per CU per kernel instantiation [f64][decode][qt][stats][geom], 0 = not asked yet
   int grid_c = 0;                   // upper bound of k_compress's grid (DCTZHIP_GRID_C; 0 = what the LDS admits)
   int nd_direct = 1;                // multi-dimensional blocks read / written in place where the shape allows (DCTZHIP_ND_DIRECT)
   void* nd_buf = nullptr;           // multi-dimensional blocks: the array laid out block after block (k_gather_nd / k_scatter_nd)
@@ -95,6 +96,7 @@ static int build_sf_tables(dctzhip_ctx* c);
 static constexpr int STATS_GRID_MAX = 2048;
 static constexpr int PART_SLOTS = 256 * 16 + 64;       // >= largest k_compress grid + 1 (fused statistics partials), >= 4/3 of the PSNR grid
 static constexpr int SPEC_COOLDOWN = 8;
+static constexpr int WG_PER_CU_MAX = 12;               // single-wave workgroups per CU: three per SIMD (k_compress<float>: 160 VGPRs, 12 KiB of LDS)
 static constexpr size_t PIN_STATS = 0, PIN_CTL = 64, PIN_TAB = 64 + sizeof(Ctl);
 static constexpr size_t PIN_BYTES = PIN_TAB + sizeof(double) * RTAB_SIZE + sizeof(double) * 64;
 
@@ -138,7 +140,7 @@ extern "C" int dctzhip_ctx_create(dctzhip_ctx** out, int device) {
   c->num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
   if (const char* e = getenv("DCTZHIP_FASTDIV")) c->fastdiv = atoi(e);
   if (const char* e = getenv("DCTZHIP_STATS_GRID")) { int v = atoi(e); if (v >= 1 && v <= STATS_GRID_MAX) c->stats_grid = v; }
-  if (const char* e = getenv("DCTZHIP_WG_PER_CU")) { int v = atoi(e); if (v >= 1 && v <= 16) c->wg_per_cu = v; }
+  if (const char* e = getenv("DCTZHIP_WG_PER_CU")) { int v = atoi(e); if (v >= 1 && v <= WG_PER_CU_MAX) c->wg_per_cu = v; }
   if (const char* e = getenv("DCTZHIP_SPECULATE")) c->speculate = atoi(e) != 0;
   if (const char* e = getenv("DCTZHIP_SPEC_MIN")) { long long v = atoll(e); if (v >= 0) c->spec_min = (size_t)v; }
   if (const char* e = getenv("DCTZHIP_SPEC_GROUP")) { int v = atoi(e); if (v >= 1 && v <= 4096) c->spec_group = (unsigned)v; }
@@ -318,8 +320,8 @@ static int ensure_scratch(dctzhip_ctx* c, size_t n, int dtype, int mode, bool co
     if ((rc = regrow(c, &c->wg_cnt, &c->tile_cap, entries, sizeof(unsigned)))) return rc;
   }
   if (!compress) return DCTZHIP_OK;
-  if (!c->ovf) {                                       // 64 x 64 items per workgroup, 8 workgroups per CU at most
-    const size_t items = (size_t)c->num_cu * 8 * 64 * 64;
+  if (!c->ovf) {                                       // 64 x 64 items per workgroup, WG_PER_CU_MAX workgroups per CU at most
+    const size_t items = (size_t)c->num_cu * WG_PER_CU_MAX * 64 * 64;
     HIPCHK(c, hipMalloc(&c->ovf, items * sizeof(double)));
     HIPCHK(c, hipMalloc(&c->ovf_j, items));
   }
@@ -443,17 +445,21 @@ static int read_timings(dctzhip_ctx* c, int nev_main_start) {
 
 struct HostStats { double max_abs, min_abs, sum; };
 
-// resident single-wave workgroups per CU of the two big kernels (LDS-limited: k_compress 8; k_decompress 4 for fp64, 7 for fp32)
+// resident single-wave workgroups per CU of the two big kernels: what the runtime's occupancy calculator says for the
+// very instantiation (registers and LDS; k_compress: 8 for fp64, 12 for fp32 EC; k_decompress: 4 / 7), cached
 template <typename T>
-static int wg_per_cu(dctzhip_ctx* c, bool decode, int mode) {
+static int wg_per_cu(dctzhip_ctx* c, bool decode, int mode, bool stats = false, int geom = GEOM_1D) {
   if (c->wg_per_cu) return c->wg_per_cu;
-  const size_t lds = decode ? decompress_lds_bytes<T>() : compress_lds_bytes<T>(mode);
-  const int v = (int)((size_t)160 * 1024 / lds);
-#ifdef DCTZ_WGCAP
-  return v < 1 ? 1 : (v > DCTZ_WGCAP ? DCTZ_WGCAP : v);
-#else
-  return v < 1 ? 1 : (v > 8 ? 8 : v);
-#endif
+  int& slot = c->occ[sizeof(T) == 8][decode ? 1 : 0][mode == DCTZHIP_QT][stats ? 1 : 0][geom];
+  if (slot == 0) {
+    int v = decode ? decompress_occupancy<T>(mode, geom) : compress_occupancy<T>(mode, stats, geom);
+    if (v <= 0) {                                   // (no answer: the LDS bound alone)
+      const size_t lds = decode ? decompress_lds_bytes<T>() : compress_lds_bytes<T>(mode);
+      v = (int)((size_t)160 * 1024 / lds);
+    }
+    slot = v < 1 ? 1 : (v > WG_PER_CU_MAX ? WG_PER_CU_MAX : v);
+  }
+  return slot;
 }
 
 // One pass of the compress kernels for a given set of statistics.  `fused`: the
@@ -506,7 +512,7 @@ static int compress_pass(dctzhip_ctx* c, const T* d_in, size_t n, double eb, int
   if (rem) { int rc = upload_rtab<T>(c, rem); if (rc) return rc; }
 
   if (c->profiling) HIPCHK(c, hipEventRecord(c->ev[2], s));
-  unsigned cap = (unsigned)(c->num_cu * wg_per_cu<T>(c, false, mode));
+  unsigned cap = (unsigned)(c->num_cu * wg_per_cu<T>(c, false, mode, fused, geom));
   if (c->grid_c > 0 && (unsigned)c->grid_c < cap) cap = (unsigned)c->grid_c;       // DCTZHIP_GRID_C (experiments)
   const int grid = (int)(cap < ntiles ? cap : ntiles);
   p.nlists_main = (unsigned)grid;
@@ -832,7 +838,7 @@ static int decompress_impl(dctzhip_ctx* c, const uint8_t* d_bin, const float* d_
   p.eb = eb;
   const bool scale = (p.sf != (T)1.0);            // :496 / :505
 
-  const unsigned cap = (unsigned)(c->num_cu * wg_per_cu<T>(c, true, mode));
+  const unsigned cap = (unsigned)(c->num_cu * wg_per_cu<T>(c, true, mode, false, geom));
   const int grid = (int)(cap < ntiles ? cap : ntiles);
   p.nwg = (unsigned)grid;
   if (c->profiling) HIPCHK(c, hipEventRecord(c->ev[0], s));
