@@ -1271,8 +1271,11 @@ __global__ __launch_bounds__(SWG) void k_count_tiles(const uint8_t* __restrict__
 template <typename T>
 size_t decompress_lds_bytes() { return (size_t)Geo<T, Phases<T>::D>::PHB + 256 * sizeof(T) + DEC_EXC_CAP * 4 + 64 * sizeof(T); }
 
+#ifndef DCTZ_WPED32
+#define DCTZ_WPED32 0
+#endif
 template <typename T, int MODE, int PH, int GEOM>
-__global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(PH))) void k_decompress(InvParams<T> p, FinArgs fin) {
+__global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu((sizeof(T) == 4 && DCTZ_WPED32) ? DCTZ_WPED32 : PH))) void k_decompress(InvParams<T> p, FinArgs fin) {
   using G = Geo<T, PH>;
   __shared__ __attribute__((aligned(1024))) unsigned char outbuf[G::PHB];
   __shared__ __attribute__((aligned(16))) T bctab[256];               // bin_center[] of gen_bins
