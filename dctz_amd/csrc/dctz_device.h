@@ -15,12 +15,15 @@ namespace dctz {
 // A TILE = 64 consecutive 64-element blocks = the work of ONE wavefront per loop trip: lane b owns block b
 // of the tile and runs its whole transform in registers (dct64_block.h).  Workgroups of the two big kernels
 // are single wavefronts.
+#ifndef DCTZ_DEC_EXC_CAP
+#define DCTZ_DEC_EXC_CAP 1024
+#endif
 constexpr int TILE_BLKS = 64;
 constexpr int TILE_ELEMS = TILE_BLKS * 64;   // 4096
 constexpr int WG = 64;                       // threads per workgroup of k_compress / k_decompress
 constexpr int SWG = 256;                     // threads per workgroup of the streaming helpers (stats, count, compact, ...)
 constexpr int EXC_BYTES = 4096;              // k_compress: the lanes' exception strips, then the 64 x 64 bin ids of the tile on their way out
-constexpr int DEC_EXC_CAP = 1024;            // decode: exact coefficients of one tile staged in LDS (floats); more -> direct gathers
+constexpr int DEC_EXC_CAP = DCTZ_DEC_EXC_CAP;            // decode: exact coefficients of one tile staged in LDS (floats); more -> direct gathers
 
 template <typename T> struct Traits;
 template <> struct Traits<double> {
