@@ -694,7 +694,7 @@ size_t compress_lds_bytes(int mode) {              // tile image + strips (+ pos
   using G = Geo<T, Phases<T>::C>;
   if (mode != DCTZHIP_QT) return (size_t)G::PHB + EXC_BYTES;
   const size_t strips = 64 * (size_t)(G::QT_DEPTH + 1) * (sizeof(T) + 1);          // items + their positions, one buffer
-  return (size_t)G::PHB + (strips > EXC_BYTES ? strips : (size_t)EXC_BYTES);
+  return (size_t)G::PHB + (strips > EXC_BYTES ? strips : (size_t)EXC_BYTES) + (sizeof(T) == 4 ? 256 : 0);   // + fp32: the per-position maxima
 }
 
 // PH = 1: the whole tile (fp32: 16 KiB) sits in LDS.  PH = 2 (fp64): half a tile at a time (16 KiB), eight single-wave
@@ -727,6 +727,14 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu((sizeof(T) =
   constexpr int STRIP_BYTES = ITEM_BYTES + POS_BYTES > EXC_BYTES ? ITEM_BYTES + POS_BYTES : EXC_BYTES;
   __shared__ __attribute__((aligned(16))) unsigned char excbuf[STRIP_BYTES];        // also: the tile's bin ids on their way out
   unsigned char* const jbuf = excbuf + ITEM_BYTES;                                   // QT: position j of every parked item
+  // QT, fp32: per-position maximum |coef| over the out-of-range coefficients (dctz-comp-lib.c:371-372 / :396-397), kept
+  // per wave while the exceptions go out (one LDS atomic per exception) and merged into Ctl::qraw at the end -- no pass
+  // over the lists for it.  (fp64 keeps the separate k_qt_max: the kernel is at its register limit, and the few
+  // registers of this path came back as eleven spills in the flush -- 0.26 -> 0.40 ms.)
+  using QBits = typename Traits<T>::Bits;
+  constexpr bool QMAX_HERE = (MODE == DCTZHIP_QT) && sizeof(T) == 4;
+  __shared__ QBits qmax_lds[QMAX_HERE ? 64 : 1];
+  if (QMAX_HERE) qmax_lds[threadIdx.x] = 0;
   // (the addresses are formed where they are used: kept in registers across the loop they cost four VGPRs for a rare path)
   // (item k of all 64 lanes side by side: the flush reads whole rows, and the lanes of a store -- all within a few items
   // of each other -- touch a handful of lines instead of 64)
@@ -795,6 +803,10 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu((sizeof(T) =
         if constexpr (sizeof(T) == 8) __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, (double)v), r_list, at * 8, 0, 0);
         else __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, (float)v), r_list, at * 4, 0, 0);
         __builtin_amdgcn_raw_buffer_store_b8(jj, r_listj, at, 0, 0);
+        if (QMAX_HERE) {
+          const T a = fabs((T)v);
+          if (a > rmax) atomicMax(&qmax_lds[jj], to_bits(a));               // positive values order like their bits
+        }
       }
     };
 #pragma unroll
@@ -1035,6 +1047,10 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu((sizeof(T) =
   STAMP(11);
   STAMP_FLUSH(p.ovf_j);
   if (lane == 0) p.tile_cnt[blockIdx.x] = run;
+  if (QMAX_HERE) {
+    const QBits m = qmax_lds[lane];
+    if (m != 0) atomicMax(&p.ctl->qraw[lane], (unsigned long long)m);
+  }
   if (STATS) {
     __syncthreads();
     acc.flush(p.stat_part, blockIdx.x, reinterpret_cast<double*>(tilebuf), 1, scale ? 8.0 * (double)sf : 8.0);
@@ -1099,7 +1115,10 @@ __global__ __launch_bounds__(64) void k_compress_rem(FwdParams<T> p, int l) {
     if (k == 0) { p.dc[p.nfull] = (float)coef; p.ctl->q0 = (unsigned long long)to_bits(coef); }
     if (exc) {
       if (MODE == DCTZHIP_EC) p.ac_tmp[start + rank] = (float)coef;
-      else { p.qt_item[start + rank] = coef; p.qt_j[start + rank] = (uint8_t)k; }
+      else {
+        p.qt_item[start + rank] = coef; p.qt_j[start + rank] = (uint8_t)k;
+        if (sizeof(T) == 4 && fabs(coef) > p.range_max) atomicMax(&p.ctl->qraw[k], (unsigned long long)to_bits(fabs(coef)));   // :371-372 / :396-397 (fp64: k_qt_max)
+      }
     }
   }
   __syncthreads();

@@ -521,7 +521,9 @@ static int compress_pass(dctzhip_ctx* c, const T* d_in, size_t n, double eb, int
   if (rem) launch_compress_rem<T>(p, mode, rem, s);
   // stitch the workgroup-local lists into AC_exact[]
   const unsigned nlists = (unsigned)grid + (rem ? 1u : 0u);
-  if (mode == DCTZHIP_QT) launch_qt_max<T>(p, nlists, (int)(nlists < 1024u ? nlists : 1024u), s);   // :371-372 over the lists
+  // QT: the per-position maxima of :371-372 -- fp32: gathered by k_compress itself while its exceptions go out; fp64:
+  // a pass over the lists (k_compress<double, QT> has no register to spare)
+  if (mode == DCTZHIP_QT && sizeof(T) == 8) launch_qt_max<T>(p, nlists, (int)(nlists < 1024u ? nlists : 1024u), s);
   // (k_compact_ac finds the place of every list itself: no scan kernel.)  With the mailbox its first workgroup hands
   // the call's results to the host as soon as the kernel starts -- all of them are in by then -- so the host is back in
   // the caller, queueing the next call's launches, while the lists are still being moved
