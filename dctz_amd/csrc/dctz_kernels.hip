@@ -1,4 +1,7 @@
-// dctz_kernels.hip -- gfx950 (MI355X) kernels of the DCTZ hot path.
+// dctz_kernels.hip -- gfx950 (MI355X) kernels of the DCTZ hot path: k_compress, k_decompress and what hangs on them
+// (remainder blocks, the QT maxima, the list placement, the flag counts, the hand-off).  The statistics passes, scaling,
+// batched transforms, gather / scatter and PSNR kernels live in dctz_kernels_aux.hip, the shared device helpers
+// (FastDiv, TileMap, LDS-DMA issue, StatAcc, ...) in dctz_kernel_common.h.
 //
 // Work decomposition (both directions):
 //   * a TILE is 64 consecutive 64-element blocks (4096 elements, 32 KiB fp64) = one loop trip of ONE
@@ -38,494 +41,9 @@
 // Reference code replaced: see include/dctz_hip.h (per entry point) and the comment on each kernel.
 // Built with -ffp-contract=off: the arithmetic that the reference does unfused (gcc, baseline x86-64,
 // reference Makefile:2) is unfused here too; the transform's fused operations are explicit.
-#include <hip/hip_runtime.h>
-#include <stdint.h>
-
-#include <type_traits>
-
-#include "dct64_block.h"
-#include "dct_nd_block.h"
-#include "dct64_block_pk.h"
-#include "dctz_device.h"
+#include "dctz_kernel_common.h"
 
 namespace dctz {
-
-typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
-typedef float f32x2 __attribute__((ext_vector_type(2)));
-#define LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
-// The twiddle block is written once at context creation and never by a kernel: reading it through the constant
-// address space lets the compiler use scalar loads (the table indices are compile-time constants, the base is a
-// kernel argument: wave-uniform).  A plain global pointer gets VECTOR loads here, because the kernels also store to
-// global memory and nothing tells the compiler that the table is not among the targets.
-template <typename T> using CTab = const __attribute__((address_space(4))) T*;
-template <typename T> __device__ __forceinline__ CTab<T> as_ctab(const T* p) { return (CTab<T>)(p); }
-// LDS-DMA: 16 bytes per lane, HBM -> LDS (lane l lands at lds + 16 l), through a buffer descriptor (range-checked: zeros
-// beyond the end).  Device pass only (the host pass of hipcc does not know the builtin).
-#if defined(__HIP_DEVICE_COMPILE__)
-#define DMA16(rsrc, lds, voff, soff, aux) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, LDS_PTR(lds), 16, voff, soff, 0, aux)
-#else
-#define DMA16(rsrc, lds, voff, soff, aux) ((void)0)
-#endif
-
-// ------------------------------------------------------------------ helpers --
-// Streaming (read-once / write-once) 16-byte accesses: the `nt` policy.  A pure 1 GiB read stream
-// runs at 6.8-7.1 TB/s with nt loads against 6.0-6.3 TB/s with plain ones (tools/ubench/stream_read.hip).
-template <typename V>
-__device__ __forceinline__ V load_stream(const V* p) {
-  static_assert(sizeof(V) == 16, "16-byte vectors only");
-  const u32x4 r = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(p));
-  V v;
-  __builtin_memcpy(&v, &r, 16);
-  return v;
-}
-template <typename V>
-__device__ __forceinline__ void store_stream(V* p, const V& v) {
-  static_assert(sizeof(V) == 16, "16-byte vectors only");
-  u32x4 r;
-  __builtin_memcpy(&r, &v, 16);
-  __builtin_nontemporal_store(r, reinterpret_cast<u32x4*>(p));
-}
-
-// Inclusive prefix sum over the 64 lanes of a wavefront with DPP row shifts / row broadcasts
-// (six dependent VALU steps instead of six ds_bpermute round trips through the LDS pipe).
-__device__ __forceinline__ unsigned wave_incl_scan(unsigned v) {
-  v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, true);    // row_shr:1
-  v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, true);    // row_shr:2
-  v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, true);    // row_shr:4
-  v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, true);    // row_shr:8
-  v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false);   // row_bcast:15 -> rows 1, 3
-  v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false);   // row_bcast:31 -> rows 2, 3
-  return v;
-}
-
-__device__ __forceinline__ unsigned long long to_bits(double v) { return (unsigned long long)__double_as_longlong(v); }
-__device__ __forceinline__ unsigned int to_bits(float v) { return __float_as_uint(v); }
-
-// ----------------------------------------------- division by a kernel constant --
-// x / d with d uniform over the launch (the scaling factor, the bin width).
-// hipcc expands an IEEE division into: v_div_scale x2, v_rcp, two (f64) / one (f32)
-// Newton steps on the reciprocal, q = x*y, r = fma(-d, q, x), fma(r, y, q) [f32:
-// one more residual step], v_div_fmas, v_div_fixup.  Everything up to the
-// reciprocal y depends on d alone, and the scale/fixup steps are the identity
-// while the exponents of x, d and x/d stay away from the overflow / denormal
-// ends.  So: y is computed once per thread with the very same instructions, x is
-// checked against a conservative exponent window, and inside it the remaining
-// 3 (f64) / 5 (f32) operations give bit-for-bit what `x / d` gives.  Outside the
-// window (and for zeros, whose sign v_div_fixup restores) the full division runs.
-// tests/test_gpu_parity.py::test_fast_division_is_exact checks the identity on
-// the GPU against the compiler's own division.
-template <typename T> struct FastDiv;
-template <> struct FastDiv<double> {
-  double d, y;
-  bool ok;                       // host: |d| in [2^-250, 2^250]
-  __device__ __forceinline__ void init(double dd, bool okk) {
-    d = dd; ok = okk;
-    double r = __builtin_amdgcn_rcp(dd);
-    double e = fma(-dd, r, 1.0); r = fma(r, e, r);
-    e = fma(-dd, r, 1.0); r = fma(r, e, r);
-    // the divisor is a kernel argument, so y is wave-uniform: keep it in SGPRs
-    y = __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(r)),
-                         __builtin_amdgcn_readfirstlane(__double2loint(r)));
-  }
-  __device__ __forceinline__ double core(double x) const {
-    const double q = x * y;
-    const double r = fma(-d, q, x);
-    return fma(r, y, q);
-  }
-  __device__ __forceinline__ double div(double x) const {          // any x
-    const unsigned ex = ((unsigned)__double2hiint(x) >> 20) & 0x7ffu;
-    if (ok && (ex - 523u) <= 1000u) return core(x);                // |x| in [2^-500, 2^501)
-    if (ok && x == 0.0) return x * y;                              // signed zero
-    return x / d;
-  }
-};
-template <> struct FastDiv<float> {
-  float d, y;
-  bool ok;                       // host: |d| in [2^-30, 2^30]
-  __device__ __forceinline__ void init(float dd, bool okk) {
-    d = dd; ok = okk;
-    const float r = __builtin_amdgcn_rcpf(dd);
-    const float e = fmaf(-dd, r, 1.0f);
-    y = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(fmaf(e, r, r))));   // wave-uniform -> SGPR
-  }
-  __device__ __forceinline__ float core(float x) const {
-    const float q = x * y;
-    const float r = fmaf(-d, q, x);
-    const float q2 = fmaf(r, y, q);
-    const float r2 = fmaf(-d, q2, x);
-    return fmaf(r2, y, q2);
-  }
-  // two quotients at once with the packed fp32 instructions of gfx950 (v_pk_mul_f32 / v_pk_fma_f32: the same IEEE
-  // operations per component, half the issue slots)
-  __device__ __forceinline__ f32x2 core2(f32x2 x) const {
-    const f32x2 dd = {d, d}, yy = {y, y};
-    const f32x2 q = x * yy;
-    const f32x2 r = __builtin_elementwise_fma(-dd, q, x);
-    const f32x2 q2 = __builtin_elementwise_fma(r, yy, q);
-    const f32x2 r2 = __builtin_elementwise_fma(-dd, q2, x);
-    return __builtin_elementwise_fma(r2, yy, q2);
-  }
-  __device__ __forceinline__ float div(float x) const {
-    const unsigned ex = (__float_as_uint(x) >> 23) & 0xffu;
-    if (ok && (ex - 64u) <= 126u) return core(x);                  // |x| in [2^-63, 2^64)
-    if (ok && x == 0.0f) return x * y;
-    return x / d;
-  }
-};
-
-// (call sites shared by the fp64 instantiations, where the packed form does not exist and the branch is compiled out)
-__device__ __forceinline__ f32x2 fastdiv_core2(const FastDiv<float>& d, f32x2 x) { return d.core2(x); }
-__device__ __forceinline__ f32x2 fastdiv_core2(const FastDiv<double>&, f32x2 x) { return x; }
-
-// Workgroup b of G owns the contiguous tiles [lo, hi) -- the same partition in k_compress / k_compact_ac
-// and in k_decompress.
-struct TileRange { unsigned lo, hi; };
-__host__ __device__ __forceinline__ TileRange tile_range(unsigned b, unsigned G, unsigned ntiles) {
-  const unsigned q = ntiles / G, r = ntiles % G;
-  TileRange tr;
-  tr.lo = b * q + (b < r ? b : r);
-  tr.hi = tr.lo + q + (b < r ? 1u : 0u);
-  return tr;
-}
-
-// ---------------------------------------------------------- the tile in LDS --
-// A tile's image in LDS is made of 1 KiB ROWS; row (jg, s) holds segment s (128 bytes) of the 8 blocks
-// 8 jg .. 8 jg + 7, and inside a block's 128 bytes the 16-byte chunks are XOR-swizzled with
-// f(block) = (block >> 1) & 7.  A row is what ONE LDS-DMA instruction writes (lane l -> bytes
-// [16 l, 16 l + 16) of the row) and what one 16-byte-per-lane store instruction reads back, and lane l's
-// share of a row is a piece of a whole 128-byte line in HBM.  Lane b = block b reads chunk ch of its block
-// with ds_read_b128 at lds_a[ch & 7] + (ch >> 3) * 1024: inside each group of 16 lanes that the LDS
-// services together, the 16 addresses fall into 16 different 16-byte bank groups (conflict-free; the
-// same for the ds_write_b128 of the inverse direction).
-template <typename T, int PH>
-struct TileMap {
-  using G = Geo<T, PH>;
-  int lds_a[8];        // LDS byte offset of chunk class g = ch & 7 of this lane's block (row part of segment 0)
-  int g_even, g_odd;   // HBM byte offset (inside a tile) of this lane's 16 bytes of row (jg, 0), jg even / odd
-  __device__ __forceinline__ void init(int lane) {
-    const int f = (lane >> 1) & 7;
-#pragma unroll
-    for (int g = 0; g < 8; g++) lds_a[g] = (lane >> 3) * G::SEGP * 1024 + (lane & 7) * 128 + ((g ^ f) * 16);
-    const int beta = lane >> 3, gam = lane & 7;
-    g_even = beta * G::BLKB + ((gam ^ (beta >> 1)) * 16);
-    g_odd = g_even ^ 64;
-  }
-};
-
-// HBM -> LDS, one phase of a tile, no registers.  rsrc covers the workgroup's input range; the range check
-// zero-fills whatever lies beyond the last whole block.
-template <typename T, int PH>
-__device__ __forceinline__ void issue_phase_dma(__amdgpu_buffer_rsrc_t rsrc, unsigned rel, int phase, unsigned char* tilebuf, const TileMap<T, PH>& tm) {
-  using G = Geo<T, PH>;
-  const int base = (int)(rel * (unsigned)G::TILEB) + phase * G::SEGP * 128;
-#pragma unroll
-  for (int jg = 0; jg < 8; jg++)
-#pragma unroll
-    for (int s = 0; s < G::SEGP; s++)
-      DMA16(rsrc, tilebuf + (jg * G::SEGP + s) * 1024, (jg & 1) ? tm.g_odd : tm.g_even, base + jg * 8 * G::BLKB + s * 128, 2 /* nt */);
-}
-
-// ---- multi-dimensional blocks straight from / to the array (NdDirect) ----
-// Byte offset of the origin of block B of the tile grid, or an offset beyond any descriptor range for B >= nblk
-// (loads return zeros there, stores are dropped).
-template <typename T>
-__device__ __forceinline__ unsigned nd_block_origin(const NdDirect& nd, unsigned B) {
-  auto divmod = [](unsigned a, unsigned d, unsigned m, unsigned& r) {
-    unsigned q = __umulhi(a, m);                     // m = floor(2^32 / d): q is the quotient or one short of it
-    r = a - q * d;
-    if (r >= d) { q++; r -= d; }
-    return q;
-  };
-  unsigned bx, elem;
-  const unsigned t = divmod(B, nd.nbx, nd.mx, bx);
-  if (nd.nd == 2) {
-    elem = t * 8u * nd.dx + bx * 8u;
-  } else {
-    unsigned by;
-    const unsigned bz = divmod(t, nd.nby, nd.my, by);
-    elem = (bz * 4u * nd.dy + by * 4u) * nd.dx + bx * 4u;
-  }
-  return B < nd.nblk ? elem * (unsigned)sizeof(T) : 0xFFFFFFF0u;
-}
-// Byte offset, inside its block's footprint in the array, of 16-byte chunk ch of the block (chunk ch = elements
-// [ch * EPV, ch * EPV + EPV) of the row-major tile: always inside one row of the tile)
-template <typename T>
-__device__ __forceinline__ unsigned nd_chunk_offset(const NdDirect& nd, int ch) {
-  const unsigned j0 = (unsigned)ch * (unsigned)Traits<T>::EPV;
-  if (nd.nd == 2) return ((j0 >> 3) * nd.dx + (j0 & 7u)) * (unsigned)sizeof(T);
-  return (((j0 >> 4) * nd.dy + ((j0 >> 2) & 3u)) * nd.dx + (j0 & 3u)) * (unsigned)sizeof(T);
-}
-// HBM -> LDS, one phase of a tile of a multi-dimensional array: same image in LDS as issue_phase_dma builds for the
-// flat layout (row (jg, s) = segment s of blocks 8 jg .. 8 jg + 7, chunks XOR-swizzled), other addresses in HBM.
-template <typename T, int PH>
-__device__ __forceinline__ void issue_phase_dma_nd(__amdgpu_buffer_rsrc_t rsrc, const NdDirect& nd, unsigned tile, int phase, unsigned char* tilebuf, int lane) {
-  using G = Geo<T, PH>;
-  const int beta = lane >> 3, gam = lane & 7;
-#pragma unroll
-  for (int jg = 0; jg < 8; jg++) {
-    const unsigned org = nd_block_origin<T>(nd, tile * (unsigned)TILE_BLKS + (unsigned)(8 * jg + beta));
-    const int cg = gam ^ (beta >> 1) ^ ((jg & 1) << 2);                // chunk of the segment this lane moves (TileMap's swizzle)
-#pragma unroll
-    for (int s = 0; s < G::SEGP; s++) {
-      const unsigned off = org + nd_chunk_offset<T>(nd, 8 * (phase * G::SEGP + s) + cg);
-      DMA16(rsrc, tilebuf + (jg * G::SEGP + s) * 1024, (int)(org >= 0xFFFFFFF0u ? org : off), 0, 2 /* nt */);
-    }
-  }
-}
-
-// LDS image of phase PHASE -> this lane's elements [PHASE * 64 / PH, (PHASE + 1) * 64 / PH) of its block
-template <typename T, int PH, int PHASE>
-__device__ __forceinline__ void read_phase(T (&x)[64], const unsigned char* tilebuf, const TileMap<T, PH>& tm) {
-  using Vec = typename Traits<T>::Vec;
-  using G = Geo<T, PH>;
-  constexpr int EPV = Traits<T>::EPV;
-#pragma unroll
-  for (int ch = 0; ch < G::CHP; ch++) {
-    const Vec v = *reinterpret_cast<const Vec*>(tilebuf + tm.lds_a[ch & 7] + (ch >> 3) * 1024);
-    Traits<T>::unpack(v, &x[(PHASE * G::CHP + ch) * EPV]);
-  }
-}
-
-template <typename T, int PH, int PHASE>
-__device__ __forceinline__ void write_phase(const T (&x)[64], unsigned char* tilebuf, const TileMap<T, PH>& tm) {
-  using Vec = typename Traits<T>::Vec;
-  using G = Geo<T, PH>;
-  constexpr int EPV = Traits<T>::EPV;
-#pragma unroll
-  for (int ch = 0; ch < G::CHP; ch++)
-    *reinterpret_cast<Vec*>(tilebuf + tm.lds_a[ch & 7] + (ch >> 3) * 1024) = Traits<T>::pack(&x[(PHASE * G::CHP + ch) * EPV]);
-}
-
-// ---------------------------------------------------- statistics on the fly --
-// calc_data_stat's reductions (util.c:18-25 / :31-38).
-template <typename T>
-struct StatAcc {
-  T mx, mn;
-  double sum;                                      // raw-domain sum (or correction term)
-  double dcs;                                      // fused path: sum of the blocks' DC coefficients (see k_compress)
-  __device__ __forceinline__ void init() { mx = T(0); mn = Traits<T>::huge(); sum = 0.0; dcs = 0.0; }
-  // one v_max / v_min with the |x| source modifier each (a NaN operand is skipped, like `a > mx ? a : mx`)
-  __device__ __forceinline__ void add(T e, bool in_sum) {
-    minmax(e);
-    if (in_sum) sum += (double)e;
-  }
-  __device__ __forceinline__ void minmax(T e) {
-    if constexpr (sizeof(T) == 8) {
-      asm("v_max_f64 %0, %1, |%2|" : "=v"(mx) : "v"(mx), "v"(e));
-      asm("v_min_f64 %0, %1, |%2|" : "=v"(mn) : "v"(mn), "v"(e));
-    } else {
-      asm("v_max_f32 %0, %1, |%2|" : "=v"(mx) : "v"(mx), "v"(e));
-      asm("v_min_f32 %0, %1, |%2|" : "=v"(mn) : "v"(mn), "v"(e));
-    }
-  }
-  // workgroup reduction -> part[3*slot .. 3*slot+2]; `s` is scratch for 3 * (threads/64) doubles
-  // dc_scale: raw-domain value of one unit of DC (8 * sf for 64-element orthonormal blocks)
-  __device__ __forceinline__ void flush(double* part, unsigned slot, double* s, int nwaves, double dc_scale = 0.0) {
-    double dmx = (double)mx, dmn = (double)mn, sm = sum + dcs * dc_scale;
-#pragma unroll
-    for (int d = 32; d > 0; d >>= 1) {
-      dmx = fmax(dmx, __shfl_down(dmx, d));
-      dmn = fmin(dmn, __shfl_down(dmn, d));
-      sm += __shfl_down(sm, d);
-    }
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    if (lane == 0) { s[wave] = dmx; s[nwaves + wave] = dmn; s[2 * nwaves + wave] = sm; }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-      for (int w = 1; w < nwaves; w++) { dmx = fmax(dmx, s[w]); dmn = fmin(dmn, s[nwaves + w]); sm += s[2 * nwaves + w]; }
-      part[3 * slot + 0] = dmx;
-      part[3 * slot + 1] = dmn;
-      part[3 * slot + 2] = sm;
-    }
-  }
-};
-
-// QT normalisation of an out-of-range coefficient (dctz-comp-lib.c:488-492 /
-// :514-518); error_bound is a double there, so f32 evaluates product and sum in
-// double and rounds once.
-__device__ __forceinline__ double qt_normalise(double item, double q, double eb, double qf, double rmin, double rmax) {
-  if (item < rmin) return (item / q) * eb * qf + rmin;
-  if (item > rmax) return (item / q) * eb * qf + rmax;
-  return item;
-}
-__device__ __forceinline__ float qt_normalise(float item, float q, double eb, float qf, float rmin, float rmax) {
-  if (item < rmin) return (float)((double)(item / q) * eb * (double)qf + (double)rmin);
-  if (item > rmax) return (float)((double)(item / q) * eb * (double)qf + (double)rmax);
-  return item;
-}
-// QT de-normalisation on decode (dctz-decomp-lib.c:404-409 / :450-454)
-__device__ __forceinline__ double qt_restore(double v, double q, double eb, double qf, double rmin, double rmax) {
-  return (v > 0) ? ((v - rmax) / (eb * qf)) * q : ((v - rmin) / (eb * qf)) * q;
-}
-__device__ __forceinline__ float qt_restore(float v, float q, double eb, float qf, float rmin, float rmax) {
-  return (v > 0) ? (float)(((double)(v - rmax) / (eb * (double)qf)) * (double)q)
-                 : (float)(((double)(v - rmin) / (eb * (double)qf)) * (double)q);
-}
-
-// ------------------------------------------------------------- host hand-off --
-// System-scope release of a sequence number into the HostBox (fine-grained pinned host
-// memory): everything this thread (and, after a barrier, its workgroup) wrote to the
-// box before is visible to the polling host thread once it reads the number.
-__device__ __forceinline__ void box_publish(volatile unsigned long long* flag, unsigned long long seq) {
-  __threadfence_system();
-  __hip_atomic_store(const_cast<unsigned long long*>(flag), seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-}
-
-// =============================================================== statistics ==
-// calc_data_stat (util.c:12-44): max|x|, min|x| and sum (x[0] is never added,
-// util.c:22 starts at i = 1).  Tree order: `sum` is NOT the reference's serial
-// order (it is never used by the codec; the host wrapper recomputes it
-// serially for the header).
-template <typename T>
-__global__ __launch_bounds__(SWG) void k_stats(const T* __restrict__ x, size_t n, double* __restrict__ part) {
-  using Vec = typename Traits<T>::Vec;
-  constexpr int EPV = Traits<T>::EPV;
-  const size_t nvec = n / EPV;
-  const Vec* src = reinterpret_cast<const Vec*>(x);
-  T mx = T(0), mn = Traits<T>::huge();
-  double sum = 0.0;
-  constexpr int UN = 4;                            // each workgroup streams 16 KiB contiguous per trip
-  for (size_t i0 = (size_t)blockIdx.x * SWG * UN + threadIdx.x; i0 < nvec; i0 += (size_t)gridDim.x * SWG * UN) {
-    Vec v[UN];
-#pragma unroll
-    for (int u = 0; u < UN; u++) {
-      const size_t i = i0 + (size_t)u * SWG;
-      v[u] = load_stream((i < nvec) ? &src[i] : &src[i0]);   // a repeated vector changes neither max nor min
-    }
-#pragma unroll
-    for (int u = 0; u < UN; u++) {
-      const size_t i = i0 + (size_t)u * SWG;
-      T e[EPV];
-      Traits<T>::unpack(v[u], e);
-#pragma unroll
-      for (int k = 0; k < EPV; k++) {
-        const T a = fabs(e[k]);
-        mx = a > mx ? a : mx;
-        mn = a < mn ? a : mn;
-        if (i < nvec && (i != 0 || k != 0)) sum += (double)e[k];
-      }
-    }
-  }
-  if (blockIdx.x == 0 && threadIdx.x == 0)
-    for (size_t i = nvec * EPV; i < n; i++) {
-      const T a = fabs(x[i]);
-      mx = a > mx ? a : mx;
-      mn = a < mn ? a : mn;
-      if (i != 0) sum += (double)x[i];
-    }
-  double dmx = (double)mx, dmn = (double)mn;
-#pragma unroll
-  for (int d = 32; d > 0; d >>= 1) {
-    dmx = fmax(dmx, __shfl_down(dmx, d));
-    dmn = fmin(dmn, __shfl_down(dmn, d));
-    sum += __shfl_down(sum, d);
-  }
-  __shared__ double s[3][SWG / 64];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  if (lane == 0) { s[0][wave] = dmx; s[1][wave] = dmn; s[2][wave] = sum; }
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    for (int w = 1; w < SWG / 64; w++) { dmx = fmax(dmx, s[0][w]); dmn = fmin(dmn, s[1][w]); sum += s[2][w]; }
-    part[3 * blockIdx.x + 0] = dmx;
-    part[3 * blockIdx.x + 1] = dmn;
-    part[3 * blockIdx.x + 2] = sum;
-  }
-}
-
-// reduction of {max, min, sum} partials by one workgroup (any size up to 256 threads); thread 0 returns with the result
-__device__ __forceinline__ void reduce_parts(const double* __restrict__ part, int nparts, double& dmx, double& dmn, double& sum) {
-  dmx = 0.0; dmn = 1.79769313486231570815e308; sum = 0.0;
-  for (int i0 = threadIdx.x; i0 < nparts; i0 += 4 * (int)blockDim.x) {      // four entries in flight per thread
-    double a[4], b[4], c[4];
-#pragma unroll
-    for (int u = 0; u < 4; u++) {
-      const int i = i0 + u * (int)blockDim.x;
-      const bool in = i < nparts;
-      a[u] = in ? part[3 * i] : 0.0; b[u] = in ? part[3 * i + 1] : 1.79769313486231570815e308; c[u] = in ? part[3 * i + 2] : 0.0;
-    }
-#pragma unroll
-    for (int u = 0; u < 4; u++) { dmx = fmax(dmx, a[u]); dmn = fmin(dmn, b[u]); sum += c[u]; }
-  }
-#pragma unroll
-  for (int d = 32; d > 0; d >>= 1) {
-    dmx = fmax(dmx, __shfl_down(dmx, d));
-    dmn = fmin(dmn, __shfl_down(dmn, d));
-    sum += __shfl_down(sum, d);
-  }
-  __shared__ double s[3][SWG / 64];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = (int)blockDim.x >> 6;
-  if (lane == 0) { s[0][wave] = dmx; s[1][wave] = dmn; s[2][wave] = sum; }
-  __syncthreads();
-  if (threadIdx.x == 0)
-    for (int w = 1; w < nw; w++) { dmx = fmax(dmx, s[0][w]); dmn = fmin(dmn, s[1][w]); sum += s[2][w]; }
-}
-
-// final reduction of the statistics partials -> device words + (optionally) the host mailbox; one workgroup
-__device__ __forceinline__ void stats_final_body(const double* part, int nparts, double* out, HostBox* box, unsigned long long seq) {
-  double dmx, dmn, sum;
-  reduce_parts(part, nparts, dmx, dmn, sum);
-  if (threadIdx.x == 0) {
-    out[0] = dmx; out[1] = dmn; out[2] = sum;
-    if (box != nullptr) {                            // hand the three numbers straight to the polling host thread
-      box->stats[0] = dmx; box->stats[1] = dmn; box->stats[2] = sum;
-      box_publish(&box->seq_stats, seq);
-    }
-  }
-}
-
-// zero != NULL: also the first kernel-side act of a compress call -- the control block back to all-zero (the
-// per-position maxima of the QT table accumulate with atomicMax, :371-372)
-__device__ __forceinline__ unsigned block_sum(unsigned v, unsigned* sh);
-
-// FastDiv's windows on the host's terms (dctz_shim.hip: divisor_in_window / value_in_window): unbiased exponent of a
-// finite non-zero double in [lo, hi)
-__device__ __forceinline__ bool exp_in(double v, int lo, int hi) {
-  const int e = (int)(((unsigned)__double2hiint(v) >> 20) & 0x7ffu) - 1023;     // subnormal / zero: -1023, inf / NaN: 1024
-  return e >= lo && e < hi;
-}
-
-__global__ __launch_bounds__(SWG) void k_stats_final(const double* part, int nparts, double* out,
-                                                    HostBox* box, unsigned long long seq, Ctl* zero) {
-  if (zero != nullptr) {
-    unsigned long long* w = reinterpret_cast<unsigned long long*>(zero);
-    for (int i = threadIdx.x; i < (int)(sizeof(Ctl) / 8); i += SWG) w[i] = 0ull;
-  }
-  stats_final_body(part, nparts, out, box, seq);
-}
-
-// The same, for a speculative compress call: the scaling factor of util.c:29 / :43 for the SAMPLED max|x| is chosen
-// here, with the host's own decade tables (SfTable), and left in device memory for k_compress -- no host round trip
-// between the sample and the main launch (the host verifies the choice against the true statistics afterwards).
-__global__ __launch_bounds__(SWG) void k_stats_final_sf(const double* part, int nparts, double* out, Ctl* zero, SfTable tab,
-                                                       SfGuess* guess, HostBox* box) {
-  if (zero != nullptr) {
-    unsigned long long* w = reinterpret_cast<unsigned long long*>(zero);
-    for (int i = threadIdx.x; i < (int)(sizeof(Ctl) / 8); i += SWG) w[i] = 0ull;
-  }
-  __shared__ double smax, smin;
-  __shared__ unsigned cnt_s[SWG / 64];
-  double dmx, dmn, sum;
-  reduce_parts(part, nparts, dmx, dmn, sum);
-  if (threadIdx.x == 0) {
-    out[0] = dmx; out[1] = dmn; out[2] = sum; smax = dmx; smin = dmn;
-    // (no sequence number here: the host reads these after the call's hand-off, which is a later kernel's)
-    if (box != nullptr) { box->stats[0] = dmx; box->stats[1] = dmn; box->stats[2] = sum; }
-  }
-  __syncthreads();
-  const double mx = smax, mn = smin;
-  unsigned below = 0;                                  // decades whose upper end lies below max|x|
-  for (int i = threadIdx.x; i < tab.nk; i += SWG) below += (tab.thr[i] < mx) ? 1u : 0u;
-  const unsigned k = block_sum(below, cnt_s);
-  if (threadIdx.x == 0) {
-    double sf = (mx == 0.0) ? 1.0 : tab.pw[k < (unsigned)tab.nk ? k : (unsigned)tab.nk];   // all-zero input: sf = 1
-    const bool f64 = tab.dtype == DCTZHIP_F64;
-    unsigned fast = (tab.fastdiv && (f64 ? exp_in(sf, -250, 250) : exp_in(sf, -30, 30))) ? 1u : 0u;
-    if (fast && tab.fastdiv >= 2 && (f64 ? (exp_in(mn, -500, 500) && exp_in(mx, -500, 500)) : (exp_in(mn, -63, 63) && exp_in(mx, -63, 63)))) fast = 2u;
-    guess->sf = sf;
-    guess->fast_sf = fast;
-  }
-}
 
 // Hand-off of a call's results to the host, by ONE workgroup: final reduction of the fused statistics (nparts > 0),
 // results -> host box, then the sequence number.  Everything it reads was written by EARLIER kernels of the call, so it
@@ -565,86 +83,6 @@ __global__ __launch_bounds__(SWG) void k_finish(FinArgs a) {
   f.ctl = a.ctl; f.part = a.part; f.nparts = a.nparts; f.box = a.box; f.seq = a.seq; f.guess = a.guess;
   f.cnt_known = false; f.err_known = false; f.cnt_total = 0; f.error = 0;
   finish_body<true>(f);
-}
-
-// Sampled statistics for the speculative path: one 4 KiB chunk out of every group of
-// `group` chunks, at a hashed position inside the group (a fixed stride would alias with
-// the row structure of power-of-two volumes).  Same partials layout as k_stats.
-template <typename T>
-__global__ __launch_bounds__(SWG) void k_stats_sample(const T* __restrict__ x, size_t n, unsigned group,
-                                                       double* __restrict__ part) {
-  using Vec = typename Traits<T>::Vec;
-  constexpr int EPV = Traits<T>::EPV;
-  const size_t nchunks = n / ((size_t)SWG * EPV);                // whole chunks only; the tail is never sampled
-  const size_t ngroups = nchunks / group;
-  const Vec* src = reinterpret_cast<const Vec*>(x);
-  StatAcc<T> acc;
-  acc.init();
-  // up to four chunks of a workgroup in flight at once (the kernel is a handful of dependent round trips otherwise)
-  for (size_t g0 = blockIdx.x; g0 < ngroups; g0 += (size_t)gridDim.x * 4) {
-    Vec v[4];
-#pragma unroll
-    for (int u = 0; u < 4; u++) {
-      const size_t g = g0 + (size_t)u * gridDim.x;
-      const size_t gg = g < ngroups ? g : g0;                    // (a repeated chunk changes neither max nor min; its sum is skipped)
-      const unsigned h = ((unsigned)gg * 2654435761u) >> 8;
-      const size_t chunk = gg * group + h % group;
-      v[u] = load_stream(&src[chunk * SWG + threadIdx.x]);
-    }
-#pragma unroll
-    for (int u = 0; u < 4; u++) {
-      const bool real = g0 + (size_t)u * gridDim.x < ngroups;
-      T e[EPV];
-      Traits<T>::unpack(v[u], e);
-#pragma unroll
-      for (int k = 0; k < EPV; k++) acc.add(e[k], real);
-    }
-  }
-  __shared__ double ss[3 * (SWG / 64)];
-  acc.flush(part, blockIdx.x, ss, SWG / 64);
-}
-
-// Serial-order sum for the header's `mean` (util.c:18-28 / :31-41): the reference
-// adds x[1..N-1] one after the other in the data type, and a tree reduction
-// cannot reproduce those roundings.  One wavefront: all lanes stage a chunk in
-// LDS with coalesced loads, lane 0 adds it up in index order.  Slow by design
-// (one dependent add per element) and OFF the critical path: the host wrapper
-// runs it on a side stream underneath the zlib tail.
-template <typename T>
-__global__ __launch_bounds__(64) void k_serial_sum(const T* __restrict__ x, size_t n, double* __restrict__ out) {
-  constexpr int CH = 4096;
-  __shared__ T buf[CH];
-  const int lane = threadIdx.x;
-  T sum = T(0);
-  for (size_t base = 0; base < n; base += CH) {
-    const size_t m = (n - base < (size_t)CH) ? n - base : (size_t)CH;
-    for (size_t i = lane; i < m; i += 64) buf[i] = x[base + i];
-    __syncthreads();
-    if (lane == 0) {
-      size_t i = (base == 0) ? 1 : 0;          // util.c:22: the loop starts at i = 1
-      for (; i < m; i++) sum += buf[i];
-    }
-    __syncthreads();
-  }
-  if (lane == 0) out[0] = (double)sum;
-}
-
-// out[i] = x[i] / sf (dctz-comp-lib.c:193-216), in place (out == x) or into the caller's copy:
-// the reference's in-place side effect on the host buffer.
-template <typename T>
-__global__ __launch_bounds__(SWG) void k_scale(const T* __restrict__ x, T* __restrict__ out, size_t n, T sf) {
-  using Vec = typename Traits<T>::Vec;
-  constexpr int EPV = Traits<T>::EPV;
-  const size_t nvec = n / EPV;
-  const Vec* v = reinterpret_cast<const Vec*>(x);
-  Vec* o = reinterpret_cast<Vec*>(out);
-  for (size_t i = (size_t)blockIdx.x * SWG + threadIdx.x; i < nvec; i += (size_t)gridDim.x * SWG) {
-    Vec a = v[i];
-    Traits<T>::div(a, sf);
-    o[i] = a;
-  }
-  if (blockIdx.x == 0 && threadIdx.x == 0)
-    for (size_t i = nvec * EPV; i < n; i++) out[i] = x[i] / sf;
 }
 
 // ================================================================= compress ==
@@ -1162,19 +600,6 @@ __global__ __launch_bounds__(SWG) void k_qt_max(FwdParams<T> p, unsigned nlists)
   if (threadIdx.x < 64 && qmax[threadIdx.x] != 0) atomicMax(&p.ctl->qraw[threadIdx.x], (unsigned long long)qmax[threadIdx.x]);
 }
 
-// Sum over a workgroup of one unsigned per thread (every thread gets the total); `sh`: one word per wave
-__device__ __forceinline__ unsigned block_sum(unsigned v, unsigned* sh) {
-#pragma unroll
-  for (int d = 32; d > 0; d >>= 1) v += __shfl_xor(v, d);
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = (int)blockDim.x >> 6;
-  __syncthreads();                                   // sh[] of an earlier call is consumed
-  if (lane == 0) sh[wave] = v;
-  __syncthreads();
-  unsigned tot = 0;
-  for (int w = 0; w < nw; w++) tot += sh[w];
-  return tot;
-}
-
 // Move every workgroup-local list to its place in AC_exact[]
 // (dctz-comp-lib.c:478-544 order: lists are already block-major, j ascending).
 // QT: clamp the table (:450-461) and normalise on the way (:488-518).
@@ -1556,262 +981,10 @@ __global__ __launch_bounds__(64) void k_decompress_rem(InvParams<T> p, int l) {
   }
 }
 
-// Diagnostics: FastDiv against the compiler's own division, element by element.
-template <typename T>
-__global__ __launch_bounds__(SWG) void k_debug_divide(const T* __restrict__ x, size_t n, T d, int ok,
-                                                     T* __restrict__ fast, T* __restrict__ ref) {
-  FastDiv<T> fd;
-  fd.init(d, ok != 0);
-  for (size_t i = (size_t)blockIdx.x * SWG + threadIdx.x; i < n; i += (size_t)gridDim.x * SWG) {
-    fast[i] = fd.div(x[i]);
-    ref[i] = x[i] / d;
-  }
-}
-
-// ============================================================ transform only ==
-// Batched dct_fftw / ifft_idct over all full blocks (dct.h:17-27; dct-test.c:81-89,144-152): one block per
-// thread, straight from / to HBM (a utility entry point, not on the codec's path).
-template <typename T, bool INVERSE>
-__global__ __launch_bounds__(WG) void k_dct_blocks(const T* __restrict__ x, T* __restrict__ out, const T* __restrict__ tab, unsigned nfull) {
-  using Vec = typename Traits<T>::Vec;
-  constexpr int EPV = Traits<T>::EPV;
-  for (unsigned blk = blockIdx.x * WG + threadIdx.x; blk < nfull; blk += gridDim.x * WG) {
-    T v[64];
-    const Vec* src = reinterpret_cast<const Vec*>(x + (size_t)blk * 64);
-#pragma unroll
-    for (int c = 0; c < 64 / EPV; c++) Traits<T>::unpack(src[c], &v[c * EPV]);
-    if (INVERSE) dct64_inv<T, CTab<T>>(v, as_ctab<T>(tab)); else dct64_fwd<T, CTab<T>>(v, as_ctab<T>(tab));
-    Vec* dst = reinterpret_cast<Vec*>(out + (size_t)blk * 64);
-#pragma unroll
-    for (int c = 0; c < 64 / EPV; c++) dst[c] = Traits<T>::pack(&v[c * EPV]);
-  }
-}
-
-template <typename T, bool INVERSE>
-__global__ __launch_bounds__(64) void k_dct_rem(const T* __restrict__ x, T* __restrict__ out, const T* __restrict__ rt, int l) {
-  __shared__ T v[128];
-  __shared__ T w[128];
-  const int k = threadIdx.x;
-  const int N = (l & 1) ? 2 * l : l;
-  v[k] = T(0); v[k + 64] = T(0); w[k] = T(0); w[k + 64] = T(0);
-  __syncthreads();
-  if (!INVERSE) {
-    if (k < l) {
-      const T a = x[k];
-      if (l & 1) { v[k] = a; v[l + (l - 1 - k)] = a; }
-      else if (k & 1) v[l - 1 - (k >> 1)] = a;
-      else v[k >> 1] = a;
-    }
-    __syncthreads();
-    if (k < l) {
-      T sr = T(0), si = T(0);
-      for (int j = 0; j < N; j++) {
-        const int tt = (j * k) % N;
-        sr = sr + v[j] * rt[RTAB_WR + tt];
-        si = si + v[j] * rt[RTAB_WI + tt];
-      }
-      out[k] = rt[RTAB_AS + k] * sr + rt[RTAB_AX + k] * si;
-    }
-  } else {
-    if (k < l) {
-      v[k] = rt[RTAB_IAS + k] * x[k];
-      w[k] = rt[RTAB_IAX + k] * x[k];
-      if ((l & 1) && k >= 1) {
-        v[l + k] = rt[RTAB_IAX + k] * x[l - k];
-        w[l + k] = -(rt[RTAB_IAS + k] * x[l - k]);
-      }
-    }
-    __syncthreads();
-    if (k < l) {
-      const int s = (l & 1) ? k : ((k & 1) ? l - 1 - (k >> 1) : (k >> 1));
-      T acc = T(0);
-      for (int j = 0; j < N; j++) {
-        const int tt = (s * j) % N;
-        acc = acc + (v[j] * rt[RTAB_WR + tt] - w[j] * rt[RTAB_WI + tt]);
-      }
-      out[k] = (l & 1) ? (acc / (T)l) / T(2) : acc / (T)l;
-    }
-  }
-}
-
-// ==================================================== multi-dimensional blocks ==
-// SURVEY section 8 f4 (not in the reference's library; the hint is dct-fftw-test.c:74-97).  A 2-D array is cut into
-// 8 x 8 tiles, a 3-D array into 4 x 4 x 4 tiles (last axis fastest; edge tiles repeat the last sample), and
-// k_gather_nd lays the tiles out block after block -- row-major over the tile grid, row-major inside a tile -- so that
-// the 1-D pipeline above runs on them unchanged with the separable block transform (GEOM).  One thread moves one
-// 16-byte piece of the block-linear side: fully coalesced there, whole rows of a tile (32 / 64 bytes) on the array side.
-// The same pass takes calc_data_stat's reductions over the ORIGINAL elements (util.c:12-44; a repeated edge sample
-// changes neither max nor min and stays out of the sum; x[0] never enters the sum, util.c:22).
-template <typename T>
-__device__ __forceinline__ void nd_locate(const NdShape& sh, size_t q, size_t (&src)[Traits<T>::EPV], bool (&real)[Traits<T>::EPV]) {
-  constexpr int EPV = Traits<T>::EPV;
-  const size_t blk = q / (64 / EPV);
-  const int j0 = (int)(q % (64 / EPV)) * EPV;                       // first element of the piece inside its block
-  if (sh.nd == 2) {
-    const size_t b0 = blk / sh.nb[1], b1 = blk % sh.nb[1];
-    const size_t r = b0 * 8 + (size_t)(j0 >> 3);
-    const bool rin = r < sh.d[0];
-    const size_t rr = rin ? r : sh.d[0] - 1;
-#pragma unroll
-    for (int k = 0; k < EPV; k++) {
-      const size_t c = b1 * 8 + (size_t)((j0 & 7) + k);
-      const bool cin = c < sh.d[1];
-      src[k] = rr * sh.d[1] + (cin ? c : sh.d[1] - 1);
-      real[k] = rin && cin;
-    }
-  } else {
-    const size_t b2 = blk % sh.nb[2], t = blk / sh.nb[2], b1 = t % sh.nb[1], b0 = t / sh.nb[1];
-    const size_t z = b0 * 4 + (size_t)(j0 >> 4), y = b1 * 4 + (size_t)((j0 >> 2) & 3);
-    const bool zin = z < sh.d[0], yin = y < sh.d[1];
-    const size_t base = ((zin ? z : sh.d[0] - 1) * sh.d[1] + (yin ? y : sh.d[1] - 1)) * sh.d[2];
-#pragma unroll
-    for (int k = 0; k < EPV; k++) {
-      const size_t xx = b2 * 4 + (size_t)((j0 & 3) + k);
-      const bool xin = xx < sh.d[2];
-      src[k] = base + (xin ? xx : sh.d[2] - 1);
-      real[k] = zin && yin && xin;
-    }
-  }
-}
-
-template <typename T>
-__global__ __launch_bounds__(SWG) void k_gather_nd(const T* __restrict__ x, T* __restrict__ lin, NdShape sh, double* __restrict__ part) {
-  using Vec = typename Traits<T>::Vec;
-  constexpr int EPV = Traits<T>::EPV;
-  const size_t nq = sh.nblk * (64 / EPV);
-  StatAcc<T> acc;
-  acc.init();
-  for (size_t q = (size_t)blockIdx.x * SWG + threadIdx.x; q < nq; q += (size_t)gridDim.x * SWG) {
-    size_t src[EPV];
-    bool real[EPV];
-    nd_locate<T>(sh, q, src, real);
-    T e[EPV];
-#pragma unroll
-    for (int k = 0; k < EPV; k++) {
-      e[k] = x[src[k]];
-      acc.minmax(e[k]);
-      if (real[k] && src[k] != 0) acc.sum += (double)e[k];
-    }
-    reinterpret_cast<Vec*>(lin)[q] = Traits<T>::pack(e);
-  }
-  __shared__ double ss[3 * (SWG / 64)];
-  acc.flush(part, blockIdx.x, ss, SWG / 64);
-}
-
-// block-linear reconstruction -> the array (the padding of edge tiles is dropped)
-template <typename T>
-__global__ __launch_bounds__(SWG) void k_scatter_nd(const T* __restrict__ lin, T* __restrict__ out, NdShape sh) {
-  using Vec = typename Traits<T>::Vec;
-  constexpr int EPV = Traits<T>::EPV;
-  const size_t nq = sh.nblk * (64 / EPV);
-  for (size_t q = (size_t)blockIdx.x * SWG + threadIdx.x; q < nq; q += (size_t)gridDim.x * SWG) {
-    size_t dst[EPV];
-    bool real[EPV];
-    nd_locate<T>(sh, q, dst, real);
-    T e[EPV];
-    Traits<T>::unpack(reinterpret_cast<const Vec*>(lin)[q], e);
-#pragma unroll
-    for (int k = 0; k < EPV; k++)
-      if (real[k]) out[dst[k]] = e[k];
-  }
-}
-
-template <typename T>
-void launch_gather_nd(const T* x, T* lin, const NdShape& sh, double* part, int nparts, hipStream_t s) {
-  hipLaunchKernelGGL(k_gather_nd<T>, dim3(nparts), dim3(SWG), 0, s, x, lin, sh, part);
-}
-template <typename T>
-void launch_scatter_nd(const T* lin, T* out, const NdShape& sh, int grid, hipStream_t s) {
-  hipLaunchKernelGGL(k_scatter_nd<T>, dim3(grid), dim3(SWG), 0, s, lin, out, sh);
-}
-
-// ===================================================================== PSNR ==
-// calc_psnr's reductions (util.c:54-104): min / max of the original, max |x - r|, sum of (x - r)^2 with the
-// difference and its square taken in the data type (util.c:72-73 / :88-89), summed in double -- in tree order,
-// so the last digits of the sum differ from the reference's serial loop (relative 1e-15).
-template <typename T>
-__global__ __launch_bounds__(SWG) void k_psnr(const T* __restrict__ x, const T* __restrict__ r, size_t n, double* __restrict__ part) {
-  double mn = 1.79769313486231570815e308, mx = -1.79769313486231570815e308, worst = 0.0, sq = 0.0;
-  for (size_t i = (size_t)blockIdx.x * SWG + threadIdx.x; i < n; i += (size_t)gridDim.x * SWG) {
-    const T a = x[i];
-    const T e = a - r[i];
-    mn = fmin(mn, (double)a); mx = fmax(mx, (double)a);
-    worst = fmax(worst, (double)fabs(e));
-    sq += (double)(e * e);
-  }
-#pragma unroll
-  for (int d = 32; d > 0; d >>= 1) {
-    mn = fmin(mn, __shfl_down(mn, d)); mx = fmax(mx, __shfl_down(mx, d));
-    worst = fmax(worst, __shfl_down(worst, d)); sq += __shfl_down(sq, d);
-  }
-  __shared__ double s[4][SWG / 64];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  if (lane == 0) { s[0][wave] = mn; s[1][wave] = mx; s[2][wave] = worst; s[3][wave] = sq; }
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    for (int w = 1; w < SWG / 64; w++) { mn = fmin(mn, s[0][w]); mx = fmax(mx, s[1][w]); worst = fmax(worst, s[2][w]); sq += s[3][w]; }
-    part[4 * blockIdx.x + 0] = mn; part[4 * blockIdx.x + 1] = mx; part[4 * blockIdx.x + 2] = worst; part[4 * blockIdx.x + 3] = sq;
-  }
-}
-__global__ __launch_bounds__(SWG) void k_psnr_final(const double* __restrict__ part, int nparts, double* __restrict__ out) {
-  double mn = 1.79769313486231570815e308, mx = -1.79769313486231570815e308, worst = 0.0, sq = 0.0;
-  for (int i = threadIdx.x; i < nparts; i += SWG) {
-    mn = fmin(mn, part[4 * i]); mx = fmax(mx, part[4 * i + 1]); worst = fmax(worst, part[4 * i + 2]); sq += part[4 * i + 3];
-  }
-#pragma unroll
-  for (int d = 32; d > 0; d >>= 1) {
-    mn = fmin(mn, __shfl_down(mn, d)); mx = fmax(mx, __shfl_down(mx, d));
-    worst = fmax(worst, __shfl_down(worst, d)); sq += __shfl_down(sq, d);
-  }
-  __shared__ double s[4][SWG / 64];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  if (lane == 0) { s[0][wave] = mn; s[1][wave] = mx; s[2][wave] = worst; s[3][wave] = sq; }
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    for (int w = 1; w < SWG / 64; w++) { mn = fmin(mn, s[0][w]); mx = fmax(mx, s[1][w]); worst = fmax(worst, s[2][w]); sq += s[3][w]; }
-    out[0] = mn; out[1] = mx; out[2] = worst; out[3] = sq;
-  }
-}
-
 // ================================================================= launchers ==
-template <typename T>
-void launch_stats(const T* x, size_t n, double* part, int nparts, double* out, hipStream_t s, HostBox* box, unsigned long long seq, Ctl* zero,
-                  const SfTable* tab, SfGuess* guess) {
-  hipLaunchKernelGGL(k_stats<T>, dim3(nparts), dim3(SWG), 0, s, x, n, part);
-  if (tab != nullptr) hipLaunchKernelGGL(k_stats_final_sf, dim3(1), dim3(SWG), 0, s, (const double*)part, nparts, out, zero, *tab, guess, box);
-  else hipLaunchKernelGGL(k_stats_final, dim3(1), dim3(SWG), 0, s, (const double*)part, nparts, out, box, seq, zero);
-}
-
-template <typename T>
-void launch_stats_sample(const T* x, size_t n, unsigned group, double* part, int nparts, double* out, hipStream_t s,
-                         HostBox* box, unsigned long long seq, Ctl* zero, const SfTable* tab, SfGuess* guess) {
-  hipLaunchKernelGGL(k_stats_sample<T>, dim3(nparts), dim3(SWG), 0, s, x, n, group, part);
-  if (tab != nullptr) hipLaunchKernelGGL(k_stats_final_sf, dim3(1), dim3(SWG), 0, s, (const double*)part, nparts, out, zero, *tab, guess, box);
-  else hipLaunchKernelGGL(k_stats_final, dim3(1), dim3(SWG), 0, s, (const double*)part, nparts, out, box, seq, zero);
-}
-void launch_stats_final(const double* part, int nparts, double* out, hipStream_t s, HostBox* box, unsigned long long seq, Ctl* zero,
-                        const SfTable* tab, SfGuess* guess) {
-  if (tab != nullptr) hipLaunchKernelGGL(k_stats_final_sf, dim3(1), dim3(SWG), 0, s, part, nparts, out, zero, *tab, guess, box);
-  else hipLaunchKernelGGL(k_stats_final, dim3(1), dim3(SWG), 0, s, part, nparts, out, box, seq, zero);
-}
 void launch_finish(Ctl* ctl, const double* part, int nparts, HostBox* box, unsigned long long seq, hipStream_t s) {
   const FinArgs f = {ctl, part, nparts, box, seq, nullptr};
   hipLaunchKernelGGL(k_finish, dim3(1), dim3(SWG), 0, s, f);
-}
-
-template <typename T>
-void launch_debug_divide(const T* x, size_t n, T d, int ok, T* fast, T* ref, hipStream_t s) {
-  hipLaunchKernelGGL(k_debug_divide<T>, dim3(1024), dim3(SWG), 0, s, x, n, d, ok, fast, ref);
-}
-
-template <typename T>
-void launch_serial_sum(const T* x, size_t n, double* out, hipStream_t s) {
-  hipLaunchKernelGGL(k_serial_sum<T>, dim3(1), dim3(64), 0, s, x, n, out);
-}
-
-template <typename T>
-void launch_scale(const T* x, T* out, size_t n, T sf, int grid, hipStream_t s) {
-  hipLaunchKernelGGL(k_scale<T>, dim3(grid), dim3(SWG), 0, s, x, out, n, sf);
 }
 
 template <typename T>
@@ -1914,47 +1087,15 @@ void launch_decompress_rem(const InvParams<T>& p, int mode, bool scale, int l, h
   }
 }
 
-template <typename T>
-void launch_dct_blocks(const T* x, T* out, const T* gtab, const T* rtab, size_t n, bool inverse, int grid,
-                       hipStream_t s) {
-  const unsigned nfull = (unsigned)(n / 64);
-  const int l = (int)(n % 64);
-  if (nfull) {
-    const int g = (int)min((unsigned)grid, (nfull + WG - 1) / WG);
-    if (inverse) hipLaunchKernelGGL((k_dct_blocks<T, true>), dim3(g), dim3(WG), 0, s, x, out, gtab, nfull);
-    else hipLaunchKernelGGL((k_dct_blocks<T, false>), dim3(g), dim3(WG), 0, s, x, out, gtab, nfull);
-  }
-  if (l) {
-    const T* xr = x + (size_t)nfull * 64;
-    T* orr = out + (size_t)nfull * 64;
-    if (inverse) hipLaunchKernelGGL((k_dct_rem<T, true>), dim3(1), dim3(64), 0, s, xr, orr, rtab, l);
-    else hipLaunchKernelGGL((k_dct_rem<T, false>), dim3(1), dim3(64), 0, s, xr, orr, rtab, l);
-  }
-}
-
-template <typename T>
-void launch_psnr(const T* x, const T* r, size_t n, double* part, int nparts, double* out, hipStream_t s) {
-  hipLaunchKernelGGL(k_psnr<T>, dim3(nparts), dim3(SWG), 0, s, x, r, n, part);
-  hipLaunchKernelGGL(k_psnr_final, dim3(1), dim3(SWG), 0, s, (const double*)part, nparts, out);
-}
-
 // explicit instantiations used by dctz_shim.hip
+
 #define INST(T)                                                                                         \
-  template void launch_stats<T>(const T*, size_t, double*, int, double*, hipStream_t, HostBox*, unsigned long long, Ctl*, const SfTable*, SfGuess*); \
-  template void launch_stats_sample<T>(const T*, size_t, unsigned, double*, int, double*, hipStream_t, HostBox*, unsigned long long, Ctl*, const SfTable*, SfGuess*); \
-  template void launch_debug_divide<T>(const T*, size_t, T, int, T*, T*, hipStream_t);                  \
-  template void launch_serial_sum<T>(const T*, size_t, double*, hipStream_t);                           \
-  template void launch_scale<T>(const T*, T*, size_t, T, int, hipStream_t);                             \
   template void launch_compress<T>(const FwdParams<T>&, int, bool, int, int, hipStream_t);              \
-  template void launch_gather_nd<T>(const T*, T*, const NdShape&, double*, int, hipStream_t);           \
-  template void launch_scatter_nd<T>(const T*, T*, const NdShape&, int, hipStream_t);                   \
   template void launch_compress_rem<T>(const FwdParams<T>&, int, int, hipStream_t);                     \
   template void launch_qt_max<T>(const FwdParams<T>&, unsigned, int, hipStream_t);                      \
   template void launch_compact_ac<T>(const FwdParams<T>&, int, double, unsigned, int, const FinArgs&, hipStream_t); \
   template void launch_decompress<T>(const InvParams<T>&, int, int, const FinArgs&, int, hipStream_t);  \
   template void launch_decompress_rem<T>(const InvParams<T>&, int, bool, int, hipStream_t);             \
-  template void launch_dct_blocks<T>(const T*, T*, const T*, const T*, size_t, bool, int, hipStream_t); \
-  template void launch_psnr<T>(const T*, const T*, size_t, double*, int, double*, hipStream_t);         \
   template int compress_occupancy<T>(int, bool, int);                                                      \
   template int decompress_occupancy<T>(int, int);                                                          \
   template size_t compress_lds_bytes<T>(int);                                                              \
