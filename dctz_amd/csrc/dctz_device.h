@@ -246,6 +246,12 @@ template <typename T> void launch_decompress_rem(const InvParams<T>& p, int mode
 template <typename T> void launch_dct_blocks(const T* x, T* out, const T* gtab, const T* rtab, size_t n,
                                              bool inverse, int grid, hipStream_t s);
 template <typename T> void launch_psnr(const T* x, const T* r, size_t n, double* part, int nparts, double* out, hipStream_t s);
+
+// GPU entropy stage (dctz_deflate.hip): one section -> one zlib stream, everything in device memory
+size_t deflate_chunk_bytes();
+size_t deflate_scratch_bytes(size_t n);
+size_t deflate_bound(size_t n);
+hipError_t launch_deflate(const void* src, size_t n, void* dst, void* scratch, unsigned long long* box_len, hipStream_t st);
 template <typename T> int compress_occupancy(int mode, bool stats, int geom);
 template <typename T> int decompress_occupancy(int mode, int geom);
 template <typename T> size_t compress_lds_bytes(int mode);

@@ -62,6 +62,10 @@ struct dctzhip_ctx {
   int occ[2][2][2][2][3] = {};      // resident workgroups per CU per kernel instantiation [f64][decode][qt][stats][geom], 0 = not asked yet
   int grid_c = 0;                   // upper bound of k_compress's grid (DCTZHIP_GRID_C; 0 = what the LDS admits)
   int nd_direct = 1;                // multi-dimensional blocks read / written in place where the shape allows (DCTZHIP_ND_DIRECT)
+  void* dfl_buf = nullptr;          // GPU entropy stage: chunk slots, sizes, offsets (dctz_deflate.hip)
+  size_t dfl_cap = 0;               // bytes
+  unsigned long long* dfl_len = nullptr;      // stream lengths of up to 8 sections (pinned host memory the kernels write)
+  unsigned long long* dfl_len_dev = nullptr;
   void* nd_buf = nullptr;           // multi-dimensional blocks: the array laid out block after block (k_gather_nd / k_scatter_nd)
   size_t nd_cap = 0;                // bytes
   // pinned host staging
@@ -193,10 +197,11 @@ extern "C" void dctzhip_ctx_destroy(dctzhip_ctx* c) {
   (void)dctzhip_comm_destroy(c);
   (void)hipStreamSynchronize(c->stream);
   if (c->side_stream) { (void)hipStreamSynchronize(c->side_stream); (void)hipStreamDestroy(c->side_stream); }
-  void* bufs[] = {c->ovf, c->ovf_j, c->ac_tmp, c->tile_cnt, c->wg_cnt, c->serial_out, c->tab_f64, c->tab_f32, c->rtab, c->qtab, c->ctl, c->part, c->stats_out, c->qt_item, c->qt_j, c->nd_buf, c->sf_thr[0], c->sf_thr[1], c->sf_pw[0], c->sf_pw[1], c->sf_guess};
+  void* bufs[] = {c->ovf, c->ovf_j, c->ac_tmp, c->tile_cnt, c->wg_cnt, c->serial_out, c->tab_f64, c->tab_f32, c->rtab, c->qtab, c->ctl, c->part, c->stats_out, c->qt_item, c->qt_j, c->nd_buf, c->dfl_buf, c->sf_thr[0], c->sf_thr[1], c->sf_pw[0], c->sf_pw[1], c->sf_guess};
   for (void* b : bufs) if (b) (void)hipFree(b);
   if (c->h_pin) (void)hipHostFree(c->h_pin);
   if (c->box) (void)hipHostFree(c->box);
+  if (c->dfl_len) (void)hipHostFree(c->dfl_len);
   for (int i = 0; i < 6; i++) if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
   if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
   delete c;
@@ -273,6 +278,45 @@ extern "C" int dctzhip_host_register(dctzhip_ctx* c, void* ptr, size_t bytes) {
 extern "C" int dctzhip_host_unregister(dctzhip_ctx* c, void* ptr) {
   if (!c || !ptr) return DCTZHIP_E_ARG;
   HIPCHK(c, hipHostUnregister(ptr));
+  return DCTZHIP_OK;
+}
+
+template <typename P> static int regrow(dctzhip_ctx* c, P** ptr, size_t* cap, size_t need, size_t elem);
+// ---------------------------------------------------------------- GPU entropy stage --
+// the zlib tail of dctz_compress (dctz-comp-lib.c:620-732) on the device.  Every section becomes
+// one zlib stream that inflate() reads (dctz-decomp-lib.c:244-322); the bytes differ from zlib's own (so do zlib's
+// between versions), the inflated content is identical.
+extern "C" size_t dctzhip_deflate_bound(size_t n) { return deflate_bound(n); }
+
+extern "C" int dctzhip_deflate(dctzhip_ctx* c, int nsec, const void* const* d_src, const size_t* n, void* const* d_dst, const size_t* cap,
+                               size_t* out_len) {
+  if (!c || nsec < 0 || nsec > 8 || (nsec && (!d_src || !n || !d_dst || !cap || !out_len))) return fail(c, DCTZHIP_E_ARG, "dctzhip_deflate: bad arguments");
+  HIPCHK(c, hipSetDevice(c->device));
+  if (!c->dfl_len) {
+    HIPCHK(c, hipHostMalloc(reinterpret_cast<void**>(&c->dfl_len), 8 * sizeof(unsigned long long), hipHostMallocCoherent | hipHostMallocMapped));
+    HIPCHK(c, hipHostGetDevicePointer(reinterpret_cast<void**>(&c->dfl_len_dev), c->dfl_len, 0));
+  }
+  size_t need = 0;
+  for (int i = 0; i < nsec; i++) {
+    if (n[i] && !d_src[i]) return fail(c, DCTZHIP_E_ARG, "dctzhip_deflate: section %d has no source", i);
+    if (!d_dst[i] || cap[i] < deflate_bound(n[i])) return fail(c, DCTZHIP_E_ARG, "dctzhip_deflate: section %d needs %zu bytes of output (dctzhip_deflate_bound)", i, deflate_bound(n[i]));
+    if ((n[i] + deflate_chunk_bytes() - 1) / deflate_chunk_bytes() > 0x7FFFFFFFull) return fail(c, DCTZHIP_E_ARG, "dctzhip_deflate: section %d is too large", i);
+    const size_t b = deflate_scratch_bytes(n[i]);
+    if (b > need) need = b;
+  }
+  {
+    char* b = (char*)c->dfl_buf;
+    int rc = regrow(c, &b, &c->dfl_cap, need, 1);
+    c->dfl_buf = b;
+    if (rc) return rc;
+  }
+  // the sections run one after the other on the stream, so they share the scratch
+  for (int i = 0; i < nsec; i++) {
+    c->dfl_len[i] = 0;
+    HIPCHK(c, launch_deflate(d_src[i], n[i], d_dst[i], c->dfl_buf, c->dfl_len_dev + i, c->stream));
+  }
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  for (int i = 0; i < nsec; i++) out_len[i] = (size_t)c->dfl_len[i];
   return DCTZHIP_OK;
 }
 extern "C" int dctzhip_sync(dctzhip_ctx* c) {

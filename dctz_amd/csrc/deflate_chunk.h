@@ -1,0 +1,225 @@
+// deflate_chunk.h -- the sequential pieces of the GPU entropy stage, written once for the device
+// (dctz_deflate.hip: one workgroup per chunk, one lane per 128-byte segment) and for the host twin under tests/emu
+// (same routines driven by plain loops), so that the two can be compared byte for byte.
+//
+// What it replaces: the reference's zlib tail -- compress-side deflateInit/deflate of bin_index, DC and AC_exact, one
+// zlib stream per section (dctz-comp-lib.c:620-732) -- which is 85-90 % of the reference's compress wall time and all
+// that is left once the block-DCT stage runs on the GPU.  The stream stays what the reference's reader inflates
+// (dctz-decomp-lib.c:244-322: inflateInit + inflate of one zlib stream per section): RFC 1950 framing, RFC 1951 blocks.
+//
+// Format of one section:   78 9C | chunk 0 | chunk 1 | ... | 03 00 | adler32 (big endian)
+// Every chunk (CHUNK input bytes) is one deflate block, not final, ending on a byte boundary:
+//   - dynamic Huffman block (BTYPE 10) followed by an empty stored block (the "sync flush" marker 00 00 FF FF), or
+//   - one stored block (BTYPE 00) when that is smaller.
+// 03 00 is the final, empty fixed-Huffman block.  Matches are searched at a fixed set of distances only (runs, the
+// previous block's pattern 64 positions back, ...) and never leave the 128-byte segment of the lane that found them, so
+// that every lane parses its segment without waiting for a neighbour; distances reach back across segment and chunk
+// boundaries (the whole input is resident in HBM).
+#pragma once
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#define DFL_HD __host__ __device__ __forceinline__
+#else
+#define DFL_HD inline
+#endif
+
+namespace dctz {
+namespace dfl {
+
+enum : int {
+  SEG = 128,             // bytes one lane tokenises
+  SEG_SHIFT = 7,
+  HIST = 256,            // bytes kept in front of the chunk (>= the largest candidate distance)
+  NCAND = 8,             // candidate distances
+  NLIT = 286,            // literal / length alphabet in use (0..255, 256 = end of block, 257..285)
+  NDIST = 30,
+  NCL = 19,
+  MAXBITS = 15,
+  MAXBITS_CL = 7,
+  MINMATCH = 3,
+  MAXMATCH = 258,
+};
+
+#ifndef DFL_CANDS
+#define DFL_CANDS {1, 2, 4, 8, 16, 32, 64, 128}
+#endif
+DFL_HD constexpr int cand_dist(int c) {
+  constexpr int d[NCAND] = DFL_CANDS;
+  return d[c];
+}
+
+DFL_HD int ilog2(uint32_t x) { return 31 - __builtin_clz(x); }
+
+// length 3..258 -> (symbol 257.., extra bit count, extra value)     RFC 1951 3.2.5
+DFL_HD void len_code(int len, int& sym, int& eb, int& ev) {
+  const int x = len - 3;
+  if (x < 8) { sym = 257 + x; eb = 0; ev = 0; return; }
+  if (x == 255) { sym = 285; eb = 0; ev = 0; return; }
+  eb = ilog2((uint32_t)x) - 2;
+  sym = 257 + 4 * (eb + 1) + ((x >> eb) & 3);
+  ev = x & ((1 << eb) - 1);
+}
+// distance 1..32768 -> (symbol 0..29, extra bit count, extra value)
+DFL_HD constexpr void dist_code(int dist, int& sym, int& eb, int& ev) {
+  const int x = dist - 1;
+  if (x < 4) { sym = x; eb = 0; ev = 0; return; }
+  int l = 0;
+  for (int t = x; t > 1; t >>= 1) l++;
+  eb = l - 1;
+  sym = 2 * eb + 2 + ((x >> eb) & 1);
+  ev = x & ((1 << eb) - 1);
+}
+DFL_HD constexpr int cand_dsym(int c) { int s = 0, e = 0, v = 0; dist_code(cand_dist(c), s, e, v); return s; }
+DFL_HD constexpr int cand_deb(int c) { int s = 0, e = 0, v = 0; dist_code(cand_dist(c), s, e, v); return e; }
+DFL_HD constexpr int cand_dev(int c) { int s = 0, e = 0, v = 0; dist_code(cand_dist(c), s, e, v); return v; }
+// the same by a run-time index (small constant tables)
+#define DFL_TAB8(f) {f(0), f(1), f(2), f(3), f(4), f(5), f(6), f(7)}
+DFL_HD int cand_dsym_rt(int c) { constexpr int t[NCAND] = DFL_TAB8(cand_dsym); return t[c]; }
+DFL_HD int cand_deb_rt(int c) { constexpr int t[NCAND] = DFL_TAB8(cand_deb); return t[c]; }
+DFL_HD int cand_dev_rt(int c) { constexpr int t[NCAND] = DFL_TAB8(cand_dev); return t[c]; }
+
+// ------------------------------------------------------------------ parse --
+// Tokens of the segment [p0, p1) of a chunk.  in(i): input byte at chunk offset i, i in [-HIST, len); avail = bytes that
+// exist in front of the chunk (HIST, or less at the head of the section).  Token record, indexed by position:
+// tok(p) = 0: literal in(p);  tok(p) = 1 + c: match at distance cand_dist(c), its length - 3 in tok(p + 1).
+// lit(sym) / dst(sym) count one use of a literal-length / distance symbol.
+template <class In, class TokW, class CountL, class CountD>
+DFL_HD void parse_segment(In in, TokW tokw, int p0, int p1, int avail, CountL lit, CountD dst) {
+  int p = p0;
+  while (p < p1) {
+    int best = 0, bc = 0;
+    if (p + MINMATCH <= p1) {
+      const int b0 = in(p), b1 = in(p + 1), b2 = in(p + 2);
+#pragma unroll
+      for (int c = 0; c < NCAND; c++) {
+        const int d = cand_dist(c);
+        if (p + avail < d) continue;
+        if (in(p - d) != b0 || in(p + 1 - d) != b1 || in(p + 2 - d) != b2) continue;
+        int l = 3;
+        while (p + l < p1 && l < MAXMATCH && in(p + l) == in(p + l - d)) l++;
+        if (l > best) { best = l; bc = c; }
+      }
+    }
+    if (best) {
+      tokw(p, 1 + bc);
+      tokw(p + 1, best - 3);
+      int s, e, v;
+      len_code(best, s, e, v);
+      lit(s);
+      dst(cand_dsym(bc));
+      p += best;
+    } else {
+      tokw(p, 0);
+      lit(in(p));
+      p++;
+    }
+  }
+}
+
+// --------------------------------------------------------------- Huffman --
+// Code lengths, limited to maxbits, of the k symbols sorted[0..k) (ascending frequency, ties by symbol; every one with
+// freq > 0; k >= 2).  Two-queue construction, leaf counts per depth, the overflow repair of zlib's trees.c gen_bitlen, then
+// the longest codes go to the rarest symbols.  Scratch: w[k] (node weights), ch[2k] (children), dep[k].
+template <class F, class S, class L>
+DFL_HD void huff_lengths(F freq, S sorted, int k, int maxbits, L len, uint32_t* w, uint16_t* ch, uint16_t* dep, uint16_t* bl_count) {
+  for (int b = 0; b <= MAXBITS; b++) bl_count[b] = 0;
+  // children: id < k = leaf sorted[id]; id >= k = internal node id - k
+  int li = 0, ii = 0, ni = 0;
+  for (; ni < k - 1; ni++) {
+    uint32_t wsum = 0;
+    for (int t = 0; t < 2; t++) {
+      const bool take_leaf = li < k && (ii >= ni || freq(sorted(li)) <= w[ii]);
+      if (take_leaf) { wsum += freq(sorted(li)); ch[2 * ni + t] = (uint16_t)li; li++; }
+      else { wsum += w[ii]; ch[2 * ni + t] = (uint16_t)(k + ii); ii++; }
+    }
+    w[ni] = wsum;
+  }
+  dep[k - 2] = 0;
+  for (int i = k - 2; i >= 0; i--) {
+    const int d = dep[i] + 1;
+    for (int t = 0; t < 2; t++) {
+      const int c = ch[2 * i + t];
+      if (c >= k) dep[c - k] = (uint16_t)d;
+      else bl_count[d > maxbits ? maxbits : d]++;
+    }
+  }
+  // leaves clamped to maxbits over-subscribe the code: every repair step (one leaf one level down, one leaf of the
+  // deepest level up as its sibling) takes 2^-maxbits off the Kraft sum
+  uint32_t kraft = 0;
+  for (int b = 1; b <= maxbits; b++) kraft += (uint32_t)bl_count[b] << (maxbits - b);
+  for (uint32_t over = kraft - (1u << maxbits); over > 0; over--) {
+    int bits = maxbits - 1;
+    while (bl_count[bits] == 0) bits--;
+    bl_count[bits]--;
+    bl_count[bits + 1] += 2;
+    bl_count[maxbits]--;
+  }
+  int h = 0;
+  for (int bits = maxbits; bits >= 1; bits--)
+    for (int n = bl_count[bits]; n > 0; n--) len(sorted(h++), bits);
+}
+
+// first canonical code of every length (RFC 1951 3.2.2)
+DFL_HD void first_codes(const uint16_t* bl_count, int maxbits, uint16_t* next_code) {
+  uint32_t code = 0;
+  next_code[0] = 0;
+  for (int bits = 1; bits <= maxbits; bits++) {
+    code = (code + (bits > 1 ? bl_count[bits - 1] : 0)) << 1;
+    next_code[bits] = (uint16_t)code;
+  }
+}
+DFL_HD uint32_t bit_reverse(uint32_t code, int len) {
+  uint32_t r = 0;
+  for (int i = 0; i < len; i++) { r = (r << 1) | (code & 1); code >>= 1; }
+  return r;
+}
+
+// ------------------------------------------------------------ bit writer --
+// LSB-first bit stream into 32-bit words that several writers share: every word is OR-ed in (orw(word index, value)),
+// so a writer may start and end in the middle of a word.
+template <class OrW>
+struct BitW {
+  OrW orw;
+  uint64_t acc;
+  int nbits;
+  uint32_t wpos;
+  DFL_HD BitW(OrW o, uint64_t bit_offset) : orw(o), acc(0), nbits((int)(bit_offset & 31)), wpos((uint32_t)(bit_offset >> 5)) {}
+  DFL_HD void put(uint32_t v, int n) {          // n <= 16
+    acc |= (uint64_t)v << nbits;
+    nbits += n;
+    if (nbits >= 32) { orw(wpos++, (uint32_t)acc); acc >>= 32; nbits -= 32; }
+  }
+  DFL_HD void flush() { if (nbits > 0) orw(wpos, (uint32_t)acc); }
+  DFL_HD uint64_t bit_pos() const { return (uint64_t)wpos * 32 + nbits; }
+};
+
+// --------------------------------------------------------- block header --
+// Run-length form of the code lengths (RFC 1951 3.2.7; the scan of zlib's trees.c scan_tree, literal and distance
+// lengths scanned separately).  Emits (symbol, extra value) pairs through out(sym, extra_bits, extra_value).
+template <class L, class Out>
+DFL_HD void rle_lengths(L len, int n, Out out) {
+  int i = 0;
+  while (i < n) {
+    const int v = len(i);
+    int run = 1;
+    while (i + run < n && len(i + run) == v) run++;
+    i += run;
+    if (v == 0) {
+      while (run >= 11) { const int r = run > 138 ? 138 : run; out(18, 7, r - 11); run -= r; }
+      if (run >= 3) { out(17, 3, run - 3); run = 0; }
+      while (run-- > 0) out(0, 0, 0);
+    } else {
+      out(v, 0, 0); run--;
+      while (run >= 3) { const int r = run > 6 ? 6 : run; out(16, 2, r - 3); run -= r; }
+      while (run-- > 0) out(v, 0, 0);
+    }
+  }
+}
+DFL_HD constexpr int cl_order(int i) {
+  constexpr int o[NCL] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
+  return o[i];
+}
+
+}  // namespace dfl
+}  // namespace dctz

@@ -78,6 +78,9 @@ _PROTOS = {
     "dctzhip_debug_divide": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_double, C.c_void_p,
                                        C.c_void_p]),
     "dctzhip_psnr_terms": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.POINTER(C.c_double)]),
+    "dctzhip_deflate_bound": (C.c_size_t, [C.c_size_t]),
+    "dctzhip_deflate": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), C.POINTER(C.c_void_p),
+                                  C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]),
     "dctzhip_comm_unique_id": (C.c_int, [C.c_void_p]),
     "dctzhip_comm_create": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "dctzhip_comm_destroy": (C.c_int, [C.c_void_p]),
@@ -267,6 +270,24 @@ class Context:
         rc = self.lib.dctzhip_psnr_terms(self.h, x.data_ptr(), r.data_ptr(), x.numel(), _dt(x.dtype), out)
         self._check(rc, "dctzhip_psnr_terms")
         return tuple(out)
+
+    def deflate(self, sections):
+        """zlib streams of byte sections, made on the GPU (dctzhip_deflate).  sections: device tensors (any dtype,
+        contiguous); returns a list of uint8 device tensors holding one zlib stream each."""
+        import torch
+        self._bind_stream()
+        k = len(sections)
+        nbytes = [t.numel() * t.element_size() for t in sections]
+        outs = [torch.empty(int(self.lib.dctzhip_deflate_bound(nb)), dtype=torch.uint8, device=sections[0].device if k else "cuda")
+                for nb in nbytes]
+        src = (C.c_void_p * max(k, 1))(*[t.data_ptr() if nb else None for t, nb in zip(sections, nbytes)])
+        dst = (C.c_void_p * max(k, 1))(*[o.data_ptr() for o in outs])
+        n = (C.c_size_t * max(k, 1))(*nbytes)
+        cap = (C.c_size_t * max(k, 1))(*[o.numel() for o in outs])
+        ln = (C.c_size_t * max(k, 1))()
+        rc = self.lib.dctzhip_deflate(self.h, k, src, n, dst, cap, ln)
+        self._check(rc, "dctzhip_deflate")
+        return [o[:int(l)] for o, l in zip(outs, ln)]
 
     # ---- multi-GPU gather of the pre-zlib streams over RCCL (include/dctz_hip.h, dctzhip_comm_*) ----
     @staticmethod

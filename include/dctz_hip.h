@@ -235,6 +235,21 @@ int dctzhip_comm_gather(dctzhip_ctx *ctx, int root, const void *d_bin, const flo
  * the reference's serial loop (relative 1e-15), min / max / maxdiff are exact. */
 int dctzhip_psnr_terms(dctzhip_ctx *ctx, const void *d_x, const void *d_r, size_t n, int dtype, double out[4]);
 
+/* ---- entropy stage on the GPU -------------------------- */
+/* Replaces the reference's zlib tail on the compress side -- deflateInit / deflate of bin_index, DC and AC_exact on
+ * three host threads, dctz-comp-lib.c:620-732 -- with kernels: every section becomes ONE standard zlib stream
+ * (RFC 1950 frame, RFC 1951 blocks) in device memory, which the reference's reader inflates unchanged
+ * (dctz-decomp-lib.c:244-322).  Compressed BYTES differ from zlib's (dynamic-Huffman blocks of 16 KiB of input with
+ * matches at a fixed set of distances; sizes within a few per cent of zlib level 6 on DCTZ streams), inflated CONTENT
+ * is identical.
+ *   nsec      sections of this call (<= 8); they share scratch and run one after the other on the context's stream
+ *   d_src[i]  n[i] bytes, device (4-byte alignment gives the fast load path)
+ *   d_dst[i]  cap[i] >= dctzhip_deflate_bound(n[i]) bytes, device
+ *   out_len   stream lengths; the call returns after the stream has drained (it needs them on the host) */
+size_t dctzhip_deflate_bound(size_t n);
+int dctzhip_deflate(dctzhip_ctx *ctx, int nsec, const void *const *d_src, const size_t *n, void *const *d_dst,
+                    const size_t *cap, size_t *out_len);
+
 /* Diagnostics: element-wise x / divisor computed (a) by the kernels' hoisted-
  * reciprocal division and (b) by the compiler's IEEE division; the two outputs
  * must be bit-identical (tests/test_gpu_parity.py::test_fast_division_is_exact). */

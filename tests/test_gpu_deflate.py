@@ -1,0 +1,148 @@
+"""GPU entropy stage (dctz_amd/csrc/dctz_deflate.hip, include/dctz_hip.h: dctzhip_deflate).
+
+Checker: zlib's own inflate -- what the reference's reader runs on every section (dctz-decomp-lib.c:244-322:
+inflateInit + one inflate per section).  The device stream must inflate to the input exactly, for every size around the
+chunk and segment boundaries, for incompressible, constant and DCTZ-shaped sections; and it must equal, byte for byte, the
+host twin of the same routines (tests/emu/emu_deflate.cpp)."""
+import ctypes as C
+import os
+import subprocess
+import zlib
+
+import numpy as np
+import pytest
+
+from oracle import oracle as O
+from tests import workloads as W
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CHUNK = 128 * 128
+
+
+def twin():
+    so = os.path.join(ROOT, "tests", "emu", "emu_deflate.so")
+    src = os.path.join(ROOT, "tests", "emu", "emu_deflate.cpp")
+    hdr = os.path.join(ROOT, "dctz_amd", "csrc", "deflate_chunk.h")
+    if not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(src), os.path.getmtime(hdr)):
+        subprocess.run(["g++", "-O2", "-std=c++17", "-shared", "-fPIC", "-I", os.path.join(ROOT, "dctz_amd", "csrc"), src, "-o", so], check=True)
+    L = C.CDLL(so)
+    L.emu_deflate.restype = C.c_size_t
+    L.emu_deflate.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_int]
+    L.emu_deflate_bound.restype = C.c_size_t
+    L.emu_deflate_bound.argtypes = [C.c_size_t, C.c_int]
+    return L
+
+
+def twin_deflate(L, data, nthr=128):
+    a = np.frombuffer(data, dtype=np.uint8)
+    cap = L.emu_deflate_bound(len(data), nthr)
+    out = np.zeros(cap, dtype=np.uint8)
+    n = L.emu_deflate(a.ctypes.data if len(data) else None, len(data), out.ctypes.data, cap, nthr)
+    assert n > 0
+    return out[:n].tobytes()
+
+
+def sections():
+    rng = np.random.default_rng(20261004)
+    out = {"empty": b"", "one": b"\x07", "two": b"ab", "three_same": b"zzz"}
+    for n in (127, 128, 129, 255, 256, 257, CHUNK - 1, CHUNK, CHUNK + 1, 3 * CHUNK + 130):
+        out[f"skew{n}"] = rng.choice([127, 128, 126, 255, 3], p=[.8, .1, .05, .03, .02], size=n).astype(np.uint8).tobytes()
+        out[f"rand{n}"] = rng.integers(0, 256, n, dtype=np.uint8).tobytes()
+    out["zeros"] = bytes(5 * CHUNK + 77)
+    out["const"] = b"\x7f" * (2 * CHUNK)
+    out["period64"] = bytes(range(64)) * 1000
+    out["floats"] = rng.standard_normal(70001).astype(np.float32).tobytes()
+    out["all_symbols"] = (bytes(range(256)) * 300)[:CHUNK * 4 + 5]
+    # a distribution that drives code lengths past 15 bits before the repair (Fibonacci-like counts)
+    fib, a, b = [], 1, 1
+    for s in range(24):
+        fib.append(bytes([s]) * a)
+        a, b = b, a + b
+    deep = b"".join(fib)
+    out["deep_tree"] = bytes(rng.permutation(np.frombuffer(deep[:CHUNK], dtype=np.uint8)))
+    return out
+
+
+# ---------------------------------------------------------------- CPU: format of the twin --
+@pytest.mark.parametrize("nthr", [128, 256])
+def test_twin_streams_inflate_to_the_input(nthr):
+    L = twin()
+    for name, data in sections().items():
+        z = twin_deflate(L, data, nthr)
+        assert zlib.decompress(z) == data, name
+        d = zlib.decompressobj()
+        assert d.decompress(z) == data and d.eof and d.unused_data == b"", name      # one complete stream, nothing after it
+        assert len(z) <= L.emu_deflate_bound(len(data), nthr)
+
+
+def test_twin_on_dctz_streams_stays_close_to_zlib():
+    """Container size with the device's method against zlib level 6 (the reference's Z_DEFAULT_COMPRESSION) on the
+    streams of a compress call: within 3 % in total."""
+    L = twin()
+    x = W.c3(96)
+    c = O.compress(x.ravel(), 1e-3, O.EC)
+    ours = ref = 0
+    for arr in (c.bin_index, c.dc, c.ac_exact):
+        b = np.ascontiguousarray(arr).tobytes()
+        z = twin_deflate(L, b)
+        assert zlib.decompress(z) == b
+        ours += len(z)
+        ref += len(zlib.compress(b, 6))
+    assert ours <= 1.03 * ref, (ours, ref)
+
+
+# ---------------------------------------------------------------- GPU --
+@pytest.fixture(scope="module")
+def ctx():
+    import dctz_amd
+    c = dctz_amd.Context(0)
+    yield c
+    c.close()
+
+
+@pytest.mark.gpu
+def test_device_streams_inflate_and_equal_the_twin(ctx):
+    import torch
+    L = twin()
+    cases = sections()
+    names = list(cases)
+    for i in range(0, len(names), 8):                      # up to 8 sections per call
+        part = names[i:i + 8]
+        dev = [torch.from_numpy(np.frombuffer(cases[k], dtype=np.uint8).copy()).to(ctx.device) for k in part]
+        outs = ctx.deflate(dev)
+        for k, o in zip(part, outs):
+            z = o.cpu().numpy().tobytes()
+            assert zlib.decompress(z) == cases[k], k
+            assert z == twin_deflate(L, cases[k]), k
+
+
+@pytest.mark.gpu
+def test_misaligned_source(ctx):
+    import torch
+    rng = np.random.default_rng(5)
+    base = rng.choice([1, 2, 3, 200], p=[.7, .1, .1, .1], size=3 * CHUNK + 11).astype(np.uint8)
+    t = torch.from_numpy(base).to(ctx.device)
+    for sh in (1, 2, 3):
+        z = ctx.deflate([t[sh:]])[0].cpu().numpy().tobytes()
+        assert zlib.decompress(z) == base[sh:].tobytes()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", [O.EC, O.QT])
+def test_streams_of_a_compress_call(ctx, mode):
+    """bin_index / DC / AC_exact as k_compress leaves them in HBM -> three zlib streams; inflated they are the oracle's
+    streams; the total stays within 3 % of zlib level 6."""
+    import torch
+    x = W.c3(128)
+    xd = torch.from_numpy(x.ravel().copy()).to(ctx.device)
+    out, info = ctx.compress(xd, 1e-3, mode)
+    cnt = int(info.cnt)
+    secs = [out["bin_index"], out["dc"], out["ac_exact"][:cnt]]
+    zs = [o.cpu().numpy().tobytes() for o in ctx.deflate(secs)]
+    c = O.compress(x.ravel(), 1e-3, mode)
+    ours = ref = 0
+    for z, want in zip(zs, (c.bin_index, c.dc, c.ac_exact)):
+        assert zlib.decompress(z) == np.ascontiguousarray(want).tobytes()
+        ours += len(z)
+        ref += len(zlib.compress(np.ascontiguousarray(want).tobytes(), 6))
+    assert ours <= 1.03 * ref, (ours, ref)
