@@ -9,7 +9,7 @@
 //                      alphabet) -> canonical codes -> bit counts + workgroup scan -> stored or dynamic -> emit
 //                      -> slot in scratch (HBM), byte count per chunk.
 // k_deflate_scan     byte offsets of the chunks inside the section (one workgroup).
-// k_deflate_gather   slots -> one contiguous stream: 78 9C | chunks | 03 00 | adler32; section length to the host box.
+// k_deflate_gather   slots -> one contiguous stream: 78 5E | chunks | 03 00 | adler32; section length to the host box.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -101,7 +101,7 @@ __global__ __launch_bounds__(NTHR) void k_deflate_chunks(const uint8_t* __restri
   const int tid = threadIdx.x;
   const unsigned long long off = (unsigned long long)blockIdx.x * CHUNK;
   const int len = (int)((n - off) < (unsigned long long)CHUNK ? (n - off) : (unsigned long long)CHUNK);
-  const int avail = off < (unsigned long long)HIST ? (int)off : HIST;
+  const int avail = 0;                                   // nothing in front of the chunk is referenced (deflate_chunk.h)
   uint8_t* slot = slots + (size_t)blockIdx.x * SLOT;
 
   // ---- load: history + chunk, dwords when the source allows it
@@ -319,7 +319,8 @@ __global__ __launch_bounds__(256) void k_deflate_gather(const uint8_t* __restric
                                                         unsigned long long* __restrict__ box_len) {
   const unsigned long long total = offs[nchunks];
   if (blockIdx.x == 0 && threadIdx.x == 0) {
-    dst[0] = 0x78; dst[1] = 0x9C;
+    dst[0] = 0x78; dst[1] = 0x5E;                        // FLG: "fastest algorithm" hint, no preset dictionary -- and this library's mark for
+                                                         // "the deflate blocks are independent chunks" (include/dctz.h: DCTZ_IX_MAGIC)
     uint8_t* t = dst + 2 + total;
     t[0] = 0x03; t[1] = 0x00;
     const uint32_t s1 = (uint32_t)((1 + adler_acc[0]) % ADLER_M), s2 = (uint32_t)((n % ADLER_M + adler_acc[1]) % ADLER_M);
@@ -351,7 +352,7 @@ size_t deflate_bound(size_t n) {
   return n + 5 * nch + 8;
 }
 
-hipError_t launch_deflate(const void* src, size_t n, void* dst, void* scratch, unsigned long long* box_len, hipStream_t st) {
+hipError_t launch_deflate(const void* src, size_t n, void* dst, void* scratch, unsigned long long* box_len, uint32_t* host_sizes, hipStream_t st) {
   const size_t nch = (n + dfl::CHUNK - 1) / dfl::CHUNK;
   uint8_t* slots = (uint8_t*)scratch;
   uint32_t* sizes = (uint32_t*)(slots + nch * dfl::SLOT);
@@ -360,6 +361,10 @@ hipError_t launch_deflate(const void* src, size_t n, void* dst, void* scratch, u
   hipError_t e = hipMemsetAsync(adler, 0, 16, st);
   if (e != hipSuccess) return e;
   if (nch) hipLaunchKernelGGL(dfl::k_deflate_chunks, dim3((unsigned)nch), dim3(dfl::NTHR), 0, st, (const uint8_t*)src, (unsigned long long)n, slots, sizes, adler);
+  if (nch && host_sizes) {                             // the chunk index of the section (bytes per chunk), for whoever writes a container
+    e = hipMemcpyAsync(host_sizes, sizes, nch * sizeof(uint32_t), hipMemcpyDeviceToHost, st);
+    if (e != hipSuccess) return e;
+  }
   hipLaunchKernelGGL(dfl::k_deflate_scan, dim3(1), dim3(1024), 0, st, sizes, (uint32_t)nch, offs);
   const unsigned g = nch ? (unsigned)(nch < 4096 ? nch : 4096) : 1u;
   hipLaunchKernelGGL(dfl::k_deflate_gather, dim3(g), dim3(256), 0, st, slots, sizes, offs, (uint32_t)nch, (unsigned long long)n, adler, (uint8_t*)dst, box_len);

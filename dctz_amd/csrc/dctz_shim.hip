@@ -287,9 +287,10 @@ template <typename P> static int regrow(dctzhip_ctx* c, P** ptr, size_t* cap, si
 // one zlib stream that inflate() reads (dctz-decomp-lib.c:244-322); the bytes differ from zlib's own (so do zlib's
 // between versions), the inflated content is identical.
 extern "C" size_t dctzhip_deflate_bound(size_t n) { return deflate_bound(n); }
+extern "C" size_t dctzhip_deflate_chunk_bytes(void) { return deflate_chunk_bytes(); }
 
 extern "C" int dctzhip_deflate(dctzhip_ctx* c, int nsec, const void* const* d_src, const size_t* n, void* const* d_dst, const size_t* cap,
-                               size_t* out_len) {
+                               size_t* out_len, uint32_t* const* chunk_sizes) {
   if (!c || nsec < 0 || nsec > 8 || (nsec && (!d_src || !n || !d_dst || !cap || !out_len))) return fail(c, DCTZHIP_E_ARG, "dctzhip_deflate: bad arguments");
   HIPCHK(c, hipSetDevice(c->device));
   if (!c->dfl_len) {
@@ -313,7 +314,7 @@ extern "C" int dctzhip_deflate(dctzhip_ctx* c, int nsec, const void* const* d_sr
   // the sections run one after the other on the stream, so they share the scratch
   for (int i = 0; i < nsec; i++) {
     c->dfl_len[i] = 0;
-    HIPCHK(c, launch_deflate(d_src[i], n[i], d_dst[i], c->dfl_buf, c->dfl_len_dev + i, c->stream));
+    HIPCHK(c, launch_deflate(d_src[i], n[i], d_dst[i], c->dfl_buf, c->dfl_len_dev + i, chunk_sizes ? chunk_sizes[i] : nullptr, c->stream));
   }
   HIPCHK(c, hipStreamSynchronize(c->stream));
   for (int i = 0; i < nsec; i++) out_len[i] = (size_t)c->dfl_len[i];

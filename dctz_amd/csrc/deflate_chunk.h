@@ -7,14 +7,15 @@
 // that is left once the block-DCT stage runs on the GPU.  The stream stays what the reference's reader inflates
 // (dctz-decomp-lib.c:244-322: inflateInit + inflate of one zlib stream per section): RFC 1950 framing, RFC 1951 blocks.
 //
-// Format of one section:   78 9C | chunk 0 | chunk 1 | ... | 03 00 | adler32 (big endian)
+// Format of one section:   78 5E | chunk 0 | chunk 1 | ... | 03 00 | adler32 (big endian)
 // Every chunk (CHUNK input bytes) is one deflate block, not final, ending on a byte boundary:
 //   - dynamic Huffman block (BTYPE 10) followed by an empty stored block (the "sync flush" marker 00 00 FF FF), or
 //   - one stored block (BTYPE 00) when that is smaller.
 // 03 00 is the final, empty fixed-Huffman block.  Matches are searched at a fixed set of distances only (runs, the
 // previous block's pattern 64 positions back, ...) and never leave the 128-byte segment of the lane that found them, so
-// that every lane parses its segment without waiting for a neighbour; distances reach back across segment and chunk
-// boundaries (the whole input is resident in HBM).
+// that every lane parses its segment without waiting for a neighbour; distances reach back across segment boundaries but
+// never across the start of the chunk: every chunk is a deflate block that can be inflated on its own, given where it
+// starts (the container's chunk index, include/dctz.h: "DZIX", lets a reader inflate the chunks of a section in parallel).
 #pragma once
 #include <stdint.h>
 
@@ -30,7 +31,7 @@ namespace dfl {
 enum : int {
   SEG = 128,             // bytes one lane tokenises
   SEG_SHIFT = 7,
-  HIST = 256,            // bytes kept in front of the chunk (>= the largest candidate distance)
+  HIST = 0,              // bytes of the previous chunk a match may reach into: none (chunks inflate independently)
   NCAND = 8,             // candidate distances
   NLIT = 286,            // literal / length alphabet in use (0..255, 256 = end of block, 257..285)
   NDIST = 30,

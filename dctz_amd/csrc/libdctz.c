@@ -29,6 +29,7 @@
 #include "dctz.h"
 
 #include <pthread.h>
+#include <unistd.h>
 #include "pdeflate.h"
 #include <stdint.h>
 #include <sys/time.h>
@@ -50,8 +51,8 @@
 /* ------------------------------------------------------------------ state -- */
 static dctzhip_ctx *g_ctx = NULL;
 static struct {
-  void *in, *bin, *dc, *ac, *out;
-  size_t in_cap, bin_cap, dc_cap, ac_cap, out_cap;
+  void *in, *bin, *dc, *ac, *out, *z[3];
+  size_t in_cap, bin_cap, dc_cap, ac_cap, out_cap, z_cap[3];
 } g_dev;
 static dctz_stage_times g_times;
 /* multi-dimensional blocks requested for the next dctz_compress call (dctz.h: dctz_set_block_dims) */
@@ -72,6 +73,11 @@ static int quiet(void) { return getenv("DCTZ_QUIET") != NULL; }
  * DCTZ_ZLIB_CHUNK: bytes per deflate job (default 256 KiB).  DCTZ_ZLIB_LEVEL: 1..9 for the chunked tail
  * only (default: zlib's default level, as the reference; a lower level trades ratio for host time). */
 static int zlib_threads(void) { const char *e = getenv("DCTZ_ZLIB_THREADS"); return e ? atoi(e) : 0; }
+/* DCTZ_ZLIB_GPU=1: the entropy stage runs on the device too (include/dctz_hip.h: dctzhip_deflate):
+ * the three sections are deflated where k_compress left them and only compressed bytes come back over PCIe.  One zlib
+ * stream per section as before (any inflate reads it, dctz-decomp-lib.c:244-322); the bytes -- and the sizes, by a per
+ * cent or so -- differ from zlib's, which is why the reference's tail stays the default. */
+static int zlib_gpu(void) { const char *e = getenv("DCTZ_ZLIB_GPU"); return e && atoi(e) != 0; }
 static size_t zlib_chunk(void) {
   const char *e = getenv("DCTZ_ZLIB_CHUNK");
   long long v = e ? atoll(e) : 0;
@@ -266,6 +272,97 @@ static void *inflate_main(void *arg) {
   return NULL;
 }
 
+/* ---- sections whose deflate blocks are independent chunks ("DZIX" trailer, dctz.h): inflated side by side ---- */
+typedef struct {
+  const unsigned char *src;   /* chunk bytes (raw deflate, byte aligned) */
+  unsigned int zlen;
+  unsigned char *dst;
+  unsigned int len;           /* bytes the chunk must inflate to */
+  uLong adler;
+  int err;
+} ix_chunk;
+typedef struct {
+  ix_chunk *chunks;
+  size_t nchunks, next;
+  pthread_mutex_t mu;
+} ix_queue;
+static void *ix_worker(void *arg) {
+  ix_queue *q = (ix_queue *)arg;
+  for (;;) {
+    pthread_mutex_lock(&q->mu);
+    size_t lo = q->next, hi = lo + 16 < q->nchunks ? lo + 16 : q->nchunks;   /* a few chunks per visit to the counter */
+    q->next = hi;
+    pthread_mutex_unlock(&q->mu);
+    if (lo >= hi) break;
+    for (size_t i = lo; i < hi; i++) {
+      ix_chunk *c = &q->chunks[i];
+      z_stream zs;
+      memset(&zs, 0, sizeof(zs));
+      if (inflateInit2(&zs, -15) != Z_OK) { c->err = 1; continue; }
+      zs.next_in = (Bytef *)c->src; zs.avail_in = c->zlen;
+      zs.next_out = c->dst; zs.avail_out = c->len;
+      const int rc = inflate(&zs, Z_SYNC_FLUSH);
+      if ((rc != Z_OK && rc != Z_BUF_ERROR) || zs.avail_in != 0 || zs.avail_out != 0) c->err = 1;
+      inflateEnd(&zs);
+      c->adler = adler32(adler32(0L, Z_NULL, 0), c->dst, c->len);
+    }
+  }
+  return NULL;
+}
+/* Returns 1 when the three sections were inflated through the index, 0 when there is no (valid) index: the caller then
+ * takes the ordinary path.  sec/zlen: the sections; dst/raw: where they inflate to and how many bytes that must be. */
+static int inflate_indexed(const unsigned char *const sec[3], const unsigned int zlen[3], unsigned char *const dst[3], const size_t raw[3],
+                           const unsigned char *trailer) {
+  for (int i = 0; i < 3; i++) if (zlen[i] < 8 || sec[i][0] != 0x78 || sec[i][1] != 0x5E) return 0;
+  unsigned int hd[5];
+  memcpy(hd, trailer, sizeof(hd));
+  if (hd[0] != DCTZ_IX_MAGIC || hd[1] < 1024 || hd[1] > 65535) return 0;
+  const size_t chunk = hd[1];
+  size_t total = 0;
+  for (int i = 0; i < 3; i++) { if (hd[2 + i] != (raw[i] + chunk - 1) / chunk) return 0; total += hd[2 + i]; }
+  ix_chunk *chunks = (ix_chunk *)calloc(total ? total : 1, sizeof(ix_chunk));
+  if (!chunks) return 0;
+  const unsigned short *e = (const unsigned short *)(trailer + sizeof(hd));
+  size_t k = 0;
+  for (int i = 0; i < 3; i++) {
+    size_t off = 2;
+    for (size_t j = 0; j < hd[2 + i]; j++, k++) {
+      unsigned short z;
+      memcpy(&z, e + k, sizeof(z));
+      chunks[k].src = sec[i] + off; chunks[k].zlen = z;
+      chunks[k].dst = dst[i] + j * chunk;
+      chunks[k].len = (unsigned int)(raw[i] - j * chunk < chunk ? raw[i] - j * chunk : chunk);
+      off += z;
+    }
+    if (off + 6 != zlen[i] || sec[i][off] != 0x03 || sec[i][off + 1] != 0x00) { free(chunks); return 0; }   /* the sizes must tile the stream */
+  }
+  int threads = zlib_threads();
+  if (threads <= 0) { long nc = sysconf(_SC_NPROCESSORS_ONLN); threads = nc > 32 ? 32 : (nc < 1 ? 1 : (int)nc); }
+  if ((size_t)threads > total) threads = total ? (int)total : 1;
+  ix_queue q;
+  q.chunks = chunks; q.nchunks = total; q.next = 0;
+  pthread_mutex_init(&q.mu, NULL);
+  pthread_t *th = (pthread_t *)malloc(sizeof(pthread_t) * (size_t)threads);
+  int started = 0;
+  if (th) for (int t = 0; t < threads - 1; t++) { if (pthread_create(&th[started], NULL, ix_worker, &q)) break; started++; }
+  ix_worker(&q);
+  for (int t = 0; t < started; t++) pthread_join(th[t], NULL);
+  free(th);
+  pthread_mutex_destroy(&q.mu);
+  int ok = 1;
+  k = 0;
+  for (int i = 0; i < 3 && ok; i++) {                   /* what inflate() checks at the end of a stream: the adler32 of the content */
+    uLong a = adler32(0L, Z_NULL, 0);
+    for (size_t j = 0; j < hd[2 + i]; j++, k++) { if (chunks[k].err) ok = 0; a = adler32_combine(a, chunks[k].adler, (z_off_t)chunks[k].len); }
+    const unsigned char *t = sec[i] + zlen[i] - 4;
+    const uLong want = ((uLong)t[0] << 24) | ((uLong)t[1] << 16) | ((uLong)t[2] << 8) | (uLong)t[3];
+    if (a != want) ok = 0;
+  }
+  free(chunks);
+  if (!ok) { fprintf(stderr, "libdctz: a chunk of an indexed section does not inflate\n"); exit(1); }
+  return 1;
+}
+
 static void dump_file(const char *name, const void *p, size_t bytes) {
   FILE *fp = fopen(name, "wb");
   if (!fp) return;
@@ -346,7 +443,8 @@ int dctz_compress(t_var *var, int N, size_t *outSize, t_var *var_z, double error
   /* a2..a9 on the GPU; the scaled array is produced in place on the device and
    * copied back over the caller's buffer (the reference's in-place "/= sf") */
   dctzhip_cinfo info;
-  const int fast_tail = zlib_threads() > 3;
+  const int gpu_tail = zlib_gpu();
+  const int fast_tail = gpu_tail || zlib_threads() > 3;
   pthread_t mean_thread;
   host_mean_job mj = {host_in, n, is_d, 0.0};
   int mean_on_host = 0;
@@ -360,14 +458,20 @@ int dctz_compress(t_var *var, int N, size_t *outSize, t_var *var_z, double error
   if (dctzhip_sync(c) != DCTZHIP_OK) die("sync");   /* (the call returns while its last kernels drain: keep the stage timers honest) */
   double t2 = now_s();
 
-  t_bin_id *bin_index = (t_bin_id *)malloc(npos);
-  float *DC = (float *)malloc(nblk * sizeof(float));
-  float *AC_exact = (float *)malloc((info.cnt ? info.cnt : 1) * sizeof(float));
-  if (!bin_index || !DC || !AC_exact) { fprintf(stderr, "Out of memory: streams\n"); exit(1); }
-  if (dctzhip_memcpy_d2h(c, bin_index, g_dev.bin, npos) != DCTZHIP_OK) die("D2H bin_index");
-  if (dctzhip_memcpy_d2h(c, DC, g_dev.dc, nblk * sizeof(float)) != DCTZHIP_OK) die("D2H DC");
-  if (info.cnt && dctzhip_memcpy_d2h(c, AC_exact, g_dev.ac, (size_t)info.cnt * sizeof(float)) != DCTZHIP_OK)
-    die("D2H AC_exact");
+  /* raw streams on the host: what the host zlib tails read, and what the dump taps write */
+  const int want_raw = !gpu_tail || getenv("DCTZ_DUMP_STREAMS") != NULL;
+  t_bin_id *bin_index = NULL;
+  float *DC = NULL, *AC_exact = NULL;
+  if (want_raw) {
+    bin_index = (t_bin_id *)malloc(npos);
+    DC = (float *)malloc(nblk * sizeof(float));
+    AC_exact = (float *)malloc((info.cnt ? info.cnt : 1) * sizeof(float));
+    if (!bin_index || !DC || !AC_exact) { fprintf(stderr, "Out of memory: streams\n"); exit(1); }
+    if (dctzhip_memcpy_d2h(c, bin_index, g_dev.bin, npos) != DCTZHIP_OK) die("D2H bin_index");
+    if (dctzhip_memcpy_d2h(c, DC, g_dev.dc, nblk * sizeof(float)) != DCTZHIP_OK) die("D2H DC");
+    if (info.cnt && dctzhip_memcpy_d2h(c, AC_exact, g_dev.ac, (size_t)info.cnt * sizeof(float)) != DCTZHIP_OK)
+      die("D2H AC_exact");
+  }
   double t3 = now_s();
 
   if (getenv("DCTZ_DUMP_STREAMS")) { /* dctz-comp-lib.c:583-595, :443-448 */
@@ -391,7 +495,27 @@ int dctz_compress(t_var *var, int N, size_t *outSize, t_var *var_z, double error
   pthread_t pd_thread;
   pd_args pda;
   size_t pd_len[3] = {0, 0, 0};
-  if (zthreads > 3) {                       /* chunked deflate, one pool for all three sections */
+  size_t gz_len[3] = {0, 0, 0};
+  uint32_t *ix[3] = {NULL, NULL, NULL};     /* compressed bytes per chunk, for the "DZIX" trailer */
+  size_t ix_n[3] = {0, 0, 0};
+  if (gpu_tail) {                           /* deflate on the device, compressed bytes only over PCIe */
+    const void *gsrc[3] = {g_dev.bin, g_dev.dc, g_dev.ac};
+    size_t gcap[3];
+    for (int i = 0; i < 3; i++) {
+      gcap[i] = dctzhip_deflate_bound(sec_bytes[i]);
+      grow(&g_dev.z[i], &g_dev.z_cap[i], gcap[i]);
+      ix_n[i] = (sec_bytes[i] + dctzhip_deflate_chunk_bytes() - 1) / dctzhip_deflate_chunk_bytes();
+      ix[i] = (uint32_t *)malloc((ix_n[i] ? ix_n[i] : 1) * sizeof(uint32_t));
+      if (!ix[i]) { fprintf(stderr, "Out of memory: chunk index\n"); exit(1); }
+    }
+    if (dctzhip_deflate(c, 3, gsrc, sec_bytes, (void *const *)g_dev.z, gcap, gz_len, (uint32_t *const *)ix) != DCTZHIP_OK) die("dctzhip_deflate");
+    /* the sections go straight from the device into the caller's container, behind the header (:775-820) */
+    unsigned char *zc = (is_d ? (unsigned char *)var_z->buf.d : (unsigned char *)var_z->buf.f) + sizeof(struct header);
+    for (int i = 0; i < 3; i++) {
+      if (dctzhip_memcpy_d2h(c, zc, g_dev.z[i], gz_len[i]) != DCTZHIP_OK) die("D2H compressed section");
+      zc += gz_len[i];
+    }
+  } else if (zthreads > 3) {                /* chunked deflate, one pool for all three sections */
     for (int i = 0; i < 3; i++) {
       jb[i].bound = (uLong)dctz_pdeflate_bound(sec_bytes[i], zlib_chunk());
       jb[i].dst = (Bytef *)malloc(jb[i].bound);
@@ -417,7 +541,9 @@ int dctz_compress(t_var *var, int N, size_t *outSize, t_var *var_z, double error
   }
 
   uLong zsz[3];
-  if (zthreads > 3) {
+  if (gpu_tail) {
+    for (int i = 0; i < 3; i++) zsz[i] = (uLong)gz_len[i];
+  } else if (zthreads > 3) {
     pthread_join(pd_thread, NULL);
     if (pda.rc) { fprintf(stderr, "libdctz: parallel deflate failed (%d)\n", pda.rc); exit(1); }
     for (int i = 0; i < 3; i++) zsz[i] = (uLong)pd_len[i];
@@ -449,11 +575,16 @@ int dctz_compress(t_var *var, int N, size_t *outSize, t_var *var_z, double error
   *outSize += BLK_SZ * ts;
 #endif
   if (nd) *outSize += 16;                      /* "DZND" + the extents */
+  const size_t ix_bytes = gpu_tail ? ((20 + 2 * (ix_n[0] + ix_n[1] + ix_n[2]) + 3) & ~(size_t)3) : 0;
+  *outSize += ix_bytes;                        /* "DZIX" chunk index (dctz.h) */
   unsigned char *cur = is_d ? (unsigned char *)var_z->buf.d : (unsigned char *)var_z->buf.f;
   memcpy(cur, &h, sizeof(h)); cur += sizeof(h);
-  memcpy(cur, jb[0].dst, zsz[0]); cur += zsz[0];
-  memcpy(cur, jb[1].dst, zsz[1]); cur += zsz[1];
-  memcpy(cur, jb[2].dst, zsz[2]); cur += zsz[2];
+  if (gpu_tail) cur += zsz[0] + zsz[1] + zsz[2];         /* already in place */
+  else {
+    memcpy(cur, jb[0].dst, zsz[0]); cur += zsz[0];
+    memcpy(cur, jb[1].dst, zsz[1]); cur += zsz[1];
+    memcpy(cur, jb[2].dst, zsz[2]); cur += zsz[2];
+  }
 #ifdef USE_QTABLE
   if (is_d) memcpy(cur, info.qtable, BLK_SZ * sizeof(double));
   else { float q[BLK_SZ]; for (int j = 0; j < BLK_SZ; j++) q[j] = (float)info.qtable[j]; memcpy(cur, q, sizeof(q)); }
@@ -462,6 +593,17 @@ int dctz_compress(t_var *var, int N, size_t *outSize, t_var *var_z, double error
   if (nd) {
     const unsigned int tr[4] = {DCTZ_ND_MAGIC, (unsigned int)dims[0], (unsigned int)dims[1], (unsigned int)(nd == 3 ? dims[2] : 0)};
     memcpy(cur, tr, sizeof(tr));
+    cur += sizeof(tr);
+  }
+  if (gpu_tail) {
+    const unsigned int hd[5] = {DCTZ_IX_MAGIC, (unsigned int)dctzhip_deflate_chunk_bytes(), (unsigned int)ix_n[0], (unsigned int)ix_n[1], (unsigned int)ix_n[2]};
+    memset(cur, 0, ix_bytes);
+    memcpy(cur, hd, sizeof(hd));
+    unsigned short *e = (unsigned short *)(cur + sizeof(hd));
+    for (int i = 0; i < 3; i++) {
+      for (size_t k = 0; k < ix_n[i]; k++) *e++ = (unsigned short)ix[i][k];
+      free(ix[i]);
+    }
   }
   for (int i = 0; i < 3; i++) free(jb[i].dst);
   free(bin_index); free(DC); free(AC_exact);
@@ -578,7 +720,21 @@ int dctz_decompress(t_var *var_z, t_var *var_r) {
   double t0 = now_s();
   /* three inflates, in order (dctz-decomp-lib.c:244-322) */
   uLong got;
-  if (zlib_threads() > 3) {                 /* the sections are independent streams: inflate them side by side */
+  const unsigned int zl[3] = {h.bindex_sz_compressed, h.DC_sz_compressed, h.AC_exact_sz_compressed};
+  const unsigned char *const secp[3] = {cur, cur + zl[0], cur + zl[0] + zl[1]};
+  unsigned char *const rawp[3] = {(unsigned char *)bin_index, (unsigned char *)DC, (unsigned char *)AC_exact};
+  const size_t rawn[3] = {npos, nblk * sizeof(float), (size_t)cnt * sizeof(float)};
+  size_t ix_off = (size_t)zl[0] + zl[1] + zl[2] + (nd ? 16 : 0);
+#ifdef USE_QTABLE
+  ix_off += BLK_SZ * ts;
+#endif
+  /* sections written by the GPU entropy stage start 78 5E and bring a chunk index: only then are the bytes behind the
+   * container looked at */
+  if (zl[0] >= 8 && zl[1] >= 8 && zl[2] >= 8 && secp[0][1] == 0x5E && secp[1][1] == 0x5E && secp[2][1] == 0x5E &&
+      inflate_indexed(secp, zl, rawp, rawn, cur + ix_off)) {
+    got = (uLong)npos;
+    cur += (size_t)zl[0] + zl[1] + zl[2];
+  } else if (zlib_threads() > 3) {                 /* the sections are independent streams: inflate them side by side */
     inflate_job ij[3] = {{cur, h.bindex_sz_compressed, (uLong)npos, 0, bin_index},
                          {cur + h.bindex_sz_compressed, h.DC_sz_compressed, (uLong)(nblk * sizeof(float)), 0, DC},
                          {cur + h.bindex_sz_compressed + h.DC_sz_compressed, h.AC_exact_sz_compressed,

@@ -79,8 +79,9 @@ _PROTOS = {
                                        C.c_void_p]),
     "dctzhip_psnr_terms": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.POINTER(C.c_double)]),
     "dctzhip_deflate_bound": (C.c_size_t, [C.c_size_t]),
+    "dctzhip_deflate_chunk_bytes": (C.c_size_t, []),
     "dctzhip_deflate": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), C.POINTER(C.c_void_p),
-                                  C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]),
+                                  C.POINTER(C.c_size_t), C.POINTER(C.c_size_t), C.POINTER(C.c_void_p)]),
     "dctzhip_comm_unique_id": (C.c_int, [C.c_void_p]),
     "dctzhip_comm_create": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "dctzhip_comm_destroy": (C.c_int, [C.c_void_p]),
@@ -271,9 +272,10 @@ class Context:
         self._check(rc, "dctzhip_psnr_terms")
         return tuple(out)
 
-    def deflate(self, sections):
+    def deflate(self, sections, want_index=False):
         """zlib streams of byte sections, made on the GPU (dctzhip_deflate).  sections: device tensors (any dtype,
-        contiguous); returns a list of uint8 device tensors holding one zlib stream each."""
+        contiguous); returns a list of uint8 device tensors holding one zlib stream each -- with want_index also the
+        list of per-chunk compressed sizes (numpy uint32) of every section."""
         import torch
         self._bind_stream()
         k = len(sections)
@@ -285,9 +287,15 @@ class Context:
         n = (C.c_size_t * max(k, 1))(*nbytes)
         cap = (C.c_size_t * max(k, 1))(*[o.numel() for o in outs])
         ln = (C.c_size_t * max(k, 1))()
-        rc = self.lib.dctzhip_deflate(self.h, k, src, n, dst, cap, ln)
+        chunk = int(self.lib.dctzhip_deflate_chunk_bytes())
+        idx = [np.zeros(max(1, (nb + chunk - 1) // chunk), np.uint32) for nb in nbytes]
+        ix = (C.c_void_p * max(k, 1))(*[a.ctypes.data for a in idx])
+        rc = self.lib.dctzhip_deflate(self.h, k, src, n, dst, cap, ln, ix if want_index else None)
         self._check(rc, "dctzhip_deflate")
-        return [o[:int(l)] for o, l in zip(outs, ln)]
+        zs = [o[:int(l)] for o, l in zip(outs, ln)]
+        if want_index:
+            return zs, [a[:(nb + chunk - 1) // chunk] for a, nb in zip(idx, nbytes)]
+        return zs
 
     # ---- multi-GPU gather of the pre-zlib streams over RCCL (include/dctz_hip.h, dctzhip_comm_*) ----
     @staticmethod

@@ -137,6 +137,13 @@ int dctz_set_block_dims(int ndims, const size_t *dims);
 #define DCTZ_GEOM_OF(datatype) (((unsigned)(datatype) >> DCTZ_GEOM_SHIFT) & 0xffu)   /* 0: flat; 2, 3: number of axes */
 #define DCTZ_TYPE_OF(datatype) ((t_datatype)((unsigned)(datatype) & 0xffu))
 #define DCTZ_ND_MAGIC 0x444E5A44u   /* "DZND" little-endian */
+/* Chunk index (optional trailer, written when the entropy stage ran on the GPU: DCTZ_ZLIB_GPU=1).  The three sections
+ * are then standard zlib streams whose deflate blocks are independent chunks (header bytes 78 5E instead of zlib's
+ * 78 9C; include/dctz_hip.h: dctzhip_deflate), and behind everything else of the container follow
+ *   "DZIX" | u32 chunk bytes | u32 chunks of section 0, 1, 2 | u16 compressed bytes of every chunk ... | pad to 4.
+ * The reference's reader never looks there (it inflates each section as one stream, dctz-decomp-lib.c:244-322);
+ * dctz_decompress here inflates the chunks side by side on DCTZ_ZLIB_THREADS host threads (default: the cores). */
+#define DCTZ_IX_MAGIC 0x58495A44u   /* "DZIX" little-endian */
 /* Stage timers of the last dctz_compress / dctz_decompress call, seconds
  * (the reference's -DTIME_DEBUG split, dctz-comp-lib.c:762-773). */
 typedef struct {

@@ -245,10 +245,16 @@ int dctzhip_psnr_terms(dctzhip_ctx *ctx, const void *d_x, const void *d_r, size_
  *   nsec      sections of this call (<= 8); they share scratch and run one after the other on the context's stream
  *   d_src[i]  n[i] bytes, device (4-byte alignment gives the fast load path)
  *   d_dst[i]  cap[i] >= dctzhip_deflate_bound(n[i]) bytes, device
- *   out_len   stream lengths; the call returns after the stream has drained (it needs them on the host) */
+ *   out_len   stream lengths; the call returns after the stream has drained (it needs them on the host)
+ *   chunk_sizes  NULL, or per section a host array of ceil(n[i] / dctzhip_deflate_chunk_bytes()) entries (or NULL) that
+ *             receives the compressed bytes of every chunk.  The stream is 2 bytes of zlib header (78 5E), the chunks
+ *             back to back, 03 00 and the adler32; every chunk is a raw deflate block sequence that starts and ends on a
+ *             byte boundary and references nothing in front of itself, so a reader that knows these sizes can inflate
+ *             the chunks in parallel (the drop-in library stores them as the container's "DZIX" trailer). */
 size_t dctzhip_deflate_bound(size_t n);
+size_t dctzhip_deflate_chunk_bytes(void);
 int dctzhip_deflate(dctzhip_ctx *ctx, int nsec, const void *const *d_src, const size_t *n, void *const *d_dst,
-                    const size_t *cap, size_t *out_len);
+                    const size_t *cap, size_t *out_len, uint32_t *const *chunk_sizes);
 
 /* Diagnostics: element-wise x / divisor computed (a) by the kernels' hoisted-
  * reciprocal division and (b) by the compiler's IEEE division; the two outputs

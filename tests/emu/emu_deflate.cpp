@@ -50,17 +50,21 @@ extern "C" size_t emu_deflate_bound(size_t n, int nthr) {
 }
 
 // returns the stream length (0 if cap is too small)
-extern "C" size_t emu_deflate(const uint8_t* src, size_t n, uint8_t* dst, size_t cap, int nthr) {
+static size_t emu_deflate_ix(const uint8_t* src, size_t n, uint8_t* dst, size_t cap, int nthr, uint32_t* sizes);
+extern "C" size_t emu_deflate(const uint8_t* src, size_t n, uint8_t* dst, size_t cap, int nthr) { return emu_deflate_ix(src, n, dst, cap, nthr, nullptr); }
+// the same, and the compressed bytes of every chunk (the container's chunk index)
+extern "C" size_t emu_deflate_index(const uint8_t* src, size_t n, uint8_t* dst, size_t cap, int nthr, uint32_t* sizes) { return emu_deflate_ix(src, n, dst, cap, nthr, sizes); }
+static size_t emu_deflate_ix(const uint8_t* src, size_t n, uint8_t* dst, size_t cap, int nthr, uint32_t* sizes) {
   const size_t chunk = (size_t)nthr * SEG;
   if (cap < emu_deflate_bound(n, nthr)) return 0;
   size_t pos = 0;
-  dst[pos++] = 0x78; dst[pos++] = 0x9C;
+  dst[pos++] = 0x78; dst[pos++] = 0x5E;
   uint32_t s1 = 1, s2 = 0;
   for (size_t i = 0; i < n; i++) { s1 = (s1 + src[i]) % 65521u; s2 = (s2 + s1) % 65521u; }
   std::vector<uint8_t> tok(chunk + 2);
   for (size_t off = 0; off < n; off += chunk) {
     const int len = (int)std::min(chunk, n - off);
-    const int avail = (int)std::min<size_t>(off, HIST);
+    const int avail = 0;
     const uint8_t* base = src + off;
     auto in = [&](int i) -> int { return base[i]; };
     uint32_t fl[NLIT] = {0}, fd[NDIST] = {0}, fc[NCL] = {0};
@@ -109,6 +113,7 @@ extern "C" size_t emu_deflate(const uint8_t* src, size_t n, uint8_t* dst, size_t
       dst[pos++] = (uint8_t)(~len & 255); dst[pos++] = (uint8_t)((~len >> 8) & 255);
       memcpy(dst + pos, base, len);
       pos += len;
+      if (sizes) sizes[off / chunk] = stored_bytes;
       continue;
     }
     Words out;
@@ -150,6 +155,7 @@ extern "C" size_t emu_deflate(const uint8_t* src, size_t n, uint8_t* dst, size_t
     out.w.resize(dyn_bytes / 4 + 2, 0);
     memcpy(dst + pos, out.w.data(), dyn_bytes);
     pos += dyn_bytes;
+    if (sizes) sizes[off / chunk] = dyn_bytes;
   }
   dst[pos++] = 0x03; dst[pos++] = 0x00;
   dst[pos++] = (uint8_t)(s2 >> 8); dst[pos++] = (uint8_t)s2; dst[pos++] = (uint8_t)(s1 >> 8); dst[pos++] = (uint8_t)s1;

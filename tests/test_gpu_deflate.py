@@ -28,18 +28,41 @@ def twin():
     L = C.CDLL(so)
     L.emu_deflate.restype = C.c_size_t
     L.emu_deflate.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_int]
+    L.emu_deflate_index.restype = C.c_size_t
+    L.emu_deflate_index.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p]
     L.emu_deflate_bound.restype = C.c_size_t
     L.emu_deflate_bound.argtypes = [C.c_size_t, C.c_int]
     return L
 
 
-def twin_deflate(L, data, nthr=128):
+def twin_deflate(L, data, nthr=128, want_index=False):
     a = np.frombuffer(data, dtype=np.uint8)
     cap = L.emu_deflate_bound(len(data), nthr)
     out = np.zeros(cap, dtype=np.uint8)
-    n = L.emu_deflate(a.ctypes.data if len(data) else None, len(data), out.ctypes.data, cap, nthr)
+    chunk = nthr * 128
+    sizes = np.zeros(max(1, (len(data) + chunk - 1) // chunk), np.uint32)
+    n = L.emu_deflate_index(a.ctypes.data if len(data) else None, len(data), out.ctypes.data, cap, nthr, sizes.ctypes.data)
     assert n > 0
+    if want_index:
+        return out[:n].tobytes(), sizes[:(len(data) + chunk - 1) // chunk]
     return out[:n].tobytes()
+
+
+def inflate_by_index(z, sizes, n, chunk=CHUNK):
+    """What a reader with the chunk index does: every chunk is a raw deflate stream of its own."""
+    assert z[:2] == b"\x78\x5e"
+    out, off = [], 2
+    for j, sz in enumerate(sizes):
+        d = zlib.decompressobj(-15)
+        piece = d.decompress(z[off:off + int(sz)])
+        assert d.unconsumed_tail == b"" and d.unused_data == b"" and not d.eof      # all of it read, no final block inside
+        assert len(piece) == min(chunk, n - j * chunk)
+        out.append(piece)
+        off += int(sz)
+    assert z[off:off + 2] == b"\x03\x00" and off + 6 == len(z)
+    data = b"".join(out)
+    assert int.from_bytes(z[-4:], "big") == zlib.adler32(data)
+    return data
 
 
 def sections():
@@ -73,6 +96,8 @@ def test_twin_streams_inflate_to_the_input(nthr):
         d = zlib.decompressobj()
         assert d.decompress(z) == data and d.eof and d.unused_data == b"", name      # one complete stream, nothing after it
         assert len(z) <= L.emu_deflate_bound(len(data), nthr)
+        z2, sizes = twin_deflate(L, data, nthr, want_index=True)
+        assert z2 == z and inflate_by_index(z, sizes, len(data), nthr * 128) == data, name     # chunks inflate on their own
 
 
 def test_twin_on_dctz_streams_stays_close_to_zlib():
@@ -109,11 +134,13 @@ def test_device_streams_inflate_and_equal_the_twin(ctx):
     for i in range(0, len(names), 8):                      # up to 8 sections per call
         part = names[i:i + 8]
         dev = [torch.from_numpy(np.frombuffer(cases[k], dtype=np.uint8).copy()).to(ctx.device) for k in part]
-        outs = ctx.deflate(dev)
-        for k, o in zip(part, outs):
+        outs, index = ctx.deflate(dev, want_index=True)
+        for k, o, ix in zip(part, outs, index):
             z = o.cpu().numpy().tobytes()
             assert zlib.decompress(z) == cases[k], k
-            assert z == twin_deflate(L, cases[k]), k
+            zt, ixt = twin_deflate(L, cases[k], want_index=True)
+            assert z == zt and np.array_equal(ix, ixt), k
+            assert inflate_by_index(z, ix, len(cases[k])) == cases[k], k
 
 
 @pytest.mark.gpu

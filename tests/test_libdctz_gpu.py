@@ -61,15 +61,19 @@ def _parse(z, dtype, qt):
                 bindex_count=struct.unpack_from("<I", z, 52)[0] if qt else None)
 
 
-@pytest.fixture(params=[0, 8], ids=["zlib_ref_3threads", "zlib_chunked_8threads"])
+@pytest.fixture(params=[0, 8, "gpu"], ids=["zlib_ref_3threads", "zlib_chunked_8threads", "deflate_on_gpu"])
 def zthreads(request):
-    """0: the reference's tail (three single-shot deflates); 8: chunked deflate (pdeflate.c)."""
-    if request.param:
+    """0: the reference's tail (three single-shot deflates); 8: chunked deflate (pdeflate.c); "gpu": the entropy stage
+    on the device (DCTZ_ZLIB_GPU=1, dctzhip_deflate) -- the container is parsed with zlib's inflate in every case."""
+    if request.param == "gpu":
+        os.environ["DCTZ_ZLIB_GPU"] = "1"
+    elif request.param:
         os.environ["DCTZ_ZLIB_THREADS"] = str(request.param)
         os.environ["DCTZ_ZLIB_CHUNK"] = "65536"
     yield request.param
     os.environ.pop("DCTZ_ZLIB_THREADS", None)
     os.environ.pop("DCTZ_ZLIB_CHUNK", None)
+    os.environ.pop("DCTZ_ZLIB_GPU", None)
 
 
 @pytest.mark.parametrize("mode", ["ec", "qt"])
@@ -104,8 +108,19 @@ def test_dropin_compress_decompress(mode, case, zthreads):
     if qt:
         assert h["bindex_count"] == n and np.array_equal(h["q"].view(np.uint8), c.qtable.view(np.uint8))
     assert np.array_equal(x.view(np.uint8), c.scaled.view(np.uint8)), "caller's buffer must hold x/sf"
-    assert out_size.value == 56 + sum(h["sizes"]) + (64 * x.itemsize if qt else 0)
-    if case == "c1" and mode == "ec" and not zthreads and zlib.ZLIB_VERSION.startswith("1.2.11"):
+    body = 56 + sum(h["sizes"]) + (64 * x.itemsize if qt else 0)
+    if zthreads == "gpu":                                  # "DZIX" chunk index behind the container (include/dctz.h)
+        nblk = (n + 63) // 64
+        nch = [(b + 16383) // 16384 for b in (n, 4 * nblk, 4 * c.cnt)]
+        assert out_size.value == body + ((20 + 2 * sum(nch) + 3) & ~3)
+        magic, chunk, n0, n1, n2 = struct.unpack_from("<IIIII", bytes(zbuf[body:body + 20]))
+        assert (magic, chunk, [n0, n1, n2]) == (0x58495A44, 16384, nch)
+        sizes = np.frombuffer(bytes(zbuf[body + 20:body + 20 + 2 * sum(nch)]), dtype=np.uint16)
+        assert [int(sizes[:n0].sum()) + 8, int(sizes[n0:n0 + n1].sum()) + 8, int(sizes[n0 + n1:].sum()) + 8] == list(h["sizes"])
+        assert all(bytes(zbuf[o:o + 2]) == b"\x78\x5e" for o in (56, 56 + h["sizes"][0], 56 + h["sizes"][0] + h["sizes"][1]))
+    else:
+        assert out_size.value == body
+    if case == "c1" and mode == "ec" and zthreads == 0 and zlib.ZLIB_VERSION.startswith("1.2.11"):
         assert out_size.value == 3763394                   # survey known answer (zlib 1.2.11)
 
     assert lib.dctz_decompress(C.byref(var_z), C.byref(var_r)) == 1
@@ -212,9 +227,13 @@ from hypothesis import HealthCheck, given, settings, strategies as st   # noqa: 
 
 @settings(max_examples=25, deadline=None, suppress_health_check=[HealthCheck.too_slow])
 @given(seed=st.integers(0, 2**31), n=st.integers(1, 300000), log_amp=st.floats(-4, 6), eb=st.sampled_from([1e-2, 1e-3, 1e-5]),
-       mode=st.sampled_from(["ec", "qt"]), dtype=st.sampled_from([np.float64, np.float32]), zthreads=st.sampled_from([0, 5]))
+       mode=st.sampled_from(["ec", "qt"]), dtype=st.sampled_from([np.float64, np.float32]), zthreads=st.sampled_from([0, 5, -1]))
 def test_dropin_fuzz(seed, n, log_amp, eb, mode, dtype, zthreads):
-    if zthreads:
+    os.environ.pop("DCTZ_ZLIB_GPU", None)
+    if zthreads < 0:                                        # the entropy stage on the device
+        os.environ["DCTZ_ZLIB_GPU"] = "1"
+        os.environ.pop("DCTZ_ZLIB_THREADS", None)
+    elif zthreads:
         os.environ["DCTZ_ZLIB_THREADS"] = str(zthreads)
         os.environ["DCTZ_ZLIB_CHUNK"] = "32768"
     else:
@@ -247,6 +266,7 @@ def test_dropin_fuzz(seed, n, log_amp, eb, mode, dtype, zthreads):
     finally:
         os.environ.pop("DCTZ_ZLIB_THREADS", None)
         os.environ.pop("DCTZ_ZLIB_CHUNK", None)
+        os.environ.pop("DCTZ_ZLIB_GPU", None)
 
 
 @pytest.mark.parametrize("dtype", [np.float64, np.float32])

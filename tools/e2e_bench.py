@@ -4,9 +4,9 @@
 timers (dctz_last_stage_times = the reference's TIME_DEBUG split, dctz-comp-lib.c:762-773).
 
 SURVEY.md section 8(d) "timing protocol": reported beside the headline, never the headline.
-Runs the reference's tail (three single-shot deflates) and the chunked tail
-(DCTZ_ZLIB_THREADS = host cores) on the same input and checks both containers inflate to the
-same streams.  Prints one JSON object.
+Runs the reference's tail (three single-shot deflates), the chunked tail (DCTZ_ZLIB_THREADS = host cores)
+and the entropy stage on the device (DCTZ_ZLIB_GPU=1) on the same input and checks that all containers
+inflate to the same streams.  Prints one JSON object.
 
   python tools/e2e_bench.py [--n 512] [--dtype f64] [--eb 1e-3] [--mode ec] [--threads 16]
 """
@@ -42,6 +42,7 @@ def main():
     ap.add_argument("--eb", type=float, default=1e-3)
     ap.add_argument("--mode", choices=["ec", "qt"], default="ec")
     ap.add_argument("--threads", type=int, default=os.cpu_count() or 8)
+    ap.add_argument("--skip-reference-tail", action="store_true", help="leave out the three single-shot deflates (7 s per GiB)")
     a = ap.parse_args()
     import numpy as np
     from tests import workloads as W
@@ -66,10 +67,12 @@ def main():
         return v
 
     def one(threads):
-        if threads:
+        os.environ.pop("DCTZ_ZLIB_GPU", None)
+        os.environ.pop("DCTZ_ZLIB_THREADS", None)
+        if threads == "gpu":
+            os.environ["DCTZ_ZLIB_GPU"] = "1"
+        elif threads:
             os.environ["DCTZ_ZLIB_THREADS"] = str(threads)
-        else:
-            os.environ.pop("DCTZ_ZLIB_THREADS", None)
         res = {}
         streams = None
         for rep in range(2):                      # first repetition warms the context / page tables
@@ -101,13 +104,14 @@ def main():
                        zlib.decompress(z[56 + s0 + s1:56 + s0 + s1 + s2]))
         return res, streams
 
-    ref, s_ref = one(0)
+    ref, s_ref = (one(0) if not a.skip_reference_tail else (None, None))
     par, s_par = one(a.threads)
-    assert s_ref == s_par, "both tails must inflate to the same three streams"
+    gpu, s_gpu = one("gpu")
+    assert (s_ref is None or s_ref == s_par) and s_par == s_gpu, "all tails must inflate to the same three streams"
     print(json.dumps({"what": "drop-in dctz_compress/dctz_decompress, host buffers, zlib included",
                       "workload": f"{a.dtype} {a.n}^3 C3 formula, {a.mode.upper()} eb={a.eb:g}", "input_bytes": x0.nbytes,
                       "host_cores": os.cpu_count(), "zlib": zlib.ZLIB_VERSION,
-                      "reference_tail_3_threads": ref, f"chunked_tail_{a.threads}_threads": par,
+                      "reference_tail_3_threads": ref, f"chunked_tail_{a.threads}_threads": par, "deflate_on_gpu": gpu,
                       "streams_identical": True}))
 
 
