@@ -50,8 +50,21 @@ int main(int argc, char *argv[]) {
   int rc = 0;
   if (verbose) {
     fseek(fp, 0, SEEK_END);
-    const long fsz = ftell(fp);
+    const long fsz_all = ftell(fp);
     const size_t ts = h.datatype == DOUBLE ? sizeof(double) : sizeof(float);
+    /* "DZIX" chunk index behind everything else (written when the entropy stage ran on the GPU, dctz.h): look where an
+     * ec and where a qt container would have it */
+    long ix_bytes = 0;
+    unsigned int ixh[5] = {0, 0, 0, 0, 0};
+    for (int qt = 0; qt < 2 && !ix_bytes; qt++) {
+      const long pos = (long)(sizeof(h) + (size_t)h.bindex_sz_compressed + h.DC_sz_compressed + h.AC_exact_sz_compressed +
+                              (qt ? BLK_SZ * ts : 0) + (geom ? 16 : 0));
+      if (pos + 20 <= fsz_all && fseek(fp, pos, SEEK_SET) == 0 && fread(ixh, sizeof(ixh), 1, fp) == 1 && ixh[0] == DCTZ_IX_MAGIC) {
+        const long want = (long)((20 + 2 * ((size_t)ixh[2] + ixh[3] + ixh[4]) + 3) & ~(size_t)3);
+        if (pos + want == fsz_all) ix_bytes = want;
+      }
+    }
+    const long fsz = fsz_all - ix_bytes;
     size_t nblk = ((size_t)h.num_elements + BLK_SZ - 1) / BLK_SZ;
     const size_t o0 = sizeof(h), o1 = o0 + h.bindex_sz_compressed, o2 = o1 + h.DC_sz_compressed;
     size_t end = o2 + h.AC_exact_sz_compressed;
@@ -98,7 +111,10 @@ int main(int argc, char *argv[]) {
       printf("LAYOUT MISMATCH: header describes %zu bytes (ec) or %zu (qt), file has %ld\n", end, end + BLK_SZ * ts, fsz);
       rc = 2;
     }
-    printf("compression ratio=%.2f\n", (double)h.num_elements * ts / (double)fsz);
+    if (ix_bytes)
+      printf("chunk index: %ld bytes at offset %ld, chunks of %u bytes: %u + %u + %u (sections made by the GPU entropy stage)\n", ix_bytes, fsz,
+             ixh[1], ixh[2], ixh[3], ixh[4]);
+    printf("compression ratio=%.2f\n", (double)h.num_elements * ts / (double)fsz_all);
   }
   fclose(fp);
   return rc;

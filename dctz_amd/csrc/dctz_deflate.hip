@@ -3,13 +3,17 @@
 // SURVEY 8(f) rank 1; replaces the reference's zlib tail, dctz-comp-lib.c:620-732 (three threads, one single-shot
 // deflate each); the output is what dctz-decomp-lib.c:244-322 inflates.  Format and method: deflate_chunk.h.
 //
-// k_deflate_chunks   one workgroup per CHUNK input bytes, one lane per 128-byte segment:
-//                      load (LDS, padded so that lanes walking their segments hit different banks) + adler32 pieces
-//                      -> parse (tokens, symbol counts) -> code lengths (rank sort in parallel, tree by one lane per
-//                      alphabet) -> canonical codes -> bit counts + workgroup scan -> stored or dynamic -> emit
-//                      -> slot in scratch (HBM), byte count per chunk.
-// k_deflate_scan     byte offsets of the chunks inside the section (one workgroup).
-// k_deflate_gather   slots -> one contiguous stream: 78 5E | chunks | 03 00 | adler32; section length to the host box.
+// Three kernels per section, so that the work that only one lane can do (building a Huffman tree) never holds the
+// LDS image of a chunk hostage:
+// k_dfl_parse   one workgroup per CHUNK input bytes, one lane per 128-byte segment: load (LDS, padded so that lanes
+//               walking their segments hit different banks), adler32 pieces, tokens + symbol counts -> HBM.
+// k_dfl_codes   one WAVE per chunk, 7 KiB of LDS (a CU keeps ~20 chunks in flight, which is what hides the serial
+//               stretches): symbol counts -> code lengths (rank sort in parallel, two-queue tree by one lane) ->
+//               canonical codes -> block header bits -> stored or dynamic, bytes of the chunk.
+// k_deflate_scan  byte offsets of the chunks inside the section (one workgroup).
+// k_dfl_emit    one workgroup per chunk: tokens + codes -> bits (bit counts per lane, workgroup scan, every lane writes
+//               at its own bit offset) -> the chunk's place in the stream; the first workgroup adds the frame
+//               78 5E ... 03 00 adler32 and hands the section length to the host box.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -24,33 +28,20 @@ namespace dfl {
 
 constexpr int NTHR = DCTZ_DFL_THREADS;               // lanes per workgroup = segments per chunk
 constexpr int CHUNK = NTHR * SEG;
-constexpr int SLOT = CHUNK + 64;                       // bytes of scratch per chunk (a chunk never grows by more than 5)
 constexpr int NSYM = NLIT + NDIST + NCL;               // the three alphabets side by side: [0,286) [286,316) [316,335)
 constexpr uint32_t ADLER_M = 65521u;
 
 __device__ __forceinline__ int pad(int i) { return i + ((i >> SEG_SHIFT) << 2); }   // 4 bytes of padding per segment
 
-struct Lds {
-  uint8_t in[HIST + CHUNK + ((HIST + CHUNK) >> SEG_SHIFT) * 4 + 16];
-  uint8_t tok[CHUNK + (CHUNK >> SEG_SHIFT) * 4 + 16];
-  uint32_t out[CHUNK / 4 + 8];
-  uint32_t freq[NSYM + 1];
-  uint16_t code[NSYM + 1];
-  uint8_t len[NSYM + 1];
-  uint16_t sorted[NLIT + NDIST + NCL + 1];
-  uint32_t w[NLIT + NDIST];
-  uint16_t ch[2 * (NLIT + NDIST)];
-  uint16_t dep[NLIT + NDIST];
-  uint16_t bl_count[3][16];
-  uint16_t next_code[3][16];
-  uint16_t cl[NLIT + NDIST + 4];                       // run-length form of the code lengths: sym | extra value << 8
-  uint32_t scan[NTHR / 64 + 1];
-  unsigned long long adler_b;
-  uint32_t adler_a;
-  int k[3];                                            // symbols in use per alphabet
-  int hlit, hdist, hclen, ncl;
-  uint32_t hbits;                                      // bits of the block header
-  uint32_t tokbits;                                    // bits of all tokens
+constexpr int META_SYMS = 320;                         // NLIT + NDIST rounded up
+constexpr int HDR_WORDS = 160;                         // >= (17 + 3 * 19 + 316 * 14) / 32 + 1
+struct ChunkMeta {                                     // what k_dfl_codes hands to k_dfl_emit
+  uint16_t code[META_SYMS];                            // bit-reversed canonical codes: [0, 286) literal/length, [286, 316) distance
+  uint8_t len[META_SYMS];
+  uint32_t hdr[HDR_WORDS];                             // the block header, bit 0 first
+  uint32_t hbits;                                      // its length in bits
+  uint32_t dyn;                                        // 1: dynamic block, 0: stored
+  uint32_t pad[2];
 };
 
 __device__ __forceinline__ uint32_t wave_incl_scan_u32(uint32_t v) {
@@ -61,10 +52,97 @@ __device__ __forceinline__ uint32_t wave_incl_scan_u32(uint32_t v) {
   }
   return v;
 }
+__device__ __forceinline__ uint32_t wave_sum_u32(uint32_t v) {
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
+  return v;
+}
+
+// ------------------------------------------------------------------ parse --
+struct LdsParse {
+  uint8_t in[CHUNK + (CHUNK >> SEG_SHIFT) * 4 + 16];
+  uint8_t tok[CHUNK + (CHUNK >> SEG_SHIFT) * 4 + 16];
+  uint32_t freq[META_SYMS];
+  unsigned long long adler_b;
+  uint32_t adler_a;
+};
+
+// chunk bytes -> padded LDS image; dwords when the source allows it
+__device__ __forceinline__ void load_chunk(uint8_t* lds, const uint8_t* g, int len, bool aligned) {
+  if (aligned) {
+    for (int i = threadIdx.x * 4; i < CHUNK; i += NTHR * 4) {
+      uint32_t v = 0;
+      if (i + 4 <= len) v = *(const uint32_t*)(g + i);
+      else
+        for (int b = 0; b < 4; b++) if (i + b < len) v |= (uint32_t)g[i + b] << (8 * b);
+      *(uint32_t*)&lds[pad(i)] = v;
+    }
+  } else {
+    for (int i = threadIdx.x; i < CHUNK; i += NTHR) lds[pad(i)] = i < len ? g[i] : (uint8_t)0;
+  }
+}
+
+__global__ __launch_bounds__(NTHR) void k_dfl_parse(const uint8_t* __restrict__ src, unsigned long long n, uint8_t* __restrict__ tok_g,
+                                                    uint32_t* __restrict__ freq_g, unsigned long long* __restrict__ adler_acc) {
+  __shared__ LdsParse s;
+  const int tid = threadIdx.x;
+  const unsigned long long off = (unsigned long long)blockIdx.x * CHUNK;
+  const int len = (int)((n - off) < (unsigned long long)CHUNK ? (n - off) : (unsigned long long)CHUNK);
+  load_chunk(s.in, src + off, len, (((uintptr_t)src) & 3) == 0);
+  for (int i = tid; i < META_SYMS; i += NTHR) s.freq[i] = 0;
+  if (tid == 0) { s.adler_a = 0; s.adler_b = 0; }
+  __syncthreads();
+
+  auto in = [&](int i) -> int { return s.in[pad(i)]; };
+  const int p0 = tid * SEG, p1 = (p0 + SEG < len) ? p0 + SEG : len;
+  if (p0 < len) {
+    uint32_t a = 0, b = 0;                                // adler32 pieces of this segment: sum d, sum (seglen - j) d_j
+    for (int p = p0; p < p1; p++) { a += (uint32_t)in(p); b += a; }
+    atomicAdd(&s.adler_a, a);
+    atomicAdd(&s.adler_b, (unsigned long long)b + (unsigned long long)a * (unsigned long long)(len - p1));
+    parse_segment(in, [&](int p, int v) { s.tok[pad(p)] = (uint8_t)v; }, p0, p1, 0,
+                  [&](int sym) { atomicAdd(&s.freq[sym], 1u); }, [&](int sym) { atomicAdd(&s.freq[NLIT + sym], 1u); });
+  }
+  __syncthreads();
+  for (int i = tid * 4; i < CHUNK; i += NTHR * 4) *(uint32_t*)(tok_g + off + i) = *(const uint32_t*)&s.tok[pad(i)];   // (scratch is a whole number of chunks)
+  for (int i = tid; i < META_SYMS; i += NTHR) freq_g[(size_t)blockIdx.x * META_SYMS + i] = s.freq[i];
+  if (tid == 0) {
+    // this chunk's share of the section's adler32: S1 = sum d, S2 = sum (n - i) d_i  (mod 65521)
+    const unsigned long long after = n - (off + (unsigned long long)len);
+    const unsigned long long a = s.adler_a, b = s.adler_b;
+    atomicAdd(&adler_acc[0], a % ADLER_M);
+    atomicAdd(&adler_acc[1], (b % ADLER_M + (a % ADLER_M) * (after % ADLER_M)) % ADLER_M);
+  }
+}
+
+// ------------------------------------------------------------------ codes --
+constexpr int CW = 64;                                 // one wave per chunk
+struct LdsCodes {
+  uint32_t freq[NSYM + 1];
+  uint16_t code[NSYM + 1];
+  uint8_t len[NSYM + 1];
+  uint16_t sorted[NSYM + 1];
+  uint32_t w[NLIT + NDIST];
+  uint16_t ch[2 * (NLIT + NDIST)];
+  uint16_t dep[NLIT + NDIST];
+  uint16_t bl_count[3][16];
+  uint16_t next_code[3][16];
+  uint16_t cl[NLIT + NDIST + 4];                       // run-length form of the code lengths: sym | extra value << 8
+  uint32_t hdr[HDR_WORDS];
+  uint32_t lw[NLIT];                                   // literal/length tree: leaf weights in sorted order
+  uint16_t par[NLIT];                                  //   parent of every internal node (pointer jumping: ancestor)
+  uint16_t pl[NLIT];                                   //   parent of every leaf
+  uint16_t up[NLIT];                                   //   distance to par[]
+  uint32_t blc[16];                                    //   leaves per depth
+  int k[3];                                            // symbols in use per alphabet
+  int hlit, hdist, hclen, ncl;
+  uint32_t hbits;
+  uint32_t forced;                                     // distance symbols counted only to complete the code
+};
 
 // symbols of one alphabet with freq > 0, ascending (freq, symbol): every lane ranks the symbols it owns
-__device__ __forceinline__ void rank_sort(Lds& s, int base, int n, int which) {
-  for (int i = threadIdx.x; i < n; i += NTHR) {
+__device__ __forceinline__ void rank_sort(LdsCodes& s, int base, int n, int which) {
+  for (int i = threadIdx.x; i < n; i += CW) {
     const uint32_t f = s.freq[base + i];
     if (!f) continue;
     int r = 0;
@@ -76,17 +154,15 @@ __device__ __forceinline__ void rank_sort(Lds& s, int base, int n, int which) {
     atomicAdd(&s.k[which], 1);
   }
 }
-
-__device__ __forceinline__ void build_lengths(Lds& s, int base, int which, int maxbits) {
+__device__ __forceinline__ void build_lengths(LdsCodes& s, int base, int which, int maxbits) {
   huff_lengths([&](int sym) { return s.freq[base + sym]; }, [&](int i) { return (int)s.sorted[base + i]; }, s.k[which], maxbits,
                [&](int sym, int bits) { s.len[base + sym] = (uint8_t)bits; }, s.w + (which == 1 ? NLIT : 0), s.ch + (which == 1 ? 2 * NLIT : 0),
                s.dep + (which == 1 ? NLIT : 0), s.bl_count[which]);
   first_codes(s.bl_count[which], maxbits, s.next_code[which]);
 }
-
 // canonical code of every symbol in use, bit-reversed (deflate sends Huffman codes most significant bit first)
-__device__ __forceinline__ void assign_codes(Lds& s, int base, int n, int which) {
-  for (int i = threadIdx.x; i < n; i += NTHR) {
+__device__ __forceinline__ void assign_codes(LdsCodes& s, int base, int n, int which) {
+  for (int i = threadIdx.x; i < n; i += CW) {
     const int l = s.len[base + i];
     if (!l) continue;
     int before = 0;
@@ -94,93 +170,111 @@ __device__ __forceinline__ void assign_codes(Lds& s, int base, int n, int which)
     s.code[base + i] = (uint16_t)bit_reverse((uint32_t)s.next_code[which][l] + before, l);
   }
 }
+// The literal/length tree by the whole wave.  Same tree as huff_lengths() (same tie rule, hence the same leaf count per
+// depth and the same lengths): the two-queue merge stays with one lane, but reads only leaf weights laid out in sorted
+// order and node weights, four values fetched together per step; depths come from pointer jumping over the parent
+// links (log2 rounds, all lanes), leaf counts per depth from LDS atomics, lengths from the rank of the leaf.
+__device__ __forceinline__ void build_lengths_wave(LdsCodes& s, int maxbits) {
+  const int tid = threadIdx.x, k = s.k[0];
+  for (int r = tid; r < k; r += CW) s.lw[r] = s.freq[s.sorted[r]];
+  if (tid < 16) s.blc[tid] = 0;
+  __syncthreads();
+  if (tid == 0) {
+    const uint32_t INF = 0xFFFFFFFFu;
+    int li = 0, ii = 0;
+    for (int ni = 0; ni < k - 1; ni++) {
+      uint32_t a0 = li < k ? s.lw[li] : INF, a1 = li + 1 < k ? s.lw[li + 1] : INF;
+      uint32_t b0 = ii < ni ? s.w[ii] : INF, b1 = ii + 1 < ni ? s.w[ii + 1] : INF;
+      uint32_t wsum = 0;
+#pragma unroll
+      for (int t = 0; t < 2; t++) {
+        if (a0 <= b0 && a0 != INF) { wsum += a0; s.pl[li] = (uint16_t)ni; li++; a0 = a1; }
+        else { wsum += b0; s.par[ii] = (uint16_t)ni; ii++; b0 = b1; }
+      }
+      s.w[ni] = wsum;
+    }
+    s.par[k - 2] = (uint16_t)(k - 2);                    // the root
+  }
+  __syncthreads();
+  const int nint = k - 1;
+  for (int i = tid; i < nint; i += CW) s.up[i] = (i == nint - 1) ? 0 : 1;
+  __syncthreads();
+  for (int span = 1; span < nint; span <<= 1) {          // after the round, up[i] = min(depth, 2 * span) hops towards the root
+    uint16_t np[(NLIT + CW - 1) / CW], nu[(NLIT + CW - 1) / CW];
+    int c = 0;
+    for (int i = tid; i < nint; i += CW, c++) { const int p = s.par[i]; nu[c] = (uint16_t)(s.up[i] + s.up[p]); np[c] = s.par[p]; }
+    __syncthreads();
+    c = 0;
+    for (int i = tid; i < nint; i += CW, c++) { s.up[i] = nu[c]; s.par[i] = np[c]; }
+    __syncthreads();
+  }
+  for (int r = tid; r < k; r += CW) {
+    const int d = s.up[s.pl[r]] + 1;
+    atomicAdd(&s.blc[d > maxbits ? maxbits : d], 1u);
+  }
+  __syncthreads();
+  if (tid == 0) {
+    // leaves clamped to maxbits over-subscribe the code: every repair step takes 2^-maxbits off the Kraft sum (deflate_chunk.h)
+    uint32_t kraft = 0;
+    for (int b = 1; b <= maxbits; b++) kraft += s.blc[b] << (maxbits - b);
+    for (uint32_t over = kraft - (1u << maxbits); over > 0; over--) {
+      int bits = maxbits - 1;
+      while (s.blc[bits] == 0) bits--;
+      s.blc[bits]--;
+      s.blc[bits + 1] += 2;
+      s.blc[maxbits]--;
+    }
+    for (int b = 0; b <= MAXBITS; b++) s.bl_count[0][b] = (uint16_t)(b <= maxbits ? s.blc[b] : 0);
+    s.bl_count[0][0] = 0;
+    first_codes(s.bl_count[0], maxbits, s.next_code[0]);
+  }
+  __syncthreads();
+  for (int r = tid; r < k; r += CW) {                    // the longest codes go to the rarest symbols
+    int bits = maxbits, upto = (int)s.blc[maxbits];
+    while (r >= upto) { bits--; upto += (int)s.blc[bits]; }
+    s.len[s.sorted[r]] = (uint8_t)bits;
+  }
+}
 
-__global__ __launch_bounds__(NTHR) void k_deflate_chunks(const uint8_t* __restrict__ src, unsigned long long n, uint8_t* __restrict__ slots,
-                                                         uint32_t* __restrict__ sizes, unsigned long long* __restrict__ adler_acc) {
-  __shared__ Lds s;
+__device__ __forceinline__ int len_extra_bits(int sym) { return (sym < 265 || sym == 285) ? 0 : (sym - 261) >> 2; }
+__device__ __forceinline__ int dist_extra_bits(int sym) { return sym < 4 ? 0 : (sym >> 1) - 1; }
+
+__global__ __launch_bounds__(CW) void k_dfl_codes(const uint32_t* __restrict__ freq_g, unsigned long long n, ChunkMeta* __restrict__ meta,
+                                                  uint32_t* __restrict__ sizes) {
+  __shared__ LdsCodes s;
   const int tid = threadIdx.x;
   const unsigned long long off = (unsigned long long)blockIdx.x * CHUNK;
   const int len = (int)((n - off) < (unsigned long long)CHUNK ? (n - off) : (unsigned long long)CHUNK);
-  const int avail = 0;                                   // nothing in front of the chunk is referenced (deflate_chunk.h)
-  uint8_t* slot = slots + (size_t)blockIdx.x * SLOT;
-
-  // ---- load: history + chunk, dwords when the source allows it
-  {
-    const uint8_t* g = src + off - HIST;                 // logical index 0 of the padded image
-    const int first = HIST - avail, last = HIST + len;   // valid logical range
-    if ((((uintptr_t)src) & 3) == 0) {
-      for (int i = tid * 4; i < HIST + CHUNK; i += NTHR * 4) {
-        uint32_t v = 0;
-        if (i >= first && i + 4 <= last) v = *(const uint32_t*)(g + i);
-        else
-          for (int b = 0; b < 4; b++) if (i + b >= first && i + b < last) v |= (uint32_t)g[i + b] << (8 * b);
-        *(uint32_t*)&s.in[pad(i)] = v;
-      }
-    } else {
-      for (int i = tid; i < HIST + CHUNK; i += NTHR) s.in[pad(i)] = (i >= first && i < last) ? g[i] : (uint8_t)0;
-    }
-  }
-  for (int i = tid; i < NSYM + 1; i += NTHR) { s.freq[i] = 0; s.len[i] = 0; s.code[i] = 0; }
-  for (int i = tid; i < CHUNK / 4 + 8; i += NTHR) s.out[i] = 0;
-  if (tid == 0) { s.adler_a = 0; s.adler_b = 0; s.k[0] = s.k[1] = s.k[2] = 0; }
-  __syncthreads();
-
-  auto in = [&](int i) -> int { return s.in[pad(i + HIST)]; };
-  const int p0 = tid * SEG, p1 = (p0 + SEG < len) ? p0 + SEG : len;
-
-  // ---- adler32 pieces of this segment, then parse
-  if (p0 < len) {
-    uint32_t a = 0, b = 0;
-    for (int p = p0; p < p1; p++) { a += (uint32_t)in(p); b += a; }
-    atomicAdd(&s.adler_a, a);
-    atomicAdd(&s.adler_b, (unsigned long long)b + (unsigned long long)a * (unsigned long long)(len - p1));
-    parse_segment(in, [&](int p, int v) { s.tok[pad(p)] = (uint8_t)v; }, p0, p1, avail,
-                  [&](int sym) { atomicAdd(&s.freq[sym], 1u); }, [&](int sym) { atomicAdd(&s.freq[NLIT + sym], 1u); });
-  }
+  for (int i = tid; i < NSYM + 1; i += CW) { s.freq[i] = i < NLIT + NDIST ? freq_g[(size_t)blockIdx.x * META_SYMS + i] : 0u; s.len[i] = 0; s.code[i] = 0; }
+  for (int i = tid; i < HDR_WORDS; i += CW) s.hdr[i] = 0;
+  if (tid == 0) { s.k[0] = s.k[1] = s.k[2] = 0; s.forced = 0; }
   __syncthreads();
   if (tid == 0) {
     s.freq[256] = 1;                                     // end of block
     // at least two distance codes in use, as zlib does it (trees.c build_tree): a complete code for any decoder
     int used = 0;
+    uint32_t forced = 0;
     for (int i = 0; i < NDIST; i++) used += s.freq[NLIT + i] ? 1 : 0;
-    for (int i = 0; used < 2; i++) if (!s.freq[NLIT + i]) { s.freq[NLIT + i] = 1; used++; }
-    // this chunk's share of the section's adler32: S1 = sum d, S2 = sum (n - i) d_i  (mod 65521)
-    const unsigned long long after = n - (off + (unsigned long long)len);
-    const unsigned long long a = s.adler_a, b = s.adler_b;
-    atomicAdd(&adler_acc[0], a % ADLER_M);
-    atomicAdd(&adler_acc[1], (b % ADLER_M + (a % ADLER_M) * (after % ADLER_M)) % ADLER_M);
+    for (int i = 0; used < 2; i++) if (!s.freq[NLIT + i]) { s.freq[NLIT + i] = 1; forced |= 1u << i; used++; }
+    s.forced = forced;
   }
   __syncthreads();
-
-  // ---- code lengths and codes of the literal/length and distance alphabets
   rank_sort(s, 0, NLIT, 0);
   rank_sort(s, NLIT, NDIST, 1);
   __syncthreads();
-  if (tid == 0) build_lengths(s, 0, 0, MAXBITS);
-  if (tid == (NTHR > 64 ? 64 : 1)) build_lengths(s, NLIT, 1, MAXBITS);
+  build_lengths_wave(s, MAXBITS);
+  if (tid == 0) build_lengths(s, NLIT, 1, MAXBITS);
   __syncthreads();
   assign_codes(s, 0, NLIT, 0);
   assign_codes(s, NLIT, NDIST, 1);
+  // bits of all tokens, from the counts: code length + extra bits per use (end of block included)
+  uint32_t bits = 0;
+  for (int i = tid; i < NLIT; i += CW) bits += s.freq[i] * (uint32_t)(s.len[i] + (i > 256 ? len_extra_bits(i) : 0));
+  for (int i = tid; i < NDIST; i += CW) if (!((s.forced >> i) & 1u)) bits += s.freq[NLIT + i] * (uint32_t)(s.len[NLIT + i] + dist_extra_bits(i));
+  const uint32_t tokbits = wave_sum_u32(bits);
+  __syncthreads();
 
-  // ---- bits of this lane's tokens
-  uint32_t mybits = 0;
-  if (p0 < len) {
-    for (int p = p0; p < p1;) {
-      const int t = s.tok[pad(p)];
-      if (t == 0) { mybits += s.len[in(p)]; p++; }
-      else {
-        const int l = s.tok[pad(p + 1)] + 3;
-        int sym, eb, ev;
-        len_code(l, sym, eb, ev);
-        mybits += s.len[sym] + eb + s.len[NLIT + cand_dsym_rt(t - 1)] + cand_deb_rt(t - 1);
-        p += l;
-      }
-    }
-  }
-  uint32_t incl = wave_incl_scan_u32(mybits);
-  if ((tid & 63) == 63) s.scan[tid >> 6] = incl;
-
-  // ---- header: run-length form of the lengths, its own Huffman code (one lane)
+  // header: run-length form of the lengths, its own Huffman code, the bits (one lane)
   if (tid == 0) {
     int hlit = NLIT, hdist = NDIST;
     while (hlit > 257 && s.len[hlit - 1] == 0) hlit--;
@@ -203,7 +297,7 @@ __global__ __launch_bounds__(NTHR) void k_deflate_chunks(const uint8_t* __restri
     }
     s.k[2] = k;
     huff_lengths([&](int sym) { return s.freq[base + sym]; }, [&](int i) { return (int)s.sorted[base + i]; }, k, MAXBITS_CL,
-                 [&](int sym, int bits) { s.len[base + sym] = (uint8_t)bits; }, s.w, s.ch, s.dep, s.bl_count[2]);
+                 [&](int sym, int b) { s.len[base + sym] = (uint8_t)b; }, s.w, s.ch, s.dep, s.bl_count[2]);
     first_codes(s.bl_count[2], MAXBITS_CL, s.next_code[2]);
     for (int i = 0; i < NCL; i++) {
       const int l = s.len[base + i];
@@ -214,44 +308,29 @@ __global__ __launch_bounds__(NTHR) void k_deflate_chunks(const uint8_t* __restri
     }
     int hclen = NCL;
     while (hclen > 4 && s.len[base + cl_order(hclen - 1)] == 0) hclen--;
-    uint32_t hb = 3 + 5 + 5 + 4 + 3 * hclen;
-    for (int i = 0; i < ncl; i++) {
-      const int sym = s.cl[i] & 31;
-      hb += s.len[base + sym] + (sym == 16 ? 2 : sym == 17 ? 3 : sym == 18 ? 7 : 0);
-    }
-    s.hlit = hlit; s.hdist = hdist; s.hclen = hclen; s.ncl = ncl; s.hbits = hb;
+    auto orw = [&](uint32_t w, uint32_t v) { s.hdr[w] |= v; };
+    BitW<decltype(orw)> bw(orw, 0);
+    bw.put(0u | (2u << 1), 3);                           // BFINAL 0, BTYPE 10
+    bw.put((uint32_t)(hlit - 257), 5);
+    bw.put((uint32_t)(hdist - 1), 5);
+    bw.put((uint32_t)(hclen - 4), 4);
+    for (int i = 0; i < hclen; i++) bw.put(s.len[base + cl_order(i)], 3);
+    bw.flush();
+    s.hlit = hlit; s.hdist = hdist; s.hclen = hclen; s.ncl = ncl;
   }
   __syncthreads();
-  uint32_t wave_base = 0, total = 0;
-  for (int w = 0; w < NTHR / 64; w++) { if (w < (tid >> 6)) wave_base += s.scan[w]; total += s.scan[w]; }
-  const uint32_t excl = wave_base + incl - mybits;
-  const uint32_t body_bits = s.hbits + total + s.len[256];
-  const uint32_t dyn_bytes = (body_bits + 3 + 7) / 8 + 4;       // + the empty stored block that ends on a byte boundary
-  const uint32_t stored_bytes = (uint32_t)len + 5;
-
-  if (dyn_bytes >= stored_bytes) {
-    // ---- stored block: 00 | LEN | ~LEN | bytes
-    if (tid == 0) {
-      slot[0] = 0;
-      slot[1] = (uint8_t)(len & 255); slot[2] = (uint8_t)(len >> 8);
-      slot[3] = (uint8_t)(~len & 255); slot[4] = (uint8_t)((~len >> 8) & 255);
-      sizes[blockIdx.x] = stored_bytes;
-    }
-    for (int i = tid; i < len; i += NTHR) slot[5 + i] = (uint8_t)in(i);
-    return;
-  }
-
-  // ---- dynamic block
-  auto orw = [&](uint32_t w, uint32_t v) { atomicOr(&s.out[w], v); };
-  if (tid == 0) {
-    BitW<decltype(orw)> bw(orw, 0);
-    const int base = NLIT + NDIST;
-    bw.put(0u | (2u << 1), 3);                           // BFINAL 0, BTYPE 10
-    bw.put((uint32_t)(s.hlit - 257), 5);
-    bw.put((uint32_t)(s.hdist - 1), 5);
-    bw.put((uint32_t)(s.hclen - 4), 4);
-    for (int i = 0; i < s.hclen; i++) bw.put(s.len[base + cl_order(i)], 3);
-    for (int i = 0; i < s.ncl; i++) {
+  {
+    // the coded lengths: every lane takes a run of entries, bit offsets from a wave scan
+    const int base = NLIT + NDIST, ncl = s.ncl, per = (ncl + CW - 1) / CW;
+    const int e0 = tid * per, e1 = (e0 + per < ncl) ? e0 + per : ncl;
+    auto ebits = [&](int sym) { return (int)s.len[base + sym] + (sym == 16 ? 2 : sym == 17 ? 3 : sym == 18 ? 7 : 0); };
+    uint32_t mine = 0;
+    for (int i = e0; i < e1; i++) mine += (uint32_t)ebits(s.cl[i] & 31);
+    const uint32_t incl = wave_incl_scan_u32(mine);
+    const uint32_t fixed = 17u + 3u * (uint32_t)s.hclen;
+    auto orw = [&](uint32_t w, uint32_t v) { atomicOr(&s.hdr[w], v); };
+    BitW<decltype(orw)> bw(orw, (uint64_t)fixed + incl - mine);
+    for (int i = e0; i < e1; i++) {
       const int sym = s.cl[i] & 31, ev = s.cl[i] >> 8;
       bw.put(s.code[base + sym], s.len[base + sym]);
       if (sym == 16) bw.put((uint32_t)ev, 2);
@@ -259,9 +338,96 @@ __global__ __launch_bounds__(NTHR) void k_deflate_chunks(const uint8_t* __restri
       else if (sym == 18) bw.put((uint32_t)ev, 7);
     }
     bw.flush();
+    if (tid == CW - 1) s.hbits = fixed + incl;
   }
+  __syncthreads();
+  const uint32_t body_bits = s.hbits + tokbits;
+  const uint32_t dyn_bytes = (body_bits + 3 + 7) / 8 + 4;       // + the empty stored block that ends on a byte boundary
+  const uint32_t stored_bytes = (uint32_t)len + 5;
+  const bool dyn = dyn_bytes < stored_bytes;
+  ChunkMeta* m = meta + blockIdx.x;
+  for (int i = tid; i < META_SYMS; i += CW) { m->code[i] = i < NLIT + NDIST ? s.code[i] : (uint16_t)0; m->len[i] = i < NLIT + NDIST ? s.len[i] : (uint8_t)0; }
+  for (int i = tid; i < HDR_WORDS; i += CW) m->hdr[i] = s.hdr[i];
+  if (tid == 0) { m->hbits = s.hbits; m->dyn = dyn ? 1u : 0u; sizes[blockIdx.x] = dyn ? dyn_bytes : stored_bytes; }
+}
+
+// ------------------------------------------------------------------- emit --
+struct LdsEmit {
+  uint8_t in[CHUNK + (CHUNK >> SEG_SHIFT) * 4 + 16];
+  uint8_t tok[CHUNK + (CHUNK >> SEG_SHIFT) * 4 + 16];
+  uint32_t out[CHUNK / 4 + 8];
+  uint16_t code[META_SYMS];
+  uint8_t len[META_SYMS];
+  uint32_t scan[NTHR / 64 + 1];
+};
+
+__global__ __launch_bounds__(NTHR) void k_dfl_emit(const uint8_t* __restrict__ src, unsigned long long n, const uint8_t* __restrict__ tok_g,
+                                                   const ChunkMeta* __restrict__ meta, const uint32_t* __restrict__ sizes,
+                                                   const unsigned long long* __restrict__ offs, uint32_t nchunks,
+                                                   const unsigned long long* __restrict__ adler_acc, uint8_t* __restrict__ dst,
+                                                   unsigned long long* __restrict__ box_len) {
+  __shared__ LdsEmit s;
+  const int tid = threadIdx.x;
+  if (blockIdx.x == 0 && tid == 0) {                      // the frame of the section
+    const unsigned long long total = offs[nchunks];
+    dst[0] = 0x78; dst[1] = 0x5E;                        // FLG: "fastest algorithm" hint, no preset dictionary -- and this library's mark for
+                                                         // "the deflate blocks are independent chunks" (include/dctz.h: DCTZ_IX_MAGIC)
+    uint8_t* t = dst + 2 + total;
+    t[0] = 0x03; t[1] = 0x00;
+    const uint32_t s1 = (uint32_t)((1 + adler_acc[0]) % ADLER_M), s2 = (uint32_t)((n % ADLER_M + adler_acc[1]) % ADLER_M);
+    t[2] = (uint8_t)(s2 >> 8); t[3] = (uint8_t)s2; t[4] = (uint8_t)(s1 >> 8); t[5] = (uint8_t)s1;
+    *box_len = total + 8;
+  }
+  if (blockIdx.x >= nchunks) return;
+  const unsigned long long off = (unsigned long long)blockIdx.x * CHUNK;
+  const int len = (int)((n - off) < (unsigned long long)CHUNK ? (n - off) : (unsigned long long)CHUNK);
+  const ChunkMeta* m = meta + blockIdx.x;
+  uint8_t* d = dst + 2 + offs[blockIdx.x];
+  if (!m->dyn) {
+    // ---- stored block: 00 | LEN | ~LEN | bytes
+    if (tid == 0) {
+      d[0] = 0;
+      d[1] = (uint8_t)(len & 255); d[2] = (uint8_t)(len >> 8);
+      d[3] = (uint8_t)(~len & 255); d[4] = (uint8_t)((~len >> 8) & 255);
+    }
+    for (int i = tid; i < len; i += NTHR) d[5 + i] = src[off + i];
+    return;
+  }
+  load_chunk(s.in, src + off, len, (((uintptr_t)src) & 3) == 0);
+  load_chunk(s.tok, tok_g + off, CHUNK, true);
+  for (int i = tid; i < META_SYMS; i += NTHR) { s.code[i] = m->code[i]; s.len[i] = m->len[i]; }
+  const uint32_t hbits = m->hbits, hwords = (hbits + 31) / 32;
+  for (int i = tid; i < CHUNK / 4 + 8; i += NTHR) s.out[i] = i < (int)hwords ? m->hdr[i] : 0u;
+  __syncthreads();
+
+  auto in = [&](int i) -> int { return s.in[pad(i)]; };
+  const int p0 = tid * SEG, p1 = (p0 + SEG < len) ? p0 + SEG : len;
+  uint32_t mybits = 0;
   if (p0 < len) {
-    BitW<decltype(orw)> bw(orw, (uint64_t)s.hbits + excl);
+    for (int p = p0; p < p1;) {
+      const int t = s.tok[pad(p)];
+      if (t == 0) { mybits += s.len[in(p)]; p++; }
+      else {
+        const int l = s.tok[pad(p + 1)] + 3;
+        int sym, eb, ev;
+        len_code(l, sym, eb, ev);
+        mybits += s.len[sym] + eb + s.len[NLIT + cand_dsym_rt(t - 1)] + cand_deb_rt(t - 1);
+        p += l;
+      }
+    }
+  }
+  const uint32_t incl = wave_incl_scan_u32(mybits);
+  if ((tid & 63) == 63) s.scan[tid >> 6] = incl;
+  __syncthreads();
+  uint32_t wave_base = 0, total = 0;
+  for (int w = 0; w < NTHR / 64; w++) { if (w < (tid >> 6)) wave_base += s.scan[w]; total += s.scan[w]; }
+  const uint32_t excl = wave_base + incl - mybits;
+  const uint32_t body_bits = hbits + total + s.len[256];
+  const uint32_t dyn_bytes = (body_bits + 3 + 7) / 8 + 4;       // == sizes[chunk]
+
+  auto orw = [&](uint32_t w, uint32_t v) { atomicOr(&s.out[w], v); };
+  if (p0 < len) {
+    BitW<decltype(orw)> bw(orw, (uint64_t)hbits + excl);
     for (int p = p0; p < p1;) {
       const int t = s.tok[pad(p)];
       if (t == 0) { const int b = in(p); bw.put(s.code[b], s.len[b]); p++; }
@@ -281,16 +447,16 @@ __global__ __launch_bounds__(NTHR) void k_deflate_chunks(const uint8_t* __restri
   }
   const uint32_t end_byte = (body_bits + 3 + 7) / 8;     // where LEN = 0 of the empty stored block starts
   if (tid == 0) {
-    BitW<decltype(orw)> bw(orw, (uint64_t)s.hbits + total);
+    BitW<decltype(orw)> bw(orw, (uint64_t)hbits + total);
     bw.put(s.code[256], s.len[256]);                     // end of block; the 3 header bits 000 and the padding are zeros already
     bw.flush();
     BitW<decltype(orw)> tail(orw, (uint64_t)(end_byte + 2) * 8);
     tail.put(0xFFFFu, 16);
     tail.flush();
-    sizes[blockIdx.x] = dyn_bytes;
   }
   __syncthreads();
-  for (int i = tid; i < (int)(dyn_bytes + 3) / 4; i += NTHR) ((uint32_t*)slot)[i] = s.out[i];
+  const uint8_t* ob = (const uint8_t*)s.out;
+  for (uint32_t i = tid; i < dyn_bytes; i += NTHR) d[i] = ob[i];
 }
 
 // byte offsets of the chunks (exclusive scan of their sizes); one workgroup
@@ -312,62 +478,57 @@ __global__ __launch_bounds__(1024) void k_deflate_scan(const uint32_t* __restric
   for (uint32_t i = lo; i < hi; i++) { offs[i] = run; run += sizes[i]; }
 }
 
-// slots -> the section's zlib stream; the first workgroup adds the frame
-__global__ __launch_bounds__(256) void k_deflate_gather(const uint8_t* __restrict__ slots, const uint32_t* __restrict__ sizes,
-                                                        const unsigned long long* __restrict__ offs, uint32_t nchunks, unsigned long long n,
-                                                        const unsigned long long* __restrict__ adler_acc, uint8_t* __restrict__ dst,
-                                                        unsigned long long* __restrict__ box_len) {
-  const unsigned long long total = offs[nchunks];
-  if (blockIdx.x == 0 && threadIdx.x == 0) {
-    dst[0] = 0x78; dst[1] = 0x5E;                        // FLG: "fastest algorithm" hint, no preset dictionary -- and this library's mark for
-                                                         // "the deflate blocks are independent chunks" (include/dctz.h: DCTZ_IX_MAGIC)
-    uint8_t* t = dst + 2 + total;
-    t[0] = 0x03; t[1] = 0x00;
-    const uint32_t s1 = (uint32_t)((1 + adler_acc[0]) % ADLER_M), s2 = (uint32_t)((n % ADLER_M + adler_acc[1]) % ADLER_M);
-    t[2] = (uint8_t)(s2 >> 8); t[3] = (uint8_t)s2; t[4] = (uint8_t)(s1 >> 8); t[5] = (uint8_t)s1;
-    *box_len = total + 8;
-  }
-  for (uint32_t c = blockIdx.x; c < nchunks; c += gridDim.x) {
-    const uint8_t* sl = slots + (size_t)c * SLOT;
-    uint8_t* d = dst + 2 + offs[c];
-    const uint32_t sz = sizes[c];
-    for (uint32_t i = threadIdx.x; i < sz; i += 256) d[i] = sl[i];
-  }
-}
-
 }  // namespace dfl
 
 // ------------------------------------------------------------------ host side --
 size_t deflate_chunk_bytes() { return (size_t)dfl::CHUNK; }
-size_t deflate_slot_bytes() { return (size_t)dfl::SLOT; }
 
-// One section.  scratch: slots (nchunks * SLOT) | sizes (u32 x nchunks, 8-byte aligned) | offs (u64 x (nchunks + 1)) | adler (2 x u64);
-// layout computed by deflate_scratch_bytes().  box_len: where the section's stream length goes (host-visible).
-size_t deflate_scratch_bytes(size_t n) {
+// scratch of one section: tokens (whole chunks) | counts | ChunkMeta | sizes | offsets | adler
+struct DflScratch {
+  uint8_t* tok;
+  uint32_t* freq;
+  dfl::ChunkMeta* meta;
+  uint32_t* sizes;
+  unsigned long long* offs;
+  unsigned long long* adler;
+  size_t bytes;
+};
+static DflScratch carve(void* base, size_t n) {
   const size_t nch = (n + dfl::CHUNK - 1) / dfl::CHUNK;
-  return nch * dfl::SLOT + ((nch * 4 + 7) & ~(size_t)7) + (nch + 1) * 8 + 16 + 64;
+  DflScratch r;
+  uint8_t* p = (uint8_t*)base;
+  r.tok = p; p += nch * dfl::CHUNK;
+  r.freq = (uint32_t*)p; p += nch * dfl::META_SYMS * sizeof(uint32_t);
+  r.meta = (dfl::ChunkMeta*)p; p += nch * sizeof(dfl::ChunkMeta);
+  r.sizes = (uint32_t*)p; p += (nch * 4 + 15) & ~(size_t)15;
+  r.offs = (unsigned long long*)p; p += (nch + 1) * 8;
+  r.adler = (unsigned long long*)p; p += 16;
+  r.bytes = (size_t)(p - (uint8_t*)base) + 64;
+  return r;
 }
+size_t deflate_scratch_bytes(size_t n) { return carve(nullptr, n).bytes; }
 size_t deflate_bound(size_t n) {
   const size_t nch = (n + dfl::CHUNK - 1) / dfl::CHUNK;
   return n + 5 * nch + 8;
 }
 
 hipError_t launch_deflate(const void* src, size_t n, void* dst, void* scratch, unsigned long long* box_len, uint32_t* host_sizes, hipStream_t st) {
+  static_assert(sizeof(dfl::ChunkMeta) % 16 == 0, "ChunkMeta is laid out in an array");
   const size_t nch = (n + dfl::CHUNK - 1) / dfl::CHUNK;
-  uint8_t* slots = (uint8_t*)scratch;
-  uint32_t* sizes = (uint32_t*)(slots + nch * dfl::SLOT);
-  unsigned long long* offs = (unsigned long long*)((uint8_t*)sizes + ((nch * 4 + 7) & ~(size_t)7));
-  unsigned long long* adler = offs + nch + 1;
-  hipError_t e = hipMemsetAsync(adler, 0, 16, st);
+  const DflScratch sc = carve(scratch, n);
+  hipError_t e = hipMemsetAsync(sc.adler, 0, 16, st);
   if (e != hipSuccess) return e;
-  if (nch) hipLaunchKernelGGL(dfl::k_deflate_chunks, dim3((unsigned)nch), dim3(dfl::NTHR), 0, st, (const uint8_t*)src, (unsigned long long)n, slots, sizes, adler);
-  if (nch && host_sizes) {                             // the chunk index of the section (bytes per chunk), for whoever writes a container
-    e = hipMemcpyAsync(host_sizes, sizes, nch * sizeof(uint32_t), hipMemcpyDeviceToHost, st);
-    if (e != hipSuccess) return e;
+  if (nch) {
+    hipLaunchKernelGGL(dfl::k_dfl_parse, dim3((unsigned)nch), dim3(dfl::NTHR), 0, st, (const uint8_t*)src, (unsigned long long)n, sc.tok, sc.freq, sc.adler);
+    hipLaunchKernelGGL(dfl::k_dfl_codes, dim3((unsigned)nch), dim3(dfl::CW), 0, st, sc.freq, (unsigned long long)n, sc.meta, sc.sizes);
+    if (host_sizes) {                                  // the chunk index of the section (bytes per chunk), for whoever writes a container
+      e = hipMemcpyAsync(host_sizes, sc.sizes, nch * sizeof(uint32_t), hipMemcpyDeviceToHost, st);
+      if (e != hipSuccess) return e;
+    }
   }
-  hipLaunchKernelGGL(dfl::k_deflate_scan, dim3(1), dim3(1024), 0, st, sizes, (uint32_t)nch, offs);
-  const unsigned g = nch ? (unsigned)(nch < 4096 ? nch : 4096) : 1u;
-  hipLaunchKernelGGL(dfl::k_deflate_gather, dim3(g), dim3(256), 0, st, slots, sizes, offs, (uint32_t)nch, (unsigned long long)n, adler, (uint8_t*)dst, box_len);
+  hipLaunchKernelGGL(dfl::k_deflate_scan, dim3(1), dim3(1024), 0, st, sc.sizes, (uint32_t)nch, sc.offs);
+  hipLaunchKernelGGL(dfl::k_dfl_emit, dim3(nch ? (unsigned)nch : 1u), dim3(dfl::NTHR), 0, st, (const uint8_t*)src, (unsigned long long)n, sc.tok, sc.meta,
+                     sc.sizes, sc.offs, (uint32_t)nch, sc.adler, (uint8_t*)dst, box_len);
   return hipGetLastError();
 }
 

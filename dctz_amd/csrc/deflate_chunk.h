@@ -76,6 +76,7 @@ DFL_HD constexpr int cand_deb(int c) { int s = 0, e = 0, v = 0; dist_code(cand_d
 DFL_HD constexpr int cand_dev(int c) { int s = 0, e = 0, v = 0; dist_code(cand_dist(c), s, e, v); return v; }
 // the same by a run-time index (small constant tables)
 #define DFL_TAB8(f) {f(0), f(1), f(2), f(3), f(4), f(5), f(6), f(7)}
+DFL_HD int cand_dist_rt(int c) { constexpr int t[NCAND] = DFL_CANDS; return t[c]; }
 DFL_HD int cand_dsym_rt(int c) { constexpr int t[NCAND] = DFL_TAB8(cand_dsym); return t[c]; }
 DFL_HD int cand_deb_rt(int c) { constexpr int t[NCAND] = DFL_TAB8(cand_deb); return t[c]; }
 DFL_HD int cand_dev_rt(int c) { constexpr int t[NCAND] = DFL_TAB8(cand_dev); return t[c]; }
@@ -92,13 +93,35 @@ DFL_HD void parse_segment(In in, TokW tokw, int p0, int p1, int avail, CountL li
     int best = 0, bc = 0;
     if (p + MINMATCH <= p1) {
       const int b0 = in(p), b1 = in(p + 1), b2 = in(p + 2);
+      // first bytes of all candidates in one batch of loads (a literal -- the common case -- costs one round trip)
+      unsigned m = 0;
 #pragma unroll
       for (int c = 0; c < NCAND; c++) {
         const int d = cand_dist(c);
-        if (p + avail < d) continue;
-        if (in(p - d) != b0 || in(p + 1 - d) != b1 || in(p + 2 - d) != b2) continue;
+        const int q = (p + avail >= d) ? p - d : p;       // (an unavailable candidate reads p itself and is masked out)
+        m |= (unsigned)((in(q) == b0) & (p + avail >= d)) << c;
+      }
+      while (m) {
+        const int c = __builtin_ctz(m);
+        m &= m - 1;
+        const int d = cand_dist_rt(c);
+        if (in(p + 1 - d) != b1 || in(p + 2 - d) != b2) continue;
         int l = 3;
-        while (p + l < p1 && l < MAXMATCH && in(p + l) == in(p + l - d)) l++;
+        for (;;) {                                        // four positions per round trip
+          const int room = p1 - (p + l) < MAXMATCH - l ? p1 - (p + l) : MAXMATCH - l;
+          if (room >= 4) {
+            const int e0 = in(p + l) == in(p + l - d), e1 = in(p + l + 1) == in(p + l + 1 - d), e2 = in(p + l + 2) == in(p + l + 2 - d),
+                      e3 = in(p + l + 3) == in(p + l + 3 - d);
+            const int run = e0 ? (e1 ? (e2 ? (e3 ? 4 : 3) : 2) : 1) : 0;
+            l += run;
+            if (run < 4) break;
+          } else {
+            int r = 0;
+            while (r < room && in(p + l + r) == in(p + l + r - d)) r++;
+            l += r;
+            break;
+          }
+        }
         if (l > best) { best = l; bc = c; }
       }
     }
@@ -108,7 +131,7 @@ DFL_HD void parse_segment(In in, TokW tokw, int p0, int p1, int avail, CountL li
       int s, e, v;
       len_code(best, s, e, v);
       lit(s);
-      dst(cand_dsym(bc));
+      dst(cand_dsym_rt(bc));
       p += best;
     } else {
       tokw(p, 0);

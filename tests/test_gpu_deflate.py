@@ -173,3 +173,54 @@ def test_streams_of_a_compress_call(ctx, mode):
         ours += len(z)
         ref += len(zlib.compress(np.ascontiguousarray(want).tobytes(), 6))
     assert ours <= 1.03 * ref, (ours, ref)
+
+
+@pytest.mark.gpu
+def test_random_sections_against_the_twin(ctx):
+    """64 sections of random length and statistics (constant stretches, periodic patterns, skewed and uniform bytes mixed
+    in random proportions): device bytes == twin bytes, and zlib inflates them to the input."""
+    import torch
+    L = twin()
+    rng = np.random.default_rng(77)
+    cases = []
+    for _ in range(64):
+        n = int(rng.integers(1, 5 * CHUNK))
+        parts, left = [], n
+        while left > 0:
+            m = int(min(left, rng.integers(1, 3000)))
+            kind = rng.integers(0, 5)
+            if kind == 0:
+                parts.append(np.full(m, rng.integers(0, 256), np.uint8))
+            elif kind == 1:
+                per = rng.integers(0, 256, int(rng.choice([2, 4, 8, 16, 64, 128, 7, 63])), dtype=np.uint8)
+                parts.append(np.resize(per, m))
+            elif kind == 2:
+                parts.append(rng.choice([127, 128, 126, 255, 0, 9], p=[.6, .2, .1, .05, .03, .02], size=m).astype(np.uint8))
+            elif kind == 3:
+                parts.append(rng.integers(0, 256, m, dtype=np.uint8))
+            else:
+                parts.append(rng.integers(0, 4, m, dtype=np.uint8))
+            left -= m
+        cases.append(np.concatenate(parts).tobytes())
+    for i in range(0, len(cases), 8):
+        part = cases[i:i + 8]
+        dev = [torch.from_numpy(np.frombuffer(b, dtype=np.uint8).copy()).to(ctx.device) for b in part]
+        outs, index = ctx.deflate(dev, want_index=True)
+        for b, o, ix in zip(part, outs, index):
+            z = o.cpu().numpy().tobytes()
+            assert zlib.decompress(z) == b
+            assert z == twin_deflate(L, b)
+            assert inflate_by_index(z, ix, len(b)) == b
+
+
+@pytest.mark.gpu
+def test_argument_checks(ctx):
+    import torch
+    import dctz_amd
+    t = torch.zeros(1000, dtype=torch.uint8, device=ctx.device)
+    small = torch.zeros(10, dtype=torch.uint8, device=ctx.device)
+    src = (C.c_void_p * 1)(t.data_ptr()); dst = (C.c_void_p * 1)(small.data_ptr())
+    n = (C.c_size_t * 1)(1000); cap = (C.c_size_t * 1)(10); ln = (C.c_size_t * 1)()
+    assert ctx.lib.dctzhip_deflate(ctx.h, 1, src, n, dst, cap, ln, None) != 0          # output below dctzhip_deflate_bound
+    assert ctx.lib.dctzhip_deflate(ctx.h, 9, src, n, dst, cap, ln, None) != 0          # more than 8 sections
+    assert int(ctx.lib.dctzhip_deflate_bound(0)) == 8 and int(ctx.lib.dctzhip_deflate_chunk_bytes()) == CHUNK
