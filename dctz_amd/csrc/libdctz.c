@@ -78,6 +78,14 @@ static int zlib_threads(void) { const char *e = getenv("DCTZ_ZLIB_THREADS"); ret
  * stream per section as before (any inflate reads it, dctz-decomp-lib.c:244-322); the bytes -- and the sizes, by a per
  * cent or so -- differ from zlib's, which is why the reference's tail stays the default. */
 static int zlib_gpu(void) { const char *e = getenv("DCTZ_ZLIB_GPU"); return e && atoi(e) != 0; }
+/* DCTZ_FAST_MEAN=1: header.mean = the tree-order sum / N that the compress kernels produce anyway, instead of the
+ * reference's serial-order sum (util.c:18-28).  The field is written but never read back (dctz-decomp-lib.c:499 is
+ * commented out); the serial chain of N dependent additions is what bounds a call once the entropy stage is on the GPU
+ * (50 ms per GiB on one host core).  Off by default: the header is then bit-identical to the reference's. */
+static int fast_mean(void) { const char *e = getenv("DCTZ_FAST_MEAN"); return e && atoi(e) != 0; }
+/* DCTZ_SCALE_HOST: 1 = x / sf is written into the caller's buffer by host threads, 0 = by the GPU + a D2H copy.
+ * Default: host threads exactly when the entropy stage runs on the GPU (the host cores are idle then). */
+static int scale_on_host(int gpu_tail) { const char *e = getenv("DCTZ_SCALE_HOST"); return e ? atoi(e) != 0 : gpu_tail; }
 static size_t zlib_chunk(void) {
   const char *e = getenv("DCTZ_ZLIB_CHUNK");
   long long v = e ? atoll(e) : 0;
@@ -248,6 +256,52 @@ static void *host_mean_main(void *arg) {
     j->mean = (double)(sum / (float)(int)j->n);
   }
   return NULL;
+}
+
+/* The reference's in-place "/= sf" (dctz-comp-lib.c:193-216) on host threads, for the device entropy stage: there the
+ * tail is too short to hide a 1 GiB write-back over PCIe, and the host cores are idle.  Same operation as the
+ * reference's loop (IEEE division in the data type), so the caller's buffer ends up bit-identical to x / sf.  It may
+ * only start once the serial-order mean has read the original values: the manager thread waits for that first. */
+typedef struct {
+  void *x;
+  size_t lo, hi;
+  int is_d;
+  double sf;
+} scale_part;
+static void *scale_part_main(void *arg) {
+  scale_part *j = (scale_part *)arg;
+  if (j->is_d) { double *x = (double *)j->x; const double sf = j->sf; for (size_t i = j->lo; i < j->hi; i++) x[i] /= sf; }
+  else { float *x = (float *)j->x; const float sf = (float)j->sf; for (size_t i = j->lo; i < j->hi; i++) x[i] /= sf; }
+  return NULL;
+}
+typedef struct {
+  void *x;
+  size_t n;
+  int is_d, threads;
+  double sf;
+  pthread_t *wait_for;          /* the serial-mean thread, or NULL */
+} scale_mgr;
+static void *scale_mgr_main(void *arg) {
+  scale_mgr *m = (scale_mgr *)arg;
+  if (m->wait_for) pthread_join(*m->wait_for, NULL);
+  int T = m->threads < 1 ? 1 : (m->threads > 64 ? 64 : m->threads);
+  if ((size_t)T > m->n / 65536 + 1) T = (int)(m->n / 65536 + 1);
+  scale_part part[64];
+  pthread_t th[64];
+  int started = 0;
+  for (int t = 0; t < T; t++) {
+    part[t].x = m->x; part[t].is_d = m->is_d; part[t].sf = m->sf;
+    part[t].lo = m->n * (size_t)t / (size_t)T; part[t].hi = m->n * (size_t)(t + 1) / (size_t)T;
+  }
+  for (int t = 1; t < T; t++) { if (pthread_create(&th[started], NULL, scale_part_main, &part[t])) scale_part_main(&part[t]); else started++; }
+  scale_part_main(&part[0]);
+  for (int t = 0; t < started; t++) pthread_join(th[t], NULL);
+  return NULL;
+}
+static int host_threads(void) {
+  int t = zlib_threads();
+  if (t <= 0) { long nc = sysconf(_SC_NPROCESSORS_ONLN); t = nc > 32 ? 32 : (nc < 1 ? 1 : (int)nc); }
+  return t;
 }
 
 typedef struct {
@@ -448,8 +502,9 @@ int dctz_compress(t_var *var, int N, size_t *outSize, t_var *var_z, double error
   pthread_t mean_thread;
   host_mean_job mj = {host_in, n, is_d, 0.0};
   int mean_on_host = 0;
-  if (fast_tail && pthread_create(&mean_thread, NULL, host_mean_main, &mj) == 0) mean_on_host = 1;
-  if (!mean_on_host && dctzhip_serial_mean_begin(c, g_dev.in, n, dtype) != DCTZHIP_OK) die("serial mean");
+  const int tree_mean = fast_mean();
+  if (!tree_mean && fast_tail && pthread_create(&mean_thread, NULL, host_mean_main, &mj) == 0) mean_on_host = 1;
+  if (!tree_mean && !mean_on_host && dctzhip_serial_mean_begin(c, g_dev.in, n, dtype) != DCTZHIP_OK) die("serial mean");
   int rc = nd ? dctzhip_compress_nd(c, g_dev.in, nd, dims, dtype, error_bound, DCTZ_MODE, g_dev.bin, (float *)g_dev.dc,
                                     (float *)g_dev.ac, NULL, &info)
               : dctzhip_compress(c, g_dev.in, n, dtype, error_bound, DCTZ_MODE, g_dev.bin, (float *)g_dev.dc,
@@ -499,6 +554,11 @@ int dctz_compress(t_var *var, int N, size_t *outSize, t_var *var_z, double error
   double t_gz = 0.0;                        /* end of the device entropy stage (the write-back of x/sf follows it) */
   uint32_t *ix[3] = {NULL, NULL, NULL};     /* compressed bytes per chunk, for the "DZIX" trailer */
   size_t ix_n[3] = {0, 0, 0};
+  const int host_scale = scale_on_host(gpu_tail) && info.sf != 1.0;
+  pthread_t scale_thread;
+  scale_mgr sm = {host_in, n, is_d, host_threads(), info.sf, mean_on_host ? &mean_thread : NULL};
+  int scale_started = 0;
+  if (host_scale && pthread_create(&scale_thread, NULL, scale_mgr_main, &sm) == 0) scale_started = 1;
   if (gpu_tail) {                           /* deflate on the device, compressed bytes only over PCIe */
     const void *gsrc[3] = {g_dev.bin, g_dev.dc, g_dev.ac};
     size_t gcap[3];
@@ -535,9 +595,12 @@ int dctz_compress(t_var *var, int N, size_t *outSize, t_var *var_z, double error
   /* while zlib runs: write x/sf back over the caller's buffer (:193-216) and
    * fetch the serial-order mean for the header */
   double mean_serial = 0.0;
-  if (mean_on_host) { pthread_join(mean_thread, NULL); mean_serial = mj.mean; }   /* before host_in is overwritten */
+  if (scale_started) pthread_join(scale_thread, NULL);                            /* (it has joined the mean thread itself) */
+  else if (mean_on_host) pthread_join(mean_thread, NULL);                         /* before host_in is overwritten */
+  if (tree_mean) mean_serial = info.mean;
+  else if (mean_on_host) mean_serial = mj.mean;
   else if (dctzhip_serial_mean_end(c, &mean_serial) != DCTZHIP_OK) die("serial mean");
-  if (info.sf != 1.0) {   /* only now may the device copy of the input change */
+  if (info.sf != 1.0 && !scale_started) {   /* only now may the device copy of the input change */
     if (dctzhip_scale_inplace(c, g_dev.in, n, dtype, info.sf) != DCTZHIP_OK) die("scale");
     if (dctzhip_memcpy_d2h(c, host_in, g_dev.in, n * ts) != DCTZHIP_OK) die("D2H scaled input");
   }

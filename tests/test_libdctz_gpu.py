@@ -130,6 +130,47 @@ def test_dropin_compress_decompress(mode, case, zthreads):
         assert abs(p["psnr"] - 96.383701092386) < 1e-6 and abs(p["maxdiff"] - 9.232739551845448e-05) < 1e-10
 
 
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_gpu_tail_knobs(dtype):
+    """DCTZ_ZLIB_GPU=1 with its two side knobs: DCTZ_SCALE_HOST=0 (x / sf written back by the GPU instead of host
+    threads) gives the same container and the same caller's buffer; DCTZ_FAST_MEAN=1 changes nothing but the header's
+    mean, which then is the tree-order sum / N (close to, not bit-identical with, the reference's serial sum)."""
+    lib = _lib("ec")
+    x0 = W.ragged(64 * 5000 + 21, dtype, scale=410.0)
+    n = x0.size
+    c = O.compress(x0, 1e-3, O.EC, O.FAST)
+
+    def run(env):
+        for k in ("DCTZ_ZLIB_GPU", "DCTZ_SCALE_HOST", "DCTZ_FAST_MEAN"):
+            os.environ.pop(k, None)
+        os.environ.update(env)
+        try:
+            x = x0.copy()
+            zbuf = np.zeros(n * x.itemsize + 65536, np.uint8)
+            var, var_z = _tvar(x), TVar()
+            var_z.datatype = var.datatype
+            var_z.buf.d = zbuf.ctypes.data_as(C.POINTER(C.c_double))
+            out_size = C.c_size_t(0)
+            assert lib.dctz_compress(C.byref(var), n, C.byref(out_size), C.byref(var_z), 1e-3) == 1
+            return bytes(zbuf[:out_size.value]), x
+        finally:
+            for k in env:
+                os.environ.pop(k, None)
+
+    z_host_scale, x_a = run({"DCTZ_ZLIB_GPU": "1"})
+    z_gpu_scale, x_b = run({"DCTZ_ZLIB_GPU": "1", "DCTZ_SCALE_HOST": "0"})
+    z_fast, x_c = run({"DCTZ_ZLIB_GPU": "1", "DCTZ_FAST_MEAN": "1"})
+    assert z_host_scale == z_gpu_scale
+    for x in (x_a, x_b, x_c):
+        assert np.array_equal(x.view(np.uint8), c.scaled.view(np.uint8))
+    assert z_fast[:32] == z_host_scale[:32] and z_fast[40:] == z_host_scale[40:]
+    w = np.dtype(dtype).itemsize
+    m_ref = np.frombuffer(z_host_scale[32:32 + w], dtype)[0]
+    m_fast = np.frombuffer(z_fast[32:32 + w], dtype)[0]
+    assert m_ref == dtype(c.mean)
+    assert abs(float(m_fast) - float(m_ref)) <= 1e-5 * float(np.abs(x0).max())
+
+
 def test_dct_h_per_block_api():
     """dct_init / dct_fftw / ifft_idct / dct_finish as dct-test.c:81-89, 144-152 drives them."""
     lib = _lib("ec")
