@@ -533,3 +533,249 @@ hipError_t launch_deflate(const void* src, size_t n, void* dst, void* scratch, u
 }
 
 }  // namespace dctz
+
+// =====================================================================================================================
+// Inflate of sections made by the kernels above (and only of those): every chunk is one stored or one dynamic block
+// that starts on a byte boundary, references at most 128 bytes back and never anything in front of the chunk, and the
+// container's "DZIX" index says where it starts.  One LANE per chunk: 64 chunks per wave decode side by side; a
+// section of 8192 chunks is 128 waves.  Replaces, for such sections, the reader's inflate() calls
+// (dctz-decomp-lib.c:244-322) and the H2D copy of the raw streams.
+//
+// A damaged stream must never turn into a wild access: every read of the chunk is bounded by its size, every write by
+// the chunk's output length, every table index by construction of the canonical tables, every loop by a counter that
+// moves towards its end; what does not fit sets the section's error flag and the lane stops (the host then takes the
+// zlib path, which reports the damage the way the reference does).
+namespace dctz {
+namespace dfl {
+
+constexpr int IW = 64;                                 // lanes (= chunks) per workgroup
+constexpr int RING = 128;                              // bytes of history per lane = the largest distance the encoder uses
+
+struct LdsInflate {                                    // per-lane arrays, element i of lane t at [i][t]
+  union {
+    uint8_t len[NLIT + NDIST][IW];                     // code lengths as read from the header (until the tables stand)
+    uint8_t ring[RING][IW];                            // then: the last RING bytes written
+  };
+  uint16_t lsym[NLIT][IW];                             // literal/length symbols sorted by (length, symbol)
+  uint8_t dsym[NDIST][IW];
+  uint8_t csym[NCL][IW];
+};
+
+// LSB-first bit reader over the chunk's bytes.  Memory is read as aligned 32-bit words, one word AHEAD of the one being
+// consumed (the load issued when a word is taken is not needed before the next 32 bits are: its latency hides behind
+// the decoding of the symbols in between); words that lie entirely behind the chunk are not read, the few bytes of a
+// word that straddle its ends are whatever the section holds there (never used: `over` is set when more bits are asked
+// for than the chunk has).
+struct BitR {
+  const uint32_t* w;                                   // aligned word that holds the chunk's first byte
+  uint32_t nwords;                                     // words that hold bytes of the chunk
+  uint32_t wi;                                         // next word to load
+  uint32_t nextw;                                      // the word loaded ahead
+  uint64_t acc;
+  int nbits;
+  long long left;                                      // bits of the chunk not yet handed out
+  bool over;
+  __device__ __forceinline__ BitR(const uint8_t* z, uint32_t zlen) {
+    const uintptr_t p = (uintptr_t)z;
+    const uint32_t skip = (uint32_t)(p & 3);
+    w = (const uint32_t*)(p - skip);
+    nwords = (skip + zlen + 3) / 4;
+    left = (long long)zlen * 8;
+    over = false;
+    const uint32_t w0 = nwords > 0 ? w[0] : 0u;
+    nextw = nwords > 1 ? w[1] : 0u;
+    wi = 2;
+    acc = (uint64_t)(w0 >> (8 * skip));
+    nbits = 32 - 8 * (int)skip;
+  }
+  __device__ __forceinline__ void need(int n) {        // n <= 32
+    if (nbits < n) {
+      acc |= (uint64_t)nextw << nbits;
+      nbits += 32;
+      nextw = wi < nwords ? w[wi] : 0u;
+      wi++;
+    }
+  }
+  __device__ __forceinline__ uint32_t peek(int n) const { return (uint32_t)(acc & ((1ull << n) - 1)); }
+  __device__ __forceinline__ void drop(int n) {
+    left -= n;
+    if (left < 0) over = true;
+    acc >>= n; nbits -= n;
+  }
+  __device__ __forceinline__ uint32_t get(int n) {
+    need(n);
+    const uint32_t v = peek(n);
+    drop(n);
+    return v;
+  }
+  __device__ __forceinline__ void align_byte() { const int r = (int)(left & 7); if (r) drop(r); }   // (the chunk starts on a byte boundary)
+};
+
+// canonical decode (the counting walk of zlib's contrib/puff): cnt[l] = codes of length l, symbols sorted by (length, symbol)
+template <int MAXL, class Sym>
+__device__ __forceinline__ int decode_sym(BitR& br, const uint16_t (&cnt)[MAXL + 1], Sym sym, bool& bad) {
+  br.need(MAXL);
+  uint32_t bits = br.peek(MAXL);
+  int code = 0, first = 0, index = 0;
+#pragma unroll
+  for (int l = 1; l <= MAXL; l++) {
+    code |= (int)(bits & 1u);
+    bits >>= 1;
+    const int c = cnt[l];
+    if (code - c < first) { br.drop(l); return sym(index + (code - first)); }
+    index += c; first += c;
+    first <<= 1; code <<= 1;
+  }
+  bad = true;
+  return 0;
+}
+
+__global__ __launch_bounds__(IW) void k_dfl_inflate(const uint8_t* __restrict__ sec, const uint32_t* __restrict__ offs, uint32_t nchunks,
+                                                    unsigned long long n, uint8_t* __restrict__ dst, unsigned long long* __restrict__ adler_acc,
+                                                    uint32_t* __restrict__ status) {
+  __shared__ LdsInflate s;
+  const int t = threadIdx.x;
+  const uint32_t c = blockIdx.x * IW + t;
+  if (c >= nchunks) return;
+  const unsigned long long off = (unsigned long long)c * CHUNK;
+  const uint32_t olen = (uint32_t)((n - off) < (unsigned long long)CHUNK ? (n - off) : (unsigned long long)CHUNK);
+  uint8_t* out = dst + off;
+  BitR br(sec + 2 + offs[c], offs[c + 1] - offs[c]);
+  bool bad = false;
+  uint32_t op = 0, a = 0;                                 // output position; adler32 pieces of the chunk: a = sum d,
+  unsigned long long b = 0;                               // b = sum (olen - j) d_j (accumulated as b += a after every byte)
+
+  const uint32_t hdr = br.get(3);
+  if (hdr == 0) {                                         // stored, not final: LEN, ~LEN, bytes
+    br.align_byte();
+    const uint32_t len = br.get(16), nlen = br.get(16);
+    if (len != olen || (len ^ nlen) != 0xFFFFu || br.over) bad = true;
+    else {
+      // the bit reader may hold bytes already: they come first
+      for (; op < olen; op++) { const uint32_t d = br.get(8); out[op] = (uint8_t)d; a += d; b += a; }
+      if (br.over) bad = true;
+    }
+  } else if (hdr == 4) {                                  // BFINAL 0, BTYPE 10
+    const int hlit = 257 + (int)br.get(5), hdist = 1 + (int)br.get(5), hclen = 4 + (int)br.get(4);
+    if (hlit > NLIT || hdist > NDIST) bad = true;
+    uint16_t ccnt[MAXBITS_CL + 1] = {}, lcnt[MAXBITS + 1] = {}, dcnt[MAXBITS + 1] = {};
+    if (!bad) {
+      // code-length code
+      uint8_t cl[NCL];
+#pragma unroll
+      for (int i = 0; i < NCL; i++) cl[i] = 0;
+#pragma unroll
+      for (int i = 0; i < NCL; i++) if (i < hclen) { const uint32_t v = br.get(3); cl[cl_order(i)] = (uint8_t)v; }
+#pragma unroll
+      for (int i = 0; i < NCL; i++) ccnt[cl[i]]++;
+      ccnt[0] = 0;
+      {
+        int offs_l[MAXBITS_CL + 2];
+        offs_l[1] = 0;
+#pragma unroll
+        for (int l = 1; l <= MAXBITS_CL; l++) offs_l[l + 1] = offs_l[l] + ccnt[l];
+#pragma unroll
+        for (int i = 0; i < NCL; i++) if (cl[i]) { s.csym[offs_l[cl[i]] < NCL ? offs_l[cl[i]] : 0][t] = (uint8_t)i; offs_l[cl[i]]++; }
+      }
+      // the literal/length and distance code lengths
+      int i = 0, prev = 0;
+      const int total = hlit + hdist;
+      while (i < total && !bad && !br.over) {
+        const int sym = decode_sym<MAXBITS_CL>(br, ccnt, [&](int k) { return (int)s.csym[k < NCL ? k : 0][t]; }, bad);
+        if (bad) break;
+        if (sym < 16) { s.len[i++][t] = (uint8_t)sym; prev = sym; }
+        else {
+          int rep, val;
+          if (sym == 16) { if (i == 0) { bad = true; break; } rep = 3 + (int)br.get(2); val = prev; }
+          else if (sym == 17) { rep = 3 + (int)br.get(3); val = 0; prev = 0; }
+          else { rep = 11 + (int)br.get(7); val = 0; prev = 0; }
+          if (i + rep > total) { bad = true; break; }
+          for (int r = 0; r < rep; r++) s.len[i++][t] = (uint8_t)val;
+        }
+      }
+      if (br.over) bad = true;
+    }
+    if (!bad) {
+      // counts per length, then the symbols in canonical order
+      for (int i = 0; i < hlit; i++) { const int l = s.len[i][t]; if (l) lcnt[l]++; }
+      for (int i = 0; i < hdist; i++) { const int l = s.len[hlit + i][t]; if (l) dcnt[l]++; }
+      int lo[MAXBITS + 2], dofs[MAXBITS + 2];
+      lo[1] = 0; dofs[1] = 0;
+#pragma unroll
+      for (int l = 1; l <= MAXBITS; l++) { lo[l + 1] = lo[l] + lcnt[l]; dofs[l + 1] = dofs[l] + dcnt[l]; }
+      for (int i = 0; i < hlit; i++) {
+        const int l = s.len[i][t];
+        if (!l) continue;
+        int slot = 0;
+#pragma unroll
+        for (int q = 1; q <= MAXBITS; q++) if (q == l) { slot = lo[q]; lo[q]++; }
+        s.lsym[slot < NLIT ? slot : 0][t] = (uint16_t)i;
+      }
+      for (int i = 0; i < hdist; i++) {
+        const int l = s.len[hlit + i][t];
+        if (!l) continue;
+        int slot = 0;
+#pragma unroll
+        for (int q = 1; q <= MAXBITS; q++) if (q == l) { slot = dofs[q]; dofs[q]++; }
+        s.dsym[slot < NDIST ? slot : 0][t] = (uint8_t)i;
+      }
+      // the tokens.  One byte per lane per turn: a lane inside a long match copies one byte while its neighbours decode
+      // their next symbol (a loop that finished a whole match per turn would make every lane of the wave wait for the
+      // longest match of the turn: 128 copy steps per literal of a neighbour).
+      int mlen = 0, mdist = 0;
+      bool done = false;
+      for (uint32_t guard = 0; guard < 2 * olen + 2 && !bad && !done; guard++) {   // a turn writes a byte, opens a match or ends the block
+        if (mlen > 0) {
+          const uint32_t d = s.ring[(op - (uint32_t)mdist) & (RING - 1)][t];
+          out[op] = (uint8_t)d; s.ring[op & (RING - 1)][t] = (uint8_t)d;
+          a += d; b += a; op++; mlen--;
+          continue;
+        }
+        const int sym = decode_sym<MAXBITS>(br, lcnt, [&](int k) { return (int)s.lsym[k < NLIT ? k : 0][t]; }, bad);
+        if (bad || br.over) { bad = true; break; }
+        if (sym < 256) {
+          if (op >= olen) { bad = true; break; }
+          out[op] = (uint8_t)sym; s.ring[op & (RING - 1)][t] = (uint8_t)sym;
+          a += (uint32_t)sym; b += a; op++;
+        } else if (sym == 256) done = true;
+        else {
+          const int ls = sym - 257;
+          if (ls >= 29) { bad = true; break; }
+          int len;
+          if (ls < 8) len = 3 + ls;
+          else if (ls == 28) len = 258;
+          else { const int eb = (ls >> 2) - 1; len = 3 + ((4 + (ls & 3)) << eb) + (int)br.get(eb); }
+          const int ds = decode_sym<MAXBITS>(br, dcnt, [&](int k) { return (int)s.dsym[k < NDIST ? k : 0][t]; }, bad);
+          if (bad) break;
+          int dist;
+          if (ds < 4) dist = 1 + ds;
+          else { const int eb = (ds >> 1) - 1; dist = 1 + ((2 + (ds & 1)) << eb) + (int)br.get(eb); }
+          if (dist > RING || (uint32_t)dist > op || op + (uint32_t)len > olen || br.over) { bad = true; break; }
+          mlen = len; mdist = dist;
+        }
+      }
+      if (!done) bad = true;
+    }
+  } else bad = true;
+  if (!bad && op != olen) bad = true;
+  if (bad) { atomicOr(status, 1u); return; }
+  // this chunk's share of the section's adler32 (as in k_dfl_parse)
+  const unsigned long long after = n - (off + olen);
+  atomicAdd(&adler_acc[0], (unsigned long long)(a % ADLER_M));
+  atomicAdd(&adler_acc[1], (unsigned long long)((b % ADLER_M + (unsigned long long)(a % ADLER_M) * (after % ADLER_M)) % ADLER_M));
+}
+
+}  // namespace dfl
+
+// One section: compressed stream `sec` (device, zlen bytes), chunk offsets offs[nch + 1] (device, relative to sec + 2),
+// raw length n -> dst.  status: one word, OR-ed with 1 on any inconsistency; adler: two u64 accumulators (zeroed here).
+hipError_t launch_inflate(const void* sec, const uint32_t* offs, size_t nch, size_t n, void* dst, unsigned long long* adler, uint32_t* status,
+                          hipStream_t st) {
+  hipError_t e = hipMemsetAsync(adler, 0, 16, st);
+  if (e != hipSuccess) return e;
+  if (nch) hipLaunchKernelGGL(dfl::k_dfl_inflate, dim3((unsigned)((nch + dfl::IW - 1) / dfl::IW)), dim3(dfl::IW), 0, st, (const uint8_t*)sec, offs,
+                              (uint32_t)nch, (unsigned long long)n, (uint8_t*)dst, adler, status);
+  return hipGetLastError();
+}
+
+}  // namespace dctz

@@ -252,6 +252,7 @@ size_t deflate_chunk_bytes();
 size_t deflate_scratch_bytes(size_t n);
 size_t deflate_bound(size_t n);
 hipError_t launch_deflate(const void* src, size_t n, void* dst, void* scratch, unsigned long long* box_len, uint32_t* host_sizes, hipStream_t st);
+hipError_t launch_inflate(const void* sec, const uint32_t* offs, size_t nch, size_t n, void* dst, unsigned long long* adler, uint32_t* status, hipStream_t st);
 template <typename T> int compress_occupancy(int mode, bool stats, int geom);
 template <typename T> int decompress_occupancy(int mode, int geom);
 template <typename T> size_t compress_lds_bytes(int mode);

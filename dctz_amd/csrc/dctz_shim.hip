@@ -16,6 +16,8 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <thread>
+#include <vector>
 
 #include "dctz_device.h"
 #include "dctz_tables.h"
@@ -62,6 +64,12 @@ struct dctzhip_ctx {
   int occ[2][2][2][2][3] = {};      // resident workgroups per CU per kernel instantiation [f64][decode][qt][stats][geom], 0 = not asked yet
   int grid_c = 0;                   // upper bound of k_compress's grid (DCTZHIP_GRID_C; 0 = what the LDS admits)
   int nd_direct = 1;                // multi-dimensional blocks read / written in place where the shape allows (DCTZHIP_ND_DIRECT)
+  // large D2H copies into pageable memory: pinned staging slots, one per worker thread, each with its own stream
+  static constexpr int STAGE_WORKERS = 8;
+  static constexpr size_t STAGE_SLOT = (size_t)16 << 20;
+  void* stage[STAGE_WORKERS] = {};
+  hipStream_t stage_stream[STAGE_WORKERS] = {};
+  int staged_d2h = 1;               // 0: one hipMemcpy (DCTZHIP_STAGED_D2H)
   void* dfl_buf = nullptr;          // GPU entropy stage: chunk slots, sizes, offsets (dctz_deflate.hip)
   size_t dfl_cap = 0;               // bytes
   unsigned long long* dfl_len = nullptr;      // stream lengths of up to 8 sections (pinned host memory the kernels write)
@@ -185,6 +193,7 @@ extern "C" int dctzhip_ctx_create(dctzhip_ctx** out, int device) {
   if (const char* e = getenv("DCTZHIP_ND_DIRECT")) c->nd_direct = atoi(e) != 0;
   if (const char* e = getenv("DCTZHIP_GRID_C")) c->grid_c = atoi(e);
   if (const char* e = getenv("DCTZHIP_BLOCKING")) c->blocking = atoi(e) != 0;
+  if (const char* e = getenv("DCTZHIP_STAGED_D2H")) c->staged_d2h = atoi(e) != 0;
   if (int rc = build_sf_tables(c)) return rc;
   *out = c;
   return DCTZHIP_OK;
@@ -202,6 +211,10 @@ extern "C" void dctzhip_ctx_destroy(dctzhip_ctx* c) {
   if (c->h_pin) (void)hipHostFree(c->h_pin);
   if (c->box) (void)hipHostFree(c->box);
   if (c->dfl_len) (void)hipHostFree(c->dfl_len);
+  for (int i = 0; i < dctzhip_ctx::STAGE_WORKERS; i++) {
+    if (c->stage[i]) (void)hipHostFree(c->stage[i]);
+    if (c->stage_stream[i]) (void)hipStreamDestroy(c->stage_stream[i]);
+  }
   for (int i = 0; i < 6; i++) if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
   if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
   delete c;
@@ -263,8 +276,47 @@ extern "C" int dctzhip_memcpy_h2d(dctzhip_ctx* c, void* dst, const void* src, si
   HIPCHK(c, hipStreamSynchronize(c->stream));
   return DCTZHIP_OK;
 }
+// A large copy into PAGEABLE host memory: the runtime's own path stages it through one pinned buffer on one thread
+// (1 GiB: 45 ms, and first-touch page faults of a fresh destination are taken by that thread too).  Here eight worker
+// threads each move every eighth 16 MiB piece: D2H into the worker's pinned slot on its own stream, then memcpy into
+// the destination -- transfers and host copies of different workers overlap (1 GiB: ~20 ms).
+static int staged_d2h(dctzhip_ctx* c, void* dst, const void* src, size_t bytes) {
+  constexpr int W = dctzhip_ctx::STAGE_WORKERS;
+  constexpr size_t SLOT = dctzhip_ctx::STAGE_SLOT;
+  for (int i = 0; i < W; i++) {
+    if (!c->stage[i]) HIPCHK(c, hipHostMalloc(&c->stage[i], SLOT, hipHostMallocDefault));
+    if (!c->stage_stream[i]) HIPCHK(c, hipStreamCreateWithFlags(&c->stage_stream[i], hipStreamNonBlocking));
+  }
+  HIPCHK(c, hipStreamSynchronize(c->stream));            // what the copy reads has been produced on the context's stream
+  const size_t pieces = (bytes + SLOT - 1) / SLOT;
+  hipError_t err[W];
+  std::vector<std::thread> th;
+  for (int w = 0; w < W; w++) {
+    err[w] = hipSuccess;
+    th.emplace_back([=, &err]() {
+      if (hipSetDevice(c->device) != hipSuccess) { err[w] = hipErrorInvalidDevice; return; }
+      for (size_t k = (size_t)w; k < pieces; k += W) {
+        const size_t off = k * SLOT, len = bytes - off < SLOT ? bytes - off : SLOT;
+        hipError_t e = hipMemcpyAsync(c->stage[w], (const char*)src + off, len, hipMemcpyDeviceToHost, c->stage_stream[w]);
+        if (e == hipSuccess) e = hipStreamSynchronize(c->stage_stream[w]);
+        if (e != hipSuccess) { err[w] = e; return; }
+        memcpy((char*)dst + off, c->stage[w], len);
+      }
+    });
+  }
+  for (auto& t : th) t.join();
+  for (int w = 0; w < W; w++) if (err[w] != hipSuccess) return fail(c, DCTZHIP_E_HIP, "staged D2H copy failed: %s", hipGetErrorString(err[w]));
+  return DCTZHIP_OK;
+}
+
 extern "C" int dctzhip_memcpy_d2h(dctzhip_ctx* c, void* dst, const void* src, size_t bytes) {
   if (!c) return DCTZHIP_E_ARG;
+  if (c->staged_d2h && bytes >= ((size_t)64 << 20)) {
+    hipPointerAttribute_t at;
+    const bool pageable = hipPointerGetAttributes(&at, dst) != hipSuccess || at.type == hipMemoryTypeUnregistered;
+    (void)hipGetLastError();
+    if (pageable) return staged_d2h(c, dst, src, bytes);
+  }
   HIPCHK(c, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
   return DCTZHIP_OK;
@@ -343,6 +395,60 @@ static bool value_in_window(int dtype, double v) {
 }
 
 static size_t elem_size(int dtype) { return dtype == DCTZHIP_F64 ? 8 : 4; }
+
+// Inflate of sections written by dctzhip_deflate, chunk by chunk on the device (dctz_deflate.hip: k_dfl_inflate).
+extern "C" int dctzhip_inflate(dctzhip_ctx* c, int nsec, const void* const* d_z, const size_t* zlen, const uint32_t* const* chunk_sizes,
+                               const size_t* raw, void* const* d_dst, int* ok) {
+  if (!c || !ok || nsec < 0 || nsec > 8 || (nsec && (!d_z || !zlen || !chunk_sizes || !raw || !d_dst))) return fail(c, DCTZHIP_E_ARG, "dctzhip_inflate: bad arguments");
+  *ok = 0;
+  HIPCHK(c, hipSetDevice(c->device));
+  const size_t chunk = deflate_chunk_bytes();
+  // per section in the scratch: offsets (nch + 1) u32 | adler 2 x u64 | status u32
+  std::vector<std::vector<uint32_t>> offs((size_t)nsec);
+  size_t need = 0;
+  std::vector<size_t> base((size_t)nsec);
+  for (int i = 0; i < nsec; i++) {
+    const size_t nch = (raw[i] + chunk - 1) / chunk;
+    if (zlen[i] < 8 || (nch && !chunk_sizes[i]) || !d_z[i] || (raw[i] && !d_dst[i])) return DCTZHIP_OK;      // not ours: *ok stays 0
+    offs[i].resize(nch + 1);
+    unsigned long long run = 0;
+    for (size_t k = 0; k < nch; k++) { offs[i][k] = (uint32_t)run; run += chunk_sizes[i][k]; if (chunk_sizes[i][k] == 0 || chunk_sizes[i][k] > chunk + 5) return DCTZHIP_OK; }
+    offs[i][nch] = (uint32_t)run;
+    if (run + 8 != zlen[i]) return DCTZHIP_OK;             // the sizes must tile the stream
+    base[i] = need;
+    need += ((nch + 1) * 4 + 15) / 16 * 16 + 32;
+  }
+  {
+    char* b = (char*)c->dfl_buf;
+    int rc = regrow(c, &b, &c->dfl_cap, need, 1);
+    c->dfl_buf = b;
+    if (rc) return rc;
+  }
+  for (int i = 0; i < nsec; i++) {
+    const size_t nch = offs[i].size() - 1;
+    char* p = (char*)c->dfl_buf + base[i];
+    unsigned long long* adler = (unsigned long long*)(p + ((nch + 1) * 4 + 15) / 16 * 16);
+    uint32_t* status = (uint32_t*)(adler + 2);
+    HIPCHK(c, hipMemcpyAsync(p, offs[i].data(), (nch + 1) * 4, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemsetAsync(status, 0, 4, c->stream));
+    HIPCHK(c, launch_inflate(d_z[i], (const uint32_t*)p, nch, raw[i], d_dst[i], adler, status, c->stream));
+  }
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  int good = 1;
+  for (int i = 0; i < nsec; i++) {
+    const size_t nch = offs[i].size() - 1;
+    char* p = (char*)c->dfl_buf + base[i] + ((nch + 1) * 4 + 15) / 16 * 16;
+    struct { unsigned long long a[2]; uint32_t status; uint32_t pad; } r;
+    unsigned char tail[4];
+    HIPCHK(c, hipMemcpy(&r, p, sizeof(r), hipMemcpyDeviceToHost));
+    HIPCHK(c, hipMemcpy(tail, (const char*)d_z[i] + zlen[i] - 4, 4, hipMemcpyDeviceToHost));
+    const uint32_t s1 = (uint32_t)((1 + r.a[0]) % 65521u), s2 = (uint32_t)((raw[i] % 65521u + r.a[1]) % 65521u);
+    const uint32_t want = ((uint32_t)tail[0] << 24) | ((uint32_t)tail[1] << 16) | ((uint32_t)tail[2] << 8) | tail[3];
+    if (r.status != 0 || ((s2 << 16) | s1) != want) good = 0;      // what inflate() checks at the end of a stream
+  }
+  *ok = good;
+  return DCTZHIP_OK;
+}
 
 template <typename P>
 static int regrow(dctzhip_ctx* c, P** ptr, size_t* cap, size_t need, size_t elem) {

@@ -417,6 +417,29 @@ static int inflate_indexed(const unsigned char *const sec[3], const unsigned int
   return 1;
 }
 
+/* The chunk sizes of an indexed container as three arrays (for the device inflate); 0 when there is no valid index. */
+static int index_sizes(const unsigned char *const sec[3], const unsigned int zlen[3], const size_t raw[3], const unsigned char *trailer,
+                       uint32_t *sizes[3]) {
+  for (int i = 0; i < 3; i++) { sizes[i] = NULL; if (zlen[i] < 8 || sec[i][0] != 0x78 || sec[i][1] != 0x5E) return 0; }
+  unsigned int hd[5];
+  memcpy(hd, trailer, sizeof(hd));
+  if (hd[0] != DCTZ_IX_MAGIC || hd[1] != (unsigned int)dctzhip_deflate_chunk_bytes()) return 0;
+  const size_t chunk = hd[1];
+  const unsigned char *e = trailer + sizeof(hd);
+  for (int i = 0; i < 3; i++) {
+    if (hd[2 + i] != (raw[i] + chunk - 1) / chunk) { for (int k = 0; k < i; k++) free(sizes[k]); return 0; }
+    sizes[i] = (uint32_t *)malloc((hd[2 + i] ? hd[2 + i] : 1) * sizeof(uint32_t));
+    if (!sizes[i]) { for (int k = 0; k < i; k++) free(sizes[k]); return 0; }
+    for (size_t j = 0; j < hd[2 + i]; j++, e += 2) { unsigned short z; memcpy(&z, e, 2); sizes[i][j] = z; }
+  }
+  return 1;
+}
+/* DCTZ_INFLATE_GPU=1: indexed sections are inflated on the device (one lane per chunk) instead of by host threads.
+ * Off by default: a lane decodes its 16 KiB alone, which takes 18 - 30 ms per section however few chunks there are
+ * (69 ms for the three sections of a 1 GiB shard), where sixteen host threads need 19 ms; it pays on hosts with few
+ * cores (the work is 0.5 core-seconds per GiB) and takes the raw streams off PCIe. */
+static int inflate_gpu(void) { const char *e = getenv("DCTZ_INFLATE_GPU"); return e && atoi(e) != 0; }
+
 static void dump_file(const char *name, const void *p, size_t bytes) {
   FILE *fp = fopen(name, "wb");
   if (!fp) return;
@@ -778,48 +801,72 @@ int dctz_decompress(t_var *var_z, t_var *var_r) {
   }
   const size_t npos = nd ? nblk * BLK_SZ : n;
 
-  t_bin_id *bin_index = (t_bin_id *)malloc(npos);
-  float *DC = (float *)malloc(nblk * sizeof(float));
-  float *AC_exact = (float *)malloc((cnt ? cnt : 1) * sizeof(float));
-  if (!bin_index || !DC || !AC_exact) { fprintf(stderr, "Out of memory: streams\n"); exit(1); }
-
   double t0 = now_s();
-  /* three inflates, in order (dctz-decomp-lib.c:244-322) */
-  uLong got;
+  dctzhip_ctx *c = ctx();
   const unsigned int zl[3] = {h.bindex_sz_compressed, h.DC_sz_compressed, h.AC_exact_sz_compressed};
   const unsigned char *const secp[3] = {cur, cur + zl[0], cur + zl[0] + zl[1]};
-  unsigned char *const rawp[3] = {(unsigned char *)bin_index, (unsigned char *)DC, (unsigned char *)AC_exact};
   const size_t rawn[3] = {npos, nblk * sizeof(float), (size_t)cnt * sizeof(float)};
   size_t ix_off = (size_t)zl[0] + zl[1] + zl[2] + (nd ? 16 : 0);
 #ifdef USE_QTABLE
   ix_off += BLK_SZ * ts;
 #endif
   /* sections written by the GPU entropy stage start 78 5E and bring a chunk index: only then are the bytes behind the
-   * container looked at */
-  if (zl[0] >= 8 && zl[1] >= 8 && zl[2] >= 8 && secp[0][1] == 0x5E && secp[1][1] == 0x5E && secp[2][1] == 0x5E &&
-      inflate_indexed(secp, zl, rawp, rawn, cur + ix_off)) {
+   * container looked at.  On request (DCTZ_INFLATE_GPU=1) they are inflated on the device, one lane per chunk -- the
+   * compressed sections go over PCIe instead of the raw streams, no host core inflates (include/dctz_hip.h:
+   * dctzhip_inflate); otherwise by host threads, chunks side by side. */
+  const int indexed = zl[0] >= 8 && zl[1] >= 8 && zl[2] >= 8 && secp[0][1] == 0x5E && secp[1][1] == 0x5E && secp[2][1] == 0x5E;
+  int on_device = 0;
+  double t_h2d_z = 0.0;
+  grow(&g_dev.bin, &g_dev.bin_cap, npos);
+  grow(&g_dev.dc, &g_dev.dc_cap, nblk * sizeof(float));
+  grow(&g_dev.ac, &g_dev.ac_cap, (cnt ? cnt : 4) * sizeof(float));
+  if (indexed && inflate_gpu()) {
+    uint32_t *sizes[3];
+    if (index_sizes(secp, zl, rawn, cur + ix_off, sizes)) {
+      size_t zlen[3];
+      for (int i = 0; i < 3; i++) {
+        zlen[i] = zl[i];
+        grow(&g_dev.z[i], &g_dev.z_cap[i], zl[i]);
+        if (dctzhip_memcpy_h2d(c, g_dev.z[i], secp[i], zl[i]) != DCTZHIP_OK) die("H2D compressed section");
+      }
+      t_h2d_z = now_s() - t0;
+      void *const ddst[3] = {g_dev.bin, g_dev.dc, g_dev.ac};
+      int ok = 0;
+      if (dctzhip_inflate(c, 3, (const void *const *)g_dev.z, zlen, (const uint32_t *const *)sizes, rawn, ddst, &ok) != DCTZHIP_OK) die("dctzhip_inflate");
+      on_device = ok;          /* 0: inconsistent -- the zlib path below decides, and reports damage like the reference */
+      for (int i = 0; i < 3; i++) free(sizes[i]);
+    }
+  }
+
+  t_bin_id *bin_index = NULL;
+  float *DC = NULL, *AC_exact = NULL;
+  uLong got = (uLong)npos;
+  if (!on_device) {
+  bin_index = (t_bin_id *)malloc(npos);
+  DC = (float *)malloc(nblk * sizeof(float));
+  AC_exact = (float *)malloc((cnt ? cnt : 1) * sizeof(float));
+  if (!bin_index || !DC || !AC_exact) { fprintf(stderr, "Out of memory: streams\n"); exit(1); }
+  /* three inflates, in order (dctz-decomp-lib.c:244-322) */
+  unsigned char *const rawp[3] = {(unsigned char *)bin_index, (unsigned char *)DC, (unsigned char *)AC_exact};
+  if (indexed && inflate_indexed(secp, zl, rawp, rawn, cur + ix_off)) {            /* chunks side by side on host threads */
     got = (uLong)npos;
-    cur += (size_t)zl[0] + zl[1] + zl[2];
   } else if (zlib_threads() > 3) {                 /* the sections are independent streams: inflate them side by side */
-    inflate_job ij[3] = {{cur, h.bindex_sz_compressed, (uLong)npos, 0, bin_index},
-                         {cur + h.bindex_sz_compressed, h.DC_sz_compressed, (uLong)(nblk * sizeof(float)), 0, DC},
-                         {cur + h.bindex_sz_compressed + h.DC_sz_compressed, h.AC_exact_sz_compressed,
-                          (uLong)((size_t)cnt * sizeof(float)), 0, AC_exact}};
+    inflate_job ij[3] = {{secp[0], zl[0], (uLong)npos, 0, bin_index},
+                         {secp[1], zl[1], (uLong)(nblk * sizeof(float)), 0, DC},
+                         {secp[2], zl[2], (uLong)((size_t)cnt * sizeof(float)), 0, AC_exact}};
     pthread_t th[2];
     int started = 0;
     for (int i = 1; i < 3; i++) { if (pthread_create(&th[started], NULL, inflate_main, &ij[i])) inflate_main(&ij[i]); else started++; }
     inflate_main(&ij[0]);
     for (int i = 0; i < started; i++) pthread_join(th[i], NULL);
     got = ij[0].produced;
-    cur += h.bindex_sz_compressed + h.DC_sz_compressed + h.AC_exact_sz_compressed;
   } else {
-    got = inflate_into(cur, h.bindex_sz_compressed, bin_index, npos);
-    cur += h.bindex_sz_compressed;
-    inflate_into(cur, h.DC_sz_compressed, DC, nblk * sizeof(float));
-    cur += h.DC_sz_compressed;
-    inflate_into(cur, h.AC_exact_sz_compressed, AC_exact, (size_t)cnt * sizeof(float));
-    cur += h.AC_exact_sz_compressed;
+    got = inflate_into(secp[0], zl[0], bin_index, npos);
+    inflate_into(secp[1], zl[1], DC, nblk * sizeof(float));
+    inflate_into(secp[2], zl[2], AC_exact, (size_t)cnt * sizeof(float));
   }
+  }
+  cur += (size_t)zl[0] + zl[1] + zl[2];
   if (!quiet()) printf("uncompressed bin_index size is: %lu\n", got); /* :260-262 */
   const void *qtable = NULL;
 #ifdef USE_QTABLE
@@ -830,14 +877,12 @@ int dctz_decompress(t_var *var_z, t_var *var_r) {
 #endif
   double t1 = now_s();
 
-  dctzhip_ctx *c = ctx();
-  grow(&g_dev.bin, &g_dev.bin_cap, npos);
-  grow(&g_dev.dc, &g_dev.dc_cap, nblk * sizeof(float));
-  grow(&g_dev.ac, &g_dev.ac_cap, (cnt ? cnt : 4) * sizeof(float));
   grow(&g_dev.out, &g_dev.out_cap, n * ts);
-  if (dctzhip_memcpy_h2d(c, g_dev.bin, bin_index, npos) != DCTZHIP_OK) die("H2D bin_index");
-  if (dctzhip_memcpy_h2d(c, g_dev.dc, DC, nblk * sizeof(float)) != DCTZHIP_OK) die("H2D DC");
-  if (cnt && dctzhip_memcpy_h2d(c, g_dev.ac, AC_exact, (size_t)cnt * sizeof(float)) != DCTZHIP_OK) die("H2D AC_exact");
+  if (!on_device) {
+    if (dctzhip_memcpy_h2d(c, g_dev.bin, bin_index, npos) != DCTZHIP_OK) die("H2D bin_index");
+    if (dctzhip_memcpy_h2d(c, g_dev.dc, DC, nblk * sizeof(float)) != DCTZHIP_OK) die("H2D DC");
+    if (cnt && dctzhip_memcpy_h2d(c, g_dev.ac, AC_exact, (size_t)cnt * sizeof(float)) != DCTZHIP_OK) die("H2D AC_exact");
+  }
   double t2 = now_s();
 
   const double sf = is_d ? h.scaling_factor.d : (double)h.scaling_factor.f;
@@ -854,6 +899,7 @@ int dctz_decompress(t_var *var_z, t_var *var_r) {
 
   free(bin_index); free(DC); free(AC_exact);
   g_times.zlib_s = t1 - t0; g_times.h2d_s = t2 - t1; g_times.gpu_s = t3 - t2; g_times.d2h_s = t4 - t3;
+  if (on_device) { g_times.zlib_s -= t_h2d_z; g_times.h2d_s += t_h2d_z; }      /* the compressed sections' way to the device is a copy, not inflate */
   g_times.total_s = now_s() - t_begin;
   return 1;
 }

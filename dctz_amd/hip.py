@@ -80,6 +80,8 @@ _PROTOS = {
     "dctzhip_psnr_terms": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.POINTER(C.c_double)]),
     "dctzhip_deflate_bound": (C.c_size_t, [C.c_size_t]),
     "dctzhip_deflate_chunk_bytes": (C.c_size_t, []),
+    "dctzhip_inflate": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), C.POINTER(C.c_void_p),
+                                  C.POINTER(C.c_size_t), C.POINTER(C.c_void_p), C.POINTER(C.c_int)]),
     "dctzhip_deflate": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), C.POINTER(C.c_void_p),
                                   C.POINTER(C.c_size_t), C.POINTER(C.c_size_t), C.POINTER(C.c_void_p)]),
     "dctzhip_comm_unique_id": (C.c_int, [C.c_void_p]),
@@ -296,6 +298,25 @@ class Context:
         if want_index:
             return zs, [a[:(nb + chunk - 1) // chunk] for a, nb in zip(idx, nbytes)]
         return zs
+
+    def inflate(self, streams, index, raw_bytes):
+        """Sections made by deflate() back to bytes on the GPU (dctzhip_inflate).  streams: uint8 device tensors; index:
+        per-chunk compressed sizes (numpy uint32) per section; raw_bytes: inflated sizes.  Returns (list of uint8 device
+        tensors, ok)."""
+        import torch
+        self._bind_stream()
+        k = len(streams)
+        outs = [torch.empty(max(int(nb), 1), dtype=torch.uint8, device=self.device) for nb in raw_bytes]
+        idx = [np.ascontiguousarray(a, dtype=np.uint32) for a in index]
+        z = (C.c_void_p * max(k, 1))(*[t.data_ptr() for t in streams])
+        zl = (C.c_size_t * max(k, 1))(*[t.numel() for t in streams])
+        ix = (C.c_void_p * max(k, 1))(*[a.ctypes.data if a.size else None for a in idx])
+        raw = (C.c_size_t * max(k, 1))(*[int(nb) for nb in raw_bytes])
+        dst = (C.c_void_p * max(k, 1))(*[o.data_ptr() for o in outs])
+        ok = C.c_int(0)
+        rc = self.lib.dctzhip_inflate(self.h, k, z, zl, ix, raw, dst, C.byref(ok))
+        self._check(rc, "dctzhip_inflate")
+        return [o[:int(nb)] for o, nb in zip(outs, raw_bytes)], bool(ok.value)
 
     # ---- multi-GPU gather of the pre-zlib streams over RCCL (include/dctz_hip.h, dctzhip_comm_*) ----
     @staticmethod

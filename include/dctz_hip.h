@@ -256,6 +256,18 @@ size_t dctzhip_deflate_chunk_bytes(void);
 int dctzhip_deflate(dctzhip_ctx *ctx, int nsec, const void *const *d_src, const size_t *n, void *const *d_dst,
                     const size_t *cap, size_t *out_len, uint32_t *const *chunk_sizes);
 
+/* The reader's side of the same stage: sections written by dctzhip_deflate inflated on the device, one lane per chunk
+ * (replaces, for such sections, inflateInit / inflate of dctz-decomp-lib.c:244-322 and the H2D copy of the raw streams).
+ *   d_z[i], zlen[i]   the section's zlib stream in device memory
+ *   chunk_sizes[i]    host array: compressed bytes of every chunk (the container's "DZIX" index)
+ *   raw[i], d_dst[i]  bytes the section inflates to, and where (device)
+ *   *ok               1: every chunk decoded, lengths and the adler32 of the content agree with the stream;
+ *                     0: something is inconsistent (or the stream is not of this kind) -- the outputs are undefined and
+ *                        the caller takes the zlib path, which reports damage the way the reference does.
+ * A damaged stream cannot make the kernel read or write outside the buffers described here. */
+int dctzhip_inflate(dctzhip_ctx *ctx, int nsec, const void *const *d_z, const size_t *zlen, const uint32_t *const *chunk_sizes,
+                    const size_t *raw, void *const *d_dst, int *ok);
+
 /* Diagnostics: element-wise x / divisor computed (a) by the kernels' hoisted-
  * reciprocal division and (b) by the compiler's IEEE division; the two outputs
  * must be bit-identical (tests/test_gpu_parity.py::test_fast_division_is_exact). */

@@ -224,3 +224,77 @@ def test_argument_checks(ctx):
     assert ctx.lib.dctzhip_deflate(ctx.h, 1, src, n, dst, cap, ln, None) != 0          # output below dctzhip_deflate_bound
     assert ctx.lib.dctzhip_deflate(ctx.h, 9, src, n, dst, cap, ln, None) != 0          # more than 8 sections
     assert int(ctx.lib.dctzhip_deflate_bound(0)) == 8 and int(ctx.lib.dctzhip_deflate_chunk_bytes()) == CHUNK
+
+
+# ---------------------------------------------------------------- inflate on the GPU --
+@pytest.mark.gpu
+def test_device_inflate_round_trip(ctx):
+    """dctzhip_inflate on what dctzhip_deflate wrote: every section of the format tests and 24 random mixtures come back
+    byte for byte, with ok = 1 (lengths and the adler32 of the content agree with the stream)."""
+    import torch
+    cases = list(sections().values())
+    rng = np.random.default_rng(99)
+    for _ in range(24):
+        n = int(rng.integers(1, 6 * CHUNK))
+        kind = rng.integers(0, 3)
+        if kind == 0:
+            b = rng.choice([127, 128, 126, 255, 0, 9], p=[.6, .2, .1, .05, .03, .02], size=n).astype(np.uint8)
+        elif kind == 1:
+            b = np.repeat(rng.integers(0, 256, n // 37 + 1, dtype=np.uint8), 37)[:n]
+        else:
+            b = rng.integers(0, 256, n, dtype=np.uint8)
+        cases.append(b.tobytes())
+    for i in range(0, len(cases), 8):
+        part = cases[i:i + 8]
+        dev = [torch.from_numpy(np.frombuffer(b, dtype=np.uint8).copy()).to(ctx.device) for b in part]
+        zs, index = ctx.deflate(dev, want_index=True)
+        outs, ok = ctx.inflate(zs, index, [len(b) for b in part])
+        assert ok
+        for b, o in zip(part, outs):
+            assert o.cpu().numpy().tobytes() == b
+
+
+@pytest.mark.gpu
+def test_device_inflate_rejects_damage_without_touching_anything_else(ctx):
+    """Single-byte damage anywhere in a stream (header of a block, code lengths, tokens, stored bytes, the frame) and a
+    wrong index: the kernel stays inside its buffers (guard bytes behind the output untouched), and either reports
+    ok = 0 or -- when the flipped bits were padding -- still returns the exact input."""
+    import torch
+    rng = np.random.default_rng(4242)
+    data = (rng.choice([127, 128, 126, 255, 0, 9], p=[.6, .2, .1, .05, .03, .02], size=3 * CHUNK + 777).astype(np.uint8).tobytes()
+            + rng.integers(0, 256, CHUNK, dtype=np.uint8).tobytes() + bytes(CHUNK // 2))
+    src = torch.from_numpy(np.frombuffer(data, dtype=np.uint8).copy()).to(ctx.device)
+    (z,), (ix,) = ctx.deflate([src], want_index=True)
+    zh = z.cpu().numpy().copy()
+    n = len(data)
+    guard = 4096
+    dst = torch.full((n + guard,), 0xA5, dtype=torch.uint8, device=ctx.device)
+
+    def run(zbytes, index):
+        zt = torch.from_numpy(zbytes).to(ctx.device)
+        dst[n:] = 0xA5
+        zp = (C.c_void_p * 1)(zt.data_ptr()); zl = (C.c_size_t * 1)(zt.numel())
+        ixa = np.ascontiguousarray(index, dtype=np.uint32)
+        ixp = (C.c_void_p * 1)(ixa.ctypes.data); raw = (C.c_size_t * 1)(n); dp = (C.c_void_p * 1)(dst.data_ptr())
+        ok = C.c_int(0)
+        assert ctx.lib.dctzhip_inflate(ctx.h, 1, zp, zl, ixp, raw, dp, C.byref(ok)) == 0
+        torch.cuda.synchronize()
+        assert bool((dst[n:] == 0xA5).all()), "wrote behind the output"
+        return bool(ok.value), dst[:n].cpu().numpy().tobytes()
+
+    ok, out = run(zh, ix)
+    assert ok and out == data
+    rejected = 0
+    for pos in list(rng.integers(0, len(zh), 150)) + [0, 1, 2, 3, len(zh) - 1, len(zh) - 5, len(zh) - 6]:
+        bad = zh.copy()
+        bad[pos] ^= np.uint8(1 << int(rng.integers(0, 8)))
+        ok, out = run(bad, ix)
+        assert (not ok) or out == data
+        rejected += not ok
+    assert rejected > 100
+    wrong = ix.copy(); wrong[0] += 1; wrong[1] -= 1                      # chunk boundaries moved by one byte
+    ok, out = run(zh, wrong)
+    assert not ok
+    wrong = ix.copy(); wrong[-1] += 1                                    # the sizes no longer tile the stream
+    ok, out = run(zh, wrong)
+    assert not ok

@@ -61,12 +61,14 @@ def _parse(z, dtype, qt):
                 bindex_count=struct.unpack_from("<I", z, 52)[0] if qt else None)
 
 
-@pytest.fixture(params=[0, 8, "gpu"], ids=["zlib_ref_3threads", "zlib_chunked_8threads", "deflate_on_gpu"])
+@pytest.fixture(params=[0, 8, "gpu", "gpu_device_inflate"], ids=["zlib_ref_3threads", "zlib_chunked_8threads", "deflate_on_gpu", "deflate_and_inflate_on_gpu"])
 def zthreads(request):
     """0: the reference's tail (three single-shot deflates); 8: chunked deflate (pdeflate.c); "gpu": the entropy stage
     on the device (DCTZ_ZLIB_GPU=1, dctzhip_deflate) -- the container is parsed with zlib's inflate in every case."""
-    if request.param == "gpu":
+    if request.param in ("gpu", "gpu_device_inflate"):
         os.environ["DCTZ_ZLIB_GPU"] = "1"
+        if request.param == "gpu_device_inflate":          # the reader's indexed path through dctzhip_inflate instead of host threads
+            os.environ["DCTZ_INFLATE_GPU"] = "1"
     elif request.param:
         os.environ["DCTZ_ZLIB_THREADS"] = str(request.param)
         os.environ["DCTZ_ZLIB_CHUNK"] = "65536"
@@ -74,6 +76,7 @@ def zthreads(request):
     os.environ.pop("DCTZ_ZLIB_THREADS", None)
     os.environ.pop("DCTZ_ZLIB_CHUNK", None)
     os.environ.pop("DCTZ_ZLIB_GPU", None)
+    os.environ.pop("DCTZ_INFLATE_GPU", None)
 
 
 @pytest.mark.parametrize("mode", ["ec", "qt"])
@@ -109,7 +112,7 @@ def test_dropin_compress_decompress(mode, case, zthreads):
         assert h["bindex_count"] == n and np.array_equal(h["q"].view(np.uint8), c.qtable.view(np.uint8))
     assert np.array_equal(x.view(np.uint8), c.scaled.view(np.uint8)), "caller's buffer must hold x/sf"
     body = 56 + sum(h["sizes"]) + (64 * x.itemsize if qt else 0)
-    if zthreads == "gpu":                                  # "DZIX" chunk index behind the container (include/dctz.h)
+    if zthreads in ("gpu", "gpu_device_inflate"):          # "DZIX" chunk index behind the container (include/dctz.h)
         nblk = (n + 63) // 64
         nch = [(b + 16383) // 16384 for b in (n, 4 * nblk, 4 * c.cnt)]
         assert out_size.value == body + ((20 + 2 * sum(nch) + 3) & ~3)

@@ -401,8 +401,9 @@ print("returned")
     bad[56 + 2 + 40] ^= 0x10                                 # inside the first chunk of bin_index
     with tempfile.NamedTemporaryFile(suffix=".z") as f:
         f.write(bytes(bad)); f.flush()
-        r = subprocess.run([sys.executable, "-c", code, f.name], capture_output=True, text=True)
-    assert r.returncode != 0 and "returned" not in r.stdout and "does not inflate" in r.stderr
+        for dev in ("0", "1"):                                # host threads; the device decoder (which hands damage on to them)
+            r = subprocess.run([sys.executable, "-c", code, f.name], capture_output=True, text=True, env=dict(os.environ, DCTZ_INFLATE_GPU=dev))
+            assert r.returncode != 0 and "returned" not in r.stdout and "does not inflate" in r.stderr
 
 
 @pytest.mark.gpu

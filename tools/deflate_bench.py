@@ -30,6 +30,19 @@ for _ in range(a.reps):
     t0 = time.perf_counter()
     zs = ctx.deflate(secs)
     ts.append(time.perf_counter() - t0)
+# the reader's side: the same sections inflated on the device, each on its own and all three in one call
+zs, index = ctx.deflate(secs, want_index=True)
+inf = {}
+for name, sel in (("bin_index", [0]), ("dc", [1]), ("ac_exact", [2]), ("all", [0, 1, 2])):
+    tt = []
+    for _ in range(max(3, a.reps // 2)):
+        t0 = time.perf_counter()
+        outs, ok = ctx.inflate([zs[i] for i in sel], [index[i] for i in sel], [raw[i] for i in sel])
+        tt.append(time.perf_counter() - t0)
+        assert ok
+    inf[name] = float(np.median(tt) * 1e3)
+for o, t in zip(outs, secs):
+    assert torch.equal(o, t.view(torch.uint8).reshape(-1)[:o.numel()])
 host = [t.cpu().numpy().tobytes() for t in secs]
 for z, h in zip(zs, host):
     assert zlib.decompress(z.cpu().numpy().tobytes()) == h
@@ -40,6 +53,7 @@ res = {"workload": f"c3 {a.n}^3 {a.dtype} {a.mode} eb {a.eb}", "raw_bytes": raw,
        "gpu_ms_median": float(np.median(ts) * 1e3), "gpu_ms_min": float(min(ts) * 1e3),
        "gpu_GBps_of_streams": sum(raw) / np.median(ts) / 1e9,
        "input_GBps": x.nbytes / np.median(ts) / 1e9,
+       "gpu_inflate_ms": inf,
        "host_zlib6_one_core_MBps": len(sample) / t_host / 1e6, "host_sample_bytes": len(sample),
        "host_zlib6_sample_ratio": len(sample) / zl}
 print(json.dumps(res))
