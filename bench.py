@@ -53,6 +53,7 @@ def parse(argv=None):
     ap.add_argument("--dtype", choices=["f64", "f32"], default="f64")
     ap.add_argument("--plumbing-only", action="store_true", help="launcher + rendezvous + gather on gloo; no kernels, no value")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-entropy-stage", action="store_true", help="skip the (untimed) report on the device entropy stage")
     ap.add_argument("--no-speculation", action="store_true", help="always run the separate statistics pass first")
     ap.add_argument("--cpu-sample", type=int, default=1 << 27, help="elements of the shard the CPU oracle is timed on")
     ap.add_argument("--cpu-repeats", type=int, default=4, help="passes of the CPU oracle over the sample (about 10 s in all)")
@@ -253,6 +254,29 @@ def run_rank(a, rank, local_rank, world):
     except (OSError, ValueError):
         pass
 
+    # ---- the entropy stage on the device, rank 0, outside the timed region: what
+    # it costs to turn the streams of the last compress call into the container's three zlib sections in HBM ----
+    entropy = None
+    if rank == 0 and not a.no_entropy_stage:
+        try:
+            cnt = int(info.cnt)
+            secs = [out["bin_index"], out["dc"], out["ac_exact"][:cnt]]
+            raw = [t.numel() * t.element_size() for t in secs]
+            zs = ctx.deflate(secs)
+            torch.cuda.synchronize()
+            tt = []
+            for _ in range(10):
+                e0 = time.perf_counter()
+                zs = ctx.deflate(secs)                     # returns after the stream has drained (it hands the lengths back)
+                tt.append(time.perf_counter() - e0)
+            med = sorted(tt)[len(tt) // 2]
+            entropy = {"what": "dctzhip_deflate of bin_index / DC / AC_exact where k_compress left them: three standard zlib streams in HBM",
+                       "ms": med * 1e3, "raw_bytes": sum(raw), "stream_bytes": int(sum(z.numel() for z in zs)),
+                       "GBps_of_streams": sum(raw) / med / 1e9, "container_ratio": n * es / float(sum(z.numel() for z in zs) + 56),
+                       "note": "not part of `value`; reference: three host threads of zlib, 6.6 s per GiB shard (profiles/r02_e2e_dropin.json)"}
+        except Exception as ex:                            # the stage is reported, never required, by the benchmark
+            entropy = {"error": str(ex)}
+
     # ---- CPU baseline: the oracle (a port), bounded sample, rank 0 only ---
     cpu = None
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
@@ -331,6 +355,7 @@ def run_rank(a, rank, local_rank, world):
             "compress_GBps_input": n * es / (t_c * 1e-3) / 1e9,
             "decompress_GBps_input": n * es / (t_d * 1e-3) / 1e9,
             "cpu_baseline": cpu,
+            "entropy_stage": entropy,
         }
         if with_gather is not None:
             line["with_gather"] = with_gather

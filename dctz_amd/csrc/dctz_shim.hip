@@ -70,6 +70,8 @@ struct dctzhip_ctx {
   void* stage[STAGE_WORKERS] = {};
   hipStream_t stage_stream[STAGE_WORKERS] = {};
   int staged_d2h = 1;               // 0: one hipMemcpy (DCTZHIP_STAGED_D2H)
+  hipEvent_t dfl_ev = nullptr;
+  int dfl_side = 1;                 // 0: the sections of a dctzhip_deflate call one after the other on one stream (DCTZHIP_DEFLATE_SIDE)
   void* dfl_buf = nullptr;          // GPU entropy stage: chunk slots, sizes, offsets (dctz_deflate.hip)
   size_t dfl_cap = 0;               // bytes
   unsigned long long* dfl_len = nullptr;      // stream lengths of up to 8 sections (pinned host memory the kernels write)
@@ -194,6 +196,7 @@ extern "C" int dctzhip_ctx_create(dctzhip_ctx** out, int device) {
   if (const char* e = getenv("DCTZHIP_GRID_C")) c->grid_c = atoi(e);
   if (const char* e = getenv("DCTZHIP_BLOCKING")) c->blocking = atoi(e) != 0;
   if (const char* e = getenv("DCTZHIP_STAGED_D2H")) c->staged_d2h = atoi(e) != 0;
+  if (const char* e = getenv("DCTZHIP_DEFLATE_SIDE")) c->dfl_side = atoi(e) != 0;
   if (int rc = build_sf_tables(c)) return rc;
   *out = c;
   return DCTZHIP_OK;
@@ -211,6 +214,7 @@ extern "C" void dctzhip_ctx_destroy(dctzhip_ctx* c) {
   if (c->h_pin) (void)hipHostFree(c->h_pin);
   if (c->box) (void)hipHostFree(c->box);
   if (c->dfl_len) (void)hipHostFree(c->dfl_len);
+  if (c->dfl_ev) (void)hipEventDestroy(c->dfl_ev);
   for (int i = 0; i < dctzhip_ctx::STAGE_WORKERS; i++) {
     if (c->stage[i]) (void)hipHostFree(c->stage[i]);
     if (c->stage_stream[i]) (void)hipStreamDestroy(c->stage_stream[i]);
@@ -354,8 +358,7 @@ extern "C" int dctzhip_deflate(dctzhip_ctx* c, int nsec, const void* const* d_sr
     if (n[i] && !d_src[i]) return fail(c, DCTZHIP_E_ARG, "dctzhip_deflate: section %d has no source", i);
     if (!d_dst[i] || cap[i] < deflate_bound(n[i])) return fail(c, DCTZHIP_E_ARG, "dctzhip_deflate: section %d needs %zu bytes of output (dctzhip_deflate_bound)", i, deflate_bound(n[i]));
     if ((n[i] + deflate_chunk_bytes() - 1) / deflate_chunk_bytes() > 0x7FFFFFFFull) return fail(c, DCTZHIP_E_ARG, "dctzhip_deflate: section %d is too large", i);
-    const size_t b = deflate_scratch_bytes(n[i]);
-    if (b > need) need = b;
+    need += (deflate_scratch_bytes(n[i]) + 255) & ~(size_t)255;
   }
   {
     char* b = (char*)c->dfl_buf;
@@ -363,11 +366,27 @@ extern "C" int dctzhip_deflate(dctzhip_ctx* c, int nsec, const void* const* d_sr
     c->dfl_buf = b;
     if (rc) return rc;
   }
-  // the sections run one after the other on the stream, so they share the scratch
+  // The sections run side by side: the first on the context's stream, the others on the staging streams behind an
+  // event of the context's stream (the small sections -- DC, AC_exact -- then cost nothing beside bin_index: each of
+  // the four kernels of a section is latency bound by itself).  Every section has its own scratch.
+  constexpr int SIDE = dctzhip_ctx::STAGE_WORKERS;
+  const bool side = c->dfl_side && nsec > 1;
+  if (side) {
+    for (int i = 0; i < SIDE && i < nsec - 1; i++)
+      if (!c->stage_stream[i]) HIPCHK(c, hipStreamCreateWithFlags(&c->stage_stream[i], hipStreamNonBlocking));
+    if (!c->dfl_ev) HIPCHK(c, hipEventCreateWithFlags(&c->dfl_ev, hipEventDisableTiming));
+    HIPCHK(c, hipEventRecord(c->dfl_ev, c->stream));
+  }
+  size_t at = 0;
   for (int i = 0; i < nsec; i++) {
     c->dfl_len[i] = 0;
-    HIPCHK(c, launch_deflate(d_src[i], n[i], d_dst[i], c->dfl_buf, c->dfl_len_dev + i, chunk_sizes ? chunk_sizes[i] : nullptr, c->stream));
+    hipStream_t st = c->stream;
+    if (side && i > 0) { st = c->stage_stream[(i - 1) % SIDE]; HIPCHK(c, hipStreamWaitEvent(st, c->dfl_ev, 0)); }
+    HIPCHK(c, launch_deflate(d_src[i], n[i], d_dst[i], (char*)c->dfl_buf + at, c->dfl_len_dev + i, chunk_sizes ? chunk_sizes[i] : nullptr, st));
+    at += (deflate_scratch_bytes(n[i]) + 255) & ~(size_t)255;
   }
+  if (side)
+    for (int i = 0; i < SIDE && i < nsec - 1; i++) HIPCHK(c, hipStreamSynchronize(c->stage_stream[i]));
   HIPCHK(c, hipStreamSynchronize(c->stream));
   for (int i = 0; i < nsec; i++) out_len[i] = (size_t)c->dfl_len[i];
   return DCTZHIP_OK;
@@ -424,15 +443,28 @@ extern "C" int dctzhip_inflate(dctzhip_ctx* c, int nsec, const void* const* d_z,
     c->dfl_buf = b;
     if (rc) return rc;
   }
+  // sections side by side, like dctzhip_deflate: a lane's 16 KiB take as long whatever the size of the section
+  constexpr int SIDE = dctzhip_ctx::STAGE_WORKERS;
+  const bool side = c->dfl_side && nsec > 1;
+  if (side) {
+    for (int i = 0; i < SIDE && i < nsec - 1; i++)
+      if (!c->stage_stream[i]) HIPCHK(c, hipStreamCreateWithFlags(&c->stage_stream[i], hipStreamNonBlocking));
+    if (!c->dfl_ev) HIPCHK(c, hipEventCreateWithFlags(&c->dfl_ev, hipEventDisableTiming));
+    HIPCHK(c, hipEventRecord(c->dfl_ev, c->stream));
+  }
   for (int i = 0; i < nsec; i++) {
     const size_t nch = offs[i].size() - 1;
     char* p = (char*)c->dfl_buf + base[i];
     unsigned long long* adler = (unsigned long long*)(p + ((nch + 1) * 4 + 15) / 16 * 16);
     uint32_t* status = (uint32_t*)(adler + 2);
-    HIPCHK(c, hipMemcpyAsync(p, offs[i].data(), (nch + 1) * 4, hipMemcpyHostToDevice, c->stream));
-    HIPCHK(c, hipMemsetAsync(status, 0, 4, c->stream));
-    HIPCHK(c, launch_inflate(d_z[i], (const uint32_t*)p, nch, raw[i], d_dst[i], adler, status, c->stream));
+    hipStream_t st = c->stream;
+    if (side && i > 0) { st = c->stage_stream[(i - 1) % SIDE]; HIPCHK(c, hipStreamWaitEvent(st, c->dfl_ev, 0)); }
+    HIPCHK(c, hipMemcpyAsync(p, offs[i].data(), (nch + 1) * 4, hipMemcpyHostToDevice, st));
+    HIPCHK(c, hipMemsetAsync(status, 0, 4, st));
+    HIPCHK(c, launch_inflate(d_z[i], (const uint32_t*)p, nch, raw[i], d_dst[i], adler, status, st));
   }
+  if (side)
+    for (int i = 0; i < SIDE && i < nsec - 1; i++) HIPCHK(c, hipStreamSynchronize(c->stage_stream[i]));
   HIPCHK(c, hipStreamSynchronize(c->stream));
   int good = 1;
   for (int i = 0; i < nsec; i++) {

@@ -436,7 +436,7 @@ static int index_sizes(const unsigned char *const sec[3], const unsigned int zle
 }
 /* DCTZ_INFLATE_GPU=1: indexed sections are inflated on the device (one lane per chunk) instead of by host threads.
  * Off by default: a lane decodes its 16 KiB alone, which takes 18 - 30 ms per section however few chunks there are
- * (69 ms for the three sections of a 1 GiB shard), where sixteen host threads need 19 ms; it pays on hosts with few
+ * (38 ms for the three sections of a 1 GiB shard side by side), where sixteen host threads need 19 ms; it pays on hosts with few
  * cores (the work is 0.5 core-seconds per GiB) and takes the raw streams off PCIe. */
 static int inflate_gpu(void) { const char *e = getenv("DCTZ_INFLATE_GPU"); return e && atoi(e) != 0; }
 
