@@ -120,6 +120,36 @@ def test_cli_harness_matches_the_reference_contract(tmp_path, variant, case):
     assert d.returncode == 0 and f"total # of AC_exact={c.cnt}" in d.stdout and f"variant={variant}" in d.stdout
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("variant", ["ec", "qt"])
+def test_cli_harness_with_the_entropy_stage_on_the_gpu(tmp_path, variant):
+    """The unchanged harness under DCTZ_ZLIB_GPU=1: same stdout contract, sections that zlib inflates to the oracle's
+    streams, the same `.z.r` as the default tail, a container dctz-dump accepts (chunk index shown)."""
+    _ensure_built()
+    mode = O.QT if variant == "qt" else O.EC
+    x = W.ragged(64 * 4000 + 9, np.float64, scale=410.0)
+    src = tmp_path / "field.bin"
+    src.write_bytes(x.tobytes())
+    env = dict(os.environ, DCTZ_ZLIB_GPU="1")
+    env.pop("DCTZ_QUIET", None)
+    r = subprocess.run([os.path.join(BIN, f"dctz-{variant}-test"), "-d", "1E-3", "var", str(src), str(x.size)],
+                       capture_output=True, text=True, env=env, cwd=tmp_path, timeout=300)
+    assert r.returncode == 0, r.stderr
+    out = r.stdout.splitlines()
+    zpath = f"{src}.{variant}.1E-3.z"
+    z = open(zpath, "rb").read()
+    assert out[-1] == "done" and f"outsize = {len(z)}" in out
+    c = O.compress(x, 1e-3, mode, O.FAST)
+    s0, s1, s2 = struct.unpack_from("<III", z, 40)
+    assert z[56:58] == b"\x78\x5e" and zlib.decompress(z[56:56 + s0]) == c.bin_index.tobytes()
+    assert zlib.decompress(z[56 + s0:56 + s0 + s1]) == c.dc.tobytes()
+    assert zlib.decompress(z[56 + s0 + s1:56 + s0 + s1 + s2]) == c.ac_exact.tobytes()
+    rec = np.frombuffer(open(zpath + ".r", "rb").read(), dtype=x.dtype)
+    assert np.array_equal(rec.view(np.uint8), O.decompress(c, O.FAST).view(np.uint8))
+    d = subprocess.run([os.path.join(BIN, "dctz-dump"), "-v", zpath], capture_output=True, text=True)
+    assert d.returncode == 0 and "chunk index:" in d.stdout and f"variant={variant}" in d.stdout and "= layout" in d.stdout, d.stdout
+
+
 @pytest.mark.parametrize("mode", [O.EC, O.QT])
 def test_container_check(mode):
     """dctz_check_container: the bounds / plausibility check a caller runs before dctz_decompress
