@@ -56,6 +56,15 @@ def main():
         for _ in range(2):
             r = ctx.decompress(out, info.cnt, n, tdt, eb, info.sf, mode, qtable=np.array(info.qtable[:])).cpu().numpy()
             ok = ok and np.array_equal(r.view(it), ref.view(it))
+        # the entropy stage on the same streams: zlib's inflate is the checker; every other case also through the device decoder
+        import zlib
+        secs = [out["bin_index"], out["dc"], out["ac_exact"][:c.cnt]]
+        zs, index = ctx.deflate(secs, want_index=True)
+        for z, want in zip(zs, (c.bin_index, c.dc, c.ac_exact)):
+            ok = ok and zlib.decompress(z.cpu().numpy().tobytes()) == want.tobytes()
+        if k % 2 == 0:
+            back, good = ctx.inflate(zs, index, [t.numel() * t.element_size() for t in secs])
+            ok = ok and good and all(torch.equal(b, t.view(torch.uint8).reshape(-1)[:b.numel()]) for b, t in zip(back, secs))
         if not ok:
             print(f"MISMATCH case {k}: n={n} dtype={dtype.__name__} mode={mode} eb={eb} amp={amp:g} noise={noise}")
             sys.exit(1)
