@@ -29,6 +29,7 @@
 #include "dctz.h"
 
 #include <pthread.h>
+#include <sched.h>
 #include <unistd.h>
 #include "pdeflate.h"
 #include <stdint.h>
@@ -54,6 +55,23 @@ static struct {
   void *in, *bin, *dc, *ac, *out, *z[3];
   size_t in_cap, bin_cap, dc_cap, ac_cap, out_cap, z_cap[3];
 } g_dev;
+/* Host copies of the raw streams (what the zlib tails read / the inflates write), kept between calls like the device
+ * buffers above: a fresh 170 MB allocation per call costs its page faults on the way in and an munmap on the way out
+ * (about 25 ms per GiB shard, more than the indexed inflate itself). */
+static struct {
+  void *p[3];
+  size_t cap[3];
+} g_host;
+static void *host_buf(int i, size_t need) {
+  if (need == 0) need = 1;
+  if (need > g_host.cap[i]) {
+    free(g_host.p[i]);
+    g_host.p[i] = malloc(need);
+    g_host.cap[i] = g_host.p[i] ? need : 0;
+    if (!g_host.p[i]) { fprintf(stderr, "Out of memory: streams\n"); exit(1); }
+  }
+  return g_host.p[i];
+}
 static dctz_stage_times g_times;
 /* multi-dimensional blocks requested for the next dctz_compress call (dctz.h: dctz_set_block_dims) */
 static int g_nd = 0;
@@ -236,66 +254,76 @@ static uLong inflate_into(const Bytef *src, uLong src_len, void *dst, size_t dst
  * reference's 7 s zlib tail), a host core ~1 ns.  With the chunked tail the zlib stage is too
  * short to hide the GPU version, so the sum runs on one host thread over the caller's array,
  * which is where the reference computes it too; it must finish before x/sf is copied back. */
+#define MEAN_BLOCK ((size_t)1 << 20)          /* elements between two progress reports of the serial sum */
 typedef struct {
   const void *x;
   size_t n;
   int is_d;
   double mean;
+  size_t progress;              /* elements the sum has consumed (released block by block: the in-place scaling follows behind) */
 } host_mean_job;
 static void *host_mean_main(void *arg) {
   host_mean_job *j = (host_mean_job *)arg;
   if (j->is_d) {
     const double *x = (const double *)j->x;
     double sum = 0.0;
-    for (size_t i = 1; i < j->n; i++) sum += x[i];          /* util.c:22: starts at i = 1 */
+    for (size_t b = 1; b < j->n; b += MEAN_BLOCK) {
+      const size_t e = b + MEAN_BLOCK < j->n ? b + MEAN_BLOCK : j->n;
+      for (size_t i = b; i < e; i++) sum += x[i];           /* util.c:22: starts at i = 1 */
+      __atomic_store_n(&j->progress, e, __ATOMIC_RELEASE);
+    }
     j->mean = sum / (double)(int)j->n;
   } else {
     const float *x = (const float *)j->x;
     float sum = 0.0f;
-    for (size_t i = 1; i < j->n; i++) sum += x[i];          /* util.c:35 */
+    for (size_t b = 1; b < j->n; b += MEAN_BLOCK) {
+      const size_t e = b + MEAN_BLOCK < j->n ? b + MEAN_BLOCK : j->n;
+      for (size_t i = b; i < e; i++) sum += x[i];           /* util.c:35 */
+      __atomic_store_n(&j->progress, e, __ATOMIC_RELEASE);
+    }
     j->mean = (double)(sum / (float)(int)j->n);
   }
+  __atomic_store_n(&j->progress, j->n, __ATOMIC_RELEASE);
   return NULL;
 }
 
 /* The reference's in-place "/= sf" (dctz-comp-lib.c:193-216) on host threads, for the device entropy stage: there the
  * tail is too short to hide a 1 GiB write-back over PCIe, and the host cores are idle.  Same operation as the
- * reference's loop (IEEE division in the data type), so the caller's buffer ends up bit-identical to x / sf.  It may
- * only start once the serial-order mean has read the original values: the manager thread waits for that first. */
-typedef struct {
-  void *x;
-  size_t lo, hi;
-  int is_d;
-  double sf;
-} scale_part;
-static void *scale_part_main(void *arg) {
-  scale_part *j = (scale_part *)arg;
-  if (j->is_d) { double *x = (double *)j->x; const double sf = j->sf; for (size_t i = j->lo; i < j->hi; i++) x[i] /= sf; }
-  else { float *x = (float *)j->x; const float sf = (float)j->sf; for (size_t i = j->lo; i < j->hi; i++) x[i] /= sf; }
-  return NULL;
-}
+ * reference's loop (IEEE division in the data type), so the caller's buffer ends up bit-identical to x / sf.  An
+ * element may only change once the serial-order mean has read it: the workers take 1 Mi-element blocks in order and
+ * follow the sum's progress counter, so the scaling ends a block after the sum does instead of starting there. */
 typedef struct {
   void *x;
   size_t n;
   int is_d, threads;
   double sf;
-  pthread_t *wait_for;          /* the serial-mean thread, or NULL */
+  pthread_t *wait_for;          /* the serial-mean thread (joined here), or NULL */
+  host_mean_job *mean;          /* its progress: elements it has read for good, or NULL = all */
+  size_t next;                  /* next block to scale (workers take blocks in order) */
 } scale_mgr;
+static void *scale_worker(void *arg) {
+  scale_mgr *m = (scale_mgr *)arg;
+  for (;;) {
+    const size_t lo = __atomic_fetch_add(&m->next, MEAN_BLOCK, __ATOMIC_RELAXED);
+    if (lo >= m->n) break;
+    const size_t hi = lo + MEAN_BLOCK < m->n ? lo + MEAN_BLOCK : m->n;
+    while (m->mean && __atomic_load_n(&m->mean->progress, __ATOMIC_ACQUIRE) < hi) sched_yield();   /* the sum still needs the originals */
+    if (m->is_d) { double *x = (double *)m->x; const double sf = m->sf; for (size_t i = lo; i < hi; i++) x[i] /= sf; }
+    else { float *x = (float *)m->x; const float sf = (float)m->sf; for (size_t i = lo; i < hi; i++) x[i] /= sf; }
+  }
+  return NULL;
+}
 static void *scale_mgr_main(void *arg) {
   scale_mgr *m = (scale_mgr *)arg;
-  if (m->wait_for) pthread_join(*m->wait_for, NULL);
   int T = m->threads < 1 ? 1 : (m->threads > 64 ? 64 : m->threads);
-  if ((size_t)T > m->n / 65536 + 1) T = (int)(m->n / 65536 + 1);
-  scale_part part[64];
+  if ((size_t)T > m->n / MEAN_BLOCK + 1) T = (int)(m->n / MEAN_BLOCK + 1);
+  if (m->mean && T > 6) T = 6;              /* behind the serial sum (one block per ~0.5 ms) a few workers keep up; more would only spin */
   pthread_t th[64];
   int started = 0;
-  for (int t = 0; t < T; t++) {
-    part[t].x = m->x; part[t].is_d = m->is_d; part[t].sf = m->sf;
-    part[t].lo = m->n * (size_t)t / (size_t)T; part[t].hi = m->n * (size_t)(t + 1) / (size_t)T;
-  }
-  for (int t = 1; t < T; t++) { if (pthread_create(&th[started], NULL, scale_part_main, &part[t])) scale_part_main(&part[t]); else started++; }
-  scale_part_main(&part[0]);
+  for (int t = 1; t < T; t++) { if (pthread_create(&th[started], NULL, scale_worker, m) == 0) started++; }
+  scale_worker(m);
   for (int t = 0; t < started; t++) pthread_join(th[t], NULL);
+  if (m->wait_for) pthread_join(*m->wait_for, NULL);
   return NULL;
 }
 static int host_threads(void) {
@@ -523,7 +551,7 @@ int dctz_compress(t_var *var, int N, size_t *outSize, t_var *var_z, double error
   const int gpu_tail = zlib_gpu();
   const int fast_tail = gpu_tail || zlib_threads() > 3;
   pthread_t mean_thread;
-  host_mean_job mj = {host_in, n, is_d, 0.0};
+  host_mean_job mj = {host_in, n, is_d, 0.0, 0};
   int mean_on_host = 0;
   const int tree_mean = fast_mean();
   if (!tree_mean && fast_tail && pthread_create(&mean_thread, NULL, host_mean_main, &mj) == 0) mean_on_host = 1;
@@ -541,10 +569,9 @@ int dctz_compress(t_var *var, int N, size_t *outSize, t_var *var_z, double error
   t_bin_id *bin_index = NULL;
   float *DC = NULL, *AC_exact = NULL;
   if (want_raw) {
-    bin_index = (t_bin_id *)malloc(npos);
-    DC = (float *)malloc(nblk * sizeof(float));
-    AC_exact = (float *)malloc((info.cnt ? info.cnt : 1) * sizeof(float));
-    if (!bin_index || !DC || !AC_exact) { fprintf(stderr, "Out of memory: streams\n"); exit(1); }
+    bin_index = (t_bin_id *)host_buf(0, npos);
+    DC = (float *)host_buf(1, nblk * sizeof(float));
+    AC_exact = (float *)host_buf(2, (size_t)info.cnt * sizeof(float));
     if (dctzhip_memcpy_d2h(c, bin_index, g_dev.bin, npos) != DCTZHIP_OK) die("D2H bin_index");
     if (dctzhip_memcpy_d2h(c, DC, g_dev.dc, nblk * sizeof(float)) != DCTZHIP_OK) die("D2H DC");
     if (info.cnt && dctzhip_memcpy_d2h(c, AC_exact, g_dev.ac, (size_t)info.cnt * sizeof(float)) != DCTZHIP_OK)
@@ -579,7 +606,7 @@ int dctz_compress(t_var *var, int N, size_t *outSize, t_var *var_z, double error
   size_t ix_n[3] = {0, 0, 0};
   const int host_scale = scale_on_host(gpu_tail) && info.sf != 1.0;
   pthread_t scale_thread;
-  scale_mgr sm = {host_in, n, is_d, host_threads(), info.sf, mean_on_host ? &mean_thread : NULL};
+  scale_mgr sm = {host_in, n, is_d, host_threads(), info.sf, mean_on_host ? &mean_thread : NULL, mean_on_host ? &mj : NULL, 0};
   int scale_started = 0;
   if (host_scale && pthread_create(&scale_thread, NULL, scale_mgr_main, &sm) == 0) scale_started = 1;
   if (gpu_tail) {                           /* deflate on the device, compressed bytes only over PCIe */
@@ -694,7 +721,6 @@ int dctz_compress(t_var *var, int N, size_t *outSize, t_var *var_z, double error
     }
   }
   for (int i = 0; i < 3; i++) free(jb[i].dst);
-  free(bin_index); free(DC); free(AC_exact);
 
   g_times.h2d_s = t1 - t0; g_times.gpu_s = t2 - t1; g_times.d2h_s = t3 - t2; g_times.zlib_s = t4 - t3;
   if (gpu_tail) { g_times.zlib_s = t_gz - t3; g_times.d2h_s += t4 - t_gz; }   /* nothing overlaps the write-back of x/sf here: count it as the copy it is */
@@ -842,10 +868,9 @@ int dctz_decompress(t_var *var_z, t_var *var_r) {
   float *DC = NULL, *AC_exact = NULL;
   uLong got = (uLong)npos;
   if (!on_device) {
-  bin_index = (t_bin_id *)malloc(npos);
-  DC = (float *)malloc(nblk * sizeof(float));
-  AC_exact = (float *)malloc((cnt ? cnt : 1) * sizeof(float));
-  if (!bin_index || !DC || !AC_exact) { fprintf(stderr, "Out of memory: streams\n"); exit(1); }
+  bin_index = (t_bin_id *)host_buf(0, npos);
+  DC = (float *)host_buf(1, nblk * sizeof(float));
+  AC_exact = (float *)host_buf(2, (size_t)cnt * sizeof(float));
   /* three inflates, in order (dctz-decomp-lib.c:244-322) */
   unsigned char *const rawp[3] = {(unsigned char *)bin_index, (unsigned char *)DC, (unsigned char *)AC_exact};
   if (indexed && inflate_indexed(secp, zl, rawp, rawn, cur + ix_off)) {            /* chunks side by side on host threads */
@@ -897,7 +922,6 @@ int dctz_decompress(t_var *var_z, t_var *var_r) {
   if (dctzhip_memcpy_d2h(c, host_out, g_dev.out, n * ts) != DCTZHIP_OK) die("D2H output");
   double t4 = now_s();
 
-  free(bin_index); free(DC); free(AC_exact);
   g_times.zlib_s = t1 - t0; g_times.h2d_s = t2 - t1; g_times.gpu_s = t3 - t2; g_times.d2h_s = t4 - t3;
   if (on_device) { g_times.zlib_s -= t_h2d_z; g_times.h2d_s += t_h2d_z; }      /* the compressed sections' way to the device is a copy, not inflate */
   g_times.total_s = now_s() - t_begin;
