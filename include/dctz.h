@@ -142,7 +142,10 @@ int dctz_set_block_dims(int ndims, const size_t *dims);
  * 78 9C; include/dctz_hip.h: dctzhip_deflate), and behind everything else of the container follow
  *   "DZIX" | u32 chunk bytes | u32 chunks of section 0, 1, 2 | u16 compressed bytes of every chunk ... | pad to 4.
  * The reference's reader never looks there (it inflates each section as one stream, dctz-decomp-lib.c:244-322);
- * dctz_decompress here inflates the chunks side by side on DCTZ_ZLIB_THREADS host threads (default: the cores). */
+ * dctz_decompress here looks for the trailer only when all three sections start 78 5E (zlib itself writes 78 9C at the
+ * reference's settings), validates it against the header (chunk counts, sizes that tile each stream exactly up to its
+ * 03 00 + adler32) and then inflates the chunks side by side on DCTZ_ZLIB_THREADS host threads (default: the cores) --
+ * or on the device with DCTZ_INFLATE_GPU=1; anything inconsistent falls back to the ordinary inflate. */
 #define DCTZ_IX_MAGIC 0x58495A44u   /* "DZIX" little-endian */
 /* Stage timers of the last dctz_compress / dctz_decompress call, seconds
  * (the reference's -DTIME_DEBUG split, dctz-comp-lib.c:762-773). */
