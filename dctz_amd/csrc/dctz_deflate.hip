@@ -549,7 +549,8 @@ namespace dctz {
 namespace dfl {
 
 constexpr int IW = 64;                                 // lanes (= chunks) per workgroup
-constexpr int RING = 128;                              // bytes of history per lane = the largest distance the encoder uses
+constexpr int RING = 128;                              // bytes of history per lane >= the largest distance the encoder uses
+static_assert(RING >= cand_maxdist() && (RING & (RING - 1)) == 0, "the decoder's ring covers every candidate distance");
 
 struct LdsInflate {                                    // per-lane arrays, element i of lane t at [i][t]
   union {

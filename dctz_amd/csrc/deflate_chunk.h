@@ -12,7 +12,7 @@
 //   - dynamic Huffman block (BTYPE 10) followed by an empty stored block (the "sync flush" marker 00 00 FF FF), or
 //   - one stored block (BTYPE 00) when that is smaller.
 // 03 00 is the final, empty fixed-Huffman block.  Matches are searched at a fixed set of distances only (runs, the
-// previous block's pattern 64 positions back, ...) and never leave the 128-byte segment of the lane that found them, so
+// previous block's pattern 64 positions back, ...: DFL_CANDS) and never leave the 128-byte segment of the lane that found them, so
 // that every lane parses its segment without waiting for a neighbour; distances reach back across segment boundaries but
 // never across the start of the chunk: every chunk is a deflate block that can be inflated on its own, given where it
 // starts (the container's chunk index, include/dctz.h: "DZIX", lets a reader inflate the chunks of a section in parallel).
@@ -32,7 +32,6 @@ enum : int {
   SEG = 128,             // bytes one lane tokenises
   SEG_SHIFT = 7,
   HIST = 0,              // bytes of the previous chunk a match may reach into: none (chunks inflate independently)
-  NCAND = 8,             // candidate distances
   NLIT = 286,            // literal / length alphabet in use (0..255, 256 = end of block, 257..285)
   NDIST = 30,
   NCL = 19,
@@ -42,13 +41,15 @@ enum : int {
   MAXMATCH = 258,
 };
 
+// Candidate distances of the match search.  On DCTZ streams two of them carry the ratio -- 1 (runs of the centre bin)
+// and 64 (the same position of the previous block) -- and every further candidate costs the parse kernel a dozen vector
+// instructions per position; measured on the test workloads (flat, 8 x 8 and 4 x 4 x 4 tiles, smooth and noisy), the sets
+// {1, 64}, {1, 2, 64, 128} and {1, 2, 4, ..., 128} give the same section sizes to 0.4 %.
 #ifndef DFL_CANDS
-#define DFL_CANDS {1, 2, 4, 8, 16, 32, 64, 128}
+#define DFL_NCAND 4
+#define DFL_CANDS {1, 2, 64, 128}
 #endif
-DFL_HD constexpr int cand_dist(int c) {
-  constexpr int d[NCAND] = DFL_CANDS;
-  return d[c];
-}
+enum : int { NCAND = DFL_NCAND };
 
 DFL_HD int ilog2(uint32_t x) { return 31 - __builtin_clz(x); }
 
@@ -71,15 +72,28 @@ DFL_HD constexpr void dist_code(int dist, int& sym, int& eb, int& ev) {
   sym = 2 * eb + 2 + ((x >> eb) & 1);
   ev = x & ((1 << eb) - 1);
 }
-DFL_HD constexpr int cand_dsym(int c) { int s = 0, e = 0, v = 0; dist_code(cand_dist(c), s, e, v); return s; }
-DFL_HD constexpr int cand_deb(int c) { int s = 0, e = 0, v = 0; dist_code(cand_dist(c), s, e, v); return e; }
-DFL_HD constexpr int cand_dev(int c) { int s = 0, e = 0, v = 0; dist_code(cand_dist(c), s, e, v); return v; }
+struct CandTab { int dist[NCAND], dsym[NCAND], deb[NCAND], dev[NCAND], maxdist; };
+DFL_HD constexpr CandTab make_cand_tab() {
+  CandTab t{};
+  constexpr int d[NCAND] = DFL_CANDS;
+  t.maxdist = 0;
+  for (int c = 0; c < NCAND; c++) {
+    t.dist[c] = d[c];
+    int s = 0, e = 0, v = 0;
+    dist_code(d[c], s, e, v);
+    t.dsym[c] = s; t.deb[c] = e; t.dev[c] = v;
+    if (d[c] > t.maxdist) t.maxdist = d[c];
+  }
+  return t;
+}
+DFL_HD constexpr int cand_dist(int c) { return make_cand_tab().dist[c]; }
+DFL_HD constexpr int cand_dsym(int c) { return make_cand_tab().dsym[c]; }
+DFL_HD constexpr int cand_maxdist() { return make_cand_tab().maxdist; }
 // the same by a run-time index (small constant tables)
-#define DFL_TAB8(f) {f(0), f(1), f(2), f(3), f(4), f(5), f(6), f(7)}
-DFL_HD int cand_dist_rt(int c) { constexpr int t[NCAND] = DFL_CANDS; return t[c]; }
-DFL_HD int cand_dsym_rt(int c) { constexpr int t[NCAND] = DFL_TAB8(cand_dsym); return t[c]; }
-DFL_HD int cand_deb_rt(int c) { constexpr int t[NCAND] = DFL_TAB8(cand_deb); return t[c]; }
-DFL_HD int cand_dev_rt(int c) { constexpr int t[NCAND] = DFL_TAB8(cand_dev); return t[c]; }
+DFL_HD int cand_dist_rt(int c) { constexpr CandTab t = make_cand_tab(); return t.dist[c]; }
+DFL_HD int cand_dsym_rt(int c) { constexpr CandTab t = make_cand_tab(); return t.dsym[c]; }
+DFL_HD int cand_deb_rt(int c) { constexpr CandTab t = make_cand_tab(); return t.deb[c]; }
+DFL_HD int cand_dev_rt(int c) { constexpr CandTab t = make_cand_tab(); return t.dev[c]; }
 
 // ------------------------------------------------------------------ parse --
 // Tokens of the segment [p0, p1) of a chunk.  in(i): input byte at chunk offset i, i in [-HIST, len); avail = bytes that
