@@ -298,3 +298,23 @@ def test_device_inflate_rejects_damage_without_touching_anything_else(ctx):
     wrong = ix.copy(); wrong[-1] += 1                                    # the sizes no longer tile the stream
     ok, out = run(zh, wrong)
     assert not ok
+
+
+def test_stream_format_matches_the_committed_digests():
+    """The bytes of the format are pinned: a change of the candidate set, the chunk size, the tie rules of the tree or
+    the header coding shows up here (containers written by an older build stay readable either way -- they are zlib
+    streams -- but the twin / device comparison alone would not notice a silent change of both)."""
+    import hashlib
+    import json
+    path = os.path.join(ROOT, "tests", "golden", "deflate_streams.json")
+    L = twin()
+    secs = sections()
+    gold = json.load(open(path))
+    if os.environ.get("DCTZ_REGEN_GOLDEN"):
+        for k in gold["streams"]:
+            z = twin_deflate(L, secs[k])
+            gold["streams"][k] = {"n": len(secs[k]), "stream_bytes": len(z), "sha256": hashlib.sha256(z).hexdigest()}
+        json.dump(gold, open(path, "w"), indent=1)
+    for k, g in gold["streams"].items():
+        z = twin_deflate(L, secs[k])
+        assert (len(secs[k]), len(z), hashlib.sha256(z).hexdigest()) == (g["n"], g["stream_bytes"], g["sha256"]), k
