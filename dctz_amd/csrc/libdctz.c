@@ -85,9 +85,9 @@ static double now_s(void) {
 
 static int quiet(void) { return getenv("DCTZ_QUIET") != NULL; }
 /* DCTZ_ZLIB_THREADS: unset / <= 3 = the reference's tail (three threads, one single-shot
- * deflate each, dctz-comp-lib.c:620-732; three inflates one after the other,
- * dctz-decomp-lib.c:244-322).  > 3: chunked deflate on that many threads (pdeflate.c;
- * still one zlib stream per section) and the three inflates run concurrently.
+ * deflate each, dctz-comp-lib.c:620-732).  > 3: chunked deflate on that many threads (pdeflate.c;
+ * still one zlib stream per section).  The reader inflates the three sections side by side unless
+ * DCTZ_ZLIB_THREADS is 1..3 (then one after the other, dctz-decomp-lib.c:244-322: same bytes out either way).
  * DCTZ_ZLIB_CHUNK: bytes per deflate job (default 256 KiB).  DCTZ_ZLIB_LEVEL: 1..9 for the chunked tail
  * only (default: zlib's default level, as the reference; a lower level trades ratio for host time). */
 static int zlib_threads(void) { const char *e = getenv("DCTZ_ZLIB_THREADS"); return e ? atoi(e) : 0; }
@@ -875,7 +875,8 @@ int dctz_decompress(t_var *var_z, t_var *var_r) {
   unsigned char *const rawp[3] = {(unsigned char *)bin_index, (unsigned char *)DC, (unsigned char *)AC_exact};
   if (indexed && inflate_indexed(secp, zl, rawp, rawn, cur + ix_off)) {            /* chunks side by side on host threads */
     got = (uLong)npos;
-  } else if (zlib_threads() > 3) {                 /* the sections are independent streams: inflate them side by side */
+  } else if (zlib_threads() == 0 || zlib_threads() > 3) {   /* the sections are independent streams: inflate them side by side
+                                                               (DCTZ_ZLIB_THREADS=1..3 keeps the reference's one-after-the-other) */
     inflate_job ij[3] = {{secp[0], zl[0], (uLong)npos, 0, bin_index},
                          {secp[1], zl[1], (uLong)(nblk * sizeof(float)), 0, DC},
                          {secp[2], zl[2], (uLong)((size_t)cnt * sizeof(float)), 0, AC_exact}};
