@@ -318,3 +318,18 @@ def test_stream_format_matches_the_committed_digests():
     for k, g in gold["streams"].items():
         z = twin_deflate(L, secs[k])
         assert (len(secs[k]), len(z), hashlib.sha256(z).hexdigest()) == (g["n"], g["stream_bytes"], g["sha256"]), k
+
+
+@pytest.mark.gpu
+def test_c_program_moves_the_zlib_tail_to_the_device(tmp_path):
+    """tests/c/entropy_stage.c (the code INTEGRATION.md section B shows): gcc against include/dctz_hip.h + zlib; the
+    sections made on the device inflate with zlib's uncompress() and decode to within the error bound."""
+    exe = str(tmp_path / "entropy_stage")
+    subprocess.check_call(["gcc", "-std=gnu99", "-O1", os.path.join(ROOT, "tests", "c", "entropy_stage.c"), "-I", os.path.join(ROOT, "include"),
+                           "-L", os.path.join(ROOT, "dctz_amd", "lib"), "-ldctzhip", "-Wl,-rpath," + os.path.join(ROOT, "dctz_amd", "lib"), "-lz", "-lm", "-o", exe])
+    n, eb = 64 * 9000 + 13, 1e-3
+    r = subprocess.run([exe, str(n), str(eb)], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    tag, n_out, cnt, raw, zbytes, err = r.stdout.split()
+    assert tag == "ENTROPY" and int(n_out) == n and int(raw) == n + 4 * ((n + 63) // 64) + 4 * int(cnt) and int(zbytes) < int(raw)
+    assert float(err) <= 8 * eb                          # sqrt(63) * eb on the scaled values
