@@ -111,9 +111,22 @@ int main(int argc, char *argv[]) {
       printf("LAYOUT MISMATCH: header describes %zu bytes (ec) or %zu (qt), file has %ld\n", end, end + BLK_SZ * ts, fsz);
       rc = 2;
     }
-    if (ix_bytes)
+    if (ix_bytes) {
       printf("chunk index: %ld bytes at offset %ld, chunks of %u bytes: %u + %u + %u (sections made by the GPU entropy stage)\n", ix_bytes, fsz,
              ixh[1], ixh[2], ixh[3], ixh[4]);
+      /* the sizes of a section's chunks + 2 (zlib header) + 6 (03 00 + adler32) must be the section's size */
+      const unsigned int zs[3] = {h.bindex_sz_compressed, h.DC_sz_compressed, h.AC_exact_sz_compressed};
+      int tiles = 1;
+      if (fseek(fp, fsz + 20, SEEK_SET) == 0) {
+        for (int i = 0; i < 3; i++) {
+          unsigned long long sum = 8;
+          for (unsigned int k = 0; k < ixh[2 + i]; k++) { unsigned short e = 0; if (fread(&e, 2, 1, fp) != 1) { tiles = 0; break; } sum += e; }
+          if (sum != zs[i]) tiles = 0;
+        }
+      } else tiles = 0;
+      printf("chunk index %s\n", tiles ? "tiles the three streams" : "does NOT tile the streams");
+      if (!tiles) rc = 2;
+    }
     printf("compression ratio=%.2f\n", (double)h.num_elements * ts / (double)fsz_all);
   }
   fclose(fp);
