@@ -82,6 +82,9 @@ __device__ __forceinline__ void load_chunk(uint8_t* lds, const uint8_t* g, int l
   }
 }
 
+// MATCH = false: the section is known not to repeat itself (float bytes: DC, AC_exact -- zlib finds next to nothing
+// there either): every byte is a literal, the kernel is a byte histogram.
+template <bool MATCH>
 __global__ __launch_bounds__(NTHR) void k_dfl_parse(const uint8_t* __restrict__ src, unsigned long long n, uint8_t* __restrict__ tok_g,
                                                     uint32_t* __restrict__ freq_g, unsigned long long* __restrict__ adler_acc) {
   __shared__ LdsParse s;
@@ -100,8 +103,11 @@ __global__ __launch_bounds__(NTHR) void k_dfl_parse(const uint8_t* __restrict__ 
     for (int p = p0; p < p1; p++) { a += (uint32_t)in(p); b += a; }
     atomicAdd(&s.adler_a, a);
     atomicAdd(&s.adler_b, (unsigned long long)b + (unsigned long long)a * (unsigned long long)(len - p1));
-    parse_segment(in, [&](int p, int v) { s.tok[pad(p)] = (uint8_t)v; }, p0, p1, 0,
-                  [&](int sym) { atomicAdd(&s.freq[sym], 1u); }, [&](int sym) { atomicAdd(&s.freq[NLIT + sym], 1u); });
+    if (MATCH)
+      parse_segment(in, [&](int p, int v) { s.tok[pad(p)] = (uint8_t)v; }, p0, p1, 0,
+                    [&](int sym) { atomicAdd(&s.freq[sym], 1u); }, [&](int sym) { atomicAdd(&s.freq[NLIT + sym], 1u); });
+    else
+      for (int p = p0; p < p1; p++) { s.tok[pad(p)] = 0; atomicAdd(&s.freq[in(p)], 1u); }
   }
   __syncthreads();
   for (int i = tid * 4; i < CHUNK; i += NTHR * 4) *(uint32_t*)(tok_g + off + i) = *(const uint32_t*)&s.tok[pad(i)];   // (scratch is a whole number of chunks)
@@ -512,14 +518,18 @@ size_t deflate_bound(size_t n) {
   return n + 5 * nch + 8;
 }
 
-hipError_t launch_deflate(const void* src, size_t n, void* dst, void* scratch, unsigned long long* box_len, uint32_t* host_sizes, hipStream_t st) {
+hipError_t launch_deflate(const void* src, size_t n, void* dst, void* scratch, unsigned long long* box_len, uint32_t* host_sizes, bool literals_only,
+                          hipStream_t st) {
   static_assert(sizeof(dfl::ChunkMeta) % 16 == 0, "ChunkMeta is laid out in an array");
   const size_t nch = (n + dfl::CHUNK - 1) / dfl::CHUNK;
   const DflScratch sc = carve(scratch, n);
   hipError_t e = hipMemsetAsync(sc.adler, 0, 16, st);
   if (e != hipSuccess) return e;
   if (nch) {
-    hipLaunchKernelGGL(dfl::k_dfl_parse, dim3((unsigned)nch), dim3(dfl::NTHR), 0, st, (const uint8_t*)src, (unsigned long long)n, sc.tok, sc.freq, sc.adler);
+    if (literals_only)
+      hipLaunchKernelGGL(dfl::k_dfl_parse<false>, dim3((unsigned)nch), dim3(dfl::NTHR), 0, st, (const uint8_t*)src, (unsigned long long)n, sc.tok, sc.freq, sc.adler);
+    else
+      hipLaunchKernelGGL(dfl::k_dfl_parse<true>, dim3((unsigned)nch), dim3(dfl::NTHR), 0, st, (const uint8_t*)src, (unsigned long long)n, sc.tok, sc.freq, sc.adler);
     hipLaunchKernelGGL(dfl::k_dfl_codes, dim3((unsigned)nch), dim3(dfl::CW), 0, st, sc.freq, (unsigned long long)n, sc.meta, sc.sizes);
     if (host_sizes) {                                  // the chunk index of the section (bytes per chunk), for whoever writes a container
       e = hipMemcpyAsync(host_sizes, sc.sizes, nch * sizeof(uint32_t), hipMemcpyDeviceToHost, st);

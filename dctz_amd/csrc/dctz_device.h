@@ -251,7 +251,8 @@ template <typename T> void launch_psnr(const T* x, const T* r, size_t n, double*
 size_t deflate_chunk_bytes();
 size_t deflate_scratch_bytes(size_t n);
 size_t deflate_bound(size_t n);
-hipError_t launch_deflate(const void* src, size_t n, void* dst, void* scratch, unsigned long long* box_len, uint32_t* host_sizes, hipStream_t st);
+hipError_t launch_deflate(const void* src, size_t n, void* dst, void* scratch, unsigned long long* box_len, uint32_t* host_sizes, bool literals_only,
+                          hipStream_t st);
 hipError_t launch_inflate(const void* sec, const uint32_t* offs, size_t nch, size_t n, void* dst, unsigned long long* adler, uint32_t* status, hipStream_t st);
 template <typename T> int compress_occupancy(int mode, bool stats, int geom);
 template <typename T> int decompress_occupancy(int mode, int geom);

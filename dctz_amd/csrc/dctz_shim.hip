@@ -345,8 +345,8 @@ template <typename P> static int regrow(dctzhip_ctx* c, P** ptr, size_t* cap, si
 extern "C" size_t dctzhip_deflate_bound(size_t n) { return deflate_bound(n); }
 extern "C" size_t dctzhip_deflate_chunk_bytes(void) { return deflate_chunk_bytes(); }
 
-extern "C" int dctzhip_deflate(dctzhip_ctx* c, int nsec, const void* const* d_src, const size_t* n, void* const* d_dst, const size_t* cap,
-                               size_t* out_len, uint32_t* const* chunk_sizes) {
+extern "C" int dctzhip_deflate_ex(dctzhip_ctx* c, int nsec, const void* const* d_src, const size_t* n, void* const* d_dst, const size_t* cap,
+                                  size_t* out_len, uint32_t* const* chunk_sizes, const unsigned* flags) {
   if (!c || nsec < 0 || nsec > 8 || (nsec && (!d_src || !n || !d_dst || !cap || !out_len))) return fail(c, DCTZHIP_E_ARG, "dctzhip_deflate: bad arguments");
   HIPCHK(c, hipSetDevice(c->device));
   if (!c->dfl_len) {
@@ -382,7 +382,8 @@ extern "C" int dctzhip_deflate(dctzhip_ctx* c, int nsec, const void* const* d_sr
     c->dfl_len[i] = 0;
     hipStream_t st = c->stream;
     if (side && i > 0) { st = c->stage_stream[(i - 1) % SIDE]; HIPCHK(c, hipStreamWaitEvent(st, c->dfl_ev, 0)); }
-    HIPCHK(c, launch_deflate(d_src[i], n[i], d_dst[i], (char*)c->dfl_buf + at, c->dfl_len_dev + i, chunk_sizes ? chunk_sizes[i] : nullptr, st));
+    HIPCHK(c, launch_deflate(d_src[i], n[i], d_dst[i], (char*)c->dfl_buf + at, c->dfl_len_dev + i, chunk_sizes ? chunk_sizes[i] : nullptr,
+                             flags && (flags[i] & DCTZHIP_DEFLATE_LITERALS), st));
     at += (deflate_scratch_bytes(n[i]) + 255) & ~(size_t)255;
   }
   if (side)
@@ -390,6 +391,10 @@ extern "C" int dctzhip_deflate(dctzhip_ctx* c, int nsec, const void* const* d_sr
   HIPCHK(c, hipStreamSynchronize(c->stream));
   for (int i = 0; i < nsec; i++) out_len[i] = (size_t)c->dfl_len[i];
   return DCTZHIP_OK;
+}
+extern "C" int dctzhip_deflate(dctzhip_ctx* c, int nsec, const void* const* d_src, const size_t* n, void* const* d_dst, const size_t* cap,
+                               size_t* out_len, uint32_t* const* chunk_sizes) {
+  return dctzhip_deflate_ex(c, nsec, d_src, n, d_dst, cap, out_len, chunk_sizes, nullptr);
 }
 extern "C" int dctzhip_sync(dctzhip_ctx* c) {
   if (!c) return DCTZHIP_E_ARG;

@@ -619,7 +619,8 @@ int dctz_compress(t_var *var, int N, size_t *outSize, t_var *var_z, double error
       ix[i] = (uint32_t *)malloc((ix_n[i] ? ix_n[i] : 1) * sizeof(uint32_t));
       if (!ix[i]) { fprintf(stderr, "Out of memory: chunk index\n"); exit(1); }
     }
-    if (dctzhip_deflate(c, 3, gsrc, sec_bytes, (void *const *)g_dev.z, gcap, gz_len, (uint32_t *const *)ix) != DCTZHIP_OK) die("dctzhip_deflate");
+    const unsigned gflags[3] = {0u, DCTZHIP_DEFLATE_LITERALS, DCTZHIP_DEFLATE_LITERALS};   /* DC and AC_exact are bytes of floats */
+    if (dctzhip_deflate_ex(c, 3, gsrc, sec_bytes, (void *const *)g_dev.z, gcap, gz_len, (uint32_t *const *)ix, gflags) != DCTZHIP_OK) die("dctzhip_deflate");
     /* the sections go straight from the device into the caller's container, behind the header (:775-820) */
     unsigned char *zc = (is_d ? (unsigned char *)var_z->buf.d : (unsigned char *)var_z->buf.f) + sizeof(struct header);
     for (int i = 0; i < 3; i++) {

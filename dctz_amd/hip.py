@@ -80,6 +80,8 @@ _PROTOS = {
     "dctzhip_psnr_terms": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.POINTER(C.c_double)]),
     "dctzhip_deflate_bound": (C.c_size_t, [C.c_size_t]),
     "dctzhip_deflate_chunk_bytes": (C.c_size_t, []),
+    "dctzhip_deflate_ex": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), C.POINTER(C.c_void_p),
+                                     C.POINTER(C.c_size_t), C.POINTER(C.c_size_t), C.POINTER(C.c_void_p), C.POINTER(C.c_uint)]),
     "dctzhip_inflate": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), C.POINTER(C.c_void_p),
                                   C.POINTER(C.c_size_t), C.POINTER(C.c_void_p), C.POINTER(C.c_int)]),
     "dctzhip_deflate": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), C.POINTER(C.c_void_p),
@@ -274,10 +276,11 @@ class Context:
         self._check(rc, "dctzhip_psnr_terms")
         return tuple(out)
 
-    def deflate(self, sections, want_index=False):
+    def deflate(self, sections, want_index=False, literals=None):
         """zlib streams of byte sections, made on the GPU (dctzhip_deflate).  sections: device tensors (any dtype,
         contiguous); returns a list of uint8 device tensors holding one zlib stream each -- with want_index also the
-        list of per-chunk compressed sizes (numpy uint32) of every section."""
+        list of per-chunk compressed sizes (numpy uint32) of every section.  literals: per section, True = no match search
+        (DCTZHIP_DEFLATE_LITERALS: bytes of floats)."""
         import torch
         self._bind_stream()
         k = len(sections)
@@ -292,7 +295,8 @@ class Context:
         chunk = int(self.lib.dctzhip_deflate_chunk_bytes())
         idx = [np.zeros(max(1, (nb + chunk - 1) // chunk), np.uint32) for nb in nbytes]
         ix = (C.c_void_p * max(k, 1))(*[a.ctypes.data for a in idx])
-        rc = self.lib.dctzhip_deflate(self.h, k, src, n, dst, cap, ln, ix if want_index else None)
+        fl = (C.c_uint * max(k, 1))(*[1 if (literals and literals[i]) else 0 for i in range(k)])
+        rc = self.lib.dctzhip_deflate_ex(self.h, k, src, n, dst, cap, ln, ix if want_index else None, fl)
         self._check(rc, "dctzhip_deflate")
         zs = [o[:int(l)] for o, l in zip(outs, ln)]
         if want_index:

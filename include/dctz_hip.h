@@ -255,6 +255,12 @@ size_t dctzhip_deflate_bound(size_t n);
 size_t dctzhip_deflate_chunk_bytes(void);
 int dctzhip_deflate(dctzhip_ctx *ctx, int nsec, const void *const *d_src, const size_t *n, void *const *d_dst,
                     const size_t *cap, size_t *out_len, uint32_t *const *chunk_sizes);
+/* The same with one flag word per section (NULL: none).  DCTZHIP_DEFLATE_LITERALS: do not search the section for
+ * matches -- for bytes of floats (DC, AC_exact), where zlib's own search finds next to nothing; the section is then
+ * coded with its byte statistics alone (same size to 0.1 %, a fifth of the parse time). */
+#define DCTZHIP_DEFLATE_LITERALS 1u
+int dctzhip_deflate_ex(dctzhip_ctx *ctx, int nsec, const void *const *d_src, const size_t *n, void *const *d_dst,
+                       const size_t *cap, size_t *out_len, uint32_t *const *chunk_sizes, const unsigned *flags);
 
 /* The reader's side of the same stage: sections written by dctzhip_deflate inflated on the device, one lane per chunk
  * (replaces, for such sections, inflateInit / inflate of dctz-decomp-lib.c:244-322 and the H2D copy of the raw streams).

@@ -50,11 +50,13 @@ extern "C" size_t emu_deflate_bound(size_t n, int nthr) {
 }
 
 // returns the stream length (0 if cap is too small)
-static size_t emu_deflate_ix(const uint8_t* src, size_t n, uint8_t* dst, size_t cap, int nthr, uint32_t* sizes);
+static size_t emu_deflate_ix(const uint8_t* src, size_t n, uint8_t* dst, size_t cap, int nthr, uint32_t* sizes, int literals = 0);
 extern "C" size_t emu_deflate(const uint8_t* src, size_t n, uint8_t* dst, size_t cap, int nthr) { return emu_deflate_ix(src, n, dst, cap, nthr, nullptr); }
 // the same, and the compressed bytes of every chunk (the container's chunk index)
 extern "C" size_t emu_deflate_index(const uint8_t* src, size_t n, uint8_t* dst, size_t cap, int nthr, uint32_t* sizes) { return emu_deflate_ix(src, n, dst, cap, nthr, sizes); }
-static size_t emu_deflate_ix(const uint8_t* src, size_t n, uint8_t* dst, size_t cap, int nthr, uint32_t* sizes) {
+// the same without the match search (DCTZHIP_DEFLATE_LITERALS)
+extern "C" size_t emu_deflate_literals(const uint8_t* src, size_t n, uint8_t* dst, size_t cap, int nthr, uint32_t* sizes) { return emu_deflate_ix(src, n, dst, cap, nthr, sizes, 1); }
+static size_t emu_deflate_ix(const uint8_t* src, size_t n, uint8_t* dst, size_t cap, int nthr, uint32_t* sizes, int literals) {
   const size_t chunk = (size_t)nthr * SEG;
   if (cap < emu_deflate_bound(n, nthr)) return 0;
   size_t pos = 0;
@@ -68,7 +70,8 @@ static size_t emu_deflate_ix(const uint8_t* src, size_t n, uint8_t* dst, size_t 
     const uint8_t* base = src + off;
     auto in = [&](int i) -> int { return base[i]; };
     uint32_t fl[NLIT] = {0}, fd[NDIST] = {0}, fc[NCL] = {0};
-    for (int t = 0; t * SEG < len; t++)
+    if (literals) for (int p = 0; p < len; p++) { tok[p] = 0; fl[base[p]]++; }
+    else for (int t = 0; t * SEG < len; t++)
       parse_segment(in, [&](int p, int v) { tok[p] = (uint8_t)v; }, t * SEG, std::min((t + 1) * SEG, len), avail, [&](int s) { fl[s]++; },
                     [&](int s) { fd[s]++; });
     fl[256] = 1;

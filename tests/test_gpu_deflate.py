@@ -30,18 +30,21 @@ def twin():
     L.emu_deflate.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_int]
     L.emu_deflate_index.restype = C.c_size_t
     L.emu_deflate_index.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p]
+    L.emu_deflate_literals.restype = C.c_size_t
+    L.emu_deflate_literals.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p]
     L.emu_deflate_bound.restype = C.c_size_t
     L.emu_deflate_bound.argtypes = [C.c_size_t, C.c_int]
     return L
 
 
-def twin_deflate(L, data, nthr=128, want_index=False):
+def twin_deflate(L, data, nthr=128, want_index=False, literals=False):
     a = np.frombuffer(data, dtype=np.uint8)
     cap = L.emu_deflate_bound(len(data), nthr)
     out = np.zeros(cap, dtype=np.uint8)
     chunk = nthr * 128
     sizes = np.zeros(max(1, (len(data) + chunk - 1) // chunk), np.uint32)
-    n = L.emu_deflate_index(a.ctypes.data if len(data) else None, len(data), out.ctypes.data, cap, nthr, sizes.ctypes.data)
+    n = (L.emu_deflate_literals if literals else L.emu_deflate_index)(a.ctypes.data if len(data) else None, len(data), out.ctypes.data, cap, nthr,
+                                                                     sizes.ctypes.data)
     assert n > 0
     if want_index:
         return out[:n].tobytes(), sizes[:(len(data) + chunk - 1) // chunk]
@@ -333,3 +336,24 @@ def test_c_program_moves_the_zlib_tail_to_the_device(tmp_path):
     tag, n_out, cnt, raw, zbytes, err = r.stdout.split()
     assert tag == "ENTROPY" and int(n_out) == n and int(raw) == n + 4 * ((n + 63) // 64) + 4 * int(cnt) and int(zbytes) < int(raw)
     assert float(err) <= 8 * eb                          # sqrt(63) * eb on the scaled values
+
+
+@pytest.mark.gpu
+def test_literals_only_sections(ctx):
+    """DCTZHIP_DEFLATE_LITERALS (what the drop-in sets for DC and AC_exact): no match search; device == twin byte for
+    byte, zlib inflates it, and on bytes of floats the section is as small as with the search (0.2 %)."""
+    import torch
+    L = twin()
+    rng = np.random.default_rng(31)
+    floats = (rng.standard_normal(150001) * 3.0).astype(np.float32).tobytes()
+    runs = bytes(3 * CHUNK + 5)
+    dev = [torch.from_numpy(np.frombuffer(b, dtype=np.uint8).copy()).to(ctx.device) for b in (floats, runs, b"")]
+    zs, index = ctx.deflate(dev, want_index=True, literals=[True, True, True])
+    for b, z, ix in zip((floats, runs, b""), zs, index):
+        zb = z.cpu().numpy().tobytes()
+        zt, ixt = twin_deflate(L, b, want_index=True, literals=True)
+        assert zb == zt and np.array_equal(ix, ixt) and zlib.decompress(zb) == b
+    with_search = ctx.deflate(dev[:1])[0].numel()
+    assert abs(zs[0].numel() - with_search) <= 0.002 * with_search
+    back, ok = ctx.inflate(zs, index, [len(floats), len(runs), 0])
+    assert ok and back[0].cpu().numpy().tobytes() == floats

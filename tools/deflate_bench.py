@@ -23,15 +23,16 @@ out, info = ctx.compress(xd, a.eb, 1 if a.mode == "qt" else 0)
 cnt = int(info.cnt)
 secs = [out["bin_index"], out["dc"], out["ac_exact"][:cnt]]
 raw = [t.numel() * t.element_size() for t in secs]
-zs = ctx.deflate(secs)
+LIT = [False, True, True]      # DC and AC_exact are bytes of floats: no match search (what the drop-in passes)
+zs = ctx.deflate(secs, literals=LIT)
 torch.cuda.synchronize()
 ts = []
 for _ in range(a.reps):
     t0 = time.perf_counter()
-    zs = ctx.deflate(secs)
+    zs = ctx.deflate(secs, literals=LIT)
     ts.append(time.perf_counter() - t0)
 # the reader's side: the same sections inflated on the device, each on its own and all three in one call
-zs, index = ctx.deflate(secs, want_index=True)
+zs, index = ctx.deflate(secs, want_index=True, literals=LIT)
 inf = {}
 for name, sel in (("bin_index", [0]), ("dc", [1]), ("ac_exact", [2]), ("all", [0, 1, 2])):
     tt = []
