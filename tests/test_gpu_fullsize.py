@@ -136,3 +136,33 @@ def test_maximum_size_array_is_periodic(dtype):
     assert torch.equal(rec[:reps * chunk].view(reps, chunk).view(it), r_s[:chunk].view(it).unsqueeze(0).expand(reps, chunk))
     assert torch.equal(rec[reps * chunk:].view(it), r_s[chunk:].view(it))
     ctx.close()
+
+
+def test_entropy_stage_on_a_section_beyond_2_gib():
+    """Section offsets are 64-bit throughout: 2^31 + 12345 bytes (a periodic skewed pattern made on the device) through
+    dctzhip_deflate; checked by the device decoder (every chunk, lengths, adler32 of the content), by the size-independent
+    structure of the stream (frame, index that tiles it) and by zlib on the first and last chunks."""
+    import torch
+    import zlib
+    ctx = _ctx()
+    n = (1 << 31) + 12345
+    chunk = 16384
+    period = 1 << 20                                         # 1 MiB of skewed bytes, repeated (the chunks never see the repeat: it is 64 chunks away)
+    rng = np.random.default_rng(8)
+    base = torch.from_numpy(rng.choice([127, 128, 126, 255, 0, 9, 200], p=[.55, .2, .1, .05, .04, .03, .03], size=period).astype(np.uint8)).to(ctx.device)
+    src = base.repeat((n + period - 1) // period)[:n].contiguous()
+    src[-5000:] = 77                                         # the tail differs from the pattern
+    (z,), (ix,) = ctx.deflate([src], want_index=True)
+    nch = (n + chunk - 1) // chunk
+    assert len(ix) == nch and int(ix.astype(np.uint64).sum()) + 8 == z.numel()
+    head = z[:2].cpu().numpy().tobytes(); tail = z[-6:].cpu().numpy().tobytes()
+    assert head == b"\x78\x5e" and tail[:2] == b"\x03\x00"
+    (back,), ok = ctx.inflate([z], [ix], [n])
+    assert ok and torch.equal(back, src)
+    offs = np.concatenate([[0], np.cumsum(ix.astype(np.uint64))]).astype(np.int64)
+    for c in (0, 1, nch // 2, nch - 2, nch - 1):             # zlib on single chunks (raw deflate, byte aligned)
+        d = zlib.decompressobj(-15)
+        piece = d.decompress(z[2 + offs[c]:2 + offs[c + 1]].cpu().numpy().tobytes())
+        want = src[c * chunk:min(n, (c + 1) * chunk)].cpu().numpy().tobytes()
+        assert piece == want and d.unused_data == b""
+    ctx.close()
