@@ -65,6 +65,9 @@ struct LdsParse {
   uint32_t freq[META_SYMS];
   unsigned long long adler_b;
   uint32_t adler_a;
+  // first and last token of every segment, for the merge across segment boundaries (deflate_chunk.h)
+  int16_t first_c[NTHR], last_c[NTHR];                 // candidate index, -1: a literal (or no token)
+  uint16_t first_len[NTHR], last_len[NTHR], last_p[NTHR], ntok[NTHR];
 };
 
 // chunk bytes -> padded LDS image; dwords when the source allows it
@@ -103,11 +106,38 @@ __global__ __launch_bounds__(NTHR) void k_dfl_parse(const uint8_t* __restrict__ 
     for (int p = p0; p < p1; p++) { a += (uint32_t)in(p); b += a; }
     atomicAdd(&s.adler_a, a);
     atomicAdd(&s.adler_b, (unsigned long long)b + (unsigned long long)a * (unsigned long long)(len - p1));
-    if (MATCH)
+    if (MATCH) {
+      int fc = -1, fl = 0, lc = -1, ll = 0, lp = p0, nt = 0;
       parse_segment(in, [&](int p, int v) { s.tok[pad(p)] = (uint8_t)v; }, p0, p1, 0,
-                    [&](int sym) { atomicAdd(&s.freq[sym], 1u); }, [&](int sym) { atomicAdd(&s.freq[NLIT + sym], 1u); });
-    else
+                    [&](int sym) { atomicAdd(&s.freq[sym], 1u); }, [&](int sym) { atomicAdd(&s.freq[NLIT + sym], 1u); },
+                    [&](int p, int l, int c) { if (nt == 0) { fc = c; fl = l; } lc = c; ll = l; lp = p; nt++; });
+      s.first_c[tid] = (int16_t)fc; s.first_len[tid] = (uint16_t)fl; s.last_c[tid] = (int16_t)lc; s.last_len[tid] = (uint16_t)ll;
+      s.last_p[tid] = (uint16_t)lp; s.ntok[tid] = (uint16_t)nt;
+    } else
       for (int p = p0; p < p1; p++) { s.tok[pad(p)] = 0; atomicAdd(&s.freq[in(p)], 1u); }
+  } else if (MATCH) { s.first_c[tid] = -1; s.last_c[tid] = -1; s.ntok[tid] = 0; s.first_len[tid] = 0; s.last_len[tid] = 0; s.last_p[tid] = 0; }
+  __syncthreads();
+  if (MATCH && p0 < len) {
+    // merge with the next segment: this lane's last token takes that segment's first one in (same distance, contiguous),
+    // decided from the two tokens as the parse left them; the counts follow (two length symbols and a distance out,
+    // one length symbol in)
+    if (tid + 1 < NTHR && p0 + SEG < len) {
+      const int lc = s.last_c[tid], ll = s.last_len[tid], lp = s.last_p[tid];
+      const int fc = s.first_c[tid + 1], fl = s.first_len[tid + 1];
+      if (lc >= 0 && lp + ll == p0 + SEG && fc == lc && ll + fl <= MAXMATCH && merge_allowed(tid, s.ntok[tid] == 1, s.ntok[tid + 1] == 1)) {
+        s.tok[pad(lp + 1)] = (uint8_t)(ll + fl - 3);
+        int sa, sb, sc, eb, ev;
+        len_code(ll, sa, eb, ev); len_code(fl, sb, eb, ev); len_code(ll + fl, sc, eb, ev);
+        atomicSub(&s.freq[sa], 1u); atomicSub(&s.freq[sb], 1u); atomicAdd(&s.freq[sc], 1u);
+        atomicSub(&s.freq[NLIT + cand_dsym_rt(lc)], 1u);
+      }
+    }
+    if (tid > 0) {                                        // the mirror image: is this segment's first token taken in by the previous one?
+      const int lc = s.last_c[tid - 1], ll = s.last_len[tid - 1], lp = s.last_p[tid - 1];
+      const int fc = s.first_c[tid], fl = s.first_len[tid];
+      if (lc >= 0 && lp + ll == p0 && fc == lc && ll + fl <= MAXMATCH && merge_allowed(tid - 1, s.ntok[tid - 1] == 1, s.ntok[tid] == 1))
+        s.tok[pad(p0)] = (uint8_t)TOK_ABSORBED;
+    }
   }
   __syncthreads();
   for (int i = tid * 4; i < CHUNK; i += NTHR * 4) *(uint32_t*)(tok_g + off + i) = *(const uint32_t*)&s.tok[pad(i)];   // (scratch is a whole number of chunks)
@@ -409,8 +439,10 @@ __global__ __launch_bounds__(NTHR) void k_dfl_emit(const uint8_t* __restrict__ s
   auto in = [&](int i) -> int { return s.in[pad(i)]; };
   const int p0 = tid * SEG, p1 = (p0 + SEG < len) ? p0 + SEG : len;
   uint32_t mybits = 0;
+  // (a segment whose first token was merged into the previous segment's last one starts behind it: deflate_chunk.h)
+  const int pstart = (p0 < len && s.tok[pad(p0)] == TOK_ABSORBED) ? p0 + s.tok[pad(p0 + 1)] + 3 : p0;
   if (p0 < len) {
-    for (int p = p0; p < p1;) {
+    for (int p = pstart; p < p1;) {
       const int t = s.tok[pad(p)];
       if (t == 0) { mybits += s.len[in(p)]; p++; }
       else {
@@ -434,7 +466,7 @@ __global__ __launch_bounds__(NTHR) void k_dfl_emit(const uint8_t* __restrict__ s
   auto orw = [&](uint32_t w, uint32_t v) { atomicOr(&s.out[w], v); };
   if (p0 < len) {
     BitW<decltype(orw)> bw(orw, (uint64_t)hbits + excl);
-    for (int p = p0; p < p1;) {
+    for (int p = pstart; p < p1;) {
       const int t = s.tok[pad(p)];
       if (t == 0) { const int b = in(p); bw.put(s.code[b], s.len[b]); p++; }
       else {

@@ -12,8 +12,9 @@
 //   - dynamic Huffman block (BTYPE 10) followed by an empty stored block (the "sync flush" marker 00 00 FF FF), or
 //   - one stored block (BTYPE 00) when that is smaller.
 // 03 00 is the final, empty fixed-Huffman block.  Matches are searched at a fixed set of distances only (runs, the
-// previous block's pattern 64 positions back, ...: DFL_CANDS) and never leave the 128-byte segment of the lane that found them, so
-// that every lane parses its segment without waiting for a neighbour; distances reach back across segment boundaries but
+// previous block's pattern 64 positions back, ...: DFL_CANDS) inside the 128-byte segment of one lane, so that every lane
+// parses its segment without waiting for a neighbour (a match that reaches its segment's end is afterwards joined with a
+// same-distance match at the start of the next one: "merge" below); distances reach back across segment boundaries but
 // never across the start of the chunk: every chunk is a deflate block that can be inflated on its own, given where it
 // starts (the container's chunk index, include/dctz.h: "DZIX", lets a reader inflate the chunks of a section in parallel).
 #pragma once
@@ -100,8 +101,10 @@ DFL_HD int cand_dev_rt(int c) { constexpr CandTab t = make_cand_tab(); return t.
 // exist in front of the chunk (HIST, or less at the head of the section).  Token record, indexed by position:
 // tok(p) = 0: literal in(p);  tok(p) = 1 + c: match at distance cand_dist(c), its length - 3 in tok(p + 1).
 // lit(sym) / dst(sym) count one use of a literal-length / distance symbol.
-template <class In, class TokW, class CountL, class CountD>
-DFL_HD void parse_segment(In in, TokW tokw, int p0, int p1, int avail, CountL lit, CountD dst) {
+// info(p, length, c): called once per token in order (c = candidate index of a match, -1 for a literal).
+struct NoTokInfo { DFL_HD void operator()(int, int, int) const {} };
+template <class In, class TokW, class CountL, class CountD, class Info = NoTokInfo>
+DFL_HD void parse_segment(In in, TokW tokw, int p0, int p1, int avail, CountL lit, CountD dst, Info info = Info()) {
   int p = p0;
   while (p < p1) {
     int best = 0, bc = 0;
@@ -146,13 +149,32 @@ DFL_HD void parse_segment(In in, TokW tokw, int p0, int p1, int avail, CountL li
       len_code(best, s, e, v);
       lit(s);
       dst(cand_dsym_rt(bc));
+      info(p, best, bc);
       p += best;
     } else {
       tokw(p, 0);
       lit(in(p));
+      info(p, 1, -1);
       p++;
     }
   }
+}
+
+// ------------------------------------------------------------------ merge --
+// A match that ends with its segment may go on into the next one: when segment t's LAST token is a match that reaches the
+// segment's end and segment t + 1 BEGINS with a match at the same distance, the two are one match of the summed length
+// (always <= 258: both are <= 128 ... 130), which halves the tokens of long runs and of repeated blocks.  Decided per
+// boundary from the two tokens alone, so that every lane can do it for its own end: tok(start of segment t + 1) becomes
+// ABSORBED (its length byte stays), the last token of segment t gets the summed length.  A segment that is ONE token
+// from end to end could be both absorbed and absorbing; it is absorbed when t is odd and absorbs when t is even.
+enum : int { TOK_ABSORBED = 255 };
+// last_p: start of segment t's last token (a match), last_len its length, single: it is the segment's only token.
+// Returns the length to add to it (0: no merge); the caller of segment t + 1 tests absorbed_by_previous() the same way.
+DFL_HD bool merge_allowed(int t, bool left_single, bool right_single) {
+  // left = segment t, right = segment t + 1
+  if (left_single && (t & 1)) return false;             // an odd single-token segment is itself absorbed (or stays), never absorbs
+  if (right_single && !((t + 1) & 1)) return false;     // an even single-token segment absorbs (or stays), is never absorbed
+  return true;
 }
 
 // --------------------------------------------------------------- Huffman --

@@ -71,9 +71,43 @@ static size_t emu_deflate_ix(const uint8_t* src, size_t n, uint8_t* dst, size_t 
     auto in = [&](int i) -> int { return base[i]; };
     uint32_t fl[NLIT] = {0}, fd[NDIST] = {0}, fc[NCL] = {0};
     if (literals) for (int p = 0; p < len; p++) { tok[p] = 0; fl[base[p]]++; }
-    else for (int t = 0; t * SEG < len; t++)
-      parse_segment(in, [&](int p, int v) { tok[p] = (uint8_t)v; }, t * SEG, std::min((t + 1) * SEG, len), avail, [&](int s) { fl[s]++; },
-                    [&](int s) { fd[s]++; });
+    else {
+      const int nseg = (len + SEG - 1) / SEG;
+      for (int t = 0; t < nseg; t++)
+        parse_segment(in, [&](int p, int v) { tok[p] = (uint8_t)v; }, t * SEG, std::min((t + 1) * SEG, len), avail, [](int) {}, [](int) {});
+      // merge across segment boundaries (deflate_chunk.h: merge_allowed), every boundary decided from the ORIGINAL tokens
+      std::vector<int> last_p(nseg), last_len(nseg), ntok(nseg), first_len(nseg), first_c(nseg), last_c(nseg);
+      for (int t = 0; t < nseg; t++) {
+        const int p0 = t * SEG, p1 = std::min((t + 1) * SEG, len);
+        int k = 0, lp = p0, ll = 0, lc = -1;
+        first_len[t] = 0; first_c[t] = -1;
+        for (int p = p0; p < p1;) {
+          int l = 1, c = -1;
+          if (tok[p]) { l = tok[p + 1] + 3; c = tok[p] - 1; }
+          if (k == 0) { first_len[t] = l; first_c[t] = c; }
+          lp = p; ll = l; lc = c; k++;
+          p += l;
+        }
+        last_p[t] = lp; last_len[t] = ll; last_c[t] = lc; ntok[t] = k;
+      }
+      for (int t = 0; t + 1 < nseg; t++) {
+        const bool reaches = last_c[t] >= 0 && last_p[t] + last_len[t] == (t + 1) * SEG;
+        if (!reaches || first_c[t + 1] != last_c[t] || last_len[t] + first_len[t + 1] > MAXMATCH) continue;
+        if (!merge_allowed(t, ntok[t] == 1, ntok[t + 1] == 1)) continue;
+        tok[last_p[t] + 1] = (uint8_t)(last_len[t] + first_len[t + 1] - 3);
+        tok[(t + 1) * SEG] = TOK_ABSORBED;
+      }
+      for (int p = 0; p < len;) {                           // counts of the merged tokens
+        if (tok[p] == 0) { fl[base[p]]++; p++; }
+        else {
+          const int l = tok[p + 1] + 3, c = tok[p] - 1;
+          int sym, eb, ev;
+          len_code(l, sym, eb, ev);
+          fl[sym]++; fd[cand_dsym_rt(c)]++;
+          p += l;
+        }
+      }
+    }
     fl[256] = 1;
     int used = 0;
     for (int i = 0; i < NDIST; i++) used += fd[i] ? 1 : 0;
