@@ -391,32 +391,48 @@ static void *ix_worker(void *arg) {
   }
   return NULL;
 }
-/* Returns 1 when the three sections were inflated through the index, 0 when there is no (valid) index: the caller then
- * takes the ordinary path.  sec/zlen: the sections; dst/raw: where they inflate to and how many bytes that must be. */
-static int inflate_indexed(const unsigned char *const sec[3], const unsigned int zlen[3], unsigned char *const dst[3], const size_t raw[3],
-                           const unsigned char *trailer) {
-  for (int i = 0; i < 3; i++) if (zlen[i] < 8 || sec[i][0] != 0x78 || sec[i][1] != 0x5E) return 0;
+/* The chunk index of a container ("DZIX", dctz.h) as three arrays of compressed sizes.  Returns 1 when the sections
+ * carry the mark (78 5E), the trailer is there and describes them exactly -- chunk counts that follow from the raw sizes,
+ * sizes that tile every stream up to its 03 00 + adler32 --, else 0 (nothing allocated): the caller then takes the
+ * ordinary inflate. */
+static int read_index(const unsigned char *const sec[3], const unsigned int zlen[3], const size_t raw[3], const unsigned char *trailer,
+                      size_t *chunk_out, uint32_t *sizes[3]) {
+  for (int i = 0; i < 3; i++) { sizes[i] = NULL; if (zlen[i] < 8 || sec[i][0] != 0x78 || sec[i][1] != 0x5E) return 0; }
   unsigned int hd[5];
   memcpy(hd, trailer, sizeof(hd));
   if (hd[0] != DCTZ_IX_MAGIC || hd[1] < 1024 || hd[1] > 65535) return 0;
   const size_t chunk = hd[1];
-  size_t total = 0;
-  for (int i = 0; i < 3; i++) { if (hd[2 + i] != (raw[i] + chunk - 1) / chunk) return 0; total += hd[2 + i]; }
+  for (int i = 0; i < 3; i++) if (hd[2 + i] != (raw[i] + chunk - 1) / chunk) return 0;
+  const unsigned char *e = trailer + sizeof(hd);
+  int ok = 1;
+  for (int i = 0; i < 3 && ok; i++) {
+    sizes[i] = (uint32_t *)malloc((hd[2 + i] ? hd[2 + i] : 1) * sizeof(uint32_t));
+    if (!sizes[i]) { ok = 0; break; }
+    size_t off = 2;
+    for (size_t j = 0; j < hd[2 + i]; j++, e += 2) { unsigned short z; memcpy(&z, e, 2); sizes[i][j] = z; off += z; }
+    if (off + 6 != zlen[i] || sec[i][off] != 0x03 || sec[i][off + 1] != 0x00) ok = 0;      /* the sizes must tile the stream */
+  }
+  if (!ok) { for (int i = 0; i < 3; i++) { free(sizes[i]); sizes[i] = NULL; } return 0; }
+  *chunk_out = chunk;
+  return 1;
+}
+
+/* The three sections of an indexed container inflated chunk by chunk on host threads (sizes / chunk from read_index). */
+static void inflate_indexed(const unsigned char *const sec[3], const unsigned int zlen[3], unsigned char *const dst[3], const size_t raw[3],
+                            size_t chunk, uint32_t *const sizes[3]) {
+  size_t nch[3], total = 0;
+  for (int i = 0; i < 3; i++) { nch[i] = (raw[i] + chunk - 1) / chunk; total += nch[i]; }
   ix_chunk *chunks = (ix_chunk *)calloc(total ? total : 1, sizeof(ix_chunk));
-  if (!chunks) return 0;
-  const unsigned short *e = (const unsigned short *)(trailer + sizeof(hd));
+  if (!chunks) { fprintf(stderr, "Out of memory: chunk list\n"); exit(1); }
   size_t k = 0;
   for (int i = 0; i < 3; i++) {
     size_t off = 2;
-    for (size_t j = 0; j < hd[2 + i]; j++, k++) {
-      unsigned short z;
-      memcpy(&z, e + k, sizeof(z));
-      chunks[k].src = sec[i] + off; chunks[k].zlen = z;
+    for (size_t j = 0; j < nch[i]; j++, k++) {
+      chunks[k].src = sec[i] + off; chunks[k].zlen = sizes[i][j];
       chunks[k].dst = dst[i] + j * chunk;
       chunks[k].len = (unsigned int)(raw[i] - j * chunk < chunk ? raw[i] - j * chunk : chunk);
-      off += z;
+      off += sizes[i][j];
     }
-    if (off + 6 != zlen[i] || sec[i][off] != 0x03 || sec[i][off + 1] != 0x00) { free(chunks); return 0; }   /* the sizes must tile the stream */
   }
   int threads = zlib_threads();
   if (threads <= 0) { long nc = sysconf(_SC_NPROCESSORS_ONLN); threads = nc > 32 ? 32 : (nc < 1 ? 1 : (int)nc); }
@@ -435,33 +451,15 @@ static int inflate_indexed(const unsigned char *const sec[3], const unsigned int
   k = 0;
   for (int i = 0; i < 3 && ok; i++) {                   /* what inflate() checks at the end of a stream: the adler32 of the content */
     uLong a = adler32(0L, Z_NULL, 0);
-    for (size_t j = 0; j < hd[2 + i]; j++, k++) { if (chunks[k].err) ok = 0; a = adler32_combine(a, chunks[k].adler, (z_off_t)chunks[k].len); }
+    for (size_t j = 0; j < nch[i]; j++, k++) { if (chunks[k].err) ok = 0; a = adler32_combine(a, chunks[k].adler, (z_off_t)chunks[k].len); }
     const unsigned char *t = sec[i] + zlen[i] - 4;
     const uLong want = ((uLong)t[0] << 24) | ((uLong)t[1] << 16) | ((uLong)t[2] << 8) | (uLong)t[3];
     if (a != want) ok = 0;
   }
   free(chunks);
   if (!ok) { fprintf(stderr, "libdctz: a chunk of an indexed section does not inflate\n"); exit(1); }
-  return 1;
 }
 
-/* The chunk sizes of an indexed container as three arrays (for the device inflate); 0 when there is no valid index. */
-static int index_sizes(const unsigned char *const sec[3], const unsigned int zlen[3], const size_t raw[3], const unsigned char *trailer,
-                       uint32_t *sizes[3]) {
-  for (int i = 0; i < 3; i++) { sizes[i] = NULL; if (zlen[i] < 8 || sec[i][0] != 0x78 || sec[i][1] != 0x5E) return 0; }
-  unsigned int hd[5];
-  memcpy(hd, trailer, sizeof(hd));
-  if (hd[0] != DCTZ_IX_MAGIC || hd[1] != (unsigned int)dctzhip_deflate_chunk_bytes()) return 0;
-  const size_t chunk = hd[1];
-  const unsigned char *e = trailer + sizeof(hd);
-  for (int i = 0; i < 3; i++) {
-    if (hd[2 + i] != (raw[i] + chunk - 1) / chunk) { for (int k = 0; k < i; k++) free(sizes[k]); return 0; }
-    sizes[i] = (uint32_t *)malloc((hd[2 + i] ? hd[2 + i] : 1) * sizeof(uint32_t));
-    if (!sizes[i]) { for (int k = 0; k < i; k++) free(sizes[k]); return 0; }
-    for (size_t j = 0; j < hd[2 + i]; j++, e += 2) { unsigned short z; memcpy(&z, e, 2); sizes[i][j] = z; }
-  }
-  return 1;
-}
 /* DCTZ_INFLATE_GPU=1: indexed sections are inflated on the device (one lane per chunk) instead of by host threads.
  * Off by default: a lane decodes its 16 KiB alone, which takes 18 - 30 ms per section however few chunks there are
  * (38 ms for the three sections of a 1 GiB shard side by side), where sixteen host threads need 19 ms; it pays on hosts with few
@@ -841,28 +839,27 @@ int dctz_decompress(t_var *var_z, t_var *var_r) {
    * container looked at.  On request (DCTZ_INFLATE_GPU=1) they are inflated on the device, one lane per chunk -- the
    * compressed sections go over PCIe instead of the raw streams, no host core inflates (include/dctz_hip.h:
    * dctzhip_inflate); otherwise by host threads, chunks side by side. */
-  const int indexed = zl[0] >= 8 && zl[1] >= 8 && zl[2] >= 8 && secp[0][1] == 0x5E && secp[1][1] == 0x5E && secp[2][1] == 0x5E;
+  uint32_t *ix_sizes[3] = {NULL, NULL, NULL};
+  size_t ix_chunk_bytes = 0;
+  const int indexed = zl[0] >= 8 && zl[1] >= 8 && zl[2] >= 8 && secp[0][1] == 0x5E && secp[1][1] == 0x5E && secp[2][1] == 0x5E &&
+                      read_index(secp, zl, rawn, cur + ix_off, &ix_chunk_bytes, ix_sizes);
   int on_device = 0;
   double t_h2d_z = 0.0;
   grow(&g_dev.bin, &g_dev.bin_cap, npos);
   grow(&g_dev.dc, &g_dev.dc_cap, nblk * sizeof(float));
   grow(&g_dev.ac, &g_dev.ac_cap, (cnt ? cnt : 4) * sizeof(float));
-  if (indexed && inflate_gpu()) {
-    uint32_t *sizes[3];
-    if (index_sizes(secp, zl, rawn, cur + ix_off, sizes)) {
-      size_t zlen[3];
-      for (int i = 0; i < 3; i++) {
-        zlen[i] = zl[i];
-        grow(&g_dev.z[i], &g_dev.z_cap[i], zl[i]);
-        if (dctzhip_memcpy_h2d(c, g_dev.z[i], secp[i], zl[i]) != DCTZHIP_OK) die("H2D compressed section");
-      }
-      t_h2d_z = now_s() - t0;
-      void *const ddst[3] = {g_dev.bin, g_dev.dc, g_dev.ac};
-      int ok = 0;
-      if (dctzhip_inflate(c, 3, (const void *const *)g_dev.z, zlen, (const uint32_t *const *)sizes, rawn, ddst, &ok) != DCTZHIP_OK) die("dctzhip_inflate");
-      on_device = ok;          /* 0: inconsistent -- the zlib path below decides, and reports damage like the reference */
-      for (int i = 0; i < 3; i++) free(sizes[i]);
+  if (indexed && inflate_gpu() && ix_chunk_bytes == dctzhip_deflate_chunk_bytes()) {
+    size_t zlen[3];
+    for (int i = 0; i < 3; i++) {
+      zlen[i] = zl[i];
+      grow(&g_dev.z[i], &g_dev.z_cap[i], zl[i]);
+      if (dctzhip_memcpy_h2d(c, g_dev.z[i], secp[i], zl[i]) != DCTZHIP_OK) die("H2D compressed section");
     }
+    t_h2d_z = now_s() - t0;
+    void *const ddst[3] = {g_dev.bin, g_dev.dc, g_dev.ac};
+    int ok = 0;
+    if (dctzhip_inflate(c, 3, (const void *const *)g_dev.z, zlen, (const uint32_t *const *)ix_sizes, rawn, ddst, &ok) != DCTZHIP_OK) die("dctzhip_inflate");
+    on_device = ok;            /* 0: inconsistent -- the host path below decides, and reports damage like the reference */
   }
 
   t_bin_id *bin_index = NULL;
@@ -874,7 +871,8 @@ int dctz_decompress(t_var *var_z, t_var *var_r) {
   AC_exact = (float *)host_buf(2, (size_t)cnt * sizeof(float));
   /* three inflates, in order (dctz-decomp-lib.c:244-322) */
   unsigned char *const rawp[3] = {(unsigned char *)bin_index, (unsigned char *)DC, (unsigned char *)AC_exact};
-  if (indexed && inflate_indexed(secp, zl, rawp, rawn, cur + ix_off)) {            /* chunks side by side on host threads */
+  if (indexed) {                                   /* chunks side by side on host threads */
+    inflate_indexed(secp, zl, rawp, rawn, ix_chunk_bytes, ix_sizes);
     got = (uLong)npos;
   } else if (zlib_threads() == 0 || zlib_threads() > 3) {   /* the sections are independent streams: inflate them side by side
                                                                (DCTZ_ZLIB_THREADS=1..3 keeps the reference's one-after-the-other) */
@@ -894,6 +892,7 @@ int dctz_decompress(t_var *var_z, t_var *var_r) {
   }
   }
   cur += (size_t)zl[0] + zl[1] + zl[2];
+  for (int i = 0; i < 3; i++) free(ix_sizes[i]);
   if (!quiet()) printf("uncompressed bin_index size is: %lu\n", got); /* :260-262 */
   const void *qtable = NULL;
 #ifdef USE_QTABLE
