@@ -159,8 +159,8 @@ struct LdsCodes {
   uint8_t len[NSYM + 1];
   uint16_t sorted[NSYM + 1];
   uint32_t w[NLIT + NDIST];
-  uint16_t ch[2 * (NLIT + NDIST)];
-  uint16_t dep[NLIT + NDIST];
+  uint16_t ch[2 * (NDIST + NCL) + 8];                  // children / depths of the two small trees (distance, code lengths), built one after the other
+  uint16_t dep[NDIST + NCL + 4];
   uint16_t bl_count[3][16];
   uint16_t next_code[3][16];
   uint16_t cl[NLIT + NDIST + 4];                       // run-length form of the code lengths: sym | extra value << 8
@@ -170,6 +170,7 @@ struct LdsCodes {
   uint16_t pl[NLIT];                                   //   parent of every leaf
   uint16_t up[NLIT];                                   //   distance to par[]
   uint32_t blc[16];                                    //   leaves per depth
+  uint16_t used[NLIT];                                 // literal/length symbols in use, ascending (k[0] of them)
   int k[3];                                            // symbols in use per alphabet
   int hlit, hdist, hclen, ncl;
   uint32_t hbits;
@@ -190,10 +191,44 @@ __device__ __forceinline__ void rank_sort(LdsCodes& s, int base, int n, int whic
     atomicAdd(&s.k[which], 1);
   }
 }
+// The same for the literal/length alphabet, through the list of symbols in use: a bin_index chunk uses a few dozen of the
+// 286 symbols, and both this ranking and the numbering of equal-length codes are quadratic in what they walk over.
+__device__ __forceinline__ void rank_sort_used(LdsCodes& s) {
+  const int lane = threadIdx.x;
+  int k = 0;
+  for (int r = 0; r < (NLIT + CW - 1) / CW; r++) {       // compaction, in symbol order
+    const int i = r * CW + lane;
+    const bool on = i < NLIT && s.freq[i] != 0;
+    const unsigned long long m = __ballot(on);
+    if (on) s.used[k + __popcll(m & ((1ull << lane) - 1))] = (uint16_t)i;
+    k += __popcll(m);
+  }
+  if (lane == 0) s.k[0] = k;
+  __syncthreads();
+  for (int a = lane; a < k; a += CW) {
+    const int i = s.used[a];
+    const uint32_t f = s.freq[i];
+    int r = 0;
+    for (int b = 0; b < k; b++) {
+      const int j = s.used[b];
+      const uint32_t g = s.freq[j];
+      r += (g < f || (g == f && j < i)) ? 1 : 0;
+    }
+    s.sorted[r] = (uint16_t)i;
+  }
+}
+__device__ __forceinline__ void assign_codes_used(LdsCodes& s) {
+  const int k = s.k[0];
+  for (int a = threadIdx.x; a < k; a += CW) {
+    const int i = s.used[a], l = s.len[i];
+    int before = 0;
+    for (int b = 0; b < a; b++) before += (s.len[s.used[b]] == l) ? 1 : 0;
+    s.code[i] = (uint16_t)bit_reverse((uint32_t)s.next_code[0][l] + before, l);
+  }
+}
 __device__ __forceinline__ void build_lengths(LdsCodes& s, int base, int which, int maxbits) {
   huff_lengths([&](int sym) { return s.freq[base + sym]; }, [&](int i) { return (int)s.sorted[base + i]; }, s.k[which], maxbits,
-               [&](int sym, int bits) { s.len[base + sym] = (uint8_t)bits; }, s.w + (which == 1 ? NLIT : 0), s.ch + (which == 1 ? 2 * NLIT : 0),
-               s.dep + (which == 1 ? NLIT : 0), s.bl_count[which]);
+               [&](int sym, int bits) { s.len[base + sym] = (uint8_t)bits; }, s.w + (which == 1 ? NLIT : 0), s.ch, s.dep, s.bl_count[which]);
   first_codes(s.bl_count[which], maxbits, s.next_code[which]);
 }
 // canonical code of every symbol in use, bit-reversed (deflate sends Huffman codes most significant bit first)
@@ -295,13 +330,13 @@ __global__ __launch_bounds__(CW) void k_dfl_codes(const uint32_t* __restrict__ f
     s.forced = forced;
   }
   __syncthreads();
-  rank_sort(s, 0, NLIT, 0);
+  rank_sort_used(s);
   rank_sort(s, NLIT, NDIST, 1);
   __syncthreads();
   build_lengths_wave(s, MAXBITS);
   if (tid == 0) build_lengths(s, NLIT, 1, MAXBITS);
   __syncthreads();
-  assign_codes(s, 0, NLIT, 0);
+  assign_codes_used(s);
   assign_codes(s, NLIT, NDIST, 1);
   // bits of all tokens, from the counts: code length + extra bits per use (end of block included)
   uint32_t bits = 0;
