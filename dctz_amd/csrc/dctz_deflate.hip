@@ -528,8 +528,20 @@ __global__ __launch_bounds__(NTHR) void k_dfl_emit(const uint8_t* __restrict__ s
     tail.flush();
   }
   __syncthreads();
+  // the chunk's bytes to its place in the stream: whole dwords of the destination (the bytes in front of the first and
+  // behind the last one singly -- neighbouring chunks own the rest of those dwords)
   const uint8_t* ob = (const uint8_t*)s.out;
-  for (uint32_t i = tid; i < dyn_bytes; i += NTHR) d[i] = ob[i];
+  uint32_t head = (uint32_t)((4 - ((uintptr_t)d & 3)) & 3);
+  if (head > dyn_bytes) head = dyn_bytes;
+  const uint32_t nd = (dyn_bytes - head) / 4;
+  for (uint32_t i = tid; i < head; i += NTHR) d[i] = ob[i];
+  uint32_t* dw = (uint32_t*)(d + head);
+  const uint32_t sh = (head & 3) * 8;
+  for (uint32_t k = tid; k < nd; k += NTHR) {
+    const uint32_t w0 = s.out[(head >> 2) + k], w1 = s.out[(head >> 2) + k + 1];
+    dw[k] = sh ? ((w0 >> sh) | (w1 << (32 - sh))) : w0;
+  }
+  for (uint32_t i = head + 4 * nd + tid; i < dyn_bytes; i += NTHR) d[i] = ob[i];
 }
 
 // byte offsets of the chunks (exclusive scan of their sizes); one workgroup
