@@ -222,6 +222,61 @@ struct InvParams {
   double eb;
 };
 
+// ---- batches of arrays (dctzhip_compress_batch / dctzhip_decompress_batch) -------------------------------------
+// k arrays of ONE element type go through ONE launch sequence: every kernel of the single-array path has a batch
+// form whose workgroups look their array up (`first[]`: first workgroup of array i in that launch, first[k] = grid)
+// and then run the single-array body on that array's own parameter block -- exactly the FwdParams / InvParams the
+// single-array launch would have been given, with the scratch pointers offset to the array's slices.  Nothing couples
+// the arrays (own statistics, sf, bin ranges, tot_AC_exact_count, QT table: dctz-comp-lib.c:186), so every array's
+// outputs are those of its own dctzhip_compress call, bit for bit.
+template <typename T>
+struct BatchFwd {
+  FwdParams<T> p;
+  double eb;
+  T* scaled;                       // receives x / sf (dctz-comp-lib.c:193-216); NULL: not asked for; may alias p.x
+  unsigned n;                      // elements
+  unsigned rem;                    // n % 64 (the short last block)
+  unsigned nlists;                 // workgroup lists of this array (+1 for the remainder block)
+  unsigned nparts, part_base;      // statistics partials of this array: part[3 * (part_base + j)], j < nparts
+  unsigned pad;
+};
+template <typename T>
+struct BatchInv {
+  InvParams<T> p;
+  unsigned n, rem, scale, cnt_wgs; // cnt_wgs: workgroups of k_count_batch for this array (max(p.nwg, 1))
+  unsigned* rem_cnt;               // flags of the remainder block (its own word)
+  T qtab[64];                      // QT: this array's table (p.qtab points at the device copy of this field)
+};
+// What a batch hands back per array (fine-grained pinned host memory, written by the hand-off workgroup)
+struct BatchResC {
+  double sf_used;                  // scaling factor the device chose (k_sf_batch), verified by the host afterwards
+  double stats[3];                 // max|x|, min|x|, sum
+  unsigned cnt, error, fast_used, pad;
+  unsigned long long q0;           // bits of the last block's DC (qtable[0])
+};
+struct BatchResQ { unsigned long long qraw[64]; };        // QT: per-position maxima, raw bits of T
+struct BatchResD { unsigned total, error; };              // decode: flags found / 2 = more than ac_count provides
+struct BatchFin {
+  HostBox* box;                    // NULL: this sequence does not publish (another one of the call does, later)
+  unsigned long long seq;
+  void* res;                       // BatchResC[k] / BatchResD[k] (device view of the host table)
+  BatchResQ* resq;                 // QT only
+};
+template <typename T> void launch_stats_batch(const BatchFwd<T>* items_src, const unsigned* first_src, unsigned k, unsigned grid,
+                                              const void* blob_src, void* blob_dst, size_t blob_bytes, double* part, hipStream_t s);
+template <typename T> void launch_sf_batch(const BatchFwd<T>* items, unsigned k, const double* part, double* bstats, SfTable tab, hipStream_t s);
+template <typename T> void launch_scale_batch(const BatchFwd<T>* items, const unsigned* first, unsigned k, unsigned grid, hipStream_t s);
+template <typename T> void launch_compress_batch(const BatchFwd<T>* items, const unsigned* first, unsigned k, unsigned grid, int mode, hipStream_t s);
+template <typename T> void launch_compress_rem_batch(const BatchFwd<T>* items, const unsigned* rem_items, unsigned nrem, int mode, hipStream_t s);
+template <typename T> void launch_qt_max_batch(const BatchFwd<T>* items, const unsigned* first, unsigned k, unsigned grid, hipStream_t s);
+template <typename T> void launch_compact_batch(const BatchFwd<T>* items, const unsigned* first, unsigned k, unsigned grid, int mode,
+                                                const double* bstats, const BatchFin& fin, hipStream_t s);
+template <typename T> void launch_count_batch(const BatchInv<T>* items_src, const unsigned* first_src, unsigned k, unsigned grid,
+                                              const void* blob_src, void* blob_dst, size_t blob_bytes, hipStream_t s);
+template <typename T> void launch_decompress_batch(const BatchInv<T>* items, const unsigned* first, unsigned k, unsigned grid, int mode,
+                                                   const BatchFin& fin, hipStream_t s);
+template <typename T> void launch_decompress_rem_batch(const BatchInv<T>* items, const unsigned* rem_items, unsigned nrem, int mode, hipStream_t s);
+
 template <typename T> void launch_stats(const T* x, size_t n, double* part, int nparts, double* out, hipStream_t s,
                                         HostBox* box = nullptr, unsigned long long seq = 0, Ctl* zero = nullptr,
                                         const SfTable* tab = nullptr, SfGuess* guess = nullptr);

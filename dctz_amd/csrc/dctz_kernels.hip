@@ -145,8 +145,11 @@ size_t compress_lds_bytes(int mode) {              // tile image + strips (+ pos
 #ifndef DCTZ_WPE32
 #define DCTZ_WPE32 0
 #endif
+// The body is shared by two launch shapes: k_compress (one array per launch: workgroup wg = blockIdx.x of nwg = gridDim.x)
+// and k_compress_batch (many arrays per launch: the workgroup looks its array up and is workgroup wg of the nwg that array
+// got).  `slot` = the workgroup's index in the launch (its overflow strips).
 template <typename T, int MODE, bool STATS, int PH, int GEOM>
-__global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu((sizeof(T) == 4 && DCTZ_WPE32) ? DCTZ_WPE32 : PH))) void k_compress(FwdParams<T> p) {
+__device__ __forceinline__ void compress_body(const FwdParams<T>& p, const unsigned wg, const unsigned nwg, const unsigned slot) {
   using G = Geo<T, PH>;
   constexpr bool DEFER = true;
   constexpr int DEPTH = (MODE == DCTZHIP_EC) ? G::EC_DEPTH : G::QT_DEPTH;
@@ -176,10 +179,10 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu((sizeof(T) =
   // (the addresses are formed where they are used: kept in registers across the loop they cost four VGPRs for a rare path)
   // (item k of all 64 lanes side by side: the flush reads whole rows, and the lanes of a store -- all within a few items
   // of each other -- touch a handful of lines instead of 64)
-  auto ovf_at = [&](unsigned k) -> Item* { return reinterpret_cast<Item*>(p.ovf) + ((size_t)blockIdx.x * 64 + k) * 64 + threadIdx.x; };
-  auto ovfj_at = [&](unsigned k) -> unsigned char* { return p.ovf_j + ((size_t)blockIdx.x * 64 + k) * 64 + threadIdx.x; };
+  auto ovf_at = [&](unsigned k) -> Item* { return reinterpret_cast<Item*>(p.ovf) + ((size_t)slot * 64 + k) * 64 + threadIdx.x; };
+  auto ovfj_at = [&](unsigned k) -> unsigned char* { return p.ovf_j + ((size_t)slot * 64 + k) * 64 + threadIdx.x; };
   const int lane = threadIdx.x;
-  const TileRange tr = tile_range(blockIdx.x, gridDim.x, p.ntiles);
+  const TileRange tr = tile_range(wg, nwg, p.ntiles);
   const unsigned list_base = tr.lo * TILE_ELEMS;     // this workgroup's exception list lives in its tiles' slots
   const size_t first_el = (size_t)tr.lo * TILE_ELEMS;
   const size_t end_el = min((size_t)p.nfull * 64, (size_t)tr.hi * TILE_ELEMS);
@@ -484,22 +487,27 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu((sizeof(T) =
   if (pend) flush();
   STAMP(11);
   STAMP_FLUSH(p.ovf_j);
-  if (lane == 0) p.tile_cnt[blockIdx.x] = run;
+  if (lane == 0) p.tile_cnt[wg] = run;
   if (QMAX_HERE) {
     const QBits m = qmax_lds[lane];
     if (m != 0) atomicMax(&p.ctl->qraw[lane], (unsigned long long)m);
   }
   if (STATS) {
     __syncthreads();
-    acc.flush(p.stat_part, blockIdx.x, reinterpret_cast<double*>(tilebuf), 1, scale ? 8.0 * (double)sf : 8.0);
+    acc.flush(p.stat_part, wg, reinterpret_cast<double*>(tilebuf), 1, scale ? 8.0 * (double)sf : 8.0);
   }
+}
+
+template <typename T, int MODE, bool STATS, int PH, int GEOM>
+__global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu((sizeof(T) == 4 && DCTZ_WPE32) ? DCTZ_WPE32 : PH))) void k_compress(FwdParams<T> p) {
+  compress_body<T, MODE, STATS, PH, GEOM>(p, blockIdx.x, gridDim.x, blockIdx.x);
 }
 
 // The last, short block (length l = N % 64): the reference re-plans a length-l
 // (l even) or 2l (l odd) FFT for it (dctz-comp-lib.c:326-336, dct.c:59-72).
 // One wavefront, definition-order DFT with host-built roots.
 template <typename T, int MODE>
-__global__ __launch_bounds__(64) void k_compress_rem(FwdParams<T> p, int l) {
+__device__ __forceinline__ void compress_rem_body(const FwdParams<T>& p, const int l) {
   __shared__ T v[128];
   const int k = threadIdx.x;
   const size_t base = (size_t)p.nfull * 64;
@@ -562,6 +570,8 @@ __global__ __launch_bounds__(64) void k_compress_rem(FwdParams<T> p, int l) {
   __syncthreads();
   if (k == 0) p.tile_cnt[p.nlists_main] = (unsigned)__popcll(m);
 }
+template <typename T, int MODE>
+__global__ __launch_bounds__(64) void k_compress_rem(FwdParams<T> p, int l) { compress_rem_body<T, MODE>(p, l); }
 
 // list l < G belongs to workgroup l of k_compress (slots of its tile range); list G is the remainder block's
 __device__ __forceinline__ size_t list_slot(unsigned l, unsigned G, unsigned ntiles) {
@@ -571,13 +581,13 @@ __device__ __forceinline__ size_t list_slot(unsigned l, unsigned G, unsigned nti
 // QT: per-position maximum |coef| over the out-of-range coefficients (dctz-comp-lib.c:371-372 / :396-397),
 // taken over the lists k_compress has just written (one workgroup per list).
 template <typename T>
-__global__ __launch_bounds__(SWG) void k_qt_max(FwdParams<T> p, unsigned nlists) {
+__device__ __forceinline__ void qt_max_body(const FwdParams<T>& p, const unsigned nlists, const unsigned wg, const unsigned nwg) {
   using Bits = typename Traits<T>::Bits;
   __shared__ Bits qmax[64];
   if (threadIdx.x < 64) qmax[threadIdx.x] = 0;
   __syncthreads();
   const unsigned G = p.nlists_main;
-  for (unsigned l = blockIdx.x; l < nlists; l += gridDim.x) {
+  for (unsigned l = wg; l < nlists; l += nwg) {
     const unsigned n = p.tile_cnt[l];
     const size_t src = list_slot(l, G, p.ntiles);
     // eight items per thread in flight (a list of some thousand items is a chain of dependent round trips otherwise:
@@ -599,6 +609,8 @@ __global__ __launch_bounds__(SWG) void k_qt_max(FwdParams<T> p, unsigned nlists)
   __syncthreads();
   if (threadIdx.x < 64 && qmax[threadIdx.x] != 0) atomicMax(&p.ctl->qraw[threadIdx.x], (unsigned long long)qmax[threadIdx.x]);
 }
+template <typename T>
+__global__ __launch_bounds__(SWG) void k_qt_max(FwdParams<T> p, unsigned nlists) { qt_max_body<T>(p, nlists, blockIdx.x, gridDim.x); }
 
 // Move every workgroup-local list to its place in AC_exact[]
 // (dctz-comp-lib.c:478-544 order: lists are already block-major, j ascending).
@@ -607,10 +619,10 @@ __global__ __launch_bounds__(SWG) void k_qt_max(FwdParams<T> p, unsigned nlists)
 // lists before it: at most 2049 of them, summed by the workgroup itself (no scan kernel); the workgroup of the last
 // list leaves the total.  fin.box set: workgroup 0 hands the call's results to the host first (finish_body).
 template <typename T, int MODE>
-__global__ __launch_bounds__(SWG) void k_compact_ac(FwdParams<T> p, double eb, unsigned nlists, FinArgs fin) {
+__device__ __forceinline__ void compact_ac_body(const FwdParams<T>& p, const double eb, const unsigned nlists, const unsigned wg, const unsigned nwg,
+                                                unsigned* sh) {
   using Bits = typename Traits<T>::Bits;
   __shared__ T q[64];
-  __shared__ unsigned sh[SWG / 64];
   if (MODE == DCTZHIP_QT) {
     if (threadIdx.x < 64) {
       T v = Traits<T>::from_bits((Bits)p.ctl->qraw[threadIdx.x]);
@@ -619,17 +631,8 @@ __global__ __launch_bounds__(SWG) void k_compact_ac(FwdParams<T> p, double eb, u
     }
     __syncthreads();
   }
-  if (fin.box != nullptr && blockIdx.x == 0) {
-    unsigned all = 0;
-    for (unsigned i = threadIdx.x; i < nlists; i += SWG) all += p.tile_cnt[i];
-    FinBody f;
-    f.ctl = fin.ctl; f.part = fin.part; f.nparts = fin.nparts; f.box = fin.box; f.seq = fin.seq; f.guess = fin.guess;
-    f.cnt_known = true; f.cnt_total = block_sum(all, sh);                // tot_AC_exact_count (:478-544)
-    f.err_known = true; f.error = 0;
-    finish_body<true>(f);
-  }
   const unsigned G = p.nlists_main;
-  for (unsigned l = blockIdx.x; l < nlists; l += gridDim.x) {
+  for (unsigned l = wg; l < nlists; l += nwg) {
     unsigned before = 0;
     for (unsigned i = threadIdx.x; i < l; i += SWG) before += p.tile_cnt[i];
     const unsigned dst = block_sum(before, sh);
@@ -658,6 +661,20 @@ __global__ __launch_bounds__(SWG) void k_compact_ac(FwdParams<T> p, double eb, u
     }
   }
 }
+template <typename T, int MODE>
+__global__ __launch_bounds__(SWG) void k_compact_ac(FwdParams<T> p, double eb, unsigned nlists, FinArgs fin) {
+  __shared__ unsigned sh[SWG / 64];
+  if (fin.box != nullptr && blockIdx.x == 0) {
+    unsigned all = 0;
+    for (unsigned i = threadIdx.x; i < nlists; i += SWG) all += p.tile_cnt[i];
+    FinBody f;
+    f.ctl = fin.ctl; f.part = fin.part; f.nparts = fin.nparts; f.box = fin.box; f.seq = fin.seq; f.guess = fin.guess;
+    f.cnt_known = true; f.cnt_total = block_sum(all, sh);                // tot_AC_exact_count (:478-544)
+    f.err_known = true; f.error = 0;
+    finish_body<true>(f);
+  }
+  compact_ac_body<T, MODE>(p, eb, nlists, blockIdx.x, gridDim.x, sh);
+}
 
 // =============================================================== decompress ==
 // Decode side, step 1: per-TILE count of "stored exactly" flags (bin id 255 at j != 0,
@@ -666,11 +683,11 @@ __global__ __launch_bounds__(SWG) void k_compact_ac(FwdParams<T> p, double eb, u
 // k_decompress finds the start of its piece of AC_exact by adding up at most a thousand words -- no scan kernel.
 // A wave takes whole tiles (4 x 1 KiB coalesced rows, plain loads: k_decompress re-reads these lines from the
 // Infinity Cache); no workgroup barrier per tile.
-__global__ __launch_bounds__(SWG) void k_count_tiles(const uint8_t* __restrict__ bin, unsigned nfull, unsigned ntiles, unsigned nwg,
-                                                     unsigned* __restrict__ tile_cnt, unsigned* __restrict__ wg_cnt) {
+__device__ __forceinline__ void count_tiles_body(const uint8_t* __restrict__ bin, unsigned nfull, unsigned ntiles, unsigned nwg,
+                                                 unsigned* __restrict__ tile_cnt, unsigned* __restrict__ wg_cnt, const unsigned wg) {
   __shared__ unsigned part[SWG / 64];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const TileRange tr = tile_range(blockIdx.x, nwg, ntiles);
+  const TileRange tr = tile_range(wg, nwg, ntiles);
   const size_t end = (size_t)nfull * 64;
   unsigned acc = 0;                                                    // this wave's share of the workgroup's count (uniform)
   for (unsigned tile = tr.lo + (unsigned)wave; tile < tr.hi; tile += SWG / 64) {
@@ -704,8 +721,12 @@ __global__ __launch_bounds__(SWG) void k_count_tiles(const uint8_t* __restrict__
     unsigned sum = 0;
 #pragma unroll
     for (int w = 0; w < SWG / 64; w++) sum += part[w];
-    wg_cnt[blockIdx.x] = sum;
+    wg_cnt[wg] = sum;
   }
+}
+__global__ __launch_bounds__(SWG) void k_count_tiles(const uint8_t* __restrict__ bin, unsigned nfull, unsigned ntiles, unsigned nwg,
+                                                     unsigned* __restrict__ tile_cnt, unsigned* __restrict__ wg_cnt) {
+  count_tiles_body(bin, nfull, ntiles, nwg, tile_cnt, wg_cnt, blockIdx.x);
 }
 
 // Fused: gen_bins (binning.c:12-50) + de-quantise (dctz-decomp-lib.c:389-417 / :438-463) -> DCT-III per block
@@ -718,15 +739,17 @@ size_t decompress_lds_bytes() { return (size_t)Geo<T, Phases<T>::D>::PHB + 256 *
 #ifndef DCTZ_WPED32
 #define DCTZ_WPED32 0
 #endif
-template <typename T, int MODE, int PH, int GEOM>
-__global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu((sizeof(T) == 4 && DCTZ_WPED32) ? DCTZ_WPED32 : PH))) void k_decompress(InvParams<T> p, FinArgs fin) {
+// (body shared by k_decompress and k_decompress_batch, like compress_body; `handoff` runs where the single-array kernel
+// hands the call's result to the host)
+template <typename T, int MODE, int PH, int GEOM, typename Handoff>
+__device__ __forceinline__ void decompress_body(const InvParams<T>& p, const unsigned wg, const unsigned nwg, Handoff&& handoff) {
   using G = Geo<T, PH>;
   __shared__ __attribute__((aligned(1024))) unsigned char outbuf[G::PHB];
   __shared__ __attribute__((aligned(16))) T bctab[256];               // bin_center[] of gen_bins
   __shared__ __attribute__((aligned(16))) float excbuf[DEC_EXC_CAP];
   __shared__ T qt[64];
   const int lane = threadIdx.x;
-  const TileRange tr = tile_range(blockIdx.x, gridDim.x, p.ntiles);
+  const TileRange tr = tile_range(wg, nwg, p.ntiles);
   const size_t first_el = (size_t)tr.lo * TILE_ELEMS;
   const size_t end_el = min((size_t)p.nfull * 64, (size_t)tr.hi * TILE_ELEMS);
   const int range_el = tr.lo < tr.hi ? (int)(end_el - first_el) : 0;
@@ -739,20 +762,9 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu((sizeof(T) =
   // AC_exact behind a descriptor based at this workgroup's first exact coefficient (32-bit offsets stay small for any N):
   // the running pos of dctz-decomp-lib.c:402-412 at the workgroup's first tile = the counts of all workgroups before it
   unsigned before = 0;
-  for (unsigned i = (unsigned)lane; i < blockIdx.x; i += WG) before += p.wg_cnt[i];
+  for (unsigned i = (unsigned)lane; i < wg; i += WG) before += p.wg_cnt[i];
   const unsigned S_wg = (unsigned)__builtin_amdgcn_readlane((int)wave_incl_scan(before), 63);
-  if (fin.box != nullptr && blockIdx.x == 0) {
-    // the one thing the host waits for on decode: does the stream promise more exact coefficients than the caller
-    // provides (all counts are in: k_count_tiles)?  Known before the first block is rebuilt -> hand it over now.
-    unsigned all = 0;
-    for (unsigned i = (unsigned)lane; i < p.nwg; i += WG) all += p.wg_cnt[i];
-    all = (unsigned)__builtin_amdgcn_readlane((int)wave_incl_scan(all), 63);
-    FinBody f;
-    f.ctl = fin.ctl; f.part = nullptr; f.nparts = 0; f.box = fin.box; f.seq = fin.seq; f.guess = nullptr;
-    f.cnt_known = true; f.cnt_total = all;
-    f.err_known = true; f.error = all > p.ac_count ? 2u : 0u;
-    finish_body<false>(f);
-  }
+  handoff();
   const size_t ac_left = S_wg < p.ac_count ? (size_t)(p.ac_count - S_wg) * 4 : 0;
   const __amdgpu_buffer_rsrc_t r_ac = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.ac + (ac_left ? S_wg : 0u)), 0, (int)min(ac_left, (size_t)0x7ffffffc), 0x00020000);
   TileMap<T, PH> tm;
@@ -925,9 +937,28 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu((sizeof(T) =
   if (underrun) atomicExch(&p.ctl->error, 2u);
 }
 
+template <typename T, int MODE, int PH, int GEOM>
+__global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu((sizeof(T) == 4 && DCTZ_WPED32) ? DCTZ_WPED32 : PH))) void k_decompress(InvParams<T> p, FinArgs fin) {
+  decompress_body<T, MODE, PH, GEOM>(p, blockIdx.x, gridDim.x, [&]() {
+    if (fin.box != nullptr && blockIdx.x == 0) {
+      // the one thing the host waits for on decode: does the stream promise more exact coefficients than the caller
+      // provides (all counts are in: k_count_tiles)?  Known before the first block is rebuilt -> hand it over now.
+      const int lane = threadIdx.x;
+      unsigned all = 0;
+      for (unsigned i = (unsigned)lane; i < p.nwg; i += WG) all += p.wg_cnt[i];
+      all = (unsigned)__builtin_amdgcn_readlane((int)wave_incl_scan(all), 63);
+      FinBody f;
+      f.ctl = fin.ctl; f.part = nullptr; f.nparts = 0; f.box = fin.box; f.seq = fin.seq; f.guess = nullptr;
+      f.cnt_known = true; f.cnt_total = all;
+      f.err_known = true; f.error = all > p.ac_count ? 2u : 0u;
+      finish_body<false>(f);
+    }
+  });
+}
+
 // Last, short block on decode (dctz-decomp-lib.c:423-428, dct.c:144-199).
-template <typename T, int MODE, bool SCALE>
-__global__ __launch_bounds__(64) void k_decompress_rem(InvParams<T> p, int l) {
+template <typename T, int MODE>
+__device__ __forceinline__ void decompress_rem_body(const InvParams<T>& p, const int l, const bool SCALE) {
   __shared__ T a[64];
   __shared__ T cr[128];
   __shared__ T ci[128];
@@ -980,6 +1011,8 @@ __global__ __launch_bounds__(64) void k_decompress_rem(InvParams<T> p, int l) {
     p.out[base + k] = val;
   }
 }
+template <typename T, int MODE, bool SCALE>
+__global__ __launch_bounds__(64) void k_decompress_rem(InvParams<T> p, int l) { decompress_rem_body<T, MODE>(p, l, SCALE); }
 
 // ================================================================= launchers ==
 void launch_finish(Ctl* ctl, const double* part, int nparts, HostBox* box, unsigned long long seq, hipStream_t s) {
@@ -1087,6 +1120,182 @@ void launch_decompress_rem(const InvParams<T>& p, int mode, bool scale, int l, h
   }
 }
 
+// ================================================================== batches ==
+// k arrays of one element type in one launch sequence (dctz_device.h: BatchFwd / BatchInv).  A workgroup finds its array
+// from the launch's `first[]` (sorted, first[k] = grid; arrays without a workgroup in this launch have an empty range),
+// copies that array's parameter block out of the item table with scalar loads and runs the single-array body on it.
+// Largest i with first[i] <= b: 64 entries per step, one ballot each (a wave is uniform in b).
+__device__ __forceinline__ unsigned batch_item_of(const unsigned* __restrict__ first, const unsigned k, const unsigned b) {
+  const unsigned lane = threadIdx.x & 63u;
+  unsigned cnt = 0;
+  for (unsigned base = 0; base < k; base += 64u) {
+    const unsigned i = base + lane;
+    const unsigned long long m = __builtin_amdgcn_ballot_w64(i < k && first[i] <= b);
+    cnt += (unsigned)__popcll(m);
+    if (m != ~0ull) break;
+  }
+  return cnt - 1u;                                   // first[0] = 0 <= b
+}
+// a parameter block out of the item table: dword by dword through the constant address space (scalar loads: the index is
+// wave-uniform, and nothing in the sequence writes the table after its first kernel)
+template <typename S>
+__device__ __forceinline__ S load_params(const S* src) {
+  static_assert(sizeof(S) % 4 == 0, "parameter blocks are whole dwords");
+  constexpr int W = (int)(sizeof(S) / 4);
+  const __attribute__((address_space(4))) unsigned* w = (const __attribute__((address_space(4))) unsigned*)(src);
+  unsigned buf[W];
+#pragma unroll
+  for (int i = 0; i < W; i++) buf[i] = w[i];
+  S v;
+  __builtin_memcpy(&v, buf, sizeof(S));
+  return v;
+}
+
+template <typename T, int MODE>
+__global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu((sizeof(T) == 4 && DCTZ_WPE32) ? DCTZ_WPE32 : Phases<T>::C)))
+void k_compress_batch(const BatchFwd<T>* items, const unsigned* __restrict__ first, unsigned k) {
+  const unsigned i = batch_item_of(first, k, blockIdx.x);
+  const FwdParams<T> p = load_params(&items[i].p);
+  compress_body<T, MODE, false, Phases<T>::C, GEOM_1D>(p, blockIdx.x - first[i], p.nlists_main, blockIdx.x);
+}
+
+template <typename T, int MODE>
+__global__ __launch_bounds__(64) void k_compress_rem_batch(const BatchFwd<T>* items, const unsigned* __restrict__ rem_items) {
+  const unsigned i = rem_items[blockIdx.x];
+  const FwdParams<T> p = load_params(&items[i].p);
+  compress_rem_body<T, MODE>(p, (int)items[i].rem);
+}
+
+// one workgroup per list, like k_compact_batch below
+template <typename T>
+__global__ __launch_bounds__(SWG) void k_qt_max_batch(const BatchFwd<T>* items, const unsigned* __restrict__ first, unsigned k) {
+  const unsigned i = batch_item_of(first, k, blockIdx.x);
+  const FwdParams<T> p = load_params(&items[i].p);
+  const unsigned nlists = items[i].nlists;
+  qt_max_body<T>(p, nlists, blockIdx.x - first[i], nlists);
+}
+
+// Hand-off of a whole batch by ONE workgroup (the first of the sequence's last kernel): per array, what the single-array
+// hand-off publishes -- everything was produced by earlier kernels of the sequence.
+template <typename T>
+__device__ __forceinline__ void batch_finish_compress(const BatchFwd<T>* items, unsigned k, const double* bstats, const BatchFin& fin, bool qt) {
+  BatchResC* res = reinterpret_cast<BatchResC*>(fin.res);
+  for (unsigned i = threadIdx.x; i < k; i += blockDim.x) {
+    const BatchFwd<T>& it = items[i];
+    unsigned cnt = 0;
+    for (unsigned l = 0; l < it.nlists; l++) cnt += it.p.tile_cnt[l];               // tot_AC_exact_count (:478-544)
+    BatchResC r;
+    r.sf_used = it.p.guess->sf; r.fast_used = it.p.guess->fast_sf;
+    r.stats[0] = bstats[3 * i]; r.stats[1] = bstats[3 * i + 1]; r.stats[2] = bstats[3 * i + 2];
+    r.cnt = cnt; r.error = 0; r.pad = 0; r.q0 = it.p.ctl->q0;
+    res[i] = r;
+  }
+  if (qt)
+    for (unsigned e = threadIdx.x; e < k * 64u; e += blockDim.x) fin.resq[e >> 6].qraw[e & 63u] = items[e >> 6].p.ctl->qraw[e & 63u];
+  __threadfence_system();
+  __syncthreads();
+  if (threadIdx.x == 0 && fin.box != nullptr) box_publish(&fin.box->seq_done, fin.seq);
+}
+
+template <typename T, int MODE>
+__global__ __launch_bounds__(SWG) void k_compact_batch(const BatchFwd<T>* items, const unsigned* __restrict__ first, unsigned k,
+                                                       const double* bstats, BatchFin fin) {
+  __shared__ unsigned sh[SWG / 64];
+  if (blockIdx.x == 0 && fin.res != nullptr) batch_finish_compress<T>(items, k, bstats, fin, MODE == DCTZHIP_QT);
+  const unsigned i = batch_item_of(first, k, blockIdx.x);
+  const FwdParams<T> p = load_params(&items[i].p);
+  const unsigned nlists = items[i].nlists;
+  compact_ac_body<T, MODE>(p, items[i].eb, nlists, blockIdx.x - first[i], nlists, sh);
+}
+
+// decode, step 1 for a batch: k_count_tiles per array (+ the flags of its remainder block, so that the hand-off knows
+// every array's total before the first block is rebuilt); the first workgroups also bring the item table from the
+// host's pinned copy into device memory for the kernels behind this one.
+template <typename T>
+__global__ __launch_bounds__(SWG) void k_count_batch(const BatchInv<T>* items, const unsigned* __restrict__ first, unsigned k,
+                                                     const uint4* __restrict__ blob_src, uint4* __restrict__ blob_dst, unsigned blob_vecs) {
+  for (unsigned v = blockIdx.x * SWG + threadIdx.x; v < blob_vecs; v += gridDim.x * SWG) blob_dst[v] = blob_src[v];
+  const unsigned i = batch_item_of(first, k, blockIdx.x);
+  const BatchInv<T>& it = items[i];
+  const unsigned wg = blockIdx.x - first[i];
+  const InvParams<T>& p = it.p;
+  if (p.nwg) count_tiles_body(p.bin, p.nfull, p.ntiles, p.nwg, const_cast<unsigned*>(p.tile_cnt), const_cast<unsigned*>(p.wg_cnt), wg);
+  if (wg == 0 && threadIdx.x < 64) {                 // dctz-decomp-lib.c:400 / :446 over the short last block
+    const unsigned t = threadIdx.x;
+    const bool flag = t != 0 && t < it.rem && p.bin[(size_t)p.nfull * 64 + t] == 255;
+    const unsigned long long m = __builtin_amdgcn_ballot_w64(flag);
+    if (t == 0) *it.rem_cnt = (unsigned)__popcll(m);
+  }
+}
+
+template <typename T>
+__device__ __forceinline__ void batch_finish_decompress(const BatchInv<T>* items, unsigned k, const BatchFin& fin) {
+  BatchResD* res = reinterpret_cast<BatchResD*>(fin.res);
+  for (unsigned i = threadIdx.x; i < k; i += blockDim.x) {
+    const BatchInv<T>& it = items[i];
+    unsigned all = *it.rem_cnt;
+    for (unsigned w = 0; w < it.p.nwg; w++) all += it.p.wg_cnt[w];
+    res[i].total = all;
+    res[i].error = all > it.p.ac_count ? 2u : 0u;    // the stream promises more exact coefficients than the caller provides
+  }
+  __threadfence_system();
+  __syncthreads();
+  if (threadIdx.x == 0 && fin.box != nullptr) box_publish(&fin.box->seq_done, fin.seq);
+}
+
+template <typename T, int MODE>
+__global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu((sizeof(T) == 4 && DCTZ_WPED32) ? DCTZ_WPED32 : Phases<T>::D)))
+void k_decompress_batch(const BatchInv<T>* items, const unsigned* __restrict__ first, unsigned k, BatchFin fin) {
+  if (blockIdx.x == 0 && fin.res != nullptr) batch_finish_decompress<T>(items, k, fin);
+  const unsigned i = batch_item_of(first, k, blockIdx.x);
+  const InvParams<T> p = load_params(&items[i].p);
+  decompress_body<T, MODE, Phases<T>::D, GEOM_1D>(p, blockIdx.x - first[i], p.nwg, []() {});
+}
+
+template <typename T, int MODE>
+__global__ __launch_bounds__(64) void k_decompress_rem_batch(const BatchInv<T>* items, const unsigned* __restrict__ rem_items) {
+  const unsigned i = rem_items[blockIdx.x];
+  const InvParams<T> p = load_params(&items[i].p);
+  decompress_rem_body<T, MODE>(p, (int)items[i].rem, items[i].scale != 0u);
+}
+
+template <typename T>
+void launch_compress_batch(const BatchFwd<T>* items, const unsigned* first, unsigned k, unsigned grid, int mode, hipStream_t s) {
+  if (mode == DCTZHIP_EC) hipLaunchKernelGGL((k_compress_batch<T, DCTZHIP_EC>), dim3(grid), dim3(WG), 0, s, items, first, k);
+  else hipLaunchKernelGGL((k_compress_batch<T, DCTZHIP_QT>), dim3(grid), dim3(WG), 0, s, items, first, k);
+}
+template <typename T>
+void launch_compress_rem_batch(const BatchFwd<T>* items, const unsigned* rem_items, unsigned nrem, int mode, hipStream_t s) {
+  if (mode == DCTZHIP_EC) hipLaunchKernelGGL((k_compress_rem_batch<T, DCTZHIP_EC>), dim3(nrem), dim3(64), 0, s, items, rem_items);
+  else hipLaunchKernelGGL((k_compress_rem_batch<T, DCTZHIP_QT>), dim3(nrem), dim3(64), 0, s, items, rem_items);
+}
+template <typename T>
+void launch_qt_max_batch(const BatchFwd<T>* items, const unsigned* first, unsigned k, unsigned grid, hipStream_t s) {
+  hipLaunchKernelGGL(k_qt_max_batch<T>, dim3(grid), dim3(SWG), 0, s, items, first, k);
+}
+template <typename T>
+void launch_compact_batch(const BatchFwd<T>* items, const unsigned* first, unsigned k, unsigned grid, int mode, const double* bstats,
+                          const BatchFin& fin, hipStream_t s) {
+  if (mode == DCTZHIP_EC) hipLaunchKernelGGL((k_compact_batch<T, DCTZHIP_EC>), dim3(grid), dim3(SWG), 0, s, items, first, k, bstats, fin);
+  else hipLaunchKernelGGL((k_compact_batch<T, DCTZHIP_QT>), dim3(grid), dim3(SWG), 0, s, items, first, k, bstats, fin);
+}
+template <typename T>
+void launch_count_batch(const BatchInv<T>* items_src, const unsigned* first_src, unsigned k, unsigned grid, const void* blob_src, void* blob_dst,
+                        size_t blob_bytes, hipStream_t s) {
+  hipLaunchKernelGGL(k_count_batch<T>, dim3(grid), dim3(SWG), 0, s, items_src, first_src, k, (const uint4*)blob_src, (uint4*)blob_dst,
+                     (unsigned)(blob_bytes / 16));
+}
+template <typename T>
+void launch_decompress_batch(const BatchInv<T>* items, const unsigned* first, unsigned k, unsigned grid, int mode, const BatchFin& fin, hipStream_t s) {
+  if (mode == DCTZHIP_EC) hipLaunchKernelGGL((k_decompress_batch<T, DCTZHIP_EC>), dim3(grid), dim3(WG), 0, s, items, first, k, fin);
+  else hipLaunchKernelGGL((k_decompress_batch<T, DCTZHIP_QT>), dim3(grid), dim3(WG), 0, s, items, first, k, fin);
+}
+template <typename T>
+void launch_decompress_rem_batch(const BatchInv<T>* items, const unsigned* rem_items, unsigned nrem, int mode, hipStream_t s) {
+  if (mode == DCTZHIP_EC) hipLaunchKernelGGL((k_decompress_rem_batch<T, DCTZHIP_EC>), dim3(nrem), dim3(64), 0, s, items, rem_items);
+  else hipLaunchKernelGGL((k_decompress_rem_batch<T, DCTZHIP_QT>), dim3(nrem), dim3(64), 0, s, items, rem_items);
+}
+
 // explicit instantiations used by dctz_shim.hip
 
 #define INST(T)                                                                                         \
@@ -1096,6 +1305,13 @@ void launch_decompress_rem(const InvParams<T>& p, int mode, bool scale, int l, h
   template void launch_compact_ac<T>(const FwdParams<T>&, int, double, unsigned, int, const FinArgs&, hipStream_t); \
   template void launch_decompress<T>(const InvParams<T>&, int, int, const FinArgs&, int, hipStream_t);  \
   template void launch_decompress_rem<T>(const InvParams<T>&, int, bool, int, hipStream_t);             \
+  template void launch_compress_batch<T>(const BatchFwd<T>*, const unsigned*, unsigned, unsigned, int, hipStream_t);                        \
+  template void launch_compress_rem_batch<T>(const BatchFwd<T>*, const unsigned*, unsigned, int, hipStream_t);                              \
+  template void launch_qt_max_batch<T>(const BatchFwd<T>*, const unsigned*, unsigned, unsigned, hipStream_t);                               \
+  template void launch_compact_batch<T>(const BatchFwd<T>*, const unsigned*, unsigned, unsigned, int, const double*, const BatchFin&, hipStream_t); \
+  template void launch_count_batch<T>(const BatchInv<T>*, const unsigned*, unsigned, unsigned, const void*, void*, size_t, hipStream_t);    \
+  template void launch_decompress_batch<T>(const BatchInv<T>*, const unsigned*, unsigned, unsigned, int, const BatchFin&, hipStream_t);     \
+  template void launch_decompress_rem_batch<T>(const BatchInv<T>*, const unsigned*, unsigned, int, hipStream_t);                            \
   template int compress_occupancy<T>(int, bool, int);                                                      \
   template int decompress_occupancy<T>(int, int);                                                          \
   template size_t compress_lds_bytes<T>(int);                                                              \

@@ -13,7 +13,7 @@ namespace dctz {
 // order (it is never used by the codec; the host wrapper recomputes it
 // serially for the header).
 template <typename T>
-__global__ __launch_bounds__(SWG) void k_stats(const T* __restrict__ x, size_t n, double* __restrict__ part) {
+__device__ __forceinline__ void stats_body(const T* __restrict__ x, size_t n, double* __restrict__ part, const unsigned wg, const unsigned nwg) {
   using Vec = typename Traits<T>::Vec;
   constexpr int EPV = Traits<T>::EPV;
   const size_t nvec = n / EPV;
@@ -21,7 +21,7 @@ __global__ __launch_bounds__(SWG) void k_stats(const T* __restrict__ x, size_t n
   T mx = T(0), mn = Traits<T>::huge();
   double sum = 0.0;
   constexpr int UN = 4;                            // each workgroup streams 16 KiB contiguous per trip
-  for (size_t i0 = (size_t)blockIdx.x * SWG * UN + threadIdx.x; i0 < nvec; i0 += (size_t)gridDim.x * SWG * UN) {
+  for (size_t i0 = (size_t)wg * SWG * UN + threadIdx.x; i0 < nvec; i0 += (size_t)nwg * SWG * UN) {
     Vec v[UN];
 #pragma unroll
     for (int u = 0; u < UN; u++) {
@@ -42,7 +42,7 @@ __global__ __launch_bounds__(SWG) void k_stats(const T* __restrict__ x, size_t n
       }
     }
   }
-  if (blockIdx.x == 0 && threadIdx.x == 0)
+  if (wg == 0 && threadIdx.x == 0)
     for (size_t i = nvec * EPV; i < n; i++) {
       const T a = fabs(x[i]);
       mx = a > mx ? a : mx;
@@ -62,10 +62,14 @@ __global__ __launch_bounds__(SWG) void k_stats(const T* __restrict__ x, size_t n
   __syncthreads();
   if (threadIdx.x == 0) {
     for (int w = 1; w < SWG / 64; w++) { dmx = fmax(dmx, s[0][w]); dmn = fmin(dmn, s[1][w]); sum += s[2][w]; }
-    part[3 * blockIdx.x + 0] = dmx;
-    part[3 * blockIdx.x + 1] = dmn;
-    part[3 * blockIdx.x + 2] = sum;
+    part[3 * wg + 0] = dmx;
+    part[3 * wg + 1] = dmn;
+    part[3 * wg + 2] = sum;
   }
+}
+template <typename T>
+__global__ __launch_bounds__(SWG) void k_stats(const T* __restrict__ x, size_t n, double* __restrict__ part) {
+  stats_body<T>(x, n, part, blockIdx.x, gridDim.x);
 }
 
 // final reduction of the statistics partials -> device words + (optionally) the host mailbox; one workgroup
@@ -95,8 +99,8 @@ __global__ __launch_bounds__(SWG) void k_stats_final(const double* part, int npa
 // The same, for a speculative compress call: the scaling factor of util.c:29 / :43 for the SAMPLED max|x| is chosen
 // here, with the host's own decade tables (SfTable), and left in device memory for k_compress -- no host round trip
 // between the sample and the main launch (the host verifies the choice against the true statistics afterwards).
-__global__ __launch_bounds__(SWG) void k_stats_final_sf(const double* part, int nparts, double* out, Ctl* zero, SfTable tab,
-                                                       SfGuess* guess, HostBox* box) {
+__device__ __forceinline__ void stats_final_sf_body(const double* part, int nparts, double* out, Ctl* zero, const SfTable& tab,
+                                                    SfGuess* guess, HostBox* box) {
   if (zero != nullptr) {
     unsigned long long* w = reinterpret_cast<unsigned long long*>(zero);
     for (int i = threadIdx.x; i < (int)(sizeof(Ctl) / 8); i += SWG) w[i] = 0ull;
@@ -123,6 +127,77 @@ __global__ __launch_bounds__(SWG) void k_stats_final_sf(const double* part, int 
     guess->sf = sf;
     guess->fast_sf = fast;
   }
+}
+__global__ __launch_bounds__(SWG) void k_stats_final_sf(const double* part, int nparts, double* out, Ctl* zero, SfTable tab,
+                                                       SfGuess* guess, HostBox* box) {
+  stats_final_sf_body(part, nparts, out, zero, tab, guess, box);
+}
+
+// ---- batches (dctz_device.h: BatchFwd): calc_data_stat of k arrays in one launch, the scaling factor of every array
+// chosen on the device (one workgroup per array), and the scaled copies.  k_stats_batch is the FIRST kernel of a batch
+// sequence: it reads the item table from the host's pinned copy and leaves it in device memory for the kernels behind it.
+__device__ __forceinline__ unsigned aux_item_of(const unsigned* __restrict__ first, const unsigned k, const unsigned b) {
+  const unsigned lane = threadIdx.x & 63u;
+  unsigned cnt = 0;
+  for (unsigned base = 0; base < k; base += 64u) {
+    const unsigned i = base + lane;
+    const unsigned long long m = __builtin_amdgcn_ballot_w64(i < k && first[i] <= b);
+    cnt += (unsigned)__popcll(m);
+    if (m != ~0ull) break;
+  }
+  return cnt - 1u;
+}
+template <typename T>
+__global__ __launch_bounds__(SWG) void k_stats_batch(const BatchFwd<T>* items, const unsigned* __restrict__ first, unsigned k,
+                                                     const uint4* __restrict__ blob_src, uint4* __restrict__ blob_dst, unsigned blob_vecs,
+                                                     double* __restrict__ part) {
+  for (unsigned v = blockIdx.x * SWG + threadIdx.x; v < blob_vecs; v += gridDim.x * SWG) blob_dst[v] = blob_src[v];
+  const unsigned i = aux_item_of(first, k, blockIdx.x);
+  const BatchFwd<T>& it = items[i];
+  stats_body<T>(it.p.x, (size_t)it.n, part + 3 * (size_t)it.part_base, blockIdx.x - first[i], it.nparts);
+}
+template <typename T>
+__global__ __launch_bounds__(SWG) void k_sf_batch(const BatchFwd<T>* items, const double* part, double* bstats, SfTable tab) {
+  const BatchFwd<T>& it = items[blockIdx.x];
+  stats_final_sf_body(part + 3 * (size_t)it.part_base, (int)it.nparts, bstats + 3 * (size_t)blockIdx.x, it.p.ctl, tab,
+                      const_cast<SfGuess*>(it.p.guess), nullptr);
+}
+// x / sf into the caller's copy (dctz-comp-lib.c:193-216), sf = what k_sf_batch chose for the array
+template <typename T>
+__global__ __launch_bounds__(SWG) void k_scale_batch(const BatchFwd<T>* items, const unsigned* __restrict__ first, unsigned k) {
+  using Vec = typename Traits<T>::Vec;
+  constexpr int EPV = Traits<T>::EPV;
+  const unsigned i = aux_item_of(first, k, blockIdx.x);
+  const BatchFwd<T>& it = items[i];
+  const unsigned wg = blockIdx.x - first[i], nwg = first[i + 1] - first[i];
+  const T sf = (T)it.p.guess->sf;
+  const T* x = it.p.x;
+  T* out = it.scaled;
+  if (sf == T(1) && out == x) return;                      // :193 / :208: nothing to do
+  const size_t n = it.n, nvec = n / EPV;
+  const Vec* v = reinterpret_cast<const Vec*>(x);
+  Vec* o = reinterpret_cast<Vec*>(out);
+  for (size_t j = (size_t)wg * SWG + threadIdx.x; j < nvec; j += (size_t)nwg * SWG) {
+    Vec a = v[j];
+    if (sf != T(1)) Traits<T>::div(a, sf);
+    o[j] = a;
+  }
+  if (wg == 0 && threadIdx.x == 0)
+    for (size_t j = nvec * EPV; j < n; j++) out[j] = (sf != T(1)) ? x[j] / sf : x[j];
+}
+template <typename T>
+void launch_stats_batch(const BatchFwd<T>* items_src, const unsigned* first_src, unsigned k, unsigned grid, const void* blob_src, void* blob_dst,
+                        size_t blob_bytes, double* part, hipStream_t s) {
+  hipLaunchKernelGGL(k_stats_batch<T>, dim3(grid), dim3(SWG), 0, s, items_src, first_src, k, (const uint4*)blob_src, (uint4*)blob_dst,
+                     (unsigned)(blob_bytes / 16), part);
+}
+template <typename T>
+void launch_sf_batch(const BatchFwd<T>* items, unsigned k, const double* part, double* bstats, SfTable tab, hipStream_t s) {
+  hipLaunchKernelGGL(k_sf_batch<T>, dim3(k), dim3(SWG), 0, s, items, part, bstats, tab);
+}
+template <typename T>
+void launch_scale_batch(const BatchFwd<T>* items, const unsigned* first, unsigned k, unsigned grid, hipStream_t s) {
+  hipLaunchKernelGGL(k_scale_batch<T>, dim3(grid), dim3(SWG), 0, s, items, first, k);
 }
 
 // Sampled statistics for the speculative path: one 4 KiB chunk out of every group of
@@ -493,7 +568,10 @@ void launch_psnr(const T* x, const T* r, size_t n, double* part, int nparts, dou
   template void launch_gather_nd<T>(const T*, T*, const NdShape&, double*, int, hipStream_t);           \
   template void launch_scatter_nd<T>(const T*, T*, const NdShape&, int, hipStream_t);                   \
   template void launch_dct_blocks<T>(const T*, T*, const T*, const T*, size_t, bool, int, hipStream_t); \
-  template void launch_psnr<T>(const T*, const T*, size_t, double*, int, double*, hipStream_t);
+  template void launch_psnr<T>(const T*, const T*, size_t, double*, int, double*, hipStream_t);         \
+  template void launch_stats_batch<T>(const BatchFwd<T>*, const unsigned*, unsigned, unsigned, const void*, void*, size_t, double*, hipStream_t); \
+  template void launch_sf_batch<T>(const BatchFwd<T>*, unsigned, const double*, double*, SfTable, hipStream_t);                           \
+  template void launch_scale_batch<T>(const BatchFwd<T>*, const unsigned*, unsigned, unsigned, hipStream_t);
 INST_AUX(double)
 INST_AUX(float)
 

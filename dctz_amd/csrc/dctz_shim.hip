@@ -102,6 +102,25 @@ struct dctzhip_ctx {
   void* comm = nullptr;             // ncclComm_t
   int comm_rank = 0, comm_world = 0;
   unsigned long long* comm_sizes_dev = nullptr;   // 3 * world u64 (all-gather target) + 3 (this rank's)
+  // batches (dctzhip_compress_batch / dctzhip_decompress_batch): per-array control blocks, device-chosen scaling factors
+  // and statistics; the item table (pinned host copy the first kernel reads + the device copy the others read); results
+  Ctl* b_ctl = nullptr;
+  SfGuess* b_guess = nullptr;
+  double* b_stats = nullptr;        // 3 per array
+  unsigned* b_remcnt = nullptr;     // decode: flags of every array's remainder block
+  size_t b_cap = 0;                 // arrays the four buffers above hold
+  int b_ctl_dirty = 1;
+  unsigned char* b_blob = nullptr;  // fine-grained pinned host memory
+  unsigned char* b_blob_hdev = nullptr;   // ... as the device sees it
+  unsigned char* b_blob_dev = nullptr;
+  size_t b_blob_cap = 0;
+  unsigned char* b_res = nullptr;   // results (fine-grained pinned host memory): BatchResC | BatchResD per array, then BatchResQ per array
+  unsigned char* b_res_hdev = nullptr;
+  size_t b_res_cap = 0;
+  void* rtab_cache[2][64] = {};     // remainder-block tables per (dtype, length), device
+  hipEvent_t b_ev[2][5] = {};       // profiling: per element-type sequence of the last batch call
+  dctzhip_timings b_last[2] = {};
+  int b_have_timings = 0;
   char err[512] = {0};
 };
 
@@ -220,6 +239,12 @@ extern "C" void dctzhip_ctx_destroy(dctzhip_ctx* c) {
     if (c->stage_stream[i]) (void)hipStreamDestroy(c->stage_stream[i]);
   }
   for (int i = 0; i < 6; i++) if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
+  for (int q = 0; q < 2; q++) for (int i = 0; i < 5; i++) if (c->b_ev[q][i]) (void)hipEventDestroy(c->b_ev[q][i]);
+  { void* bb[] = {c->b_ctl, c->b_guess, c->b_stats, c->b_remcnt, c->b_blob_dev};
+    for (void* b : bb) if (b) (void)hipFree(b);
+    for (int q = 0; q < 2; q++) for (int l = 0; l < 64; l++) if (c->rtab_cache[q][l]) (void)hipFree(c->rtab_cache[q][l]);
+    if (c->b_blob) (void)hipHostFree(c->b_blob);
+    if (c->b_res) (void)hipHostFree(c->b_res); }
   if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
   delete c;
 }
@@ -1262,6 +1287,526 @@ extern "C" int dctzhip_psnr_terms(dctzhip_ctx* c, const void* d_x, const void* d
   HIPCHK(c, hipStreamSynchronize(c->stream));
   for (int i = 0; i < 4; i++) out[i] = hs[i];
   return DCTZHIP_OK;
+}
+
+// ---- batches of arrays (include/dctz_hip.h: dctzhip_compress_batch / dctzhip_decompress_batch) ---------------------
+// The reference's own workloads are lists of small arrays, one dctz_compress call each (tests/test-dctz.sh:13-56 over
+// tests/list-msst19.txt:1-6: 12 960 ... 37 024 doubles).  One such call is four or five launches and a host hand-off
+// around a few microseconds of kernel work; a batch puts the arrays of one element type through ONE launch sequence
+// (statistics -> scaling factors -> block DCT + binning -> remainder blocks -> [QT maxima] -> list placement -> scaled
+// copies) with ONE hand-off, every workgroup running the single-array body on its array's own parameter block.
+static constexpr int BATCH_MAX = 1024;                    // arrays per launch sequence (longer batches: several sequences, one hand-off)
+static constexpr size_t BATCH_BIG = (size_t)1 << 24;      // arrays from this size on take the single-array path (fused statistics)
+
+template <typename T>
+static int rtab_for(dctzhip_ctx* c, int l, const T** out) {
+  const int dt = sizeof(T) == 8 ? DCTZHIP_F64 : DCTZHIP_F32;
+  if (!c->rtab_cache[dt][l]) {
+    T h[RTAB_SIZE];
+    fill_rem_tab<T>(l, h);
+    void* d = nullptr;
+    HIPCHK(c, hipMalloc(&d, sizeof(T) * RTAB_SIZE));
+    HIPCHK(c, hipMemcpy(d, h, sizeof(T) * RTAB_SIZE, hipMemcpyHostToDevice));
+    c->rtab_cache[dt][l] = d;
+  }
+  *out = reinterpret_cast<const T*>(c->rtab_cache[dt][l]);
+  return DCTZHIP_OK;
+}
+
+static int ensure_batch(dctzhip_ctx* c, size_t K, size_t blob_bytes, size_t res_bytes) {
+  if (K > c->b_cap) {
+    const size_t cap = K + K / 2 + 16;
+    void* old[] = {c->b_ctl, c->b_guess, c->b_stats, c->b_remcnt};
+    for (void* b : old) if (b) HIPCHK(c, hipFree(b));
+    c->b_ctl = nullptr; c->b_guess = nullptr; c->b_stats = nullptr; c->b_remcnt = nullptr; c->b_cap = 0;
+    HIPCHK(c, hipMalloc(&c->b_ctl, cap * sizeof(Ctl)));
+    HIPCHK(c, hipMalloc(&c->b_guess, cap * sizeof(SfGuess)));
+    HIPCHK(c, hipMalloc(&c->b_stats, cap * 3 * sizeof(double)));
+    HIPCHK(c, hipMalloc(&c->b_remcnt, cap * sizeof(unsigned)));
+    c->b_cap = cap;
+    c->b_ctl_dirty = 1;
+  }
+  if (blob_bytes > c->b_blob_cap) {
+    const size_t cap = (blob_bytes + blob_bytes / 2 + 4095) & ~(size_t)4095;
+    if (c->b_blob) HIPCHK(c, hipHostFree(c->b_blob));
+    if (c->b_blob_dev) HIPCHK(c, hipFree(c->b_blob_dev));
+    c->b_blob = nullptr; c->b_blob_dev = nullptr; c->b_blob_cap = 0;
+    HIPCHK(c, hipHostMalloc(reinterpret_cast<void**>(&c->b_blob), cap, hipHostMallocCoherent | hipHostMallocMapped));
+    HIPCHK(c, hipHostGetDevicePointer(reinterpret_cast<void**>(&c->b_blob_hdev), c->b_blob, 0));
+    HIPCHK(c, hipMalloc(&c->b_blob_dev, cap));
+    c->b_blob_cap = cap;
+  }
+  if (res_bytes > c->b_res_cap) {
+    const size_t cap = (res_bytes + res_bytes / 2 + 4095) & ~(size_t)4095;
+    if (c->b_res) HIPCHK(c, hipHostFree(c->b_res));
+    c->b_res = nullptr; c->b_res_cap = 0;
+    HIPCHK(c, hipHostMalloc(reinterpret_cast<void**>(&c->b_res), cap, hipHostMallocCoherent | hipHostMallocMapped));
+    HIPCHK(c, hipHostGetDevicePointer(reinterpret_cast<void**>(&c->b_res_hdev), c->b_res, 0));
+    c->b_res_cap = cap;
+  }
+  return DCTZHIP_OK;
+}
+
+static size_t align16(size_t v) { return (v + 15) & ~(size_t)15; }
+
+// share of `cap` workgroups an array of `ntiles` tiles gets when the whole sequence has `total` tiles (>= 1 per array
+// that has a tile; never more than its tiles)
+static unsigned share_of(unsigned ntiles, size_t total, unsigned cap) {
+  if (ntiles == 0) return 0;
+  if (total <= cap) return ntiles;
+  const unsigned g = (unsigned)((size_t)cap * ntiles / total);
+  return g < 1 ? 1u : (g > ntiles ? ntiles : g);
+}
+
+namespace {
+struct SeqC {                       // one launch sequence of a compress batch: arrays idx[] (all of one element type)
+  std::vector<int> idx;
+  int dtype = 0;
+  std::vector<unsigned> nfull, rem, ntiles, G, nparts, part_base, tile_base, list_base, scale_wgs;
+  size_t tiles_total = 0, lists_total = 0, parts_total = 0;
+  unsigned grid_main = 0, grid_list = 0, grid_scale = 0, grid_stats = 0, nrem = 0;
+  size_t blob_off = 0, blob_bytes = 0, item_off = 0;    // item_off: first array of this sequence in b_ctl / b_guess / b_stats / results
+};
+struct SeqD {
+  std::vector<int> idx;
+  int dtype = 0;
+  std::vector<unsigned> nfull, rem, ntiles, nwg, tile_base, wg_base;
+  size_t tiles_total = 0, wgs_total = 0;
+  unsigned grid_cnt = 0, grid_main = 0, nrem = 0;
+  size_t blob_off = 0, blob_bytes = 0, item_off = 0;
+};
+}  // namespace
+
+template <typename T>
+static void plan_compress(dctzhip_ctx* c, const dctzhip_batch_citem* items, int mode, SeqC& q) {
+  const size_t k = q.idx.size();
+  constexpr int EPV = Traits<T>::EPV;
+  unsigned cap = (unsigned)(c->num_cu * wg_per_cu<T>(c, false, mode, false, GEOM_1D));
+  if (c->grid_c > 0 && (unsigned)c->grid_c < cap) cap = (unsigned)c->grid_c;
+  cap = cap > 2 * (unsigned)k ? cap - (unsigned)k : cap / 2 + 1;      // (every array with a tile gets at least one workgroup)
+  size_t tiles = 0;
+  q.nfull.resize(k); q.rem.resize(k); q.ntiles.resize(k); q.G.resize(k); q.nparts.resize(k); q.part_base.resize(k);
+  q.tile_base.resize(k); q.list_base.resize(k); q.scale_wgs.resize(k);
+  for (size_t j = 0; j < k; j++) {
+    const size_t n = items[q.idx[j]].n;
+    q.nfull[j] = (unsigned)(n / 64); q.rem[j] = (unsigned)(n % 64);
+    q.ntiles[j] = (q.nfull[j] + TILE_BLKS - 1) / TILE_BLKS;
+    tiles += q.ntiles[j];
+  }
+  const unsigned maxp = (unsigned)((size_t)(PART_SLOTS - 64) / k) < 1u ? 1u : (unsigned)((size_t)(PART_SLOTS - 64) / k);
+  for (size_t j = 0; j < k; j++) {
+    const size_t n = items[q.idx[j]].n;
+    q.G[j] = share_of(q.ntiles[j], tiles, cap);
+    const size_t nvec = n / EPV;
+    size_t sg = (nvec + SWG * 4 - 1) / (SWG * 4);          // the single-array path's statistics grid (same partials, same sum)
+    if (sg < 1) sg = 1;
+    if (sg > (size_t)c->stats_grid) sg = (size_t)c->stats_grid;
+    if (sg > maxp) sg = maxp;
+    q.nparts[j] = (unsigned)sg;
+    q.part_base[j] = (unsigned)q.parts_total; q.parts_total += sg;
+    q.tile_base[j] = (unsigned)q.tiles_total; q.tiles_total += q.ntiles[j] + 1;     // + the remainder block's list
+    q.list_base[j] = (unsigned)q.lists_total; q.lists_total += q.G[j] + 1;
+    q.grid_main += q.G[j];
+    q.grid_list += q.G[j] + (q.rem[j] ? 1u : 0u);
+    q.nrem += q.rem[j] ? 1u : 0u;
+    unsigned sw = 0;
+    if (items[q.idx[j]].d_scaled) { size_t w = (nvec + SWG * 4 - 1) / (SWG * 4); sw = (unsigned)(w < 1 ? 1 : (w > 256 ? 256 : w)); }
+    q.scale_wgs[j] = sw; q.grid_scale += sw;
+  }
+  q.grid_stats = (unsigned)q.parts_total;
+  q.blob_bytes = align16(k * sizeof(BatchFwd<T>)) + align16(4 * (k + 1) * sizeof(unsigned) + (size_t)q.nrem * sizeof(unsigned));
+}
+
+template <typename T>
+static int launch_compress_seq(dctzhip_ctx* c, const dctzhip_batch_citem* items, int mode, const SeqC& q, bool publish,
+                               unsigned long long seq, bool first_of_dtype) {
+  const int dtype = sizeof(T) == 8 ? DCTZHIP_F64 : DCTZHIP_F32;
+  const size_t k = q.idx.size();
+  hipStream_t s = c->stream;
+  if ((size_t)q.grid_main > (size_t)c->num_cu * WG_PER_CU_MAX)
+    return fail(c, DCTZHIP_E_INTERNAL, "batch: %u workgroups exceed the %d overflow strips", q.grid_main, c->num_cu * WG_PER_CU_MAX);
+  if (q.parts_total > (size_t)PART_SLOTS || q.lists_total + 2 > c->tile_cap)
+    return fail(c, DCTZHIP_E_INTERNAL, "batch: scratch plan exceeds its buffers");
+  unsigned char* hb = c->b_blob + q.blob_off;
+  BatchFwd<T>* hi = reinterpret_cast<BatchFwd<T>*>(hb);
+  unsigned* hfirst = reinterpret_cast<unsigned*>(hb + align16(k * sizeof(BatchFwd<T>)));
+  unsigned* f_stats = hfirst, *f_main = hfirst + (k + 1), *f_list = hfirst + 2 * (k + 1), *f_scale = hfirst + 3 * (k + 1);
+  unsigned* rem_items = hfirst + 4 * (k + 1);
+  const size_t first_off = align16(k * sizeof(BatchFwd<T>));
+  const int half = DCTZHIP_NBINS / 2;
+  unsigned a_stats = 0, a_main = 0, a_list = 0, a_scale = 0, nrem = 0;
+  for (size_t j = 0; j < k; j++) {
+    const dctzhip_batch_citem& it = items[q.idx[j]];
+    const double eb = it.error_bound;
+    BatchFwd<T>& b = hi[j];
+    memset(&b, 0, sizeof(b));
+    FwdParams<T>& p = b.p;
+    p.x = (const T*)it.d_in; p.bin = (uint8_t*)it.d_bin_index; p.dc = it.d_dc; p.ac = it.d_ac_exact; p.coef = nullptr;
+    const size_t slot0 = (size_t)q.tile_base[j] * TILE_ELEMS;
+    p.ac_tmp = c->ac_tmp ? c->ac_tmp + slot0 : nullptr;
+    p.qt_item = c->qt_item ? reinterpret_cast<T*>(c->qt_item) + slot0 : nullptr;
+    p.qt_j = c->qt_j ? c->qt_j + slot0 : nullptr;
+    p.tile_cnt = c->tile_cnt + q.list_base[j];
+    p.ovf = c->ovf; p.ovf_j = c->ovf_j;
+    p.tab = tab_of<T>(c); p.rtab = nullptr;
+    if (q.rem[j]) { int rc = rtab_for<T>(c, (int)q.rem[j], &p.rtab); if (rc) return rc; }
+    p.ctl = c->b_ctl + q.item_off + j;
+    p.guess = c->b_guess + q.item_off + j;           // the scaling factor is chosen on the device (k_sf_batch), verified afterwards
+    p.stat_part = nullptr;
+    p.nfull = q.nfull[j]; p.ntiles = q.ntiles[j]; p.last_is_full = q.rem[j] ? 0u : 1u;
+    p.nlists_main = q.G[j];
+    p.sf = (T)1; p.fast_sf = 0;                       // (placeholders: p.guess is set)
+    p.bin_width = (T)(eb * 2.0 * 1.0);                // dctz-comp-lib.c:271-281, as compress_pass
+    p.range_min = (T)(-(half * 2 + 1) * (eb * 1.0));
+    p.range_max = (T)((half * 2 + 1) * (eb * 1.0));
+    p.fast_bw = c->fastdiv ? divisor_in_window(dtype, (double)p.bin_width) : 0u;
+    {
+      volatile T u = (T)(p.range_max - p.range_min);
+      volatile T qq = (T)(u / p.bin_width);
+      if (p.fast_bw && c->fastdiv >= 2 && qq >= (T)255) p.fast_bw |= 2u;
+    }
+    b.eb = eb; b.scaled = (T*)it.d_scaled; b.n = (unsigned)it.n; b.rem = q.rem[j];
+    b.nlists = q.G[j] + (q.rem[j] ? 1u : 0u);
+    b.nparts = q.nparts[j]; b.part_base = q.part_base[j];
+    f_stats[j] = a_stats; a_stats += q.nparts[j];
+    f_main[j] = a_main; a_main += q.G[j];
+    f_list[j] = a_list; a_list += b.nlists;
+    f_scale[j] = a_scale; a_scale += q.scale_wgs[j];
+    if (q.rem[j]) rem_items[nrem++] = (unsigned)j;
+  }
+  f_stats[k] = a_stats; f_main[k] = a_main; f_list[k] = a_list; f_scale[k] = a_scale;
+  __atomic_thread_fence(__ATOMIC_SEQ_CST);             // the table is complete in host memory before the first launch reads it
+
+  const BatchFwd<T>* it_h = reinterpret_cast<const BatchFwd<T>*>(c->b_blob_hdev + q.blob_off);
+  const unsigned* first_h = reinterpret_cast<const unsigned*>(c->b_blob_hdev + q.blob_off + first_off);
+  unsigned char* db = c->b_blob_dev + q.blob_off;
+  const BatchFwd<T>* it_d = reinterpret_cast<const BatchFwd<T>*>(db);
+  const unsigned* first_d = reinterpret_cast<const unsigned*>(db + first_off);
+  const bool prof = c->profiling && first_of_dtype;
+  hipEvent_t* ev = c->b_ev[dtype];
+  if (prof) for (int i = 0; i < 5; i++) if (!ev[i]) HIPCHK(c, hipEventCreate(&ev[i]));
+  if (prof) HIPCHK(c, hipEventRecord(ev[0], s));
+  launch_stats_batch<T>(it_h, first_h, (unsigned)k, q.grid_stats, c->b_blob_hdev + q.blob_off, db, q.blob_bytes, c->part, s);
+  const SfTable tab = {c->sf_thr[dtype], c->sf_pw[dtype], c->sf_nk[dtype], c->fastdiv, dtype};
+  launch_sf_batch<T>(it_d, (unsigned)k, c->part, c->b_stats + 3 * q.item_off, tab, s);
+  if (prof) HIPCHK(c, hipEventRecord(ev[1], s));
+  if (q.grid_main) launch_compress_batch<T>(it_d, first_d + (k + 1), (unsigned)k, q.grid_main, mode, s);
+  if (prof) HIPCHK(c, hipEventRecord(ev[2], s));
+  if (nrem) launch_compress_rem_batch<T>(it_d, first_d + 4 * (k + 1), nrem, mode, s);
+  if (mode == DCTZHIP_QT && sizeof(T) == 8 && q.grid_list) launch_qt_max_batch<T>(it_d, first_d + 2 * (k + 1), (unsigned)k, q.grid_list, s);
+  BatchFin fin;
+  fin.box = publish ? c->box_dev : nullptr; fin.seq = seq;
+  fin.res = c->b_res_hdev + q.item_off * sizeof(BatchResC);
+  fin.resq = mode == DCTZHIP_QT ? reinterpret_cast<BatchResQ*>(c->b_res_hdev + c->b_cap * sizeof(BatchResC)) + q.item_off : nullptr;
+  // (every array has at least one list or a remainder block: n >= 1)
+  launch_compact_batch<T>(it_d, first_d + 2 * (k + 1), (unsigned)k, q.grid_list, mode, c->b_stats + 3 * q.item_off, fin, s);
+  if (prof) HIPCHK(c, hipEventRecord(ev[3], s));
+  if (q.grid_scale) launch_scale_batch<T>(it_d, first_d + 3 * (k + 1), (unsigned)k, q.grid_scale, s);
+  if (prof) HIPCHK(c, hipEventRecord(ev[4], s));
+  HIPCHK(c, hipGetLastError());
+  return DCTZHIP_OK;
+}
+
+static int batch_timings(dctzhip_ctx* c, int dtype) {
+  hipEvent_t* ev = c->b_ev[dtype];
+  HIPCHK(c, hipEventSynchronize(ev[4]));
+  float a = 0, b = 0, d = 0, e = 0;
+  HIPCHK(c, hipEventElapsedTime(&a, ev[0], ev[1]));
+  HIPCHK(c, hipEventElapsedTime(&b, ev[1], ev[2]));
+  HIPCHK(c, hipEventElapsedTime(&d, ev[2], ev[3]));
+  HIPCHK(c, hipEventElapsedTime(&e, ev[3], ev[4]));
+  c->b_last[dtype].stats_ms = a; c->b_last[dtype].main_ms = b; c->b_last[dtype].tail_ms = d + e; c->b_last[dtype].total_ms = a + b + d + e;
+  return DCTZHIP_OK;
+}
+
+extern "C" int dctzhip_last_batch_timings(dctzhip_ctx* c, dctzhip_timings t[2]) {
+  if (!c || !t) return DCTZHIP_E_ARG;
+  if (!c->b_have_timings) return fail(c, DCTZHIP_E_ARG, "no batch timings recorded (enable profiling first)");
+  t[0] = c->b_last[0]; t[1] = c->b_last[1];
+  return DCTZHIP_OK;
+}
+
+extern "C" int dctzhip_compress_batch(dctzhip_ctx* c, int k, const dctzhip_batch_citem* items, int mode, dctzhip_cinfo* infos) {
+  if (!c) return DCTZHIP_E_ARG;
+  if (k < 0 || (k && !items)) return fail(c, DCTZHIP_E_ARG, "dctzhip_compress_batch: bad arguments");
+  if (k == 0) return DCTZHIP_OK;
+  for (int i = 0; i < k; i++) {
+    const dctzhip_batch_citem& it = items[i];
+    int rc = check_common(c, it.n, it.dtype, mode);
+    if (rc) return rc;
+    if (!it.d_in || !it.d_bin_index || !it.d_dc || !it.d_ac_exact) return fail(c, DCTZHIP_E_ARG, "array %d: null device buffer", i);
+    if (!aligned16(it.d_in) || !aligned16(it.d_bin_index) || !aligned16(it.d_dc) || !aligned16(it.d_ac_exact) || (it.d_scaled && !aligned16(it.d_scaled)))
+      return fail(c, DCTZHIP_E_ARG, "array %d: device buffers must be 16-byte aligned", i);
+    if (it.error_bound < 1E-6) return fail(c, DCTZHIP_E_BOUND, "array %d: ERROR BOUND is not acceptable", i);   // dctz-comp-lib.c:135-138
+  }
+  HIPCHK(c, hipSetDevice(c->device));
+  const bool box = c->handoff != 0 && c->dev_sf && c->sf_nk[0] > 0 && c->sf_nk[1] > 0;
+  // arrays that gain nothing from a batch (launch cost is noise beside their kernels, and the single-array path saves
+  // them the statistics pass) -- and every array when the platform has no mailbox -- take the single-array path
+  std::vector<int> single;
+  std::vector<SeqC> seqs;
+  for (int dt = 1; dt >= 0; dt--) {                   // fp64 sequences first, then fp32
+    SeqC cur; cur.dtype = dt;
+    for (int i = 0; i < k; i++) {
+      if (items[i].dtype != dt) continue;
+      if (!box || items[i].n >= BATCH_BIG) { if (dt == items[i].dtype) single.push_back(i); continue; }
+      cur.idx.push_back(i);
+      if ((int)cur.idx.size() == BATCH_MAX) { seqs.push_back(cur); cur = SeqC(); cur.dtype = dt; }
+    }
+    if (!cur.idx.empty()) seqs.push_back(cur);
+  }
+  size_t K = 0, blob = 0, tiles_max = 0;
+  for (SeqC& q : seqs) {
+    if (q.dtype == DCTZHIP_F64) plan_compress<double>(c, items, mode, q); else plan_compress<float>(c, items, mode, q);
+    q.item_off = K; K += q.idx.size();
+    q.blob_off = blob; blob += q.blob_bytes;
+    if (q.tiles_total > tiles_max) tiles_max = q.tiles_total;
+  }
+  if (!seqs.empty()) {
+    // scratch of the largest sequence (sequences follow each other on the stream and reuse it), in the widest element type
+    int rc = ensure_scratch(c, tiles_max * TILE_ELEMS, DCTZHIP_F64, mode);
+    if (rc) return rc;
+    rc = ensure_batch(c, K, blob, 0);
+    if (rc) return rc;
+    rc = ensure_batch(c, K, blob, c->b_cap * (sizeof(BatchResC) + (mode == DCTZHIP_QT ? sizeof(BatchResQ) : 0)));
+    if (rc) return rc;
+    hipStream_t s = c->stream;
+    const unsigned long long seq = ++c->seq;
+    bool seen[2] = {false, false};
+    for (size_t qi = 0; qi < seqs.size(); qi++) {
+      const SeqC& q = seqs[qi];
+      const bool last = qi + 1 == seqs.size();
+      rc = (q.dtype == DCTZHIP_F64) ? launch_compress_seq<double>(c, items, mode, q, last, seq, !seen[q.dtype])
+                                    : launch_compress_seq<float>(c, items, mode, q, last, seq, !seen[q.dtype]);
+      if (rc) return rc;
+      seen[q.dtype] = true;
+    }
+    (void)s;
+    rc = wait_seq(c, &c->box->seq_done, seq, "compress batch");
+    if (rc) return rc;
+    if (c->profiling) {
+      c->b_last[0] = dctzhip_timings{0, 0, 0, 0}; c->b_last[1] = dctzhip_timings{0, 0, 0, 0};
+      for (int dt = 0; dt < 2; dt++) if (seen[dt]) { rc = batch_timings(c, dt); if (rc) return rc; }
+      c->b_have_timings = 1;
+    }
+    // results; the device's choice of every scaling factor against the host's own expression (util.c:29 / :43)
+    const BatchResC* res = reinterpret_cast<const BatchResC*>(c->b_res);
+    const BatchResQ* resq = reinterpret_cast<const BatchResQ*>(c->b_res + c->b_cap * sizeof(BatchResC));
+    for (const SeqC& q : seqs) {
+      for (size_t j = 0; j < q.idx.size(); j++) {
+        const int i = q.idx[j];
+        const BatchResC& r = res[q.item_off + j];
+        const int dtype = q.dtype;
+        const double true_sf = scaling_factor(dtype, r.stats[0]);
+        const bool same = dtype == DCTZHIP_F64 ? true_sf == r.sf_used : (float)true_sf == (float)r.sf_used;
+        const bool window_ok = r.fast_used != 2 || (value_in_window(dtype, r.stats[1]) && value_in_window(dtype, r.stats[0]));
+        if (!same || !window_ok) { single.push_back(i); continue; }     // (a table bug: never seen; the array is done again on its own)
+        if (!infos) continue;
+        dctzhip_cinfo* info = &infos[i];
+        memset(info, 0, sizeof(*info));
+        const size_t n = items[i].n;
+        info->sf = true_sf;
+        info->mean = (dtype == DCTZHIP_F64) ? r.stats[2] / (double)(int)n : (double)((float)r.stats[2] / (float)(int)n);
+        info->max_abs = r.stats[0]; info->min_abs = r.stats[1];
+        info->cnt = r.cnt; info->nblk = (uint32_t)((n + 63) / 64);
+        if (mode == DCTZHIP_QT) {
+          const BatchResQ& rq = resq[q.item_off + j];
+          for (int jj = 0; jj < 64; jj++) {
+            double v;
+            if (dtype == DCTZHIP_F64) { unsigned long long b = rq.qraw[jj]; memcpy(&v, &b, 8); }
+            else { unsigned int b = (unsigned int)rq.qraw[jj]; float f; memcpy(&f, &b, 4); v = f; }
+            info->qtable_raw[jj] = v;
+            info->qtable[jj] = (jj >= 1 && v < 1.0) ? 1.0 : v;          // :450-461
+          }
+          double q0;
+          if (dtype == DCTZHIP_F64) { unsigned long long b = r.q0; memcpy(&q0, &b, 8); }
+          else { unsigned int b = (unsigned int)r.q0; float f; memcpy(&f, &b, 4); q0 = f; }
+          info->qtable[0] = info->qtable_raw[0] = q0;                 // :355-360
+        }
+      }
+    }
+  }
+  for (int i : single) {
+    const dctzhip_batch_citem& it = items[i];
+    int rc = dctzhip_compress(c, it.d_in, it.n, it.dtype, it.error_bound, mode, it.d_bin_index, it.d_dc, it.d_ac_exact, it.d_scaled, nullptr,
+                              infos ? &infos[i] : nullptr);
+    if (rc) return rc;
+  }
+  if (c->blocking) HIPCHK(c, hipStreamSynchronize(c->stream));
+  return DCTZHIP_OK;
+}
+
+// ---- decode side of a batch ----
+template <typename T>
+static void plan_decompress(dctzhip_ctx* c, const dctzhip_batch_ditem* items, int mode, SeqD& q) {
+  const size_t k = q.idx.size();
+  unsigned cap = (unsigned)(c->num_cu * wg_per_cu<T>(c, true, mode, false, GEOM_1D));
+  cap = cap > 2 * (unsigned)k ? cap - (unsigned)k : cap / 2 + 1;
+  size_t tiles = 0;
+  q.nfull.resize(k); q.rem.resize(k); q.ntiles.resize(k); q.nwg.resize(k); q.tile_base.resize(k); q.wg_base.resize(k);
+  for (size_t j = 0; j < k; j++) {
+    const size_t n = items[q.idx[j]].n;
+    q.nfull[j] = (unsigned)(n / 64); q.rem[j] = (unsigned)(n % 64);
+    q.ntiles[j] = (q.nfull[j] + TILE_BLKS - 1) / TILE_BLKS;
+    tiles += q.ntiles[j];
+  }
+  for (size_t j = 0; j < k; j++) {
+    q.nwg[j] = share_of(q.ntiles[j], tiles, cap);
+    q.tile_base[j] = (unsigned)q.tiles_total; q.tiles_total += q.ntiles[j];
+    q.wg_base[j] = (unsigned)q.wgs_total; q.wgs_total += q.nwg[j];
+    q.grid_main += q.nwg[j];
+    q.grid_cnt += q.nwg[j] ? q.nwg[j] : 1u;
+    q.nrem += q.rem[j] ? 1u : 0u;
+  }
+  q.blob_bytes = align16(k * sizeof(BatchInv<T>)) + align16(2 * (k + 1) * sizeof(unsigned) + (size_t)q.nrem * sizeof(unsigned));
+}
+
+template <typename T>
+static int launch_decompress_seq(dctzhip_ctx* c, const dctzhip_batch_ditem* items, int mode, const SeqD& q, bool publish, unsigned long long seq,
+                                 bool first_of_dtype) {
+  const int dtype = sizeof(T) == 8 ? DCTZHIP_F64 : DCTZHIP_F32;
+  const size_t k = q.idx.size();
+  hipStream_t s = c->stream;
+  if (q.tiles_total + 2 > c->tile_cap || q.wgs_total + 2 > c->tile_cap) return fail(c, DCTZHIP_E_INTERNAL, "batch: scratch plan exceeds its buffers");
+  unsigned char* hb = c->b_blob + q.blob_off;
+  BatchInv<T>* hi = reinterpret_cast<BatchInv<T>*>(hb);
+  const size_t first_off = align16(k * sizeof(BatchInv<T>));
+  unsigned* f_cnt = reinterpret_cast<unsigned*>(hb + first_off), *f_main = f_cnt + (k + 1), *rem_items = f_cnt + 2 * (k + 1);
+  unsigned char* db = c->b_blob_dev + q.blob_off;
+  unsigned a_cnt = 0, a_main = 0, nrem = 0;
+  for (size_t j = 0; j < k; j++) {
+    const dctzhip_batch_ditem& it = items[q.idx[j]];
+    BatchInv<T>& b = hi[j];
+    memset(&b, 0, sizeof(b));
+    InvParams<T>& p = b.p;
+    p.bin = (const uint8_t*)it.d_bin_index; p.dc = it.d_dc; p.ac = it.d_ac_exact; p.out = (T*)it.d_out;
+    p.tab = tab_of<T>(c); p.rtab = nullptr;
+    if (q.rem[j]) { int rc = rtab_for<T>(c, (int)q.rem[j], &p.rtab); if (rc) return rc; }
+    p.qtab = reinterpret_cast<const T*>(db + j * sizeof(BatchInv<T>) + offsetof(BatchInv<T>, qtab));
+    if (mode == DCTZHIP_QT) memcpy(b.qtab, it.qtable_host, sizeof(T) * 64);
+    p.tile_cnt = c->tile_cnt + q.tile_base[j]; p.wg_cnt = c->wg_cnt + q.wg_base[j];
+    p.ctl = c->b_ctl + q.item_off + j;
+    p.nfull = q.nfull[j]; p.ntiles = q.ntiles[j]; p.ac_count = it.ac_count; p.nwg = q.nwg[j];
+    p.sf = (T)it.sf;
+    p.bin_width = (T)((T)it.error_bound * 2 * 1.0);   // gen_bins / gen_bins_f (binning.c:17 / :37), as decompress_impl
+    p.range_max = (T)(it.error_bound * DCTZHIP_NBINS); // dctz-decomp-lib.c:372-381
+    p.range_min = (T)(-it.error_bound * DCTZHIP_NBINS);
+    p.eb = it.error_bound;
+    b.n = (unsigned)it.n; b.rem = q.rem[j]; b.scale = (p.sf != (T)1.0) ? 1u : 0u; b.cnt_wgs = q.nwg[j] ? q.nwg[j] : 1u;
+    b.rem_cnt = c->b_remcnt + q.item_off + j;
+    f_cnt[j] = a_cnt; a_cnt += b.cnt_wgs;
+    f_main[j] = a_main; a_main += q.nwg[j];
+    if (q.rem[j]) rem_items[nrem++] = (unsigned)j;
+  }
+  f_cnt[k] = a_cnt; f_main[k] = a_main;
+  __atomic_thread_fence(__ATOMIC_SEQ_CST);
+  const BatchInv<T>* it_h = reinterpret_cast<const BatchInv<T>*>(c->b_blob_hdev + q.blob_off);
+  const unsigned* first_h = reinterpret_cast<const unsigned*>(c->b_blob_hdev + q.blob_off + first_off);
+  const BatchInv<T>* it_d = reinterpret_cast<const BatchInv<T>*>(db);
+  const unsigned* first_d = reinterpret_cast<const unsigned*>(db + first_off);
+  const bool prof = c->profiling && first_of_dtype;
+  hipEvent_t* ev = c->b_ev[dtype];
+  if (prof) for (int i = 0; i < 5; i++) if (!ev[i]) HIPCHK(c, hipEventCreate(&ev[i]));
+  if (prof) HIPCHK(c, hipEventRecord(ev[0], s));
+  launch_count_batch<T>(it_h, first_h, (unsigned)k, q.grid_cnt, c->b_blob_hdev + q.blob_off, db, q.blob_bytes, s);
+  if (prof) HIPCHK(c, hipEventRecord(ev[1], s));
+  BatchFin fin;
+  fin.box = publish ? c->box_dev : nullptr; fin.seq = seq;
+  fin.res = c->b_res_hdev + q.item_off * sizeof(BatchResD); fin.resq = nullptr;
+  if (q.grid_main) launch_decompress_batch<T>(it_d, first_d + (k + 1), (unsigned)k, q.grid_main, mode, fin, s);
+  if (prof) HIPCHK(c, hipEventRecord(ev[2], s));
+  if (nrem) launch_decompress_rem_batch<T>(it_d, first_d + 2 * (k + 1), nrem, mode, s);
+  if (prof) { HIPCHK(c, hipEventRecord(ev[3], s)); HIPCHK(c, hipEventRecord(ev[4], s)); }
+  HIPCHK(c, hipGetLastError());
+  return DCTZHIP_OK;
+}
+
+extern "C" int dctzhip_decompress_batch(dctzhip_ctx* c, int k, const dctzhip_batch_ditem* items, int mode, int* status) {
+  if (!c) return DCTZHIP_E_ARG;
+  if (k < 0 || (k && !items)) return fail(c, DCTZHIP_E_ARG, "dctzhip_decompress_batch: bad arguments");
+  if (k == 0) return DCTZHIP_OK;
+  for (int i = 0; i < k; i++) {
+    const dctzhip_batch_ditem& it = items[i];
+    int rc = check_common(c, it.n, it.dtype, mode);
+    if (rc) return rc;
+    if (!it.d_bin_index || !it.d_dc || !it.d_out || (it.ac_count && !it.d_ac_exact)) return fail(c, DCTZHIP_E_ARG, "array %d: null device buffer", i);
+    if (!aligned16(it.d_bin_index) || !aligned16(it.d_out)) return fail(c, DCTZHIP_E_ARG, "array %d: device buffers must be 16-byte aligned", i);
+    if (mode == DCTZHIP_QT && !it.qtable_host) return fail(c, DCTZHIP_E_ARG, "array %d: QT mode needs the 64-entry table", i);
+    if (status) status[i] = DCTZHIP_OK;
+  }
+  HIPCHK(c, hipSetDevice(c->device));
+  const bool box = c->handoff != 0;
+  std::vector<int> single;
+  std::vector<SeqD> seqs;
+  for (int dt = 1; dt >= 0; dt--) {
+    SeqD cur; cur.dtype = dt;
+    for (int i = 0; i < k; i++) {
+      if (items[i].dtype != dt) continue;
+      // (an array with tiles but no mailbox, or without any full tile, keeps the single-array path: the batch hands off in
+      // the first workgroup of k_decompress_batch)
+      if (!box || items[i].n >= BATCH_BIG) { single.push_back(i); continue; }
+      cur.idx.push_back(i);
+      if ((int)cur.idx.size() == BATCH_MAX) { seqs.push_back(cur); cur = SeqD(); cur.dtype = dt; }
+    }
+    if (!cur.idx.empty()) seqs.push_back(cur);
+  }
+  int worst = DCTZHIP_OK;
+  size_t K = 0, blob = 0, tiles_max = 0;
+  for (SeqD& q : seqs) {
+    if (q.dtype == DCTZHIP_F64) plan_decompress<double>(c, items, mode, q); else plan_decompress<float>(c, items, mode, q);
+    q.item_off = K; K += q.idx.size();
+    q.blob_off = blob; blob += q.blob_bytes;
+    if (q.tiles_total > tiles_max) tiles_max = q.tiles_total;
+  }
+  // a sequence whose arrays have no full tile at all has no k_decompress_batch launch to hand off from: single path
+  for (size_t qi = 0; qi < seqs.size();) {
+    if (seqs[qi].grid_main == 0) { for (int i : seqs[qi].idx) single.push_back(i); seqs.erase(seqs.begin() + qi); } else qi++;
+  }
+  if (!seqs.empty()) {
+    int rc = ensure_scratch(c, (tiles_max + 1) * TILE_ELEMS, DCTZHIP_F64, DCTZHIP_EC, false);
+    if (rc) return rc;
+    rc = ensure_batch(c, K, blob, 0);
+    if (rc) return rc;
+    rc = ensure_batch(c, K, blob, c->b_cap * sizeof(BatchResD));
+    if (rc) return rc;
+    hipStream_t s = c->stream;
+    if (c->b_ctl_dirty) { HIPCHK(c, hipMemsetAsync(c->b_ctl, 0, c->b_cap * sizeof(Ctl), s)); c->b_ctl_dirty = 0; }
+    const unsigned long long seq = ++c->seq;
+    bool seen[2] = {false, false};
+    for (size_t qi = 0; qi < seqs.size(); qi++) {
+      const SeqD& q = seqs[qi];
+      const bool last = qi + 1 == seqs.size();
+      rc = (q.dtype == DCTZHIP_F64) ? launch_decompress_seq<double>(c, items, mode, q, last, seq, !seen[q.dtype])
+                                    : launch_decompress_seq<float>(c, items, mode, q, last, seq, !seen[q.dtype]);
+      if (rc) return rc;
+      seen[q.dtype] = true;
+    }
+    rc = wait_seq(c, &c->box->seq_done, seq, "decompress batch");
+    if (rc) return rc;
+    if (c->profiling) {
+      c->b_last[0] = dctzhip_timings{0, 0, 0, 0}; c->b_last[1] = dctzhip_timings{0, 0, 0, 0};
+      for (int dt = 0; dt < 2; dt++) if (seen[dt]) { rc = batch_timings(c, dt); if (rc) return rc; }
+      c->b_have_timings = 1;
+    }
+    const BatchResD* res = reinterpret_cast<const BatchResD*>(c->b_res);
+    for (const SeqD& q : seqs)
+      for (size_t j = 0; j < q.idx.size(); j++)
+        if (res[q.item_off + j].error) {
+          c->b_ctl_dirty = 1;
+          worst = DCTZHIP_E_ARG;
+          if (status) status[q.idx[j]] = DCTZHIP_E_ARG;
+          fail(c, DCTZHIP_E_ARG, "array %d: bin_index flags more exact coefficients than ac_count provides", q.idx[j]);
+        }
+  }
+  for (int i : single) {
+    const dctzhip_batch_ditem& it = items[i];
+    int rc = dctzhip_decompress(c, it.d_bin_index, it.d_dc, it.d_ac_exact, it.ac_count, it.qtable_host, it.n, it.dtype, it.error_bound, it.sf, mode,
+                                it.d_out);
+    if (rc == DCTZHIP_E_ARG) { worst = rc; if (status) status[i] = rc; continue; }
+    if (rc) return rc;
+  }
+  if (worst == DCTZHIP_OK && c->blocking) HIPCHK(c, hipStreamSynchronize(c->stream));
+  return worst;
 }
 
 // ---- multi-GPU gather over RCCL -----------------------------------------------------------------------------------

@@ -11,6 +11,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 F32, F64 = 0, 1
 EC, QT = 0, 1
+OK, E_ARG, E_BOUND, E_HIP, E_INTERNAL = 0, -1, -2, -3, -4      # DCTZHIP_OK / DCTZHIP_E_*
 
 
 class DctzHipError(RuntimeError):
@@ -35,6 +36,17 @@ INFO_RESPUN = 2        # guess wrong: the compress kernels ran a second time wit
 class Timings(C.Structure):
     _fields_ = [("stats_ms", C.c_float), ("main_ms", C.c_float), ("tail_ms", C.c_float),
                 ("total_ms", C.c_float)]
+
+
+class BatchCItem(C.Structure):       # dctzhip_batch_citem
+    _fields_ = [("d_in", C.c_void_p), ("n", C.c_size_t), ("dtype", C.c_int), ("error_bound", C.c_double),
+                ("d_bin_index", C.c_void_p), ("d_dc", C.c_void_p), ("d_ac_exact", C.c_void_p), ("d_scaled", C.c_void_p)]
+
+
+class BatchDItem(C.Structure):       # dctzhip_batch_ditem
+    _fields_ = [("d_bin_index", C.c_void_p), ("d_dc", C.c_void_p), ("d_ac_exact", C.c_void_p), ("ac_count", C.c_uint32),
+                ("qtable_host", C.c_void_p), ("n", C.c_size_t), ("dtype", C.c_int), ("error_bound", C.c_double),
+                ("sf", C.c_double), ("d_out", C.c_void_p)]
 
 
 _lib = None
@@ -65,6 +77,9 @@ _PROTOS = {
                                      C.c_void_p, C.c_size_t, C.c_int, C.c_double, C.c_double, C.c_int,
                                      C.c_void_p]),
     "dctzhip_set_blocking": (C.c_int, [C.c_void_p, C.c_int]),
+    "dctzhip_compress_batch": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(BatchCItem), C.c_int, C.POINTER(CompressInfo)]),
+    "dctzhip_decompress_batch": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(BatchDItem), C.c_int, C.POINTER(C.c_int)]),
+    "dctzhip_last_batch_timings": (C.c_int, [C.c_void_p, C.POINTER(Timings)]),
     "dctzhip_nd_blocks": (C.c_size_t, [C.c_int, C.POINTER(C.c_size_t)]),
     "dctzhip_compress_nd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_size_t), C.c_int, C.c_double, C.c_int,
                                       C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(CompressInfo)]),
@@ -106,7 +121,12 @@ def load_library():
                                "there is no CPU fallback")
         lib = C.CDLL(p)
         for name, (res, args) in _PROTOS.items():
-            fn = getattr(lib, name)          # AttributeError if the ABI lost a symbol
+            try:
+                fn = getattr(lib, name)      # AttributeError if the ABI lost a symbol
+            except AttributeError:
+                if os.environ.get("DCTZHIP_LIBRARY"):      # an older A/B build of the library: that entry point is just absent
+                    continue
+                raise
             fn.restype, fn.argtypes = res, args
         _lib = lib
     return _lib
@@ -224,6 +244,64 @@ class Context:
             float(eb), float(sf), mode, dst.data_ptr())
         self._check(rc, "dctzhip_decompress")
         return dst
+
+    # ---- batches of arrays (include/dctz_hip.h: dctzhip_compress_batch / dctzhip_decompress_batch) ----
+    def compress_batch(self, xs, ebs, mode=EC, outs=None, scaled=None, prepared=None):
+        """k arrays (1-D contiguous CUDA tensors, float32 | float64 each) through one launch sequence per element type.
+        ebs: one bound or one per array.  Returns (outs, infos, prepared); pass `prepared` back in to repeat the very
+        same call without rebuilding the argument table."""
+        self._bind_stream()
+        if prepared is None:
+            k = len(xs)
+            ebs = [float(ebs)] * k if not hasattr(ebs, "__len__") else [float(e) for e in ebs]
+            if outs is None:
+                outs = [self.alloc_outputs(x.numel(), x.dtype) for x in xs]
+            items = (BatchCItem * max(k, 1))()
+            for i, x in enumerate(xs):
+                assert x.is_cuda and x.is_contiguous() and x.dim() == 1
+                it = items[i]
+                it.d_in, it.n, it.dtype, it.error_bound = x.data_ptr(), x.numel(), _dt(x.dtype), ebs[i]
+                it.d_bin_index, it.d_dc, it.d_ac_exact = outs[i]["bin_index"].data_ptr(), outs[i]["dc"].data_ptr(), outs[i]["ac_exact"].data_ptr()
+                it.d_scaled = scaled[i].data_ptr() if (scaled is not None and scaled[i] is not None) else None
+            prepared = (k, items, (CompressInfo * max(k, 1))(), outs, (xs, scaled))       # (keeps the tensors alive)
+        k, items, infos, outs, _ = prepared
+        self._check(self.lib.dctzhip_compress_batch(self.h, k, items, mode, infos), "dctzhip_compress_batch")
+        return outs, [infos[i] for i in range(k)], prepared
+
+    def decompress_batch(self, outs, cnts, ns, dtypes, ebs, sfs, mode=EC, qtables=None, dsts=None, prepared=None, check=True):
+        """The decode side of a batch.  Returns (dsts, status, prepared); raises on an under-run unless check=False."""
+        t = self.torch
+        self._bind_stream()
+        if prepared is None:
+            k = len(outs)
+            ebs = [float(ebs)] * k if not hasattr(ebs, "__len__") else [float(e) for e in ebs]
+            if dsts is None:
+                dsts = [t.empty(int(ns[i]), dtype=dtypes[i], device=self.device) for i in range(k)]
+            items = (BatchDItem * max(k, 1))()
+            keep = []
+            for i in range(k):
+                it = items[i]
+                it.d_bin_index, it.d_dc, it.d_ac_exact = outs[i]["bin_index"].data_ptr(), outs[i]["dc"].data_ptr(), outs[i]["ac_exact"].data_ptr()
+                it.ac_count, it.n, it.dtype, it.error_bound, it.sf = int(cnts[i]), int(ns[i]), _dt(dtypes[i]), ebs[i], float(sfs[i])
+                it.d_out = dsts[i].data_ptr()
+                if mode == QT:
+                    q = np.ascontiguousarray(qtables[i], dtype=np.float64 if dtypes[i] == t.float64 else np.float32)
+                    assert q.size == 64
+                    keep.append(q)
+                    it.qtable_host = q.ctypes.data
+            prepared = (k, items, (C.c_int * max(k, 1))(), dsts, (outs, keep))
+        k, items, status, dsts, _ = prepared
+        rc = self.lib.dctzhip_decompress_batch(self.h, k, items, mode, status)
+        if check:
+            self._check(rc, "dctzhip_decompress_batch")
+        return dsts, [status[i] for i in range(k)], prepared
+
+    def batch_timings(self):
+        """Device time of the last batch call per element-type sequence: {"f32": {...}, "f64": {...}} (profiling on)."""
+        tt = (Timings * 2)()
+        self._check(self.lib.dctzhip_last_batch_timings(self.h, tt), "last_batch_timings")
+        return {name: {"stats_ms": tt[i].stats_ms, "main_ms": tt[i].main_ms, "tail_ms": tt[i].tail_ms, "total_ms": tt[i].total_ms}
+                for i, name in ((F32, "f32"), (F64, "f64"))}
 
     # ---- multi-dimensional blocks (include/dctz_hip.h: 8 x 8 tiles of a 2-D array, 4 x 4 x 4 tiles of a 3-D array) ----
     def nd_blocks(self, shape):

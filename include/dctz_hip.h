@@ -172,6 +172,48 @@ int dctzhip_decompress(dctzhip_ctx *ctx, const void *d_bin_index, const float *d
                        const void *qtable_host, size_t n, int dtype,
                        double error_bound, double sf, int mode, void *d_out);
 
+/* ---- batches of arrays ------------------------------------------------------ */
+/* The reference's own workloads are LISTS of small arrays, one dctz_compress() call and one process each
+ * (tests/test-dctz.sh:13-56 over tests/list-msst19.txt:1-6: 12 960 ... 37 024 doubles; tests/list-CESM-ATM-tylor.txt:1-5).
+ * On a GPU one such call is four or five launches and a host hand-off around a few microseconds of kernel work.  A batch
+ * runs k arrays -- own element type, error bound, buffers and results each; nothing in the reference couples two arrays
+ * (own calc_data_stat, sf, bin ranges, tot_AC_exact_count, QT table: dctz-comp-lib.c:186 onwards) -- through ONE launch
+ * sequence per element type with ONE hand-off.  Every array's outputs (streams, scaled copy, *info) are bit for bit
+ * those of its own dctzhip_compress() / dctzhip_decompress() call.  Arrays of 2^24 elements or more are handed to the
+ * single-array path inside the call (their kernels dwarf the launch cost, and that path saves the statistics pass).
+ * Fields have the meaning of the same-named arguments of dctzhip_compress / dctzhip_decompress. */
+typedef struct {
+  const void *d_in;          /* n elements of dtype, device, 16-byte aligned; not modified */
+  size_t n;
+  int dtype;                 /* DCTZHIP_F32 | DCTZHIP_F64, per array */
+  double error_bound;        /* per array */
+  void *d_bin_index;         /* n bytes out */
+  float *d_dc;               /* ceil(n / 64) floats out */
+  float *d_ac_exact;         /* capacity n floats out */
+  void *d_scaled;            /* optional: x / sf (dctz-comp-lib.c:193-216); may be NULL, may alias d_in */
+} dctzhip_batch_citem;
+typedef struct {
+  const void *d_bin_index;
+  const float *d_dc;
+  const float *d_ac_exact;
+  uint32_t ac_count;         /* header.tot_AC_exact_count of this array */
+  const void *qtable_host;   /* QT: 64 values in the data type, host memory; EC: NULL */
+  size_t n;
+  int dtype;
+  double error_bound;
+  double sf;                 /* header scaling factor of this array */
+  void *d_out;               /* n elements out */
+} dctzhip_batch_ditem;
+/* infos: k entries (may be NULL).  On return every infos[i] is filled; outputs are complete in STREAM order. */
+int dctzhip_compress_batch(dctzhip_ctx *ctx, int k, const dctzhip_batch_citem *items, int mode, dctzhip_cinfo *infos);
+/* status: k entries (may be NULL): DCTZHIP_OK, or DCTZHIP_E_ARG for an array whose bin_index flags more exact coefficients
+ * than its ac_count provides (the call then returns DCTZHIP_E_ARG; the other arrays are reconstructed all the same). */
+int dctzhip_decompress_batch(dctzhip_ctx *ctx, int k, const dctzhip_batch_ditem *items, int mode, int *status);
+/* Device time of the last batch call per element-type sequence, t[DCTZHIP_F32] and t[DCTZHIP_F64] (profiling on):
+ * stats_ms = statistics + scaling factors (decode: flag counts), main_ms = k_compress_batch / k_decompress_batch,
+ * tail_ms = remainder blocks + QT maxima + list placement + scaled copies. */
+int dctzhip_last_batch_timings(dctzhip_ctx *ctx, dctzhip_timings t[2]);
+
 /* ---- multi-dimensional blocks (optional mode) ------------------------------ */
 /* SURVEY section 8 f4.  NOT a path of the reference's library, which treats every array as flat
  * (dctz-test.c:77-91); the hint is its stand-alone experiment dct-fftw-test.c:74-97 (FFTW_REDFT10 /
