@@ -25,6 +25,11 @@ pre-zlib streams to rank 0 over RCCL (dctzhip_comm_gather) -- INSIDE the step
 `--plumbing-only`: the launcher, the rendezvous and the gather alone (gloo, synthetic byte
 streams, no kernels, no GPU, no `value`): what the CPU test of the N > 1 path runs.
 
+`--config c1|c2|c3|c4|c5` selects one of BASELINE.json's five configurations at its own size (default c4 = the headline:
+the line's shape is the same for all of them).  c5 is a LIST of arrays (the six list-msst19 lengths in fp64 and the five
+CESM-sized fp32 fields, error bounds 1e-3 .. 1e-6 each): its step is one dctzhip_compress_batch + one
+dctzhip_decompress_batch over the whole list, and the line also carries the same list done one call per array ("looped").
+
 Prints ONE JSON line on rank 0.
 """
 import argparse
@@ -47,9 +52,11 @@ def parse(argv=None):
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200, help="timed steps (0.5 ms each: the default is a tenth of a second of GPU time)")
     ap.add_argument("--warmup", type=int, default=20, help="untimed steps first (clocks and caches settle over the first dozens of steps)")
+    ap.add_argument("--config", choices=["c1", "c2", "c3", "c4", "c5"], default="c4",
+                    help="BASELINE.json configuration (c4 = the headline shard; --n / --eb / --mode / --dtype vary c3 / c4 only)")
     ap.add_argument("--n", type=int, default=512, help="volume edge (512 -> 1 GiB fp64 shard)")
-    ap.add_argument("--eb", type=float, default=1e-3)
-    ap.add_argument("--mode", choices=["ec", "qt"], default="ec")
+    ap.add_argument("--eb", type=float, default=None)
+    ap.add_argument("--mode", choices=["ec", "qt"], default=None)
     ap.add_argument("--dtype", choices=["f64", "f32"], default="f64")
     ap.add_argument("--plumbing-only", action="store_true", help="launcher + rendezvous + gather on gloo; no kernels, no value")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -57,7 +64,43 @@ def parse(argv=None):
     ap.add_argument("--no-speculation", action="store_true", help="always run the separate statistics pass first")
     ap.add_argument("--cpu-sample", type=int, default=1 << 27, help="elements of the shard the CPU oracle is timed on")
     ap.add_argument("--cpu-repeats", type=int, default=4, help="passes of the CPU oracle over the sample (about 10 s in all)")
-    return ap.parse_args(argv)
+    a = ap.parse_args(argv)
+    if a.mode is None:
+        a.mode = "qt" if a.config == "c3" else "ec"
+    if a.eb is None:
+        a.eb = 1e-4 if a.config == "c2" else 1e-3
+    if a.config == "c2":
+        a.dtype = "f32"
+    elif a.config in ("c1", "c5"):
+        a.dtype = "f64"
+    return a
+
+
+def workload(a, rank):
+    """The arrays of one rank for --config: (name, [host arrays], [error bounds])."""
+    import numpy as np
+    from tests import workloads as W
+    if a.config == "c1":
+        return ("C1: 2^20 uniform[0,1) doubles (default_rng(12345+rank)), EC eb=1e-3 (91.5 % of the coefficients stored exactly)",
+                [np.random.default_rng(12345 + rank).random(1 << 20)], [a.eb])
+    if a.config == "c2":
+        return ("C2: CESM-ATM stand-in, smooth 1800x3600 fp32 field (seed 2024+rank), EC eb=1e-4", [W.c2(2024 + rank)], [a.eb])
+    if a.config == "c5":
+        xs, ebs = [], []
+        for i, n in enumerate(W.MSST19_LENGTHS):
+            for eb in (1e-3, 1e-4, 1e-5, 1e-6):
+                xs.append(W.c5_fp64(n, 100 + i + 1000 * rank)); ebs.append(eb)
+        for f in range(5):                                     # tests/list-CESM-ATM-tylor.txt:1-5: five 3600 x 1800 fp32 fields
+            x = W.c2(3000 + f + 1000 * rank)
+            for eb in (1e-3, 1e-4, 1e-5, 1e-6):
+                xs.append(x); ebs.append(eb)
+        return ("C5: list-msst19 lengths (6 fp64 arrays of 12 960 .. 37 024) + 5 CESM-sized fp32 fields (1800x3600), "
+                f"eb 1e-3 .. 1e-6 each = {len(xs)} arrays, {a.mode.upper()}; step = ONE dctzhip_compress_batch + ONE dctzhip_decompress_batch",
+                xs, ebs)
+    np_dtype = np.float64 if a.dtype == "f64" else np.float32
+    tag = "C3" if a.config == "c3" else "C4 shard per GPU"
+    return (f"{tag}: synthetic {a.dtype} {a.n}^3 volume (C3 formula, seed 512+rank), {a.mode.upper()} eb={a.eb:g}",
+            [W.c3(a.n, seed=512 + rank, dtype=np_dtype)], [a.eb])
 
 
 # ------------------------------------------------------------------ launcher --
@@ -128,7 +171,6 @@ def run_rank(a, rank, local_rank, world):
     import torch
     import dctz_amd
     from dctz_amd import shard
-    from tests import workloads as W
 
     dist = None
     if world > 1:
@@ -150,30 +192,46 @@ def run_rank(a, rank, local_rank, world):
     else:
         devices = [me]
 
-    np_dtype = np.float64 if a.dtype == "f64" else np.float32
-    t_dtype = torch.float64 if a.dtype == "f64" else torch.float32
     mode = dctz_amd.QT if a.mode == "qt" else dctz_amd.EC
-    x_host = W.c3(a.n, seed=512 + rank, dtype=np_dtype)
-    n = x_host.size
-    es = x_host.itemsize
-    x = torch.from_numpy(x_host).to(ctx.device)
-    out = ctx.alloc_outputs(n)
-    rec = torch.empty(n, dtype=t_dtype, device=ctx.device)
-    ctx.reserve(n, t_dtype, mode)
+    qt = mode == dctz_amd.QT
+    wl_name, xs_host, ebs = workload(a, rank)
+    many = len(xs_host) > 1                                # a list of arrays: the batch entry points
+    tdt = [torch.float64 if x.dtype == np.float64 else torch.float32 for x in xs_host]
+    uniq = {}                                              # (the same field under several bounds is uploaded once)
+    xs = []
+    for x in xs_host:
+        if id(x) not in uniq:
+            uniq[id(x)] = torch.from_numpy(x).to(ctx.device)
+        xs.append(uniq[id(x)])
+    ns = [x.size for x in xs_host]
+    in_bytes = sum(x.size * x.itemsize for x in xs_host)   # input bytes of one step on this rank
+    outs = [ctx.alloc_outputs(n) for n in ns]
+    recs = [torch.empty(n, dtype=d, device=ctx.device) for n, d in zip(ns, tdt)]
+    if not many:
+        ctx.reserve(ns[0], tdt[0], mode)
     if a.no_speculation:
         ctx.set_speculation(False)
-    qt = mode == dctz_amd.QT
+    x, out, rec, n, es = xs[0], outs[0], recs[0], ns[0], xs_host[0].itemsize
+    state = {}
 
     def step():
-        _, info = ctx.compress(x, a.eb, mode, out=out)
-        ctx.decompress(out, info.cnt, n, t_dtype, a.eb, info.sf, mode, qtable=info.qtable if qt else None, dst=rec)
-        return info
+        if not many:
+            _, info = ctx.compress(x, ebs[0], mode, out=out)
+            ctx.decompress(out, info.cnt, n, tdt[0], ebs[0], info.sf, mode, qtable=info.qtable if qt else None, dst=rec)
+            return [info]
+        _, infos, state["cp"] = ctx.compress_batch(xs, ebs, mode, outs=outs, prepared=state.get("cp"))
+        if "dp" not in state:                              # (the list is compressed again every step to the same streams)
+            _, _, state["dp"] = ctx.decompress_batch(outs, [i.cnt for i in infos], ns, tdt, ebs, [i.sf for i in infos], mode,
+                                                     qtables=[np.array(i.qtable[:]) for i in infos] if qt else None, dsts=recs)
+        else:
+            ctx.decompress_batch(None, None, None, None, None, None, mode, prepared=state["dp"])
+        return infos
 
-    info = None
+    infos = None
     for _ in range(a.warmup):
-        info = step()
-    if info is None:
-        info = step()
+        infos = step()
+    if infos is None:
+        infos = step()
 
     def barrier():
         torch.cuda.synchronize()
@@ -185,14 +243,66 @@ def run_rank(a, rank, local_rank, world):
     barrier()
     t0 = time.perf_counter()
     for _ in range(a.steps):
-        info = step()
+        infos = step()
     barrier()
     elapsed = shard.max_over_ranks(time.perf_counter() - t0, ctx.device)
     ms_per_step = elapsed * 1e3 / a.steps
+    info = infos[0]
+
+    # ---- a list of arrays: the same list with one call per array (what the batch entry points replace) ----
+    looped = None
+    if many:
+        def loop_step():
+            for j in range(len(xs)):
+                _, ij = ctx.compress(xs[j], ebs[j], mode, out=outs[j])
+                ctx.decompress(outs[j], ij.cnt, ns[j], tdt[j], ebs[j], ij.sf, mode, qtable=ij.qtable if qt else None, dst=recs[j])
+        loop_step()
+        k_loop = max(3, min(a.steps, 20))
+        barrier()
+        l0 = time.perf_counter()
+        for _ in range(k_loop):
+            loop_step()
+        barrier()
+        l_ms = shard.max_over_ranks(time.perf_counter() - l0, ctx.device) * 1e3 / k_loop
+        looped = {"ms_per_step": l_ms, "value": in_bytes * world / (l_ms * 1e-3) / 1e9, "steps": k_loop, "speedup_of_the_batch": l_ms / ms_per_step,
+                  "note": "the same arrays, one dctzhip_compress + one dctzhip_decompress call per array"}
+
+        # the launch-bound part of the list by itself: the 24 small fp64 arrays, and those + ONE fp32 field at C2's bound
+        # (the list a single `tests/test-dctz.sh` + one CESM run amounts to), batch against one call per array
+        def sub(sel):
+            sx, se, so, sr = [xs[j] for j in sel], [ebs[j] for j in sel], [outs[j] for j in sel], [recs[j] for j in sel]
+            sn, sd = [ns[j] for j in sel], [tdt[j] for j in sel]
+            _, si, cp = ctx.compress_batch(sx, se, mode, outs=so)
+            _, _, dp = ctx.decompress_batch(so, [i.cnt for i in si], sn, sd, se, [i.sf for i in si], mode,
+                                            qtables=[np.array(i.qtable[:]) for i in si] if qt else None, dsts=sr)
+            def b_step():
+                ctx.compress_batch(None, None, mode, prepared=cp)
+                ctx.decompress_batch(None, None, None, None, None, None, mode, prepared=dp)
+            def l_step():
+                for j in sel:
+                    _, ij = ctx.compress(xs[j], ebs[j], mode, out=outs[j])
+                    ctx.decompress(outs[j], ij.cnt, ns[j], tdt[j], ebs[j], ij.sf, mode, qtable=ij.qtable if qt else None, dst=recs[j])
+            res = {}
+            for nm, fn, reps in (("batch", b_step, max(20, a.steps)), ("looped", l_step, max(5, min(a.steps, 20)))):
+                for _ in range(3):
+                    fn()
+                torch.cuda.synchronize()
+                q0 = time.perf_counter()
+                for _ in range(reps):
+                    fn()
+                torch.cuda.synchronize()
+                res[nm + "_ms"] = (time.perf_counter() - q0) * 1e3 / reps
+            sb = sum(ns[j] * xs_host[j].itemsize for j in sel)
+            res.update({"arrays": len(sel), "bytes": int(sb), "speedup_of_the_batch": res["looped_ms"] / res["batch_ms"],
+                        "batch_GBps": sb / (res["batch_ms"] * 1e-3) / 1e9, "looped_GBps": sb / (res["looped_ms"] * 1e-3) / 1e9})
+            return res
+        small = [j for j in range(len(xs)) if xs_host[j].itemsize == 8]
+        c2_like = [j for j in range(len(xs)) if xs_host[j].itemsize == 4 and ebs[j] == 1e-4][:1]
+        looped["subsets"] = {"msst19_24_small_fp64": sub(small), "msst19_24_plus_one_fp32_field_at_1e-4": sub(small + c2_like)}
 
     # ---- N > 1: the same K steps with the gather of the streams to rank 0 inside the step ----
     with_gather = None
-    if dist is not None:
+    if dist is not None and not many:
         ids = [dctz_amd.Context.comm_unique_id() if rank == 0 else None]
         dist.broadcast_object_list(ids, src=0)
         ctx.comm_create(rank, world, ids[0])
@@ -200,7 +310,7 @@ def run_rank(a, rank, local_rank, world):
         barrier()
         g0 = time.perf_counter()
         for _ in range(a.steps):
-            info = step()
+            info = step()[0]
             ctx.comm_gather(out, info.cnt, n, root=0)
         barrier()
         g_ms = shard.max_over_ranks(time.perf_counter() - g0, ctx.device) * 1e3 / a.steps
@@ -210,46 +320,84 @@ def run_rank(a, rank, local_rank, world):
     # ---- per-kernel durations (HIP events on the launch stream), same K steps --
     ctx.set_profiling(True)
     acc = {"c_stats": 0.0, "c_main": 0.0, "c_tail": 0.0, "d_pre": 0.0, "d_main": 0.0, "d_tail": 0.0}
+    seqs = {"f64": dict(acc), "f32": dict(acc)}                # a list: per element-type launch sequence
     t_c = t_d = 0.0
     for _ in range(a.steps):
         torch.cuda.synchronize()
         s0 = time.perf_counter()
-        _, info = ctx.compress(x, a.eb, mode, out=out)
+        if many:
+            _, infos, _ = ctx.compress_batch(None, None, mode, prepared=state["cp"])
+        else:
+            _, info = ctx.compress(x, ebs[0], mode, out=out)
         s1 = time.perf_counter()
-        tm = ctx.timings()
-        acc["c_stats"] += tm["stats_ms"]; acc["c_main"] += tm["main_ms"]; acc["c_tail"] += tm["tail_ms"]
+        if many:
+            bt = ctx.batch_timings()
+            for nm in seqs:
+                seqs[nm]["c_stats"] += bt[nm]["stats_ms"]; seqs[nm]["c_main"] += bt[nm]["main_ms"]; seqs[nm]["c_tail"] += bt[nm]["tail_ms"]
+        else:
+            tm = ctx.timings()
+            acc["c_stats"] += tm["stats_ms"]; acc["c_main"] += tm["main_ms"]; acc["c_tail"] += tm["tail_ms"]
         s2 = time.perf_counter()
-        ctx.decompress(out, info.cnt, n, t_dtype, a.eb, info.sf, mode, qtable=info.qtable if qt else None, dst=rec)
+        if many:
+            ctx.decompress_batch(None, None, None, None, None, None, mode, prepared=state["dp"])
+        else:
+            ctx.decompress(out, info.cnt, n, tdt[0], ebs[0], info.sf, mode, qtable=info.qtable if qt else None, dst=rec)
         s3 = time.perf_counter()
-        tm = ctx.timings()
-        acc["d_pre"] += tm["stats_ms"]; acc["d_main"] += tm["main_ms"]; acc["d_tail"] += tm["tail_ms"]
+        if many:
+            bt = ctx.batch_timings()
+            for nm in seqs:
+                seqs[nm]["d_pre"] += bt[nm]["stats_ms"]; seqs[nm]["d_main"] += bt[nm]["main_ms"]; seqs[nm]["d_tail"] += bt[nm]["tail_ms"]
+        else:
+            tm = ctx.timings()
+            acc["d_pre"] += tm["stats_ms"]; acc["d_main"] += tm["main_ms"]; acc["d_tail"] += tm["tail_ms"]
         t_c += s1 - s0; t_d += s3 - s2
     ctx.set_profiling(False)
-    for k in acc:
-        acc[k] /= a.steps
+    info = infos[0] if many else info
+
+    # algorithmic bytes per element: transform pass of compress reads s, writes 1 (bin) + 4/64 (DC) + 4p
+    # (AC_exact); decompress reads 1 + 4/64 + 4p, writes s.  A list: the arrays of the element type that carries most
+    # of the list's bytes (its launch sequence holds the dominant kernel)
+    def alg_bytes(js):
+        return sum(ns[j] * (xs_host[j].itemsize + 1.0 + 4.0 / 64.0 + 4.0 * infos_all[j].cnt / ns[j]) for j in js)
+    infos_all = infos if many else [info]
+    kern_name = {"c": "k_compress", "d": "k_decompress"}
+    if many:
+        by = {"f64": [j for j in range(len(xs)) if xs_host[j].itemsize == 8], "f32": [j for j in range(len(xs)) if xs_host[j].itemsize == 4]}
+        dom_seq = max(by, key=lambda nm: sum(ns[j] * xs_host[j].itemsize for j in by[nm]))
+        for nm in seqs:
+            for k in seqs[nm]:
+                seqs[nm][k] /= a.steps
+        acc = dict(seqs[dom_seq])
+        bytes_main = alg_bytes(by[dom_seq])
+        bytes_stats = sum(ns[j] * xs_host[j].itemsize for j in by[dom_seq])
+        kern_name = {"c": f"k_compress_batch<{'double' if dom_seq == 'f64' else 'float'}>", "d": f"k_decompress_batch<{'double' if dom_seq == 'f64' else 'float'}>"}
+        other = "f32" if dom_seq == "f64" else "f64"
+        kern_all = sum(seqs[nm][k] for nm in seqs for k in seqs[nm])
+    else:
+        for k in acc:
+            acc[k] /= a.steps
+        bytes_main = alg_bytes([0])
+        bytes_stats = n * es
+        kern_all = sum(acc.values())
     t_c = t_c * 1e3 / a.steps
     t_d = t_d * 1e3 / a.steps
 
     fused = bool(info.flags & dctz_amd.hip.INFO_STATS_FUSED)     # statistics computed inside k_compress (guess verified)
-    p = info.cnt / n                                            # exception fraction
-    # algorithmic bytes per element: transform pass of compress reads s,
-    # writes 1 (bin) + 4/64 (DC) + 4p (AC_exact); decompress reads 1 + 4/64 + 4p, writes s
-    bytes_main = n * (es + 1.0 + 4.0 / 64.0 + 4.0 * p)
-    bytes_stats = n * es
+    p = sum(i.cnt for i in infos_all) / float(sum(ns))          # exception fraction (of the whole list)
     ach_c = bytes_main / (acc["c_main"] * 1e-3) / 1e9
     ach_d = bytes_main / (acc["d_main"] * 1e-3) / 1e9
     ach_s = bytes_stats / (acc["c_stats"] * 1e-3) / 1e9
-    dominant = "k_compress" if acc["c_main"] >= acc["d_main"] else "k_decompress"
+    dominant = "c" if acc["c_main"] >= acc["d_main"] else "d"
 
     # HBM traffic of the dominant kernel: NOT measured in this run (PMC counters need rocprofv3 passes of their own);
     # the committed record of the same command on the same build is quoted with its source, or null
     traffic, traffic_source = None, None
     try:
-        src = os.path.join("profiles", "r02_pmc_traffic.json")
+        src = os.path.join("profiles", "r03_pmc_traffic.json")
         rec_t = json.load(open(os.path.join(ROOT, src)))
-        key = f"{a.dtype}_{a.n}_{a.mode}_{a.eb:g}"
-        if key in rec_t.get(dominant, {}):
-            traffic = rec_t[dominant][key]["hbm_bytes_per_launch"]
+        key = f"{a.config}_{a.dtype}_{a.n}_{a.mode}_{a.eb:g}"
+        if key in rec_t.get(kern_name[dominant], {}):
+            traffic = rec_t[kern_name[dominant]][key]["hbm_bytes_per_launch"]
             traffic_source = src + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, gfx950 correction applied)"
     except (OSError, ValueError):
         pass
@@ -257,7 +405,7 @@ def run_rank(a, rank, local_rank, world):
     # ---- the entropy stage on the device, rank 0, outside the timed region: what
     # it costs to turn the streams of the last compress call into the container's three zlib sections in HBM ----
     entropy = None
-    if rank == 0 and not a.no_entropy_stage:
+    if rank == 0 and not a.no_entropy_stage and not many:
         try:
             cnt = int(info.cnt)
             secs = [out["bin_index"], out["dc"], out["ac_exact"][:cnt]]
@@ -281,60 +429,74 @@ def run_rank(a, rank, local_rank, world):
     cpu = None
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         from oracle import oracle as O
-        m = min(n, a.cpu_sample)
-        xs = x_host[:m]
         omode = O.QT if a.mode == "qt" else O.EC
+        # the sample: the rank-0 arrays themselves (each bounded by --cpu-sample elements), passed over until about
+        # ten seconds of CPU work are on the clock (a 1 GiB shard: --cpu-repeats passes)
+        samp = [xh[:min(xh.size, a.cpu_sample)] for xh in xs_host]
+        s_bytes = sum(v.size * v.itemsize for v in samp)
         tc = td = 0.0
-        reps = max(1, a.cpu_repeats)
-        for _ in range(reps):
-            c0 = time.perf_counter()
-            c = O.compress(xs, a.eb, omode, O.FAST)
-            c1 = time.perf_counter()
-            O.decompress(c, O.FAST)
-            c2 = time.perf_counter()
-            tc += c1 - c0
-            td += c2 - c1
+        reps = 0
+        while True:
+            for v, eb in zip(samp, ebs):
+                c0 = time.perf_counter()
+                c = O.compress(v, eb, omode, O.FAST)
+                c1 = time.perf_counter()
+                O.decompress(c, O.FAST)
+                c2 = time.perf_counter()
+                tc += c1 - c0
+                td += c2 - c1
+            reps += 1
+            if (reps >= max(1, a.cpu_repeats) and tc + td >= 3.0) or tc + td >= 20.0 or reps >= 4000:
+                break
         # the same port on ALL host cores at once ("all cores via one process per shard", core count stated):
-        # contiguous block-aligned slices of the sample, one thread each (the C oracle runs outside the GIL)
+        # contiguous block-aligned slices of the sample, one thread each (the C oracle runs outside the GIL); a list of
+        # arrays: whole arrays dealt round to the threads
         from concurrent.futures import ThreadPoolExecutor
         nthr = max(1, len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1))
-        cuts = [(m * i // nthr) // 64 * 64 for i in range(nthr)] + [m]
+        if many:
+            jobs = [(v, eb) for v, eb in zip(samp, ebs)]
+        else:
+            m = samp[0].size
+            cuts = [(m * i // nthr) // 64 * 64 for i in range(nthr)] + [m]
+            jobs = [(samp[0][cuts[i]:cuts[i + 1]], ebs[0]) for i in range(nthr)]
 
-        def one(i):
-            sl = xs[cuts[i]:cuts[i + 1]]
-            if sl.size:
-                O.decompress(O.compress(sl, a.eb, omode, O.FAST), O.FAST)
+        def one(job):
+            if job[0].size:
+                O.decompress(O.compress(job[0], job[1], omode, O.FAST), O.FAST)
 
         with ThreadPoolExecutor(nthr) as ex:
-            list(ex.map(one, range(nthr)))                  # warm the threads / page in
+            list(ex.map(one, jobs))                         # warm the threads / page in
             m0 = time.perf_counter()
-            list(ex.map(one, range(nthr)))
+            list(ex.map(one, jobs))
             tm_all = time.perf_counter() - m0
-        cpu = {"value": reps * m * es / (tc + td) / 1e9, "unit": "GB/s (input bytes, compress+decompress)",
+        cpu = {"value": reps * s_bytes / (tc + td) / 1e9, "unit": "GB/s (input bytes, compress+decompress)",
                "cores": 1, "kind": "port",
-               "sample": f"first {m} elements of the rank-0 shard ({m * es / 2**20:.0f} MiB) x {reps} passes, oracle FAST "
+               "sample": f"the rank-0 workload ({len(samp)} array(s), {s_bytes / 2**20:.1f} MiB) x {reps} passes, oracle FAST "
                          f"flow, compress {tc:.2f} s + decompress {td:.2f} s in all; zlib excluded on both sides",
-               "compress_GBps": reps * m * es / tc / 1e9, "decompress_GBps": reps * m * es / td / 1e9,
-               "all_cores": {"cores": nthr, "host_cpu_count": os.cpu_count(), "value": m * es / tm_all / 1e9,
-                             "note": "same port, one pass, the sample cut into one slice per available core (each slice its own sf)"}}
+               "compress_GBps": reps * s_bytes / tc / 1e9, "decompress_GBps": reps * s_bytes / td / 1e9,
+               "all_cores": {"cores": nthr, "host_cpu_count": os.cpu_count(), "value": s_bytes / tm_all / 1e9,
+                             "note": "same port, one pass: " + ("whole arrays dealt to the threads" if many else
+                                     "the sample cut into one slice per available core (each slice its own sf)")}}
 
     if rank == 0:
-        value = n * es * world / (ms_per_step * 1e-3) / 1e9
-        kern_sum = acc["c_stats"] + acc["c_main"] + acc["c_tail"] + acc["d_pre"] + acc["d_main"] + acc["d_tail"]
-        dom = {"k_compress": (acc["c_main"], ach_c), "k_decompress": (acc["d_main"], ach_d)}[dominant]
+        value = in_bytes * world / (ms_per_step * 1e-3) / 1e9
+        kern_sum = kern_all
+        dom = {"c": (acc["c_main"], ach_c), "d": (acc["d_main"], ach_d)}[dominant]
+        headline = a.config == "c4" and a.dtype == "f64" and a.mode == "ec" and a.eb == 1e-3
         line = {
-            "metric": "compress+decompress GB/s (input bytes), fp64 1e-3 EC" if (a.dtype == "f64" and a.mode == "ec")
-                      else f"compress+decompress GB/s (input bytes), {a.dtype} {a.eb:g} {a.mode.upper()}",
+            "metric": "compress+decompress GB/s (input bytes), fp64 1e-3 EC" if headline
+                      else f"compress+decompress GB/s (input bytes), config {a.config}: {a.dtype if not many else 'fp64+fp32 list'} "
+                           f"{a.mode.upper()}" + ("" if many else f" eb={a.eb:g}"),
             "value": value, "unit": "GB/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": a.dtype, "data": "synthetic",
-            "config": {"workload": f"C4 shard per GPU: synthetic {a.dtype} {a.n}^3 volume (C3 formula, seed 512+rank), "
-                                   f"{a.mode.upper()} eb={a.eb:g}; step = dctzhip_compress + dctzhip_decompress, "
-                                   "inputs resident in HBM",
-                       "elements_per_gpu": n, "exception_fraction": p, "parallelism": f"shard-per-gpu x{world}"},
+            "dtype": a.dtype if not many else "f64+f32", "data": "synthetic",
+            "config": {"workload": wl_name + ("; step = dctzhip_compress + dctzhip_decompress" if not many else "") + ", inputs resident in HBM",
+                       "config": a.config, "arrays_per_gpu": len(xs), "elements_per_gpu": int(sum(ns)), "bytes_per_gpu": int(in_bytes),
+                       "exception_fraction": p, "parallelism": f"shard-per-gpu x{world}"},
             "ranks_seen": len({d["rank"] for d in devices}), "devices": devices,
-            "pct_hbm_peak_input": 100.0 * (n * es / (ms_per_step * 1e-3) / 1e9) / HBM_PEAK_GBPS,
-            "roofline": {"bound": "hbm", "kernel": dominant + " (the longer of the two big kernels in THIS run)",
+            "pct_hbm_peak_input": 100.0 * (in_bytes / (ms_per_step * 1e-3) / 1e9) / HBM_PEAK_GBPS,
+            "roofline": {"bound": "hbm", "kernel": kern_name[dominant] + " (the longer of the two big kernels in THIS run"
+                                                   + (f", launch sequence of the {dom_seq} arrays: they carry most of the list's bytes)" if many else ")"),
                          "achieved": dom[1], "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": dom[1] / HBM_PEAK_GBPS,
                          "traffic": traffic, "traffic_source": traffic_source,
                          "algorithmic_bytes_per_launch": bytes_main, "avg_launch_ms": dom[0],
@@ -352,11 +514,14 @@ def run_rank(a, rank, local_rank, world):
             # running (early hand-off) the unprofiled step can be SHORTER than their sum -- the difference is then negative
             "host_gap_ms": ms_per_step - kern_sum,
             "host_call_ms": {"compress": t_c, "decompress": t_d},
-            "compress_GBps_input": n * es / (t_c * 1e-3) / 1e9,
-            "decompress_GBps_input": n * es / (t_d * 1e-3) / 1e9,
+            "compress_GBps_input": in_bytes / (t_c * 1e-3) / 1e9,
+            "decompress_GBps_input": in_bytes / (t_d * 1e-3) / 1e9,
             "cpu_baseline": cpu,
             "entropy_stage": entropy,
         }
+        if many:
+            line["kernels"]["other_sequence"] = {"element_type": other, **seqs[other]}
+            line["looped"] = looped
         if with_gather is not None:
             line["with_gather"] = with_gather
         print(json.dumps(line), flush=True)

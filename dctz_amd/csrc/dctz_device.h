@@ -257,7 +257,8 @@ struct BatchResC {
 struct BatchResQ { unsigned long long qraw[64]; };        // QT: per-position maxima, raw bits of T
 struct BatchResD { unsigned total, error; };              // decode: flags found / 2 = more than ac_count provides
 struct BatchFin {
-  HostBox* box;                    // NULL: this sequence does not publish (another one of the call does, later)
+  unsigned long long* word;        // mailbox word (device view) this sequence publishes `seq` into; NULL: it does not publish
+                                   // (a later sequence of its chain does)
   unsigned long long seq;
   void* res;                       // BatchResC[k] / BatchResD[k] (device view of the host table)
   BatchResQ* resq;                 // QT only

@@ -1180,21 +1180,39 @@ __global__ __launch_bounds__(SWG) void k_qt_max_batch(const BatchFwd<T>* items, 
 template <typename T>
 __device__ __forceinline__ void batch_finish_compress(const BatchFwd<T>* items, unsigned k, const double* bstats, const BatchFin& fin, bool qt) {
   BatchResC* res = reinterpret_cast<BatchResC*>(fin.res);
-  for (unsigned i = threadIdx.x; i < k; i += blockDim.x) {
+  auto put = [&](unsigned i, unsigned cnt) {
     const BatchFwd<T>& it = items[i];
-    unsigned cnt = 0;
-    for (unsigned l = 0; l < it.nlists; l++) cnt += it.p.tile_cnt[l];               // tot_AC_exact_count (:478-544)
     BatchResC r;
     r.sf_used = it.p.guess->sf; r.fast_used = it.p.guess->fast_sf;
     r.stats[0] = bstats[3 * i]; r.stats[1] = bstats[3 * i + 1]; r.stats[2] = bstats[3 * i + 2];
     r.cnt = cnt; r.error = 0; r.pad = 0; r.q0 = it.p.ctl->q0;
     res[i] = r;
+  };
+  // tot_AC_exact_count (:478-544) of every array = the sum of its list lengths: a wave per array for the long ones (a
+  // thread alone would walk some thousand words one round trip after the other), a thread per array while the lists are
+  // few (small arrays: one list per tile)
+  constexpr unsigned SHORT = 16;
+  const unsigned lane = threadIdx.x & 63u, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
+  for (unsigned i = wave; i < k; i += nwaves) {
+    const unsigned nl = items[i].nlists;
+    if (nl <= SHORT) continue;
+    unsigned c = 0;
+    for (unsigned l = lane; l < nl; l += 64u) c += items[i].p.tile_cnt[l];
+    c = (unsigned)__builtin_amdgcn_readlane((int)wave_incl_scan(c), 63);
+    if (lane == 0) put(i, c);
+  }
+  for (unsigned i = threadIdx.x; i < k; i += blockDim.x) {
+    const unsigned nl = items[i].nlists;
+    if (nl > SHORT) continue;
+    unsigned c = 0;
+    for (unsigned l = 0; l < nl; l++) c += items[i].p.tile_cnt[l];
+    put(i, c);
   }
   if (qt)
     for (unsigned e = threadIdx.x; e < k * 64u; e += blockDim.x) fin.resq[e >> 6].qraw[e & 63u] = items[e >> 6].p.ctl->qraw[e & 63u];
   __threadfence_system();
   __syncthreads();
-  if (threadIdx.x == 0 && fin.box != nullptr) box_publish(&fin.box->seq_done, fin.seq);
+  if (threadIdx.x == 0 && fin.word != nullptr) box_publish(fin.word, fin.seq);
 }
 
 template <typename T, int MODE>
@@ -1231,16 +1249,33 @@ __global__ __launch_bounds__(SWG) void k_count_batch(const BatchInv<T>* items, c
 template <typename T>
 __device__ __forceinline__ void batch_finish_decompress(const BatchInv<T>* items, unsigned k, const BatchFin& fin) {
   BatchResD* res = reinterpret_cast<BatchResD*>(fin.res);
+  auto put = [&](unsigned i, unsigned all) {
+    BatchResD r;
+    r.total = all;
+    r.error = all > items[i].p.ac_count ? 2u : 0u;   // the stream promises more exact coefficients than the caller provides
+    res[i] = r;
+  };
+  // (a wave per array with many workgroups, a thread per array otherwise: as batch_finish_compress)
+  constexpr unsigned SHORT = 16;
+  const unsigned lane = threadIdx.x & 63u, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
+  for (unsigned i = wave; i < k; i += nwaves) {
+    const unsigned nw = items[i].p.nwg;
+    if (nw <= SHORT) continue;
+    unsigned c = 0;
+    for (unsigned w = lane; w < nw; w += 64u) c += items[i].p.wg_cnt[w];
+    c = (unsigned)__builtin_amdgcn_readlane((int)wave_incl_scan(c), 63);
+    if (lane == 0) put(i, c + *items[i].rem_cnt);
+  }
   for (unsigned i = threadIdx.x; i < k; i += blockDim.x) {
-    const BatchInv<T>& it = items[i];
-    unsigned all = *it.rem_cnt;
-    for (unsigned w = 0; w < it.p.nwg; w++) all += it.p.wg_cnt[w];
-    res[i].total = all;
-    res[i].error = all > it.p.ac_count ? 2u : 0u;    // the stream promises more exact coefficients than the caller provides
+    const unsigned nw = items[i].p.nwg;
+    if (nw > SHORT) continue;
+    unsigned all = *items[i].rem_cnt;
+    for (unsigned w = 0; w < nw; w++) all += items[i].p.wg_cnt[w];
+    put(i, all);
   }
   __threadfence_system();
   __syncthreads();
-  if (threadIdx.x == 0 && fin.box != nullptr) box_publish(&fin.box->seq_done, fin.seq);
+  if (threadIdx.x == 0 && fin.word != nullptr) box_publish(fin.word, fin.seq);
 }
 
 template <typename T, int MODE>

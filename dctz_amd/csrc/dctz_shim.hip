@@ -118,6 +118,8 @@ struct dctzhip_ctx {
   unsigned char* b_res_hdev = nullptr;
   size_t b_res_cap = 0;
   void* rtab_cache[2][64] = {};     // remainder-block tables per (dtype, length), device
+  hipStream_t b_stream = nullptr;   // a mixed batch runs its fp32 sequences here, beside the fp64 ones on the context's stream
+  hipEvent_t b_fork = nullptr, b_join = nullptr;
   hipEvent_t b_ev[2][5] = {};       // profiling: per element-type sequence of the last batch call
   dctzhip_timings b_last[2] = {};
   int b_have_timings = 0;
@@ -186,7 +188,7 @@ extern "C" int dctzhip_ctx_create(dctzhip_ctx** out, int device) {
   HIPCHK(nullptr, hipMalloc(&c->rtab, sizeof(double) * RTAB_SIZE));
   HIPCHK(nullptr, hipMalloc(&c->qtab, sizeof(double) * 64));
   HIPCHK(nullptr, hipMalloc(&c->ctl, sizeof(Ctl)));
-  HIPCHK(nullptr, hipMalloc(&c->part, sizeof(double) * 3 * PART_SLOTS));
+  HIPCHK(nullptr, hipMalloc(&c->part, sizeof(double) * 3 * PART_SLOTS * 2));      // (second half: the second chain of a mixed batch)
   HIPCHK(nullptr, hipMalloc(&c->stats_out, sizeof(double) * 4));
   HIPCHK(nullptr, hipHostMalloc(&c->h_pin, PIN_BYTES, hipHostMallocDefault));
   // the mailbox needs fine-grained (coherent) pinned host memory that kernels can write; where the
@@ -240,6 +242,9 @@ extern "C" void dctzhip_ctx_destroy(dctzhip_ctx* c) {
   }
   for (int i = 0; i < 6; i++) if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
   for (int q = 0; q < 2; q++) for (int i = 0; i < 5; i++) if (c->b_ev[q][i]) (void)hipEventDestroy(c->b_ev[q][i]);
+  if (c->b_stream) { (void)hipStreamSynchronize(c->b_stream); (void)hipStreamDestroy(c->b_stream); }
+  if (c->b_fork) (void)hipEventDestroy(c->b_fork);
+  if (c->b_join) (void)hipEventDestroy(c->b_join);
   { void* bb[] = {c->b_ctl, c->b_guess, c->b_stats, c->b_remcnt, c->b_blob_dev};
     for (void* b : bb) if (b) (void)hipFree(b);
     for (int q = 0; q < 2; q++) for (int l = 0; l < 64; l++) if (c->rtab_cache[q][l]) (void)hipFree(c->rtab_cache[q][l]);
@@ -523,9 +528,10 @@ static int regrow(dctzhip_ctx* c, P** ptr, size_t* cap, size_t need, size_t elem
 }
 
 // compress = true: scratch of the compress stage (workgroup-local lists); else decode (per-tile counts only)
-static int ensure_scratch(dctzhip_ctx* c, size_t n, int dtype, int mode, bool compress = true) {
+static int ensure_scratch(dctzhip_ctx* c, size_t n, int dtype, int mode, bool compress = true, size_t min_entries = 0) {
   const size_t ntiles = (n / 64 + TILE_BLKS - 1) / TILE_BLKS;
-  const size_t entries = (ntiles > (size_t)PART_SLOTS ? ntiles : (size_t)PART_SLOTS) + 2;   // lists (<= grid + 1) or tiles, + the total
+  size_t entries = (ntiles > (size_t)PART_SLOTS ? ntiles : (size_t)PART_SLOTS) + 2;   // lists (<= grid + 1) or tiles, + the total
+  if (entries < min_entries) entries = min_entries;
   int rc;
   {
     size_t cap = c->tile_cap;
@@ -1366,6 +1372,17 @@ struct SeqC {                       // one launch sequence of a compress batch: 
   size_t tiles_total = 0, lists_total = 0, parts_total = 0;
   unsigned grid_main = 0, grid_list = 0, grid_scale = 0, grid_stats = 0, nrem = 0;
   size_t blob_off = 0, blob_bytes = 0, item_off = 0;    // item_off: first array of this sequence in b_ctl / b_guess / b_stats / results
+  int chain = 0;
+};
+// A mixed batch runs as two CHAINS of sequences side by side -- fp64 on the context's stream, fp32 on a second one --
+// each with its own region of the scratch buffers and its own mailbox word; sequences of one chain follow each other
+// and reuse the chain's region.
+struct Chain {
+  hipStream_t s = nullptr;
+  size_t tile_off = 0, list_off = 0, part_off = 0, slot_off = 0;      // first tile slot / list-length entry / partial slot / overflow strip
+  volatile unsigned long long* word = nullptr;                         // host view of the mailbox word the chain's last sequence publishes
+  volatile unsigned long long* word_dev = nullptr;
+  int last = -1;                                                       // index of the chain's last sequence
 };
 struct SeqD {
   std::vector<int> idx;
@@ -1374,14 +1391,37 @@ struct SeqD {
   size_t tiles_total = 0, wgs_total = 0;
   unsigned grid_cnt = 0, grid_main = 0, nrem = 0;
   size_t blob_off = 0, blob_bytes = 0, item_off = 0;
+  int chain = 0;
 };
 }  // namespace
 
+// fork: the second chain's stream starts behind everything queued on the context's stream so far
+static int chains_fork(dctzhip_ctx* c, Chain* ch, bool two) {
+  ch[0].s = c->stream; ch[1].s = c->stream;
+  ch[0].word = &c->box->seq_done; ch[0].word_dev = &c->box_dev->seq_done;
+  ch[1].word = &c->box->seq_stats; ch[1].word_dev = &c->box_dev->seq_stats;
+  if (!two) return DCTZHIP_OK;
+  if (!c->b_stream) HIPCHK(c, hipStreamCreateWithFlags(&c->b_stream, hipStreamNonBlocking));
+  if (!c->b_fork) HIPCHK(c, hipEventCreateWithFlags(&c->b_fork, hipEventDisableTiming));
+  if (!c->b_join) HIPCHK(c, hipEventCreateWithFlags(&c->b_join, hipEventDisableTiming));
+  ch[1].s = c->b_stream;
+  HIPCHK(c, hipEventRecord(c->b_fork, c->stream));
+  HIPCHK(c, hipStreamWaitEvent(c->b_stream, c->b_fork, 0));
+  return DCTZHIP_OK;
+}
+// join: whatever is queued on the context's stream after the call runs behind both chains
+static int chains_join(dctzhip_ctx* c, bool two) {
+  if (!two) return DCTZHIP_OK;
+  HIPCHK(c, hipEventRecord(c->b_join, c->b_stream));
+  HIPCHK(c, hipStreamWaitEvent(c->stream, c->b_join, 0));
+  return DCTZHIP_OK;
+}
+
 template <typename T>
-static void plan_compress(dctzhip_ctx* c, const dctzhip_batch_citem* items, int mode, SeqC& q) {
+static void plan_compress(dctzhip_ctx* c, const dctzhip_batch_citem* items, int mode, SeqC& q, unsigned cap_div) {
   const size_t k = q.idx.size();
   constexpr int EPV = Traits<T>::EPV;
-  unsigned cap = (unsigned)(c->num_cu * wg_per_cu<T>(c, false, mode, false, GEOM_1D));
+  unsigned cap = (unsigned)(c->num_cu * wg_per_cu<T>(c, false, mode, false, GEOM_1D)) / cap_div;      // (two chains share the chip)
   if (c->grid_c > 0 && (unsigned)c->grid_c < cap) cap = (unsigned)c->grid_c;
   cap = cap > 2 * (unsigned)k ? cap - (unsigned)k : cap / 2 + 1;      // (every array with a tile gets at least one workgroup)
   size_t tiles = 0;
@@ -1418,14 +1458,15 @@ static void plan_compress(dctzhip_ctx* c, const dctzhip_batch_citem* items, int 
 }
 
 template <typename T>
-static int launch_compress_seq(dctzhip_ctx* c, const dctzhip_batch_citem* items, int mode, const SeqC& q, bool publish,
+static int launch_compress_seq(dctzhip_ctx* c, const dctzhip_batch_citem* items, int mode, const SeqC& q, const Chain& ch, bool publish,
                                unsigned long long seq, bool first_of_dtype) {
   const int dtype = sizeof(T) == 8 ? DCTZHIP_F64 : DCTZHIP_F32;
   const size_t k = q.idx.size();
-  hipStream_t s = c->stream;
-  if ((size_t)q.grid_main > (size_t)c->num_cu * WG_PER_CU_MAX)
-    return fail(c, DCTZHIP_E_INTERNAL, "batch: %u workgroups exceed the %d overflow strips", q.grid_main, c->num_cu * WG_PER_CU_MAX);
-  if (q.parts_total > (size_t)PART_SLOTS || q.lists_total + 2 > c->tile_cap)
+  hipStream_t s = ch.s;
+  // launch-time checks of the plan against the buffers it indexes (overflow strips: one per workgroup of the launch)
+  if (ch.slot_off + (size_t)q.grid_main > (size_t)c->num_cu * WG_PER_CU_MAX)
+    return fail(c, DCTZHIP_E_INTERNAL, "batch: %zu workgroups exceed the %d overflow strips", ch.slot_off + (size_t)q.grid_main, c->num_cu * WG_PER_CU_MAX);
+  if (q.parts_total > (size_t)PART_SLOTS || ch.list_off + q.lists_total + 2 > c->tile_cap)
     return fail(c, DCTZHIP_E_INTERNAL, "batch: scratch plan exceeds its buffers");
   unsigned char* hb = c->b_blob + q.blob_off;
   BatchFwd<T>* hi = reinterpret_cast<BatchFwd<T>*>(hb);
@@ -1442,12 +1483,13 @@ static int launch_compress_seq(dctzhip_ctx* c, const dctzhip_batch_citem* items,
     memset(&b, 0, sizeof(b));
     FwdParams<T>& p = b.p;
     p.x = (const T*)it.d_in; p.bin = (uint8_t*)it.d_bin_index; p.dc = it.d_dc; p.ac = it.d_ac_exact; p.coef = nullptr;
-    const size_t slot0 = (size_t)q.tile_base[j] * TILE_ELEMS;
+    const size_t slot0 = (ch.tile_off + (size_t)q.tile_base[j]) * TILE_ELEMS;
     p.ac_tmp = c->ac_tmp ? c->ac_tmp + slot0 : nullptr;
-    p.qt_item = c->qt_item ? reinterpret_cast<T*>(c->qt_item) + slot0 : nullptr;
+    // (the chain's region starts at a byte offset that is right for either element type)
+    p.qt_item = c->qt_item ? reinterpret_cast<T*>((char*)c->qt_item + ch.tile_off * TILE_ELEMS * sizeof(double)) + (size_t)q.tile_base[j] * TILE_ELEMS : nullptr;
     p.qt_j = c->qt_j ? c->qt_j + slot0 : nullptr;
-    p.tile_cnt = c->tile_cnt + q.list_base[j];
-    p.ovf = c->ovf; p.ovf_j = c->ovf_j;
+    p.tile_cnt = c->tile_cnt + ch.list_off + q.list_base[j];
+    p.ovf = (char*)c->ovf + ch.slot_off * 64 * 64 * sizeof(double); p.ovf_j = c->ovf_j + ch.slot_off * 64 * 64;
     p.tab = tab_of<T>(c); p.rtab = nullptr;
     if (q.rem[j]) { int rc = rtab_for<T>(c, (int)q.rem[j], &p.rtab); if (rc) return rc; }
     p.ctl = c->b_ctl + q.item_off + j;
@@ -1486,16 +1528,17 @@ static int launch_compress_seq(dctzhip_ctx* c, const dctzhip_batch_citem* items,
   hipEvent_t* ev = c->b_ev[dtype];
   if (prof) for (int i = 0; i < 5; i++) if (!ev[i]) HIPCHK(c, hipEventCreate(&ev[i]));
   if (prof) HIPCHK(c, hipEventRecord(ev[0], s));
-  launch_stats_batch<T>(it_h, first_h, (unsigned)k, q.grid_stats, c->b_blob_hdev + q.blob_off, db, q.blob_bytes, c->part, s);
+  double* part = c->part + 3 * ch.part_off;
+  launch_stats_batch<T>(it_h, first_h, (unsigned)k, q.grid_stats, c->b_blob_hdev + q.blob_off, db, q.blob_bytes, part, s);
   const SfTable tab = {c->sf_thr[dtype], c->sf_pw[dtype], c->sf_nk[dtype], c->fastdiv, dtype};
-  launch_sf_batch<T>(it_d, (unsigned)k, c->part, c->b_stats + 3 * q.item_off, tab, s);
+  launch_sf_batch<T>(it_d, (unsigned)k, part, c->b_stats + 3 * q.item_off, tab, s);
   if (prof) HIPCHK(c, hipEventRecord(ev[1], s));
   if (q.grid_main) launch_compress_batch<T>(it_d, first_d + (k + 1), (unsigned)k, q.grid_main, mode, s);
   if (prof) HIPCHK(c, hipEventRecord(ev[2], s));
   if (nrem) launch_compress_rem_batch<T>(it_d, first_d + 4 * (k + 1), nrem, mode, s);
   if (mode == DCTZHIP_QT && sizeof(T) == 8 && q.grid_list) launch_qt_max_batch<T>(it_d, first_d + 2 * (k + 1), (unsigned)k, q.grid_list, s);
   BatchFin fin;
-  fin.box = publish ? c->box_dev : nullptr; fin.seq = seq;
+  fin.word = publish ? const_cast<unsigned long long*>(ch.word_dev) : nullptr; fin.seq = seq;
   fin.res = c->b_res_hdev + q.item_off * sizeof(BatchResC);
   fin.resq = mode == DCTZHIP_QT ? reinterpret_cast<BatchResQ*>(c->b_res_hdev + c->b_cap * sizeof(BatchResC)) + q.item_off : nullptr;
   // (every array has at least one list or a remainder block: n >= 1)
@@ -1555,35 +1598,50 @@ extern "C" int dctzhip_compress_batch(dctzhip_ctx* c, int k, const dctzhip_batch
     }
     if (!cur.idx.empty()) seqs.push_back(cur);
   }
-  size_t K = 0, blob = 0, tiles_max = 0;
-  for (SeqC& q : seqs) {
-    if (q.dtype == DCTZHIP_F64) plan_compress<double>(c, items, mode, q); else plan_compress<float>(c, items, mode, q);
+  size_t K = 0, blob = 0;
+  bool has[2] = {false, false};
+  for (const SeqC& q : seqs) has[q.dtype] = true;
+  const bool two = has[0] && has[1];                   // mixed batch: the fp32 sequences run beside the fp64 ones
+  size_t tiles_max[2] = {0, 0}, lists_max[2] = {0, 0}, grid_max[2] = {0, 0};
+  Chain ch[2];
+  for (size_t qi = 0; qi < seqs.size(); qi++) {
+    SeqC& q = seqs[qi];
+    q.chain = (two && q.dtype == DCTZHIP_F32) ? 1 : 0;
+    if (q.dtype == DCTZHIP_F64) plan_compress<double>(c, items, mode, q, two ? 2u : 1u); else plan_compress<float>(c, items, mode, q, two ? 2u : 1u);
     q.item_off = K; K += q.idx.size();
     q.blob_off = blob; blob += q.blob_bytes;
-    if (q.tiles_total > tiles_max) tiles_max = q.tiles_total;
+    if (q.tiles_total > tiles_max[q.chain]) tiles_max[q.chain] = q.tiles_total;
+    if (q.lists_total > lists_max[q.chain]) lists_max[q.chain] = q.lists_total;
+    if (q.grid_main > grid_max[q.chain]) grid_max[q.chain] = q.grid_main;
+    ch[q.chain].last = (int)qi;
   }
   if (!seqs.empty()) {
-    // scratch of the largest sequence (sequences follow each other on the stream and reuse it), in the widest element type
-    int rc = ensure_scratch(c, tiles_max * TILE_ELEMS, DCTZHIP_F64, mode);
+    // scratch: one region per chain, sized for the chain's largest sequence (its sequences follow each other on the
+    // chain's stream and reuse it), in the widest element type
+    ch[1].tile_off = tiles_max[0]; ch[1].list_off = lists_max[0] + 2; ch[1].part_off = PART_SLOTS; ch[1].slot_off = grid_max[0];
+    int rc = ensure_scratch(c, (tiles_max[0] + tiles_max[1]) * TILE_ELEMS, DCTZHIP_F64, mode, true, lists_max[0] + lists_max[1] + 6);
     if (rc) return rc;
     rc = ensure_batch(c, K, blob, 0);
     if (rc) return rc;
     rc = ensure_batch(c, K, blob, c->b_cap * (sizeof(BatchResC) + (mode == DCTZHIP_QT ? sizeof(BatchResQ) : 0)));
     if (rc) return rc;
-    hipStream_t s = c->stream;
+    rc = chains_fork(c, ch, two);
+    if (rc) return rc;
     const unsigned long long seq = ++c->seq;
     bool seen[2] = {false, false};
     for (size_t qi = 0; qi < seqs.size(); qi++) {
       const SeqC& q = seqs[qi];
-      const bool last = qi + 1 == seqs.size();
-      rc = (q.dtype == DCTZHIP_F64) ? launch_compress_seq<double>(c, items, mode, q, last, seq, !seen[q.dtype])
-                                    : launch_compress_seq<float>(c, items, mode, q, last, seq, !seen[q.dtype]);
+      const bool last = ch[q.chain].last == (int)qi;
+      rc = (q.dtype == DCTZHIP_F64) ? launch_compress_seq<double>(c, items, mode, q, ch[q.chain], last, seq, !seen[q.dtype])
+                                    : launch_compress_seq<float>(c, items, mode, q, ch[q.chain], last, seq, !seen[q.dtype]);
       if (rc) return rc;
       seen[q.dtype] = true;
     }
-    (void)s;
-    rc = wait_seq(c, &c->box->seq_done, seq, "compress batch");
+    rc = chains_join(c, two);
     if (rc) return rc;
+    rc = wait_seq(c, ch[0].word, seq, "compress batch");
+    if (rc) return rc;
+    if (two) { rc = wait_seq(c, ch[1].word, seq, "compress batch (second chain)"); if (rc) return rc; }
     if (c->profiling) {
       c->b_last[0] = dctzhip_timings{0, 0, 0, 0}; c->b_last[1] = dctzhip_timings{0, 0, 0, 0};
       for (int dt = 0; dt < 2; dt++) if (seen[dt]) { rc = batch_timings(c, dt); if (rc) return rc; }
@@ -1638,9 +1696,9 @@ extern "C" int dctzhip_compress_batch(dctzhip_ctx* c, int k, const dctzhip_batch
 
 // ---- decode side of a batch ----
 template <typename T>
-static void plan_decompress(dctzhip_ctx* c, const dctzhip_batch_ditem* items, int mode, SeqD& q) {
+static void plan_decompress(dctzhip_ctx* c, const dctzhip_batch_ditem* items, int mode, SeqD& q, unsigned cap_div) {
   const size_t k = q.idx.size();
-  unsigned cap = (unsigned)(c->num_cu * wg_per_cu<T>(c, true, mode, false, GEOM_1D));
+  unsigned cap = (unsigned)(c->num_cu * wg_per_cu<T>(c, true, mode, false, GEOM_1D)) / cap_div;
   cap = cap > 2 * (unsigned)k ? cap - (unsigned)k : cap / 2 + 1;
   size_t tiles = 0;
   q.nfull.resize(k); q.rem.resize(k); q.ntiles.resize(k); q.nwg.resize(k); q.tile_base.resize(k); q.wg_base.resize(k);
@@ -1662,12 +1720,13 @@ static void plan_decompress(dctzhip_ctx* c, const dctzhip_batch_ditem* items, in
 }
 
 template <typename T>
-static int launch_decompress_seq(dctzhip_ctx* c, const dctzhip_batch_ditem* items, int mode, const SeqD& q, bool publish, unsigned long long seq,
-                                 bool first_of_dtype) {
+static int launch_decompress_seq(dctzhip_ctx* c, const dctzhip_batch_ditem* items, int mode, const SeqD& q, const Chain& ch, bool publish,
+                                 unsigned long long seq, bool first_of_dtype) {
   const int dtype = sizeof(T) == 8 ? DCTZHIP_F64 : DCTZHIP_F32;
   const size_t k = q.idx.size();
-  hipStream_t s = c->stream;
-  if (q.tiles_total + 2 > c->tile_cap || q.wgs_total + 2 > c->tile_cap) return fail(c, DCTZHIP_E_INTERNAL, "batch: scratch plan exceeds its buffers");
+  hipStream_t s = ch.s;
+  if (ch.tile_off + q.tiles_total + 2 > c->tile_cap || ch.list_off + q.wgs_total + 2 > c->tile_cap)
+    return fail(c, DCTZHIP_E_INTERNAL, "batch: scratch plan exceeds its buffers");
   unsigned char* hb = c->b_blob + q.blob_off;
   BatchInv<T>* hi = reinterpret_cast<BatchInv<T>*>(hb);
   const size_t first_off = align16(k * sizeof(BatchInv<T>));
@@ -1684,7 +1743,7 @@ static int launch_decompress_seq(dctzhip_ctx* c, const dctzhip_batch_ditem* item
     if (q.rem[j]) { int rc = rtab_for<T>(c, (int)q.rem[j], &p.rtab); if (rc) return rc; }
     p.qtab = reinterpret_cast<const T*>(db + j * sizeof(BatchInv<T>) + offsetof(BatchInv<T>, qtab));
     if (mode == DCTZHIP_QT) memcpy(b.qtab, it.qtable_host, sizeof(T) * 64);
-    p.tile_cnt = c->tile_cnt + q.tile_base[j]; p.wg_cnt = c->wg_cnt + q.wg_base[j];
+    p.tile_cnt = c->tile_cnt + ch.tile_off + q.tile_base[j]; p.wg_cnt = c->wg_cnt + ch.list_off + q.wg_base[j];
     p.ctl = c->b_ctl + q.item_off + j;
     p.nfull = q.nfull[j]; p.ntiles = q.ntiles[j]; p.ac_count = it.ac_count; p.nwg = q.nwg[j];
     p.sf = (T)it.sf;
@@ -1711,7 +1770,7 @@ static int launch_decompress_seq(dctzhip_ctx* c, const dctzhip_batch_ditem* item
   launch_count_batch<T>(it_h, first_h, (unsigned)k, q.grid_cnt, c->b_blob_hdev + q.blob_off, db, q.blob_bytes, s);
   if (prof) HIPCHK(c, hipEventRecord(ev[1], s));
   BatchFin fin;
-  fin.box = publish ? c->box_dev : nullptr; fin.seq = seq;
+  fin.word = publish ? const_cast<unsigned long long*>(ch.word_dev) : nullptr; fin.seq = seq;
   fin.res = c->b_res_hdev + q.item_off * sizeof(BatchResD); fin.resq = nullptr;
   if (q.grid_main) launch_decompress_batch<T>(it_d, first_d + (k + 1), (unsigned)k, q.grid_main, mode, fin, s);
   if (prof) HIPCHK(c, hipEventRecord(ev[2], s));
@@ -1751,38 +1810,55 @@ extern "C" int dctzhip_decompress_batch(dctzhip_ctx* c, int k, const dctzhip_bat
     if (!cur.idx.empty()) seqs.push_back(cur);
   }
   int worst = DCTZHIP_OK;
-  size_t K = 0, blob = 0, tiles_max = 0;
-  for (SeqD& q : seqs) {
-    if (q.dtype == DCTZHIP_F64) plan_decompress<double>(c, items, mode, q); else plan_decompress<float>(c, items, mode, q);
+  size_t K = 0, blob = 0;
+  // a sequence whose arrays have no full tile at all has no k_decompress_batch launch to hand off from: single path
+  // (planned once to find out: the grid does not depend on the chains)
+  for (size_t qi = 0; qi < seqs.size();) {
+    SeqD probe = seqs[qi];
+    if (probe.dtype == DCTZHIP_F64) plan_decompress<double>(c, items, mode, probe, 1u); else plan_decompress<float>(c, items, mode, probe, 1u);
+    if (probe.grid_main == 0) { for (int i : seqs[qi].idx) single.push_back(i); seqs.erase(seqs.begin() + qi); } else qi++;
+  }
+  bool has[2] = {false, false};
+  for (const SeqD& q : seqs) has[q.dtype] = true;
+  const bool two = has[0] && has[1];
+  size_t tiles_max[2] = {0, 0}, wgs_max[2] = {0, 0};
+  Chain ch[2];
+  for (size_t qi = 0; qi < seqs.size(); qi++) {
+    SeqD& q = seqs[qi];
+    q.chain = (two && q.dtype == DCTZHIP_F32) ? 1 : 0;
+    if (q.dtype == DCTZHIP_F64) plan_decompress<double>(c, items, mode, q, two ? 2u : 1u); else plan_decompress<float>(c, items, mode, q, two ? 2u : 1u);
     q.item_off = K; K += q.idx.size();
     q.blob_off = blob; blob += q.blob_bytes;
-    if (q.tiles_total > tiles_max) tiles_max = q.tiles_total;
-  }
-  // a sequence whose arrays have no full tile at all has no k_decompress_batch launch to hand off from: single path
-  for (size_t qi = 0; qi < seqs.size();) {
-    if (seqs[qi].grid_main == 0) { for (int i : seqs[qi].idx) single.push_back(i); seqs.erase(seqs.begin() + qi); } else qi++;
+    if (q.tiles_total > tiles_max[q.chain]) tiles_max[q.chain] = q.tiles_total;
+    if (q.wgs_total > wgs_max[q.chain]) wgs_max[q.chain] = q.wgs_total;
+    ch[q.chain].last = (int)qi;
   }
   if (!seqs.empty()) {
-    int rc = ensure_scratch(c, (tiles_max + 1) * TILE_ELEMS, DCTZHIP_F64, DCTZHIP_EC, false);
+    ch[1].tile_off = tiles_max[0] + 2; ch[1].list_off = wgs_max[0] + 2;
+    int rc = ensure_scratch(c, (tiles_max[0] + tiles_max[1] + 6) * TILE_ELEMS, DCTZHIP_F64, DCTZHIP_EC, false, wgs_max[0] + wgs_max[1] + 6);
     if (rc) return rc;
     rc = ensure_batch(c, K, blob, 0);
     if (rc) return rc;
     rc = ensure_batch(c, K, blob, c->b_cap * sizeof(BatchResD));
     if (rc) return rc;
-    hipStream_t s = c->stream;
-    if (c->b_ctl_dirty) { HIPCHK(c, hipMemsetAsync(c->b_ctl, 0, c->b_cap * sizeof(Ctl), s)); c->b_ctl_dirty = 0; }
+    if (c->b_ctl_dirty) { HIPCHK(c, hipMemsetAsync(c->b_ctl, 0, c->b_cap * sizeof(Ctl), c->stream)); c->b_ctl_dirty = 0; }
+    rc = chains_fork(c, ch, two);
+    if (rc) return rc;
     const unsigned long long seq = ++c->seq;
     bool seen[2] = {false, false};
     for (size_t qi = 0; qi < seqs.size(); qi++) {
       const SeqD& q = seqs[qi];
-      const bool last = qi + 1 == seqs.size();
-      rc = (q.dtype == DCTZHIP_F64) ? launch_decompress_seq<double>(c, items, mode, q, last, seq, !seen[q.dtype])
-                                    : launch_decompress_seq<float>(c, items, mode, q, last, seq, !seen[q.dtype]);
+      const bool last = ch[q.chain].last == (int)qi;
+      rc = (q.dtype == DCTZHIP_F64) ? launch_decompress_seq<double>(c, items, mode, q, ch[q.chain], last, seq, !seen[q.dtype])
+                                    : launch_decompress_seq<float>(c, items, mode, q, ch[q.chain], last, seq, !seen[q.dtype]);
       if (rc) return rc;
       seen[q.dtype] = true;
     }
-    rc = wait_seq(c, &c->box->seq_done, seq, "decompress batch");
+    rc = chains_join(c, two);
     if (rc) return rc;
+    rc = wait_seq(c, ch[0].word, seq, "decompress batch");
+    if (rc) return rc;
+    if (two) { rc = wait_seq(c, ch[1].word, seq, "decompress batch (second chain)"); if (rc) return rc; }
     if (c->profiling) {
       c->b_last[0] = dctzhip_timings{0, 0, 0, 0}; c->b_last[1] = dctzhip_timings{0, 0, 0, 0};
       for (int dt = 0; dt < 2; dt++) if (seen[dt]) { rc = batch_timings(c, dt); if (rc) return rc; }

@@ -11,13 +11,13 @@ def c1():
     return np.random.default_rng(12345).random(1 << 20)
 
 
-def c2():
+def c2(seed=2024):
     """CESM-ATM stand-in: smooth 1800x3600 fp32 field + 1 % noise."""
     x = np.linspace(0, 1, 3600)
     y = np.linspace(0, 1, 1800)
     yy, xx = np.meshgrid(y, x, indexing="ij")
     f = (np.sin(6 * np.pi * xx) * np.cos(4 * np.pi * yy) + 0.3 * np.sin(40 * np.pi * xx * yy)
-         + 0.01 * np.random.default_rng(2024).standard_normal((1800, 3600)))
+         + 0.01 * np.random.default_rng(seed).standard_normal((1800, 3600)))
     return f.astype(np.float32).ravel()
 
 
