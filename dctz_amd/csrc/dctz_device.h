@@ -6,6 +6,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <type_traits>
+
 #include "../../include/dctz_hip.h"
 #include "dct64_block.h"
 #include "dct_nd_block.h"
@@ -54,15 +56,6 @@ template <> struct Traits<float> {
 // Geometry of a tile in bytes for element type T, moved through LDS in PH phases (elements [64 p / PH, 64 (p + 1) / PH)
 // of every block per phase).  PH = 2 halves a wave's LDS footprint (fp64: 16 KiB), which leaves room for two waves per
 // SIMD: one issues instructions while the other waits.
-#ifndef DCTZ_EC_DEPTH
-#define DCTZ_EC_DEPTH 12   /* 14 measured: -3 % at p = 17 %, +1 % at p = 5 % */
-#endif
-#ifndef DCTZ_QT_DEPTH64
-#define DCTZ_QT_DEPTH64 10    /* 64 * 11 * (8 + 1) = 6336 bytes: 7 workgroups per CU (14 items: 6; 6 items reach 8 per CU but spill and overflow more: measured equal) */
-#endif
-#ifndef DCTZ_QT_DEPTH32
-#define DCTZ_QT_DEPTH32 12    /* 64 * 13 * (4 + 1) = 4160 bytes */
-#endif
 template <typename T, int PHASES = 1> struct Geo {
   static constexpr int BLKB = 64 * (int)sizeof(T);      // bytes per block (512 / 256)
   static constexpr int NSEG = BLKB / 128;               // 128-byte segments per block (4 / 2)
@@ -74,9 +67,29 @@ template <typename T, int PHASES = 1> struct Geo {
   static constexpr int CHP = NCH / PH;                   // 16-byte chunks of a block per phase
   static constexpr int PHB = TILEB / PH;                 // bytes of a phase image
   static_assert(NSEG % PH == 0, "a phase is a whole number of 128-byte segments");
-  // exceptions of a block that a lane parks in its LDS strip (DEPTH + 1 items); the rest goes to global overflow strips
-  static constexpr int EC_DEPTH = DCTZ_EC_DEPTH;                                  // floats:  64 * 13 * 4 = 3328 bytes per wave
-  static constexpr int QT_DEPTH = sizeof(T) == 8 ? DCTZ_QT_DEPTH64 : DCTZ_QT_DEPTH32;   // full-precision items + their positions
+};
+// The "stored exactly" coefficients of a tile leave k_compress as SUB-LISTS: the coefficients j in [q QW, (q + 1) QW) of
+// all 64 blocks, block after block, compacted in LDS by the whole wave (one prefix sum over the lanes' counts per
+// sub-list) and written out in whole rows of 64 items.  The staging buffer holds one sub-list: 64 x QW items, of which
+// the last 64 slots are the lanes' dump slots (a coefficient that is not stored exactly is written there), so a
+// sub-list with more than CAP items goes out in two rounds.  k_compact_ac puts the sub-lists of a tile back into the
+// reference's order (dctz-comp-lib.c:478-544: block-major, j ascending) from the per-block counts k_compress leaves:
+// one word per block, CBITS bits per sub-list.  An item is a float (EC: what AC_exact stores) or the coefficient in
+// full precision plus its position (QT: the normalisation needs the table of the whole array first).
+template <typename T, int MODE> struct Sub {
+  using Item = typename std::conditional<MODE == DCTZHIP_EC, float, T>::type;
+  static constexpr int QW = (MODE == DCTZHIP_QT && sizeof(T) == 8) ? 8 : 16;      // coefficients per sub-list
+  static constexpr int NQ = 64 / QW;                                                // sub-lists per tile (4 | 8)
+  static constexpr int SLOTS = 64 * QW;
+  static constexpr int CAP = SLOTS - 64;
+  static constexpr int ITEM_BYTES = SLOTS * (int)sizeof(Item);                      // 4 KiB in every case
+  static constexpr int POS_BYTES = (MODE == DCTZHIP_QT) ? SLOTS : 0;
+  static constexpr int BYTES = ITEM_BYTES + POS_BYTES > EXC_BYTES ? ITEM_BYTES + POS_BYTES : EXC_BYTES;
+  static constexpr int CBITS = 32 / NQ;                                             // bits per count in a block's word (8 | 4; counts <= QW)
+  // k_compact_ac: the counts of several sub-lists share a dword for the prefix sums over the blocks of a tile
+  static constexpr int FB = (NQ == 4) ? 16 : 10;                                    // bits per field (sums <= 64 QW = 1024 | 512)
+  static constexpr int FPD = 32 / FB;                                               // fields per dword (2 | 3)
+  static constexpr int NPK = (NQ + FPD - 1) / FPD;                                  // dwords (2 | 3)
 };
 // phases of k_compress / k_decompress per element type (build knobs for A/B runs)
 #ifndef DCTZ_PHC64
@@ -187,8 +200,8 @@ struct FwdParams {
   unsigned* tile_cnt;              // list lengths, one per workgroup (+1 for the remainder block)
   T* qt_item;                      // QT scratch: flagged coefficients, full precision (same list layout as ac_tmp)
   uint8_t* qt_j;                   // QT scratch: their position j
-  void* ovf;                       // overflow strips: 64 items per lane of every workgroup (blocks with more exceptions than a strip holds)
-  uint8_t* ovf_j;                  // QT: their positions
+  unsigned* qcnt;                  // per block: how many of its coefficients every sub-list of its tile holds (Sub::CBITS bits each)
+  unsigned* ttot;                  // per tile: its "stored exactly" coefficients
   const T* tab;                    // TB_* block (device)
   const T* rtab;                   // RTAB_* block (device), remainder block only
   Ctl* ctl;

@@ -106,8 +106,7 @@ __device__ __forceinline__ float bin_value(T item, T q, T range_max) {
   return h;
 }
 
-// diagnostic phase timers (-DDCTZ_STAMP builds only): cycles of thread 0 of every workgroup, summed into the first
-// 16 words of the positions overflow buffer (unused by EC runs)
+// diagnostic phase timers (-DDCTZ_STAMP builds only): cycles of thread 0 of every workgroup per phase of the tile loop
 #ifdef DCTZ_STAMP
 #define STAMP_DECL unsigned long long st_last = __builtin_amdgcn_s_memtime(), st_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}
 #define STAMP(i) do { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); st_acc[i] += t_ - st_last; st_last = t_; } while (0)
@@ -120,25 +119,30 @@ __device__ __forceinline__ float bin_value(T item, T q, T range_max) {
 
 #ifdef DCTZ_STAMP
 __device__ unsigned long long g_dec_stamps[12];      // k_decompress's phase timers (diagnostic builds)
+__device__ unsigned long long g_cmp_stamps[12];      // k_compress's
 void read_dec_stamps(unsigned long long* out12) {
   (void)hipMemcpyFromSymbol(out12, HIP_SYMBOL(g_dec_stamps), 96);
   unsigned long long z[12] = {0};
   (void)hipMemcpyToSymbol(HIP_SYMBOL(g_dec_stamps), z, 96);
 }
+void read_cmp_stamps(unsigned long long* out12) {
+  (void)hipMemcpyFromSymbol(out12, HIP_SYMBOL(g_cmp_stamps), 96);
+  unsigned long long z[12] = {0};
+  (void)hipMemcpyToSymbol(HIP_SYMBOL(g_cmp_stamps), z, 96);
+}
 #endif
 
 template <typename T>
-size_t compress_lds_bytes(int mode) {              // tile image + strips (+ positions, QT); must match k_compress's static arrays
+size_t compress_lds_bytes(int mode) {              // tile image + sub-list staging (+ positions, QT); must match k_compress's static arrays
   using G = Geo<T, Phases<T>::C>;
-  if (mode != DCTZHIP_QT) return (size_t)G::PHB + EXC_BYTES;
-  const size_t strips = 64 * (size_t)(G::QT_DEPTH + 1) * (sizeof(T) + 1);          // items + their positions, one buffer
-  return (size_t)G::PHB + (strips > EXC_BYTES ? strips : (size_t)EXC_BYTES) + (sizeof(T) == 4 ? 256 : 0);   // + fp32: the per-position maxima
+  if (mode != DCTZHIP_QT) return (size_t)G::PHB + Sub<T, DCTZHIP_EC>::BYTES;
+  return (size_t)G::PHB + Sub<T, DCTZHIP_QT>::BYTES + (sizeof(T) == 4 ? 256 : 0);   // + fp32: the per-position maxima
 }
 
 // PH = 1: the whole tile (fp32: 16 KiB) sits in LDS.  PH = 2 (fp64): half a tile at a time (16 KiB), eight single-wave
-// workgroups per CU = two waves per SIMD that cover each other's waits.  Either way the outputs of tile k are flushed
-// only after the next DMA of tile k + 1 has been issued, so that the wait for tile k + 1's first phase never sits
-// behind tile k's stores.
+// workgroups per CU = two waves per SIMD that cover each other's waits.  The bin ids / DC / per-block counts of tile k
+// are flushed only after the next DMA of tile k + 1 has been issued, so that the wait for tile k + 1's first phase
+// never sits behind them.
 // GEOM: what the 64 values of a block are -- the reference's 64 consecutive elements (GEOM_1D), or an 8 x 8 / 4 x 4 x 4
 // tile of a multi-dimensional array that k_gather_nd has laid out block after block (dct_nd_block.h); only the
 // transform differs.
@@ -147,43 +151,29 @@ size_t compress_lds_bytes(int mode) {              // tile image + strips (+ pos
 #endif
 // The body is shared by two launch shapes: k_compress (one array per launch: workgroup wg = blockIdx.x of nwg = gridDim.x)
 // and k_compress_batch (many arrays per launch: the workgroup looks its array up and is workgroup wg of the nwg that array
-// got).  `slot` = the workgroup's index in the launch (its overflow strips).
+// got).
 template <typename T, int MODE, bool STATS, int PH, int GEOM>
-__device__ __forceinline__ void compress_body(const FwdParams<T>& p, const unsigned wg, const unsigned nwg, const unsigned slot) {
+__device__ __forceinline__ void compress_body(const FwdParams<T>& p, const unsigned wg, const unsigned nwg) {
   using G = Geo<T, PH>;
-  constexpr bool DEFER = true;
-  constexpr int DEPTH = (MODE == DCTZHIP_EC) ? G::EC_DEPTH : G::QT_DEPTH;
-  using Item = typename std::conditional<MODE == DCTZHIP_EC, float, T>::type;        // what a parked exception is
-  // separate arrays, so that the compiler can tell the DMA target from the staging strips (a pending LDS-DMA
+  using S = Sub<T, MODE>;
+  using Item = typename S::Item;                     // what a "stored exactly" coefficient is on its way out (dctz_device.h: Sub)
+  constexpr int QW = S::QW, NQ = S::NQ;
+  // separate arrays, so that the compiler can tell the DMA target from the staging buffer (a pending LDS-DMA
   // forces a vmcnt(0) in front of every LDS read it may alias)
   __shared__ __attribute__((aligned(1024))) unsigned char tilebuf[G::PHB];
-  // lane l parks the exceptions of its block in a strip of STRIDE = DEPTH + 1 items in LDS (the last slot only ever
-  // holds a coefficient parked "in case"; the odd stride in dwords spreads the lanes over the banks); what does not fit
-  // (a block with more than DEPTH exceptions: rare on smooth data) goes to the lane's overflow strip in global memory
-  constexpr int STRIDE = DEPTH + 1;
-  // QT: the positions j of the parked items sit behind the items in the same buffer (a separate 1 KiB array cost the
-  // eighth workgroup per CU: with 6 / 10 items per lane, fp64 / fp32, everything fits the 4 KiB the bin ids need anyway)
-  constexpr int ITEM_BYTES = 64 * STRIDE * (int)sizeof(Item);
-  constexpr int POS_BYTES = (MODE == DCTZHIP_QT) ? 64 * STRIDE : 0;
-  constexpr int STRIP_BYTES = ITEM_BYTES + POS_BYTES > EXC_BYTES ? ITEM_BYTES + POS_BYTES : EXC_BYTES;
-  __shared__ __attribute__((aligned(16))) unsigned char excbuf[STRIP_BYTES];        // also: the tile's bin ids on their way out
-  unsigned char* const jbuf = excbuf + ITEM_BYTES;                                   // QT: position j of every parked item
+  __shared__ __attribute__((aligned(16))) unsigned char excbuf[S::BYTES];            // one sub-list; also: the tile's bin ids on their way out
+  Item* const items = reinterpret_cast<Item*>(excbuf);
+  unsigned char* const jbuf = excbuf + S::ITEM_BYTES;                                // QT: position j of every staged item
   // QT, fp32: per-position maximum |coef| over the out-of-range coefficients (dctz-comp-lib.c:371-372 / :396-397), kept
-  // per wave while the exceptions go out (one LDS atomic per exception) and merged into Ctl::qraw at the end -- no pass
-  // over the lists for it.  (fp64 keeps the separate k_qt_max: the kernel is at its register limit, and the few
-  // registers of this path came back as eleven spills in the flush -- 0.26 -> 0.40 ms.)
+  // per wave while the sub-lists go out (one LDS atomic per item) and merged into Ctl::qraw at the end -- no pass over
+  // the lists for it.  (fp64 keeps the separate k_qt_max: the kernel is at its register limit.)
   using QBits = typename Traits<T>::Bits;
   constexpr bool QMAX_HERE = (MODE == DCTZHIP_QT) && sizeof(T) == 4;
   __shared__ QBits qmax_lds[QMAX_HERE ? 64 : 1];
   if (QMAX_HERE) qmax_lds[threadIdx.x] = 0;
-  // (the addresses are formed where they are used: kept in registers across the loop they cost four VGPRs for a rare path)
-  // (item k of all 64 lanes side by side: the flush reads whole rows, and the lanes of a store -- all within a few items
-  // of each other -- touch a handful of lines instead of 64)
-  auto ovf_at = [&](unsigned k) -> Item* { return reinterpret_cast<Item*>(p.ovf) + ((size_t)slot * 64 + k) * 64 + threadIdx.x; };
-  auto ovfj_at = [&](unsigned k) -> unsigned char* { return p.ovf_j + ((size_t)slot * 64 + k) * 64 + threadIdx.x; };
   const int lane = threadIdx.x;
   const TileRange tr = tile_range(wg, nwg, p.ntiles);
-  const unsigned list_base = tr.lo * TILE_ELEMS;     // this workgroup's exception list lives in its tiles' slots
+  const unsigned list_base = tr.lo * TILE_ELEMS;     // this workgroup's list lives in its tiles' slots
   const size_t first_el = (size_t)tr.lo * TILE_ELEMS;
   const size_t end_el = min((size_t)p.nfull * 64, (size_t)tr.hi * TILE_ELEMS);
   const int range_el = tr.lo < tr.hi ? (int)(end_el - first_el) : 0;                  // whole blocks only
@@ -204,7 +194,8 @@ __device__ __forceinline__ void compress_body(const FwdParams<T>& p, const unsig
   };
   const __amdgpu_buffer_rsrc_t r_bin = __builtin_amdgcn_make_buffer_rsrc(p.bin + first_el, 0, range_el, 0x00020000);
   const __amdgpu_buffer_rsrc_t r_dc = __builtin_amdgcn_make_buffer_rsrc(p.dc + first_el / 64, 0, range_el / 64 * 4, 0x00020000);
-  // the workgroup's exception list(s) behind descriptors too: 32-bit offsets, no 64-bit pointers to keep alive (or spill)
+  const __amdgpu_buffer_rsrc_t r_qc = __builtin_amdgcn_make_buffer_rsrc(p.qcnt + first_el / 64, 0, range_el / 64 * 4, 0x00020000);
+  // the workgroup's list(s) behind descriptors too: 32-bit offsets, no 64-bit pointers to keep alive (or spill)
   const int list_slots = (int)((tr.hi - tr.lo) * (unsigned)TILE_ELEMS);
   const __amdgpu_buffer_rsrc_t r_list = (MODE == DCTZHIP_EC)
       ? __builtin_amdgcn_make_buffer_rsrc(p.ac_tmp + list_base, 0, list_slots * 4, 0x00020000)
@@ -223,45 +214,15 @@ __device__ __forceinline__ void compress_body(const FwdParams<T>& p, const unsig
   acc.init();
   unsigned run = 0;                                  // length of the workgroup's list so far (uniform)
 
-  // outputs of a tile on their way out (DEFER: those of the previous tile)
+  // bin ids, DC and per-block counts of a tile on their way out (those of the previous tile)
   bool pend = false;
-  unsigned p_rel = 0, p_n = 0, p_dst = 0;
+  unsigned p_rel = 0, p_qc = 0;
   unsigned pw[16];
   float p_dc = 0.f;
 
   auto flush = [&]() {
-    // parked exceptions -> the workgroup's list, block after block (dctz-comp-lib.c:478-544 order).  Two loops on
-    // purpose: one loop that picks the LDS strip or the global overflow strip per trip turns into FLAT loads, and a
-    // flat access waits for vmcnt(0) -- i.e. for the tile DMA that has just been issued
-    auto put = [&](int e, Item v, unsigned char jj) {
-#if defined(DCTZ_CUT) && (DCTZ_CUT == 5 || DCTZ_CUT == 7)
-      if (p.nfull != 0xffffffffu) return;
-#endif
-      const int at = (int)(p_dst + (unsigned)e);                                        // index inside the workgroup's list
-      if (MODE == DCTZHIP_EC) {
-        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, (float)v), r_list, at * 4, 0, 0);   // :535-537
-      } else {
-        if constexpr (sizeof(T) == 8) __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, (double)v), r_list, at * 8, 0, 0);
-        else __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, (float)v), r_list, at * 4, 0, 0);
-        __builtin_amdgcn_raw_buffer_store_b8(jj, r_listj, at, 0, 0);
-        if (QMAX_HERE) {
-          const T a = fabs((T)v);
-          if (a > rmax) atomicMax(&qmax_lds[jj], to_bits(a));               // positive values order like their bits
-        }
-      }
-    };
-#pragma unroll
-    for (int e = 0; e < DEPTH; e++) {
-      if (!__builtin_amdgcn_ballot_w64((unsigned)e < p_n)) break;
-      if ((unsigned)e < p_n) put(e, reinterpret_cast<const Item*>(excbuf)[lane * STRIDE + e], MODE == DCTZHIP_QT ? jbuf[lane * STRIDE + e] : (unsigned char)0);
-    }
-    if (__builtin_amdgcn_ballot_w64(p_n > (unsigned)DEPTH)) {                             // rare: blocks that overflowed their strip
-      for (int e = DEPTH; e < 63; e++) {
-        if (!__builtin_amdgcn_ballot_w64((unsigned)e < p_n)) break;
-        if ((unsigned)e < p_n) put(e, *ovf_at((unsigned)(e - DEPTH)), MODE == DCTZHIP_QT ? *ovfj_at((unsigned)(e - DEPTH)) : (unsigned char)0);
-      }
-    }
-    // bin ids: 64 bytes per lane -> (through the strip, now free) 1 KiB rows of 16 consecutive blocks
+    // bin ids: 64 bytes per lane -> (through the staging buffer, free between two tiles' sub-lists) 1 KiB rows of 16
+    // consecutive blocks
     int lo = lane;
     asm volatile("" : "+v"(lo));                     // (re-derived per trip, see tile_map below)
     const int f2 = (lo >> 1) & 3;
@@ -273,12 +234,10 @@ __device__ __forceinline__ void compress_body(const FwdParams<T>& p, const unsig
 #pragma unroll
     for (int i = 0; i < 4; i++) {
       const u32x4 v = *reinterpret_cast<const u32x4*>(excbuf + i * 1024 + lo * 16);
-#if defined(DCTZ_CUT) && (DCTZ_CUT == 6 || DCTZ_CUT == 7)
-      if (p.nfull == 0xffffffffu)
-#endif
       __builtin_amdgcn_raw_buffer_store_b128(v, r_bin, voff + i * 1024, 0, 0);
     }
     __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, p_dc), r_dc, (int)(p_rel * 64u + (unsigned)lo) * 4, 0, 0);   // :350-351 USE_TRUNCATE
+    __builtin_amdgcn_raw_buffer_store_b32(p_qc, r_qc, (int)(p_rel * 64u + (unsigned)lo) * 4, 0, 0);
   };
 
   // one phase of the block in registers: calc_data_stat's max|x| / min|x| over the raw values (util.c:18-25), then the
@@ -371,15 +330,9 @@ __device__ __forceinline__ void compress_body(const FwdParams<T>& p, const unsig
       if (pend) flush();
       stats_scale(x, std::integral_constant<int, 0>{}, active, tile == 0);
     }
-#if defined(DCTZ_CUT) && DCTZ_CUT == 2
-    { T sx = x[0]; for (int j = 1; j < 64; j++) sx += x[j]; if (sx == T(1.2345e300)) p.dc[0] = (float)sx; pend = false; continue; }
-#endif
     __builtin_amdgcn_sched_barrier(0);
     block_fwd<T, CTab<T>, GEOM, (PH > 1)>(x, tab);
     STAMP(6);
-#if defined(DCTZ_CUT) && DCTZ_CUT == 3
-    { T sx = x[0]; for (int j = 1; j < 64; j++) sx += x[j]; if (sx == T(1.2345e300)) p.dc[0] = (float)sx; pend = false; continue; }
-#endif
     if (p.coef != nullptr && active) {               // test tap: the coefficients as computed
 #pragma unroll
       for (int j = 0; j < 64; j++) p.coef[((size_t)tile * TILE_BLKS + lane) * 64 + j] = x[j];
@@ -390,16 +343,22 @@ __device__ __forceinline__ void compress_body(const FwdParams<T>& p, const unsig
     }
 
     unsigned w[16];
-    unsigned n = 0;
+    unsigned qc = 0;                                 // this block's counts, one field per sub-list
+    unsigned ttot = 0;                               // "stored exactly" coefficients of the tile (uniform)
     __builtin_amdgcn_sched_barrier(0);               // the binning phase is scheduled on its own (the transform before it peaks in registers)
-    auto bin_loop = [&](auto fast, auto safe, auto half) {
-      // four coefficients = one dword of bin ids at a time, stage by stage, so that the four dependent chains
-      // (subtract, divide, floor, map, convert, pack) interleave; the coefficients of a group are only parked in the
-      // lane's strip when SOME lane of the wave has an exception in that group (the high-frequency groups of a
-      // smooth field never do)
-      constexpr int G0 = decltype(half)::value * 8;
+    // One sub-list = the coefficients [Q QW, (Q + 1) QW) of every block of the tile:
+    //   * pass-1 binning (:363-414), four coefficients = one dword of bin ids at a time, stage by stage, so that the four
+    //     dependent chains (subtract, divide, floor, map, convert, pack) interleave;
+    //   * the coefficients that are stored exactly (:478-544) keep their converted value and a flag bit; a prefix sum of
+    //     the lanes' counts gives every block its place in the sub-list, the lanes write their items there (the others
+    //     go to the lane's dump slot) and the sub-list leaves in whole rows of 64 items.
+    auto sub_list = [&](auto qi, auto fast, auto safe) {
+      constexpr int Q = decltype(qi)::value, J0 = Q * QW;
+      Item fq[QW];
+      unsigned m = 0;
 #pragma unroll
-      for (int g = G0; g < G0 + 8; g++) {
+      for (int gg = 0; gg < QW / 4; gg++) {
+        const int g = J0 / 4 + gg;
         float h[4];
         if constexpr (sizeof(T) == 4 && decltype(fast)::value) {
 #pragma unroll
@@ -418,48 +377,65 @@ __device__ __forceinline__ void compress_body(const FwdParams<T>& p, const unsig
             h[i] = bin_value<T, decltype(safe)::value>(x[j], q, rmax);
           }
         }
-        if (g == 0) h[0] = 0.0f;                     // j = 0 is the DC slot (:361): never an exception, its id is set below
-        unsigned wg = 0u;
+        if (g == 0) h[0] = 0.0f;                     // j = 0 is the DC slot (:361): never stored exactly, its id is set below
+        unsigned wgd = 0u;
 #pragma unroll
-        for (int i = 0; i < 4; i++) wg = __builtin_amdgcn_cvt_pk_u8_f32(h[i], i, wg);
-        asm volatile("" : "+v"(wg));                 // packed HERE: left alone, the compiler sinks all 64 conversions below the
-        w[g] = wg;                                   // last group and keeps 64 fp64 bin values alive (128 registers) until then
-        const bool any = (h[0] >= 255.0f) | (h[1] >= 255.0f) | (h[2] >= 255.0f) | (h[3] >= 255.0f);
-#if !(defined(DCTZ_CUT) && DCTZ_CUT == 4)
-        if (__builtin_amdgcn_ballot_w64(any)) {
-          // park the coefficients at the lane's current slot whether they are exceptions or not: the slot only
-          // advances when they are, so the next one overwrites it
-          if (!__builtin_amdgcn_ballot_w64(n + 4u > (unsigned)DEPTH)) {          // the usual case: every lane has room for 4 more
+        for (int i = 0; i < 4; i++) wgd = __builtin_amdgcn_cvt_pk_u8_f32(h[i], i, wgd);
+        asm volatile("" : "+v"(wgd));                // packed HERE: left alone, the compiler sinks all 64 conversions below the
+        w[g] = wgd;                                  // last group and keeps 64 fp64 bin values alive (128 registers) until then
 #pragma unroll
-            for (int i = 0; i < 4; i++) {
-              const int j = 4 * g + i;
-              if (j == 0) continue;
-              reinterpret_cast<Item*>(excbuf)[lane * STRIDE + n] = (Item)x[j];
-              if (MODE == DCTZHIP_QT) jbuf[lane * STRIDE + n] = (unsigned char)j;
-              n += (h[i] >= 255.0f) ? 1u : 0u;
-            }
-          } else {                                     // some strip is (nearly) full: the surplus goes to the overflow strips
+        for (int i = 0; i < 4; i++) {
+          fq[4 * gg + i] = (Item)x[4 * g + i];       // :496-497 / :535-537 USE_TRUNCATE (EC); QT: full precision
+          m |= (h[i] >= 255.0f ? 1u : 0u) << (4 * gg + i);
+        }
+        __builtin_amdgcn_sched_barrier(0);           // keep the groups apart: hoisting all 64 quotients first costs 128 registers
+      }
+      if (!active) m = 0;
+      const unsigned n = (unsigned)__popc(m);
+      qc |= n << (Q * S::CBITS);
+      const unsigned incl = wave_incl_scan(n);
+      const unsigned tot = (unsigned)__builtin_amdgcn_readlane((int)incl, 63);
+      const unsigned base = incl - n;                // this block's place in the sub-list
+      for (unsigned lo = 0; lo < tot; lo += (unsigned)S::CAP) {      // (one round unless nearly every coefficient is stored exactly)
+        unsigned pos = base - lo;                    // (wraps for blocks in front of the round's window: never < CAP then)
 #pragma unroll
-            for (int i = 0; i < 4; i++) {
-              const int j = 4 * g + i;
-              if (j == 0) continue;
-              const unsigned slot = min(n, (unsigned)DEPTH);
-              reinterpret_cast<Item*>(excbuf)[lane * STRIDE + slot] = (Item)x[j];
-              if (MODE == DCTZHIP_QT) jbuf[lane * STRIDE + slot] = (unsigned char)j;
-              if (n >= (unsigned)DEPTH) { *ovf_at(n - DEPTH) = (Item)x[j]; if (MODE == DCTZHIP_QT) *ovfj_at(n - DEPTH) = (unsigned char)j; }
-              n += (h[i] >= 255.0f) ? 1u : 0u;
+        for (int i = 0; i < QW; i++) {
+          const bool f = ((m >> i) & 1u) != 0u;
+          const unsigned at = (f && pos < (unsigned)S::CAP) ? pos : (unsigned)(S::CAP + lane);
+          items[at] = fq[i];
+          if (MODE == DCTZHIP_QT) jbuf[at] = (unsigned char)(J0 + i);
+          pos += f ? 1u : 0u;
+        }
+        const unsigned cnt = min(tot - lo, (unsigned)S::CAP);
+        for (unsigned r = 0; r * 64u < cnt; r++) {   // whole rows -> the workgroup's list; lanes beyond the end fall outside the descriptor
+          const unsigned e = r * 64u + (unsigned)lane;
+          const Item v = items[e];
+          const bool in = e < cnt;
+          const int at = (int)(run + lo + e);
+          if (MODE == DCTZHIP_EC) {
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, (float)v), r_list, in ? at * 4 : 0x7FFFFFF0, 0, 0);
+          } else {
+            const unsigned char jj = jbuf[e];
+            if constexpr (sizeof(T) == 8) __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, (double)v), r_list, in ? at * 8 : 0x7FFFFFF0, 0, 0);
+            else __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, (float)v), r_list, in ? at * 4 : 0x7FFFFFF0, 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b8(jj, r_listj, in ? at : 0x7FFFFFF0, 0, 0);
+            if (QMAX_HERE && in) {
+              const T a = fabs((T)v);
+              if (a > rmax) atomicMax(&qmax_lds[jj], to_bits(a));               // positive values order like their bits
             }
           }
         }
-#endif
-        __builtin_amdgcn_sched_barrier(0);           // keep the groups apart: hoisting all 64 quotients first costs 128 registers
       }
+      run += tot;
+      ttot += tot;
     };
-    auto bin_half = [&](auto half) {
-      if (bwd.ok) { if (p.fast_bw & 2u) bin_loop(std::true_type{}, std::false_type{}, half); else bin_loop(std::true_type{}, std::true_type{}, half); }
-      else bin_loop(std::false_type{}, std::true_type{}, half);
+    auto sub = [&](auto qi) {
+      if (bwd.ok) { if (p.fast_bw & 2u) sub_list(qi, std::true_type{}, std::false_type{}); else sub_list(qi, std::true_type{}, std::true_type{}); }
+      else sub_list(qi, std::false_type{}, std::true_type{});
     };
-    bin_half(std::integral_constant<int, 0>{});
+    sub(std::integral_constant<int, 0>{});
+    sub(std::integral_constant<int, 1>{});
+    if constexpr (NQ == 8) { sub(std::integral_constant<int, 2>{}); sub(std::integral_constant<int, 3>{}); }
     STAMP(7);
     if (PH == 2 && tile + 1 < tr.hi) {               // the next tile's first half (see above)
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -470,23 +446,21 @@ __device__ __forceinline__ void compress_body(const FwdParams<T>& p, const unsig
       stats_scale(xn, std::integral_constant<int, 0>{}, (unsigned)lane < min((unsigned)TILE_BLKS, p.nfull - (tile + 1) * TILE_BLKS), false);
       STAMP(9);
     }
-    bin_half(std::integral_constant<int, 1>{});
+    sub(std::integral_constant<int, NQ / 2>{});
+    sub(std::integral_constant<int, NQ / 2 + 1>{});
+    if constexpr (NQ == 8) { sub(std::integral_constant<int, 6>{}); sub(std::integral_constant<int, 7>{}); }
     STAMP(10);
     w[0] |= 0xFFu;                                   // :361 DC slot
-    if (!active) n = 0;
-
-    const unsigned incl = wave_incl_scan(n);
-    const unsigned total = (unsigned)__builtin_amdgcn_readlane((int)incl, 63);
-    const unsigned dst = run + (incl - n);            // index inside the workgroup's list
-    run += total;
-    pend = true; p_rel = rel; p_n = n; p_dst = dst; p_dc = (float)x[0];
+    if (lane == 0) p.ttot[tile] = ttot;
+    pend = true; p_rel = rel; p_qc = qc; p_dc = (float)x[0];
 #pragma unroll
     for (int i = 0; i < 16; i++) pw[i] = w[i];
-    if (!DEFER) { flush(); pend = false; }
   }
   if (pend) flush();
   STAMP(11);
-  STAMP_FLUSH(p.ovf_j);
+#ifdef DCTZ_STAMP
+  STAMP_FLUSH(g_cmp_stamps);
+#endif
   if (lane == 0) p.tile_cnt[wg] = run;
   if (QMAX_HERE) {
     const QBits m = qmax_lds[lane];
@@ -500,7 +474,7 @@ __device__ __forceinline__ void compress_body(const FwdParams<T>& p, const unsig
 
 template <typename T, int MODE, bool STATS, int PH, int GEOM>
 __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu((sizeof(T) == 4 && DCTZ_WPE32) ? DCTZ_WPE32 : PH))) void k_compress(FwdParams<T> p) {
-  compress_body<T, MODE, STATS, PH, GEOM>(p, blockIdx.x, gridDim.x, blockIdx.x);
+  compress_body<T, MODE, STATS, PH, GEOM>(p, blockIdx.x, gridDim.x);
 }
 
 // The last, short block (length l = N % 64): the reference re-plans a length-l
@@ -612,26 +586,44 @@ __device__ __forceinline__ void qt_max_body(const FwdParams<T>& p, const unsigne
 template <typename T>
 __global__ __launch_bounds__(SWG) void k_qt_max(FwdParams<T> p, unsigned nlists) { qt_max_body<T>(p, nlists, blockIdx.x, gridDim.x); }
 
-// Move every workgroup-local list to its place in AC_exact[]
-// (dctz-comp-lib.c:478-544 order: lists are already block-major, j ascending).
+// Move every workgroup-local list to its place in AC_exact[], the sub-lists of every tile back in the reference's order
+// (dctz-comp-lib.c:478-544: block after block, j ascending -- k_compress leaves a tile as NQ sub-lists, each block-major
+// over a range of j; the remainder block's list is in order already).
 // QT: clamp the table (:450-461) and normalise on the way (:488-518).
 // The place of list l -- the running tot_AC_exact_count of :478-544 in front of it -- is the sum of the lengths of the
 // lists before it: at most 2049 of them, summed by the workgroup itself (no scan kernel); the workgroup of the last
-// list leaves the total.  fin.box set: workgroup 0 hands the call's results to the host first (finish_body).
+// list leaves the total.
+// A wave takes a tile: lane b reads block b's counts, prefix sums over the lanes give every (block, sub-list) run its
+// place in the tile's piece of the list and every block its place in the output; then the lanes walk the OUTPUT
+// positions (coalesced stores), look the owning block up (binary search over the blocks' first positions), the sub-list
+// from the block's counts, and fetch the item from its run.
 template <typename T, int MODE>
 __device__ __forceinline__ void compact_ac_body(const FwdParams<T>& p, const double eb, const unsigned nlists, const unsigned wg, const unsigned nwg,
                                                 unsigned* sh) {
   using Bits = typename Traits<T>::Bits;
-  __shared__ T q[64];
+  using S = Sub<T, MODE>;
+  constexpr int NQ = S::NQ, CB = S::CBITS, FB = S::FB, FPD = S::FPD, NPK = S::NPK;
+  constexpr unsigned CMASK = (1u << CB) - 1u, FMASK = (1u << FB) - 1u;
+  __shared__ T qtab[64];
+  __shared__ unsigned rb[SWG / 64][64];              // per wave: first output position of every block of the tile
+  __shared__ unsigned cb[SWG / 64][64];              // ... its counts (k_compress's word)
+  __shared__ unsigned qb[SWG / 64][NPK][64];         // ... the start of its run inside every sub-list (FB bits each)
   if (MODE == DCTZHIP_QT) {
     if (threadIdx.x < 64) {
       T v = Traits<T>::from_bits((Bits)p.ctl->qraw[threadIdx.x]);
       if (v < T(1)) v = T(1);
-      q[threadIdx.x] = v;
+      qtab[threadIdx.x] = v;
     }
     __syncthreads();
   }
   const unsigned G = p.nlists_main;
+  const unsigned lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+  // The in-range else-branch of :502-506 cannot fire for finite data and stores nothing; every flagged coefficient is
+  // appended.
+  auto fetch = [&](size_t at) -> float {
+    if (MODE == DCTZHIP_EC) return p.ac_tmp[at];
+    return (float)qt_normalise(p.qt_item[at], qtab[p.qt_j[at]], eb, T(10), p.range_min, p.range_max);
+  };
   for (unsigned l = wg; l < nlists; l += nwg) {
     unsigned before = 0;
     for (unsigned i = threadIdx.x; i < l; i += SWG) before += p.tile_cnt[i];
@@ -639,24 +631,63 @@ __device__ __forceinline__ void compact_ac_body(const FwdParams<T>& p, const dou
     const unsigned n = p.tile_cnt[l];
     if (l == nlists - 1 && threadIdx.x == 0) p.ctl->cnt_total = dst + n;
     const size_t src = list_slot(l, G, p.ntiles);
-    // four independent loads in flight per thread (a list is ~3 K items: the copy is latency-bound)
-    for (unsigned i0 = threadIdx.x; i0 < n; i0 += 4 * SWG) {
-      float v[4];
+    if (l >= G) {                                    // the remainder block's list: already in order
+      for (unsigned i = threadIdx.x; i < n; i += SWG) p.ac[dst + i] = fetch(src + i);
+      continue;
+    }
+    const TileRange tr = tile_range(l, G, p.ntiles);
+    for (unsigned t = tr.lo + wave; t < tr.hi; t += SWG / 64) {
+      unsigned pre = 0;                              // items of this list in front of tile t
+      for (unsigned u = tr.lo + lane; u < t; u += 64u) pre += p.ttot[u];
+      pre = (unsigned)__builtin_amdgcn_readlane((int)wave_incl_scan(pre), 63);
+      const unsigned blk = t * (unsigned)TILE_BLKS + lane;
+      const unsigned c = blk < p.nfull ? p.qcnt[blk] : 0u;
+      // prefix sums over the blocks, several sub-lists per dword
+      unsigned ex[NPK], tot[NPK];
 #pragma unroll
-      for (int u = 0; u < 4; u++) {
-        const unsigned i = i0 + (unsigned)u * SWG;
-        v[u] = 0.f;
-        if (i < n) {
-          if (MODE == DCTZHIP_EC) v[u] = p.ac_tmp[src + i];
-          // The in-range else-branch of :502-506 cannot fire for finite data and stores nothing; every flagged
-          // coefficient is appended.
-          else v[u] = (float)qt_normalise(p.qt_item[src + i], q[p.qt_j[src + i]], eb, T(10), p.range_min, p.range_max);
-        }
+      for (int d = 0; d < NPK; d++) {
+        unsigned v = 0;
+#pragma unroll
+        for (int f = 0; f < FPD; f++) if (d * FPD + f < NQ) v |= ((c >> ((d * FPD + f) * CB)) & CMASK) << (f * FB);
+        const unsigned incl = wave_incl_scan(v);
+        ex[d] = incl - v;
+        tot[d] = (unsigned)__builtin_amdgcn_readlane((int)incl, 63);
       }
+      unsigned rowbase = 0, qoff[NQ], acc_q = 0;     // qoff: where every sub-list starts in the tile's piece (uniform)
 #pragma unroll
-      for (int u = 0; u < 4; u++) {
-        const unsigned i = i0 + (unsigned)u * SWG;
-        if (i < n) p.ac[dst + i] = v[u];
+      for (int q = 0; q < NQ; q++) {
+        rowbase += (ex[q / FPD] >> ((q % FPD) * FB)) & FMASK;
+        qoff[q] = acc_q;
+        acc_q += (tot[q / FPD] >> ((q % FPD) * FB)) & FMASK;
+      }
+      const unsigned tt = acc_q;                     // == ttot[t]
+      rb[wave][lane] = rowbase;
+      cb[wave][lane] = c;
+#pragma unroll
+      for (int d = 0; d < NPK; d++) qb[wave][d][lane] = ex[d];
+      // (one wave writes and reads its own tables: LDS operations of a wave are in order)
+      for (unsigned o = lane; o < tt; o += 64u) {
+        unsigned b = 0;                              // largest b with rb[b] <= o: the block that owns output position o
+#pragma unroll
+        for (unsigned s = 32; s > 0; s >>= 1) b += (rb[wave][b + s] <= o) ? s : 0u;
+        unsigned r = o - rb[wave][b];
+        const unsigned cc = cb[wave][b];
+        unsigned q = 0;                              // the sub-list the r-th item of the block sits in
+#pragma unroll
+        for (int qq = 0; qq < NQ - 1; qq++) {
+          const unsigned nq = (cc >> (qq * CB)) & CMASK;
+          const bool adv = (q == (unsigned)qq) && r >= nq;
+          r -= adv ? nq : 0u;
+          q += adv ? 1u : 0u;
+        }
+        unsigned so = 0, qstart = 0;
+#pragma unroll
+        for (int qq = 0; qq < NQ; qq++) {
+          const unsigned e = (qb[wave][qq / FPD][b] >> ((qq % FPD) * FB)) & FMASK;
+          so = (q == (unsigned)qq) ? e : so;
+          qstart = (q == (unsigned)qq) ? qoff[qq] : qstart;
+        }
+        p.ac[dst + pre + o] = fetch(src + pre + qstart + so + r);
       }
     }
   }
@@ -1156,7 +1187,7 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu((sizeof(T) =
 void k_compress_batch(const BatchFwd<T>* items, const unsigned* __restrict__ first, unsigned k) {
   const unsigned i = batch_item_of(first, k, blockIdx.x);
   const FwdParams<T> p = load_params(&items[i].p);
-  compress_body<T, MODE, false, Phases<T>::C, GEOM_1D>(p, blockIdx.x - first[i], p.nlists_main, blockIdx.x);
+  compress_body<T, MODE, false, Phases<T>::C, GEOM_1D>(p, blockIdx.x - first[i], p.nlists_main);
 }
 
 template <typename T, int MODE>
@@ -1332,6 +1363,11 @@ void launch_decompress_rem_batch(const BatchInv<T>* items, const unsigned* rem_i
 }
 
 // explicit instantiations used by dctz_shim.hip
+// (development: tools/dev_one.sh compiles ONE kernel instantiation alone -- seconds instead of a minute -- for
+// register-allocation experiments)
+#ifdef DCTZ_DEV_ONE
+template __global__ void DCTZ_DEV_ONE(DCTZ_DEV_ARGS);
+#else
 
 #define INST(T)                                                                                         \
   template void launch_compress<T>(const FwdParams<T>&, int, bool, int, int, hipStream_t);              \
@@ -1353,5 +1389,6 @@ void launch_decompress_rem_batch(const BatchInv<T>* items, const unsigned* rem_i
   template size_t decompress_lds_bytes<T>();
 INST(double)
 INST(float)
+#endif
 
 }  // namespace dctz

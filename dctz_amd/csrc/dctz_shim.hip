@@ -48,8 +48,9 @@ struct dctzhip_ctx {
   unsigned* tile_cnt = nullptr;     // list lengths (compress) / per-tile flag counts (decode) and their exclusive prefix
   unsigned* wg_cnt = nullptr;       // decode: flag counts per workgroup of k_decompress
   size_t tile_cap = 0;              // entries
-  void* ovf = nullptr;              // k_compress overflow strips (dctz_device.h: FwdParams::ovf), sized for the largest grid
-  uint8_t* ovf_j = nullptr;
+  unsigned* qcnt = nullptr;         // k_compress -> k_compact_ac: per block, the counts of its tile's sub-lists (dctz_device.h: Sub)
+  unsigned* ttot = nullptr;         // ... per tile, its "stored exactly" coefficients
+  size_t qcnt_cap = 0;              // tiles the two hold
   void* qt_item = nullptr;
   uint8_t* qt_j = nullptr;
   size_t qt_cap = 0;                // bytes of qt_item
@@ -230,7 +231,7 @@ extern "C" void dctzhip_ctx_destroy(dctzhip_ctx* c) {
   (void)dctzhip_comm_destroy(c);
   (void)hipStreamSynchronize(c->stream);
   if (c->side_stream) { (void)hipStreamSynchronize(c->side_stream); (void)hipStreamDestroy(c->side_stream); }
-  void* bufs[] = {c->ovf, c->ovf_j, c->ac_tmp, c->tile_cnt, c->wg_cnt, c->serial_out, c->tab_f64, c->tab_f32, c->rtab, c->qtab, c->ctl, c->part, c->stats_out, c->qt_item, c->qt_j, c->nd_buf, c->dfl_buf, c->sf_thr[0], c->sf_thr[1], c->sf_pw[0], c->sf_pw[1], c->sf_guess};
+  void* bufs[] = {c->qcnt, c->ttot, c->ac_tmp, c->tile_cnt, c->wg_cnt, c->serial_out, c->tab_f64, c->tab_f32, c->rtab, c->qtab, c->ctl, c->part, c->stats_out, c->qt_item, c->qt_j, c->nd_buf, c->dfl_buf, c->sf_thr[0], c->sf_thr[1], c->sf_pw[0], c->sf_pw[1], c->sf_guess};
   for (void* b : bufs) if (b) (void)hipFree(b);
   if (c->h_pin) (void)hipHostFree(c->h_pin);
   if (c->box) (void)hipHostFree(c->box);
@@ -539,10 +540,13 @@ static int ensure_scratch(dctzhip_ctx* c, size_t n, int dtype, int mode, bool co
     if ((rc = regrow(c, &c->wg_cnt, &c->tile_cap, entries, sizeof(unsigned)))) return rc;
   }
   if (!compress) return DCTZHIP_OK;
-  if (!c->ovf) {                                       // 64 x 64 items per workgroup, WG_PER_CU_MAX workgroups per CU at most
-    const size_t items = (size_t)c->num_cu * WG_PER_CU_MAX * 64 * 64;
-    HIPCHK(c, hipMalloc(&c->ovf, items * sizeof(double)));
-    HIPCHK(c, hipMalloc(&c->ovf_j, items));
+  if (ntiles + 2 > c->qcnt_cap) {                      // one word per block / per tile
+    if (c->qcnt) HIPCHK(c, hipFree(c->qcnt));
+    if (c->ttot) HIPCHK(c, hipFree(c->ttot));
+    c->qcnt = nullptr; c->ttot = nullptr; c->qcnt_cap = 0;
+    HIPCHK(c, hipMalloc(&c->qcnt, (ntiles + 2) * TILE_BLKS * sizeof(unsigned)));
+    HIPCHK(c, hipMalloc(&c->ttot, (ntiles + 2) * sizeof(unsigned)));
+    c->qcnt_cap = ntiles + 2;
   }
   const size_t slots = (ntiles + 1) * TILE_ELEMS;      // list of workgroup b at the slot of its first tile; the remainder block's behind them
   if (mode == DCTZHIP_QT) {
@@ -702,7 +706,7 @@ static int compress_pass(dctzhip_ctx* c, const T* d_in, size_t n, double eb, int
   FwdParams<T> p;
   p.x = d_in; p.bin = d_bin; p.dc = d_dc; p.ac = d_ac; p.coef = d_coef;
   p.qt_item = reinterpret_cast<T*>(c->qt_item); p.qt_j = c->qt_j;
-  p.ovf = c->ovf; p.ovf_j = c->ovf_j;
+  p.qcnt = c->qcnt; p.ttot = c->ttot;
   p.ac_tmp = c->ac_tmp;
   p.tile_cnt = c->tile_cnt;
   p.tab = tab_of<T>(c); p.rtab = reinterpret_cast<const T*>(c->rtab);
@@ -1379,7 +1383,7 @@ struct SeqC {                       // one launch sequence of a compress batch: 
 // and reuse the chain's region.
 struct Chain {
   hipStream_t s = nullptr;
-  size_t tile_off = 0, list_off = 0, part_off = 0, slot_off = 0;      // first tile slot / list-length entry / partial slot / overflow strip
+  size_t tile_off = 0, list_off = 0, part_off = 0;                    // first tile slot / list-length entry / partial slot
   volatile unsigned long long* word = nullptr;                         // host view of the mailbox word the chain's last sequence publishes
   volatile unsigned long long* word_dev = nullptr;
   int last = -1;                                                       // index of the chain's last sequence
@@ -1463,10 +1467,8 @@ static int launch_compress_seq(dctzhip_ctx* c, const dctzhip_batch_citem* items,
   const int dtype = sizeof(T) == 8 ? DCTZHIP_F64 : DCTZHIP_F32;
   const size_t k = q.idx.size();
   hipStream_t s = ch.s;
-  // launch-time checks of the plan against the buffers it indexes (overflow strips: one per workgroup of the launch)
-  if (ch.slot_off + (size_t)q.grid_main > (size_t)c->num_cu * WG_PER_CU_MAX)
-    return fail(c, DCTZHIP_E_INTERNAL, "batch: %zu workgroups exceed the %d overflow strips", ch.slot_off + (size_t)q.grid_main, c->num_cu * WG_PER_CU_MAX);
-  if (q.parts_total > (size_t)PART_SLOTS || ch.list_off + q.lists_total + 2 > c->tile_cap)
+  // launch-time checks of the plan against the buffers it indexes
+  if (q.parts_total > (size_t)PART_SLOTS || ch.list_off + q.lists_total + 2 > c->tile_cap || ch.tile_off + q.tiles_total > c->qcnt_cap)
     return fail(c, DCTZHIP_E_INTERNAL, "batch: scratch plan exceeds its buffers");
   unsigned char* hb = c->b_blob + q.blob_off;
   BatchFwd<T>* hi = reinterpret_cast<BatchFwd<T>*>(hb);
@@ -1489,7 +1491,7 @@ static int launch_compress_seq(dctzhip_ctx* c, const dctzhip_batch_citem* items,
     p.qt_item = c->qt_item ? reinterpret_cast<T*>((char*)c->qt_item + ch.tile_off * TILE_ELEMS * sizeof(double)) + (size_t)q.tile_base[j] * TILE_ELEMS : nullptr;
     p.qt_j = c->qt_j ? c->qt_j + slot0 : nullptr;
     p.tile_cnt = c->tile_cnt + ch.list_off + q.list_base[j];
-    p.ovf = (char*)c->ovf + ch.slot_off * 64 * 64 * sizeof(double); p.ovf_j = c->ovf_j + ch.slot_off * 64 * 64;
+    p.qcnt = c->qcnt + (ch.tile_off + (size_t)q.tile_base[j]) * TILE_BLKS; p.ttot = c->ttot + ch.tile_off + q.tile_base[j];
     p.tab = tab_of<T>(c); p.rtab = nullptr;
     if (q.rem[j]) { int rc = rtab_for<T>(c, (int)q.rem[j], &p.rtab); if (rc) return rc; }
     p.ctl = c->b_ctl + q.item_off + j;
@@ -1602,7 +1604,7 @@ extern "C" int dctzhip_compress_batch(dctzhip_ctx* c, int k, const dctzhip_batch
   bool has[2] = {false, false};
   for (const SeqC& q : seqs) has[q.dtype] = true;
   const bool two = has[0] && has[1];                   // mixed batch: the fp32 sequences run beside the fp64 ones
-  size_t tiles_max[2] = {0, 0}, lists_max[2] = {0, 0}, grid_max[2] = {0, 0};
+  size_t tiles_max[2] = {0, 0}, lists_max[2] = {0, 0};
   Chain ch[2];
   for (size_t qi = 0; qi < seqs.size(); qi++) {
     SeqC& q = seqs[qi];
@@ -1612,13 +1614,12 @@ extern "C" int dctzhip_compress_batch(dctzhip_ctx* c, int k, const dctzhip_batch
     q.blob_off = blob; blob += q.blob_bytes;
     if (q.tiles_total > tiles_max[q.chain]) tiles_max[q.chain] = q.tiles_total;
     if (q.lists_total > lists_max[q.chain]) lists_max[q.chain] = q.lists_total;
-    if (q.grid_main > grid_max[q.chain]) grid_max[q.chain] = q.grid_main;
     ch[q.chain].last = (int)qi;
   }
   if (!seqs.empty()) {
     // scratch: one region per chain, sized for the chain's largest sequence (its sequences follow each other on the
     // chain's stream and reuse it), in the widest element type
-    ch[1].tile_off = tiles_max[0]; ch[1].list_off = lists_max[0] + 2; ch[1].part_off = PART_SLOTS; ch[1].slot_off = grid_max[0];
+    ch[1].tile_off = tiles_max[0]; ch[1].list_off = lists_max[0] + 2; ch[1].part_off = PART_SLOTS;
     int rc = ensure_scratch(c, (tiles_max[0] + tiles_max[1]) * TILE_ELEMS, DCTZHIP_F64, mode, true, lists_max[0] + lists_max[1] + 6);
     if (rc) return rc;
     rc = ensure_batch(c, K, blob, 0);
@@ -2010,7 +2011,7 @@ extern "C" int dctzhip_comm_gather(dctzhip_ctx* c, int root, const void* d_bin, 
 }
 
 #ifdef DCTZ_STAMP
-namespace dctz { void read_dec_stamps(unsigned long long* out12); }
+namespace dctz { void read_dec_stamps(unsigned long long* out12); void read_cmp_stamps(unsigned long long* out12); }
 extern "C" int dctzhip_debug_stamps_dec(dctzhip_ctx* c, unsigned long long* out12) {
   if (!c) return DCTZHIP_E_ARG;
   HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -2019,9 +2020,9 @@ extern "C" int dctzhip_debug_stamps_dec(dctzhip_ctx* c, unsigned long long* out1
 }
 // diagnostic builds only: the 12 phase-cycle sums of k_compress (dctz_kernels.hip, STAMP), read and reset
 extern "C" int dctzhip_debug_stamps(dctzhip_ctx* c, unsigned long long* out12) {
-  if (!c || !c->ovf_j) return DCTZHIP_E_ARG;
-  HIPCHK(c, hipMemcpy(out12, c->ovf_j, 96, hipMemcpyDeviceToHost));
-  HIPCHK(c, hipMemset(c->ovf_j, 0, 96));
+  if (!c) return DCTZHIP_E_ARG;
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  dctz::read_cmp_stamps(out12);
   return DCTZHIP_OK;
 }
 #endif
