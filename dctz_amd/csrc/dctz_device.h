@@ -68,28 +68,28 @@ template <typename T, int PHASES = 1> struct Geo {
   static constexpr int PHB = TILEB / PH;                 // bytes of a phase image
   static_assert(NSEG % PH == 0, "a phase is a whole number of 128-byte segments");
 };
-// The "stored exactly" coefficients of a tile leave k_compress as SUB-LISTS: the coefficients j in [q QW, (q + 1) QW) of
-// all 64 blocks, block after block, compacted in LDS by the whole wave (one prefix sum over the lanes' counts per
-// sub-list) and written out in whole rows of 64 items.  The staging buffer holds one sub-list: 64 x QW items, of which
-// the last 64 slots are the lanes' dump slots (a coefficient that is not stored exactly is written there), so a
-// sub-list with more than CAP items goes out in two rounds.  k_compact_ac puts the sub-lists of a tile back into the
-// reference's order (dctz-comp-lib.c:478-544: block-major, j ascending) from the per-block counts k_compress leaves:
-// one word per block, CBITS bits per sub-list.  An item is a float (EC: what AC_exact stores) or the coefficient in
-// full precision plus its position (QT: the normalisation needs the table of the whole array first).
+// The "stored exactly" coefficients of a tile leave k_compress as NQ = 4 SUB-LISTS: the coefficients j in [16 q, 16 q + 16)
+// of all 64 blocks, block after block, compacted in LDS by the whole wave (one prefix sum over the lanes' counts per
+// sub-list) and written out in whole rows of 64 items.  The staging buffer holds SLOTS items, of which the last 64 are
+// the lanes' dump slots (a coefficient that is not stored exactly is written there); a sub-list with more than CAP items
+// goes out in several rounds.  k_compact_ac puts the sub-lists of a tile back into the reference's order
+// (dctz-comp-lib.c:478-544: block-major, j ascending) from the per-block counts k_compress leaves: one word per block,
+// a byte per sub-list.  An item is a float (EC: what AC_exact stores) or the coefficient in full precision plus its
+// position (QT: the normalisation needs the table of the whole array first).
 template <typename T, int MODE> struct Sub {
   using Item = typename std::conditional<MODE == DCTZHIP_EC, float, T>::type;
-  static constexpr int QW = (MODE == DCTZHIP_QT && sizeof(T) == 8) ? 8 : 16;      // coefficients per sub-list
-  static constexpr int NQ = 64 / QW;                                                // sub-lists per tile (4 | 8)
-  static constexpr int SLOTS = 64 * QW;
+  static constexpr int QW = 16;                                                     // coefficients per sub-list
+  static constexpr int NQ = 64 / QW;                                                // sub-lists per tile
+  static constexpr int SLOTS = EXC_BYTES / (int)sizeof(Item);                       // 1024 floats | 512 doubles
   static constexpr int CAP = SLOTS - 64;
-  static constexpr int ITEM_BYTES = SLOTS * (int)sizeof(Item);                      // 4 KiB in every case
+  static constexpr int ITEM_BYTES = SLOTS * (int)sizeof(Item);                      // 4 KiB: what the tile's bin ids need on their way out too
   static constexpr int POS_BYTES = (MODE == DCTZHIP_QT) ? SLOTS : 0;
-  static constexpr int BYTES = ITEM_BYTES + POS_BYTES > EXC_BYTES ? ITEM_BYTES + POS_BYTES : EXC_BYTES;
-  static constexpr int CBITS = 32 / NQ;                                             // bits per count in a block's word (8 | 4; counts <= QW)
-  // k_compact_ac: the counts of several sub-lists share a dword for the prefix sums over the blocks of a tile
-  static constexpr int FB = (NQ == 4) ? 16 : 10;                                    // bits per field (sums <= 64 QW = 1024 | 512)
-  static constexpr int FPD = 32 / FB;                                               // fields per dword (2 | 3)
-  static constexpr int NPK = (NQ + FPD - 1) / FPD;                                  // dwords (2 | 3)
+  static constexpr int BYTES = ITEM_BYTES + POS_BYTES;
+  static constexpr int CBITS = 32 / NQ;                                             // bits per count in a block's word (counts <= QW)
+  // k_compact_ac: the counts of two sub-lists share a dword for the prefix sums over the blocks of a tile (sums <= 1024)
+  static constexpr int FB = 16;
+  static constexpr int FPD = 32 / FB;
+  static constexpr int NPK = (NQ + FPD - 1) / FPD;
 };
 // phases of k_compress / k_decompress per element type (build knobs for A/B runs)
 #ifndef DCTZ_PHC64

@@ -354,7 +354,7 @@ __device__ __forceinline__ void compress_body(const FwdParams<T>& p, const unsig
     //     go to the lane's dump slot) and the sub-list leaves in whole rows of 64 items.
     auto sub_list = [&](auto qi, auto fast, auto safe) {
       constexpr int Q = decltype(qi)::value, J0 = Q * QW;
-      Item fq[QW];
+      Item fq[QW] = {};
       unsigned m = 0;
 #pragma unroll
       for (int gg = 0; gg < QW / 4; gg++) {
@@ -383,10 +383,14 @@ __device__ __forceinline__ void compress_body(const FwdParams<T>& p, const unsig
         for (int i = 0; i < 4; i++) wgd = __builtin_amdgcn_cvt_pk_u8_f32(h[i], i, wgd);
         asm volatile("" : "+v"(wgd));                // packed HERE: left alone, the compiler sinks all 64 conversions below the
         w[g] = wgd;                                  // last group and keeps 64 fp64 bin values alive (128 registers) until then
+        // "stored exactly" = id 255: bit 7 of byte i of mm.  A group is only looked at further when SOME lane of the wave
+        // has such a coefficient in it (the high-frequency groups of a smooth field never do)
+        const unsigned nw = ~wgd;
+        const unsigned mm = ~(((nw & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | nw) & 0x80808080u;
+        if (__builtin_amdgcn_ballot_w64(mm != 0u)) {
 #pragma unroll
-        for (int i = 0; i < 4; i++) {
-          fq[4 * gg + i] = (Item)x[4 * g + i];       // :496-497 / :535-537 USE_TRUNCATE (EC); QT: full precision
-          m |= (h[i] >= 255.0f ? 1u : 0u) << (4 * gg + i);
+          for (int i = 0; i < 4; i++) fq[4 * gg + i] = (Item)x[4 * g + i];       // :496-497 / :535-537 USE_TRUNCATE (EC); QT: full precision
+          m |= (((mm >> 7) | (mm >> 14) | (mm >> 21) | (mm >> 28)) & 0xFu) << (4 * gg);
         }
         __builtin_amdgcn_sched_barrier(0);           // keep the groups apart: hoisting all 64 quotients first costs 128 registers
       }
@@ -396,14 +400,18 @@ __device__ __forceinline__ void compress_body(const FwdParams<T>& p, const unsig
       const unsigned incl = wave_incl_scan(n);
       const unsigned tot = (unsigned)__builtin_amdgcn_readlane((int)incl, 63);
       const unsigned base = incl - n;                // this block's place in the sub-list
-      for (unsigned lo = 0; lo < tot; lo += (unsigned)S::CAP) {      // (one round unless nearly every coefficient is stored exactly)
+      for (unsigned lo = 0; lo < tot; lo += (unsigned)S::CAP) {      // (one round unless most coefficients are stored exactly)
         unsigned pos = base - lo;                    // (wraps for blocks in front of the round's window: never < CAP then)
+        // (QT: the positions J0 + i come from ONE register the compiler cannot see through -- as 16 constants per
+        // sub-list they are hoisted out of the tile loop and cost 64 registers, i.e. 60 spilled ones)
+        unsigned jv = (unsigned)J0;
+        if (MODE == DCTZHIP_QT) asm volatile("" : "+v"(jv));
 #pragma unroll
         for (int i = 0; i < QW; i++) {
           const bool f = ((m >> i) & 1u) != 0u;
           const unsigned at = (f && pos < (unsigned)S::CAP) ? pos : (unsigned)(S::CAP + lane);
           items[at] = fq[i];
-          if (MODE == DCTZHIP_QT) jbuf[at] = (unsigned char)(J0 + i);
+          if (MODE == DCTZHIP_QT) jbuf[at] = (unsigned char)(jv + (unsigned)i);
           pos += f ? 1u : 0u;
         }
         const unsigned cnt = min(tot - lo, (unsigned)S::CAP);
@@ -435,7 +443,6 @@ __device__ __forceinline__ void compress_body(const FwdParams<T>& p, const unsig
     };
     sub(std::integral_constant<int, 0>{});
     sub(std::integral_constant<int, 1>{});
-    if constexpr (NQ == 8) { sub(std::integral_constant<int, 2>{}); sub(std::integral_constant<int, 3>{}); }
     STAMP(7);
     if (PH == 2 && tile + 1 < tr.hi) {               // the next tile's first half (see above)
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -446,9 +453,8 @@ __device__ __forceinline__ void compress_body(const FwdParams<T>& p, const unsig
       stats_scale(xn, std::integral_constant<int, 0>{}, (unsigned)lane < min((unsigned)TILE_BLKS, p.nfull - (tile + 1) * TILE_BLKS), false);
       STAMP(9);
     }
-    sub(std::integral_constant<int, NQ / 2>{});
-    sub(std::integral_constant<int, NQ / 2 + 1>{});
-    if constexpr (NQ == 8) { sub(std::integral_constant<int, 6>{}); sub(std::integral_constant<int, 7>{}); }
+    sub(std::integral_constant<int, 2>{});
+    sub(std::integral_constant<int, 3>{});
     STAMP(10);
     w[0] |= 0xFFu;                                   // :361 DC slot
     if (lane == 0) p.ttot[tile] = ttot;
