@@ -78,7 +78,10 @@ template <typename T, int PHASES = 1> struct Geo {
 // position (QT: the normalisation needs the table of the whole array first).
 template <typename T, int MODE> struct Sub {
   using Item = typename std::conditional<MODE == DCTZHIP_EC, float, T>::type;
-  static constexpr int QW = 16;                                                     // coefficients per sub-list
+#ifndef DCTZ_QW64
+#define DCTZ_QW64 8
+#endif
+  static constexpr int QW = sizeof(T) == 8 ? DCTZ_QW64 : 16;                        // coefficients per sub-list
   static constexpr int NQ = 64 / QW;                                                // sub-lists per tile
   static constexpr int SLOTS = EXC_BYTES / (int)sizeof(Item);                       // 1024 floats | 512 doubles
   static constexpr int CAP = SLOTS - 64;

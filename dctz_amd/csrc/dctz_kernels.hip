@@ -354,7 +354,7 @@ __device__ __forceinline__ void compress_body(const FwdParams<T>& p, const unsig
     //     go to the lane's dump slot) and the sub-list leaves in whole rows of 64 items.
     auto sub_list = [&](auto qi, auto fast, auto safe) {
       constexpr int Q = decltype(qi)::value, J0 = Q * QW;
-      Item fq[QW] = {};
+      Item fq[QW];
       unsigned m = 0;
 #pragma unroll
       for (int gg = 0; gg < QW / 4; gg++) {
@@ -442,7 +442,8 @@ __device__ __forceinline__ void compress_body(const FwdParams<T>& p, const unsig
       else sub_list(qi, std::false_type{}, std::true_type{});
     };
     sub(std::integral_constant<int, 0>{});
-    sub(std::integral_constant<int, 1>{});
+    if constexpr (NQ >= 4) sub(std::integral_constant<int, 1>{});
+    if constexpr (NQ >= 8) { sub(std::integral_constant<int, 2>{}); sub(std::integral_constant<int, 3>{}); }
     STAMP(7);
     if (PH == 2 && tile + 1 < tr.hi) {               // the next tile's first half (see above)
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -453,8 +454,9 @@ __device__ __forceinline__ void compress_body(const FwdParams<T>& p, const unsig
       stats_scale(xn, std::integral_constant<int, 0>{}, (unsigned)lane < min((unsigned)TILE_BLKS, p.nfull - (tile + 1) * TILE_BLKS), false);
       STAMP(9);
     }
-    sub(std::integral_constant<int, 2>{});
-    sub(std::integral_constant<int, 3>{});
+    sub(std::integral_constant<int, NQ / 2>{});
+    if constexpr (NQ >= 4) sub(std::integral_constant<int, NQ / 2 + 1>{});
+    if constexpr (NQ >= 8) { sub(std::integral_constant<int, 6>{}); sub(std::integral_constant<int, 7>{}); }
     STAMP(10);
     w[0] |= 0xFFu;                                   // :361 DC slot
     if (lane == 0) p.ttot[tile] = ttot;
