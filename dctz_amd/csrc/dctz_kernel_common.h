@@ -34,6 +34,27 @@ template <typename T> __device__ __forceinline__ CTab<T> as_ctab(const T* p) { r
 #define DMA16(rsrc, lds, voff, soff, aux) ((void)0)
 #endif
 
+// LDS stores the compiler does not see as such.  A pending LDS-DMA (the next tile on its way into its image) makes the
+// compiler put `s_waitcnt vmcnt(0)` in front of every LDS STORE it cannot prove disjoint from the DMA's target -- and
+// it proves that for loads only (the disassembly of round 2's k_compress had such a wait in front of every parked
+// group: the DMA that was meant to land under the arithmetic was waited for at the first store behind its issue).  The
+// staging buffers these helpers write are arrays of their own, never a DMA target.  LDS operations of a wave execute
+// in order, so a compiler-visible load behind such a store sees its data.
+__device__ __forceinline__ unsigned lds_offset(const void* p) { return (unsigned)(size_t)LDS_PTR(p); }
+#if defined(__HIP_DEVICE_COMPILE__)
+__device__ __forceinline__ void lds_store_b8(unsigned at, unsigned v) { asm volatile("ds_write_b8 %0, %1" :: "v"(at), "v"(v) : "memory"); }
+__device__ __forceinline__ void lds_store_b32(unsigned at, unsigned v) { asm volatile("ds_write_b32 %0, %1" :: "v"(at), "v"(v) : "memory"); }
+__device__ __forceinline__ void lds_store_b64(unsigned at, u32x2 v) { asm volatile("ds_write_b64 %0, %1" :: "v"(at), "v"(v) : "memory"); }
+__device__ __forceinline__ void lds_store_b128(unsigned at, u32x4 v) { asm volatile("ds_write_b128 %0, %1" :: "v"(at), "v"(v) : "memory"); }
+#else
+__device__ __forceinline__ void lds_store_b8(unsigned, unsigned) {}
+__device__ __forceinline__ void lds_store_b32(unsigned, unsigned) {}
+__device__ __forceinline__ void lds_store_b64(unsigned, u32x2) {}
+__device__ __forceinline__ void lds_store_b128(unsigned, u32x4) {}
+#endif
+__device__ __forceinline__ void lds_store_item(unsigned at, float v) { lds_store_b32(at, __builtin_bit_cast(unsigned, v)); }
+__device__ __forceinline__ void lds_store_item(unsigned at, double v) { lds_store_b64(at, __builtin_bit_cast(u32x2, v)); }
+
 // ------------------------------------------------------------------ helpers --
 // Streaming (read-once / write-once) 16-byte accesses: the `nt` policy.  A pure 1 GiB read stream
 // runs at 6.8-7.1 TB/s with nt loads against 6.0-6.3 TB/s with plain ones (tools/ubench/stream_read.hip).

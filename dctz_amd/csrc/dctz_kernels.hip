@@ -164,6 +164,7 @@ __device__ __forceinline__ void compress_body(const FwdParams<T>& p, const unsig
   __shared__ __attribute__((aligned(16))) unsigned char excbuf[S::BYTES];            // one sub-list; also: the tile's bin ids on their way out
   Item* const items = reinterpret_cast<Item*>(excbuf);
   unsigned char* const jbuf = excbuf + S::ITEM_BYTES;                                // QT: position j of every staged item
+  const unsigned exc_at = lds_offset(excbuf);                                        // (stores into it: dctz_kernel_common.h, lds_store_*)
   // QT, fp32: per-position maximum |coef| over the out-of-range coefficients (dctz-comp-lib.c:371-372 / :396-397), kept
   // per wave while the sub-lists go out (one LDS atomic per item) and merged into Ctl::qraw at the end -- no pass over
   // the lists for it.  (fp64 keeps the separate k_qt_max: the kernel is at its register limit.)
@@ -228,7 +229,7 @@ __device__ __forceinline__ void compress_body(const FwdParams<T>& p, const unsig
     const int f2 = (lo >> 1) & 3;
 #pragma unroll
     for (int i = 0; i < 4; i++)
-      *reinterpret_cast<u32x4*>(excbuf + (lo * 4 + (i ^ f2)) * 16) = u32x4{pw[4 * i], pw[4 * i + 1], pw[4 * i + 2], pw[4 * i + 3]};
+      lds_store_b128(exc_at + (unsigned)((lo * 4 + (i ^ f2)) * 16), u32x4{pw[4 * i], pw[4 * i + 1], pw[4 * i + 2], pw[4 * i + 3]});
     const int bin_goff = (lo >> 2) * 64 + (((lo & 3) ^ ((lo >> 3) & 3)) * 16);
     const int voff = (int)(p_rel * (unsigned)TILE_ELEMS) + bin_goff;
 #pragma unroll
@@ -410,8 +411,8 @@ __device__ __forceinline__ void compress_body(const FwdParams<T>& p, const unsig
         for (int i = 0; i < QW; i++) {
           const bool f = ((m >> i) & 1u) != 0u;
           const unsigned at = (f && pos < (unsigned)S::CAP) ? pos : (unsigned)(S::CAP + lane);
-          items[at] = fq[i];
-          if (MODE == DCTZHIP_QT) jbuf[at] = (unsigned char)(jv + (unsigned)i);
+          lds_store_item(exc_at + at * (unsigned)sizeof(Item), fq[i]);
+          if (MODE == DCTZHIP_QT) lds_store_b8(exc_at + (unsigned)S::ITEM_BYTES + at, jv + (unsigned)i);
           pos += f ? 1u : 0u;
         }
         const unsigned cnt = min(tot - lo, (unsigned)S::CAP);

@@ -45,7 +45,7 @@ def main():
         ctxs.append((spec, c))
     out = ctxs[0][1].alloc_outputs(n)
     rec = torch.empty(n, dtype=tdt, device="cuda")
-    res = {spec: {"c": [], "d": [], "s": []} for spec, _ in ctxs}
+    res = {spec: {"c": [], "d": [], "s": [], "ct": [], "dt": [], "dp": []} for spec, _ in ctxs}
     ref = None
     for r in range(a.rounds + 1):
         for spec, c in ctxs:
@@ -59,6 +59,7 @@ def main():
                 assert sig == ref, (spec, sig, ref)
                 continue
             res[spec]["c"].append(tc["main_ms"]); res[spec]["d"].append(td["main_ms"]); res[spec]["s"].append(tc["stats_ms"])
+            res[spec]["ct"].append(tc["tail_ms"]); res[spec]["dt"].append(td["tail_ms"]); res[spec]["dp"].append(td["stats_ms"])
     es = x.element_size()
     p = info.cnt / n
     bc = n * (es + 1.0625 + 4 * p)
@@ -66,7 +67,9 @@ def main():
         mc, md, ms = (statistics.median(res[spec][k]) for k in ("c", "d", "s"))
         print(json.dumps({"variant": spec, "compress_ms": round(mc, 4), "decompress_ms": round(md, 4), "stats_ms": round(ms, 4),
                           "compress_frac_hbm": round(bc / (mc * 1e-3) / 8e12, 4), "decompress_frac_hbm": round(bc / (md * 1e-3) / 8e12, 4),
-                          "min_c": round(min(res[spec]["c"]), 4), "min_d": round(min(res[spec]["d"]), 4)}))
+                          "min_c": round(min(res[spec]["c"]), 4), "min_d": round(min(res[spec]["d"]), 4),
+                          "compress_tail_ms": round(statistics.median(res[spec]["ct"]), 4), "decompress_count_ms": round(statistics.median(res[spec]["dp"]), 4),
+                          "p": round(p, 4)}))
 
 
 if __name__ == "__main__":
