@@ -286,7 +286,7 @@ template <typename T> void launch_scale_batch(const BatchFwd<T>* items, const un
 template <typename T> void launch_compress_batch(const BatchFwd<T>* items, const unsigned* first, unsigned k, unsigned grid, int mode, hipStream_t s);
 template <typename T> void launch_compress_rem_batch(const BatchFwd<T>* items, const unsigned* rem_items, unsigned nrem, int mode, hipStream_t s);
 template <typename T> void launch_qt_max_batch(const BatchFwd<T>* items, const unsigned* first, unsigned k, unsigned grid, hipStream_t s);
-template <typename T> void launch_compact_batch(const BatchFwd<T>* items, const unsigned* first, unsigned k, unsigned grid, int mode,
+template <typename T> void launch_compact_batch(const BatchFwd<T>* items, const unsigned* first, unsigned k, unsigned grid, unsigned chunks, int mode,
                                                 const double* bstats, const BatchFin& fin, hipStream_t s);
 template <typename T> void launch_count_batch(const BatchInv<T>* items_src, const unsigned* first_src, unsigned k, unsigned grid,
                                               const void* blob_src, void* blob_dst, size_t blob_bytes, hipStream_t s);

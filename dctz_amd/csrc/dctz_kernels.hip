@@ -602,21 +602,34 @@ __global__ __launch_bounds__(SWG) void k_qt_max(FwdParams<T> p, unsigned nlists)
 // The place of list l -- the running tot_AC_exact_count of :478-544 in front of it -- is the sum of the lengths of the
 // lists before it: at most 2049 of them, summed by the workgroup itself (no scan kernel); the workgroup of the last
 // list leaves the total.
-// A wave takes a tile: lane b reads block b's counts, prefix sums over the lanes give every (block, sub-list) run its
-// place in the tile's piece of the list and every block its place in the output; then the lanes walk the OUTPUT
-// positions (coalesced stores), look the owning block up (binary search over the blocks' first positions), the sub-list
-// from the block's counts, and fetch the item from its run.
+// Grid: (list, chunk of COMPACT_TPW tiles of the list); a WAVE takes a tile, so that all tiles of the array are in flight
+// at once (the work of a tile is a chain of dependent round trips).  Lane b reads block b's counts; prefix sums over
+// the lanes give every (block, sub-list) run its place in the tile's piece of the list and every block its first place
+// in the output.  Then the lanes walk the OUTPUT positions (coalesced stores): the owning block of a position comes
+// from an owner map in LDS (every block marks its first position, a running maximum fills the gaps), the sub-list from
+// the block's counts, the item from its run.
+constexpr int COMPACT_TPW = SWG / 64;                // tiles per workgroup of k_compact_ac: one per wave
+__device__ __forceinline__ unsigned wave_incl_max_scan(unsigned v) {
+  v = max(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, true));    // row_shr:1
+  v = max(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, true));    // row_shr:2
+  v = max(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, true));    // row_shr:4
+  v = max(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, true));    // row_shr:8
+  v = max(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false));   // row_bcast:15 -> rows 1, 3
+  v = max(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false));   // row_bcast:31 -> rows 2, 3
+  return v;
+}
 template <typename T, int MODE>
-__device__ __forceinline__ void compact_ac_body(const FwdParams<T>& p, const double eb, const unsigned nlists, const unsigned wg, const unsigned nwg,
+__device__ __forceinline__ void compact_ac_body(const FwdParams<T>& p, const double eb, const unsigned nlists, const unsigned l, const unsigned chunk,
                                                 unsigned* sh) {
   using Bits = typename Traits<T>::Bits;
   using S = Sub<T, MODE>;
   constexpr int NQ = S::NQ, CB = S::CBITS, FB = S::FB, FPD = S::FPD, NPK = S::NPK;
   constexpr unsigned CMASK = (1u << CB) - 1u, FMASK = (1u << FB) - 1u;
   __shared__ T qtab[64];
-  __shared__ unsigned rb[SWG / 64][64];              // per wave: first output position of every block of the tile
-  __shared__ unsigned cb[SWG / 64][64];              // ... its counts (k_compress's word)
-  __shared__ unsigned qb[SWG / 64][NPK][64];         // ... the start of its run inside every sub-list (FB bits each)
+  __shared__ unsigned rb[COMPACT_TPW][64];           // per wave: first output position of every block of the tile
+  __shared__ unsigned cb[COMPACT_TPW][64];           // ... its counts (k_compress's word)
+  __shared__ unsigned qb[COMPACT_TPW][NPK][64];      // ... the start of its run inside every sub-list (FB bits each)
+  __shared__ __attribute__((aligned(16))) unsigned char own[COMPACT_TPW][TILE_ELEMS];   // ... owner map: block that owns an output position
   if (MODE == DCTZHIP_QT) {
     if (threadIdx.x < 64) {
       T v = Traits<T>::from_bits((Bits)p.ctl->qraw[threadIdx.x]);
@@ -633,78 +646,91 @@ __device__ __forceinline__ void compact_ac_body(const FwdParams<T>& p, const dou
     if (MODE == DCTZHIP_EC) return p.ac_tmp[at];
     return (float)qt_normalise(p.qt_item[at], qtab[p.qt_j[at]], eb, T(10), p.range_min, p.range_max);
   };
-  for (unsigned l = wg; l < nlists; l += nwg) {
-    unsigned before = 0;
-    for (unsigned i = threadIdx.x; i < l; i += SWG) before += p.tile_cnt[i];
-    const unsigned dst = block_sum(before, sh);
-    const unsigned n = p.tile_cnt[l];
-    if (l == nlists - 1 && threadIdx.x == 0) p.ctl->cnt_total = dst + n;
-    const size_t src = list_slot(l, G, p.ntiles);
-    if (l >= G) {                                    // the remainder block's list: already in order
+  unsigned before = 0;
+  for (unsigned i = threadIdx.x; i < l; i += SWG) before += p.tile_cnt[i];
+  const unsigned dst = block_sum(before, sh);
+  const unsigned n = p.tile_cnt[l];
+  if (l == nlists - 1 && chunk == 0 && threadIdx.x == 0) p.ctl->cnt_total = dst + n;
+  const size_t src = list_slot(l, G, p.ntiles);
+  if (l >= G) {                                      // the remainder block's list: already in order
+    if (chunk == 0)
       for (unsigned i = threadIdx.x; i < n; i += SWG) p.ac[dst + i] = fetch(src + i);
-      continue;
-    }
-    const TileRange tr = tile_range(l, G, p.ntiles);
-    for (unsigned t = tr.lo + wave; t < tr.hi; t += SWG / 64) {
-      unsigned pre = 0;                              // items of this list in front of tile t
-      for (unsigned u = tr.lo + lane; u < t; u += 64u) pre += p.ttot[u];
-      pre = (unsigned)__builtin_amdgcn_readlane((int)wave_incl_scan(pre), 63);
-      const unsigned blk = t * (unsigned)TILE_BLKS + lane;
-      const unsigned c = blk < p.nfull ? p.qcnt[blk] : 0u;
-      // prefix sums over the blocks, several sub-lists per dword
-      unsigned ex[NPK], tot[NPK];
+    return;
+  }
+  const TileRange tr = tile_range(l, G, p.ntiles);
+  const unsigned t = tr.lo + chunk * (unsigned)COMPACT_TPW + wave;
+  if (t >= tr.hi) return;
+  unsigned pre = 0;                                  // items of this list in front of tile t
+  for (unsigned u = tr.lo + lane; u < t; u += 64u) pre += p.ttot[u];
+  pre = (unsigned)__builtin_amdgcn_readlane((int)wave_incl_scan(pre), 63);
+  const unsigned blk = t * (unsigned)TILE_BLKS + lane;
+  const unsigned c = blk < p.nfull ? p.qcnt[blk] : 0u;
+  // prefix sums over the blocks, FPD sub-lists per dword
+  unsigned ex[NPK], tot[NPK];
+#pragma unroll
+  for (int d = 0; d < NPK; d++) {
+    unsigned v = 0;
+#pragma unroll
+    for (int f = 0; f < FPD; f++) if (d * FPD + f < NQ) v |= ((c >> ((d * FPD + f) * CB)) & CMASK) << (f * FB);
+    const unsigned incl = wave_incl_scan(v);
+    ex[d] = incl - v;
+    tot[d] = (unsigned)__builtin_amdgcn_readlane((int)incl, 63);
+  }
+  unsigned rowbase = 0, nb = 0, qoff[NQ], acc_q = 0;  // qoff: where every sub-list starts in the tile's piece (uniform)
+#pragma unroll
+  for (int q = 0; q < NQ; q++) {
+    rowbase += (ex[q / FPD] >> ((q % FPD) * FB)) & FMASK;
+    nb += (c >> (q * CB)) & CMASK;
+    qoff[q] = acc_q;
+    acc_q += (tot[q / FPD] >> ((q % FPD) * FB)) & FMASK;
+  }
+  const unsigned tt = acc_q;                         // == ttot[t]
+  if (tt == 0) return;
+  // (one wave writes and reads its own tables: LDS operations of a wave are in order)
+  rb[wave][lane] = rowbase;
+  cb[wave][lane] = c;
+#pragma unroll
+  for (int d = 0; d < NPK; d++) qb[wave][d][lane] = ex[d];
+  for (unsigned o = lane * 16u; o < tt; o += 1024u) *reinterpret_cast<u32x4*>(&own[wave][o]) = u32x4{0u, 0u, 0u, 0u};
+  if (nb != 0) own[wave][rowbase] = (unsigned char)lane;
+  unsigned carry = 0;
+  for (unsigned o0 = 0; o0 < tt; o0 += 64u) {
+    const unsigned o = o0 + lane;
+    unsigned b = wave_incl_max_scan((unsigned)own[wave][o]);
+    b = max(b, carry);
+    carry = (unsigned)__builtin_amdgcn_readlane((int)b, 63);
+    if (o < tt) {
+      unsigned r = o - rb[wave][b];
+      const unsigned cc = cb[wave][b];
+      unsigned q = 0;                                // the sub-list the r-th item of the block sits in
+#pragma unroll
+      for (int qq = 0; qq < NQ - 1; qq++) {
+        const unsigned nq = (cc >> (qq * CB)) & CMASK;
+        const bool adv = (q == (unsigned)qq) && r >= nq;
+        r -= adv ? nq : 0u;
+        q += adv ? 1u : 0u;
+      }
+      unsigned so = 0, qstart = 0;
 #pragma unroll
       for (int d = 0; d < NPK; d++) {
-        unsigned v = 0;
+        const unsigned e = qb[wave][d][b];
 #pragma unroll
-        for (int f = 0; f < FPD; f++) if (d * FPD + f < NQ) v |= ((c >> ((d * FPD + f) * CB)) & CMASK) << (f * FB);
-        const unsigned incl = wave_incl_scan(v);
-        ex[d] = incl - v;
-        tot[d] = (unsigned)__builtin_amdgcn_readlane((int)incl, 63);
-      }
-      unsigned rowbase = 0, qoff[NQ], acc_q = 0;     // qoff: where every sub-list starts in the tile's piece (uniform)
-#pragma unroll
-      for (int q = 0; q < NQ; q++) {
-        rowbase += (ex[q / FPD] >> ((q % FPD) * FB)) & FMASK;
-        qoff[q] = acc_q;
-        acc_q += (tot[q / FPD] >> ((q % FPD) * FB)) & FMASK;
-      }
-      const unsigned tt = acc_q;                     // == ttot[t]
-      rb[wave][lane] = rowbase;
-      cb[wave][lane] = c;
-#pragma unroll
-      for (int d = 0; d < NPK; d++) qb[wave][d][lane] = ex[d];
-      // (one wave writes and reads its own tables: LDS operations of a wave are in order)
-      for (unsigned o = lane; o < tt; o += 64u) {
-        unsigned b = 0;                              // largest b with rb[b] <= o: the block that owns output position o
-#pragma unroll
-        for (unsigned s = 32; s > 0; s >>= 1) b += (rb[wave][b + s] <= o) ? s : 0u;
-        unsigned r = o - rb[wave][b];
-        const unsigned cc = cb[wave][b];
-        unsigned q = 0;                              // the sub-list the r-th item of the block sits in
-#pragma unroll
-        for (int qq = 0; qq < NQ - 1; qq++) {
-          const unsigned nq = (cc >> (qq * CB)) & CMASK;
-          const bool adv = (q == (unsigned)qq) && r >= nq;
-          r -= adv ? nq : 0u;
-          q += adv ? 1u : 0u;
+        for (int f = 0; f < FPD; f++) {
+          const int qq = d * FPD + f;
+          if (qq < NQ) {
+            so = (q == (unsigned)qq) ? ((e >> (f * FB)) & FMASK) : so;
+            qstart = (q == (unsigned)qq) ? qoff[qq] : qstart;
+          }
         }
-        unsigned so = 0, qstart = 0;
-#pragma unroll
-        for (int qq = 0; qq < NQ; qq++) {
-          const unsigned e = (qb[wave][qq / FPD][b] >> ((qq % FPD) * FB)) & FMASK;
-          so = (q == (unsigned)qq) ? e : so;
-          qstart = (q == (unsigned)qq) ? qoff[qq] : qstart;
-        }
-        p.ac[dst + pre + o] = fetch(src + pre + qstart + so + r);
       }
+      p.ac[dst + pre + o] = fetch(src + pre + qstart + so + r);
     }
   }
 }
 template <typename T, int MODE>
 __global__ __launch_bounds__(SWG) void k_compact_ac(FwdParams<T> p, double eb, unsigned nlists, FinArgs fin) {
   __shared__ unsigned sh[SWG / 64];
-  if (fin.box != nullptr && blockIdx.x == 0) {
+  if (fin.box != nullptr && blockIdx.x == 0 && blockIdx.y == 0) {
     unsigned all = 0;
     for (unsigned i = threadIdx.x; i < nlists; i += SWG) all += p.tile_cnt[i];
     FinBody f;
@@ -713,7 +739,7 @@ __global__ __launch_bounds__(SWG) void k_compact_ac(FwdParams<T> p, double eb, u
     f.err_known = true; f.error = 0;
     finish_body<true>(f);
   }
-  compact_ac_body<T, MODE>(p, eb, nlists, blockIdx.x, gridDim.x, sh);
+  compact_ac_body<T, MODE>(p, eb, nlists, blockIdx.x, blockIdx.y, sh);
 }
 
 // =============================================================== decompress ==
@@ -1131,8 +1157,11 @@ void launch_count_tiles(const uint8_t* bin, unsigned nfull, unsigned ntiles, uns
 
 template <typename T>
 void launch_compact_ac(const FwdParams<T>& p, int mode, double eb, unsigned nlists, int grid, const FinArgs& fin, hipStream_t s) {
-  if (mode == DCTZHIP_EC) hipLaunchKernelGGL((k_compact_ac<T, DCTZHIP_EC>), dim3(grid), dim3(SWG), 0, s, p, eb, nlists, fin);
-  else hipLaunchKernelGGL((k_compact_ac<T, DCTZHIP_QT>), dim3(grid), dim3(SWG), 0, s, p, eb, nlists, fin);
+  // (grid = nlists; second dimension: chunks of COMPACT_TPW tiles of the longest list)
+  const unsigned per_list = p.nlists_main ? (p.ntiles + p.nlists_main - 1) / p.nlists_main : 0u;
+  const unsigned chunks = per_list ? (per_list + COMPACT_TPW - 1) / COMPACT_TPW : 1u;
+  if (mode == DCTZHIP_EC) hipLaunchKernelGGL((k_compact_ac<T, DCTZHIP_EC>), dim3(grid, chunks), dim3(SWG), 0, s, p, eb, nlists, fin);
+  else hipLaunchKernelGGL((k_compact_ac<T, DCTZHIP_QT>), dim3(grid, chunks), dim3(SWG), 0, s, p, eb, nlists, fin);
 }
 
 template <typename T>
@@ -1259,11 +1288,10 @@ template <typename T, int MODE>
 __global__ __launch_bounds__(SWG) void k_compact_batch(const BatchFwd<T>* items, const unsigned* __restrict__ first, unsigned k,
                                                        const double* bstats, BatchFin fin) {
   __shared__ unsigned sh[SWG / 64];
-  if (blockIdx.x == 0 && fin.res != nullptr) batch_finish_compress<T>(items, k, bstats, fin, MODE == DCTZHIP_QT);
+  if (blockIdx.x == 0 && blockIdx.y == 0 && fin.res != nullptr) batch_finish_compress<T>(items, k, bstats, fin, MODE == DCTZHIP_QT);
   const unsigned i = batch_item_of(first, k, blockIdx.x);
   const FwdParams<T> p = load_params(&items[i].p);
-  const unsigned nlists = items[i].nlists;
-  compact_ac_body<T, MODE>(p, items[i].eb, nlists, blockIdx.x - first[i], nlists, sh);
+  compact_ac_body<T, MODE>(p, items[i].eb, items[i].nlists, blockIdx.x - first[i], blockIdx.y, sh);
 }
 
 // decode, step 1 for a batch: k_count_tiles per array (+ the flags of its remainder block, so that the hand-off knows
@@ -1349,10 +1377,10 @@ void launch_qt_max_batch(const BatchFwd<T>* items, const unsigned* first, unsign
   hipLaunchKernelGGL(k_qt_max_batch<T>, dim3(grid), dim3(SWG), 0, s, items, first, k);
 }
 template <typename T>
-void launch_compact_batch(const BatchFwd<T>* items, const unsigned* first, unsigned k, unsigned grid, int mode, const double* bstats,
+void launch_compact_batch(const BatchFwd<T>* items, const unsigned* first, unsigned k, unsigned grid, unsigned chunks, int mode, const double* bstats,
                           const BatchFin& fin, hipStream_t s) {
-  if (mode == DCTZHIP_EC) hipLaunchKernelGGL((k_compact_batch<T, DCTZHIP_EC>), dim3(grid), dim3(SWG), 0, s, items, first, k, bstats, fin);
-  else hipLaunchKernelGGL((k_compact_batch<T, DCTZHIP_QT>), dim3(grid), dim3(SWG), 0, s, items, first, k, bstats, fin);
+  if (mode == DCTZHIP_EC) hipLaunchKernelGGL((k_compact_batch<T, DCTZHIP_EC>), dim3(grid, chunks), dim3(SWG), 0, s, items, first, k, bstats, fin);
+  else hipLaunchKernelGGL((k_compact_batch<T, DCTZHIP_QT>), dim3(grid, chunks), dim3(SWG), 0, s, items, first, k, bstats, fin);
 }
 template <typename T>
 void launch_count_batch(const BatchInv<T>* items_src, const unsigned* first_src, unsigned k, unsigned grid, const void* blob_src, void* blob_dst,
@@ -1388,7 +1416,7 @@ template __global__ void DCTZ_DEV_ONE(DCTZ_DEV_ARGS);
   template void launch_compress_batch<T>(const BatchFwd<T>*, const unsigned*, unsigned, unsigned, int, hipStream_t);                        \
   template void launch_compress_rem_batch<T>(const BatchFwd<T>*, const unsigned*, unsigned, int, hipStream_t);                              \
   template void launch_qt_max_batch<T>(const BatchFwd<T>*, const unsigned*, unsigned, unsigned, hipStream_t);                               \
-  template void launch_compact_batch<T>(const BatchFwd<T>*, const unsigned*, unsigned, unsigned, int, const double*, const BatchFin&, hipStream_t); \
+  template void launch_compact_batch<T>(const BatchFwd<T>*, const unsigned*, unsigned, unsigned, unsigned, int, const double*, const BatchFin&, hipStream_t); \
   template void launch_count_batch<T>(const BatchInv<T>*, const unsigned*, unsigned, unsigned, const void*, void*, size_t, hipStream_t);    \
   template void launch_decompress_batch<T>(const BatchInv<T>*, const unsigned*, unsigned, unsigned, int, const BatchFin&, hipStream_t);     \
   template void launch_decompress_rem_batch<T>(const BatchInv<T>*, const unsigned*, unsigned, int, hipStream_t);                            \

@@ -1544,7 +1544,10 @@ static int launch_compress_seq(dctzhip_ctx* c, const dctzhip_batch_citem* items,
   fin.res = c->b_res_hdev + q.item_off * sizeof(BatchResC);
   fin.resq = mode == DCTZHIP_QT ? reinterpret_cast<BatchResQ*>(c->b_res_hdev + c->b_cap * sizeof(BatchResC)) + q.item_off : nullptr;
   // (every array has at least one list or a remainder block: n >= 1)
-  launch_compact_batch<T>(it_d, first_d + 2 * (k + 1), (unsigned)k, q.grid_list, mode, c->b_stats + 3 * q.item_off, fin, s);
+  unsigned chunks = 1;                               // second grid dimension: chunks of tiles of the longest list (one tile per wave)
+  for (size_t j = 0; j < k; j++)
+    if (q.G[j]) { const unsigned per = (q.ntiles[j] + q.G[j] - 1) / q.G[j], ch = (per + SWG / 64 - 1) / (SWG / 64); if (ch > chunks) chunks = ch; }
+  launch_compact_batch<T>(it_d, first_d + 2 * (k + 1), (unsigned)k, q.grid_list, chunks, mode, c->b_stats + 3 * q.item_off, fin, s);
   if (prof) HIPCHK(c, hipEventRecord(ev[3], s));
   if (q.grid_scale) launch_scale_batch<T>(it_d, first_d + 3 * (k + 1), (unsigned)k, q.grid_scale, s);
   if (prof) HIPCHK(c, hipEventRecord(ev[4], s));
