@@ -146,9 +146,12 @@ size_t compress_lds_bytes(int mode) {              // tile image + sub-list stag
 // GEOM: what the 64 values of a block are -- the reference's 64 consecutive elements (GEOM_1D), or an 8 x 8 / 4 x 4 x 4
 // tile of a multi-dimensional array that k_gather_nd has laid out block after block (dct_nd_block.h); only the
 // transform differs.
+// Waves per SIMD the register allocation of k_compress aims at: fp32 EC fits three (12 KiB of LDS per wave; a few
+// registers over the 168 that allows are spilled: 0.166 against 0.180 ms at p = 17 %), everything else two.
 #ifndef DCTZ_WPE32
-#define DCTZ_WPE32 0
+#define DCTZ_WPE32 3
 #endif
+template <typename T, int MODE, int PH> constexpr int compress_waves() { return (sizeof(T) == 4 && MODE == DCTZHIP_EC && DCTZ_WPE32) ? DCTZ_WPE32 : PH; }
 // The body is shared by two launch shapes: k_compress (one array per launch: workgroup wg = blockIdx.x of nwg = gridDim.x)
 // and k_compress_batch (many arrays per launch: the workgroup looks its array up and is workgroup wg of the nwg that array
 // got).
@@ -482,7 +485,7 @@ __device__ __forceinline__ void compress_body(const FwdParams<T>& p, const unsig
 }
 
 template <typename T, int MODE, bool STATS, int PH, int GEOM>
-__global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu((sizeof(T) == 4 && DCTZ_WPE32) ? DCTZ_WPE32 : PH))) void k_compress(FwdParams<T> p) {
+__global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(compress_waves<T, MODE, PH>()))) void k_compress(FwdParams<T> p) {
   compress_body<T, MODE, STATS, PH, GEOM>(p, blockIdx.x, gridDim.x);
 }
 
@@ -646,6 +649,17 @@ __device__ __forceinline__ void compact_ac_body(const FwdParams<T>& p, const dou
     if (MODE == DCTZHIP_EC) return p.ac_tmp[at];
     return (float)qt_normalise(p.qt_item[at], qtab[p.qt_j[at]], eb, T(10), p.range_min, p.range_max);
   };
+  // (the tile's own words are asked for first: they do not depend on the list's place, and a workgroup's life is a chain
+  // of round trips -- list lengths, tile totals, block counts, items)
+  const TileRange tr = tile_range(l < G ? l : 0u, G ? G : 1u, p.ntiles);
+  const unsigned t = tr.lo + chunk * (unsigned)COMPACT_TPW + wave;
+  const bool tile_here = l < G && t < tr.hi;
+  unsigned pre = 0, c = 0;                           // items of this list in front of tile t; block `lane`'s counts
+  if (tile_here) {
+    for (unsigned u = tr.lo + lane; u < t; u += 64u) pre += p.ttot[u];
+    const unsigned blk = t * (unsigned)TILE_BLKS + lane;
+    c = blk < p.nfull ? p.qcnt[blk] : 0u;
+  }
   unsigned before = 0;
   for (unsigned i = threadIdx.x; i < l; i += SWG) before += p.tile_cnt[i];
   const unsigned dst = block_sum(before, sh);
@@ -657,14 +671,8 @@ __device__ __forceinline__ void compact_ac_body(const FwdParams<T>& p, const dou
       for (unsigned i = threadIdx.x; i < n; i += SWG) p.ac[dst + i] = fetch(src + i);
     return;
   }
-  const TileRange tr = tile_range(l, G, p.ntiles);
-  const unsigned t = tr.lo + chunk * (unsigned)COMPACT_TPW + wave;
-  if (t >= tr.hi) return;
-  unsigned pre = 0;                                  // items of this list in front of tile t
-  for (unsigned u = tr.lo + lane; u < t; u += 64u) pre += p.ttot[u];
+  if (!tile_here) return;
   pre = (unsigned)__builtin_amdgcn_readlane((int)wave_incl_scan(pre), 63);
-  const unsigned blk = t * (unsigned)TILE_BLKS + lane;
-  const unsigned c = blk < p.nfull ? p.qcnt[blk] : 0u;
   // prefix sums over the blocks, FPD sub-lists per dword
   unsigned ex[NPK], tot[NPK];
 #pragma unroll
@@ -693,37 +701,58 @@ __device__ __forceinline__ void compact_ac_body(const FwdParams<T>& p, const dou
   for (int d = 0; d < NPK; d++) qb[wave][d][lane] = ex[d];
   for (unsigned o = lane * 16u; o < tt; o += 1024u) *reinterpret_cast<u32x4*>(&own[wave][o]) = u32x4{0u, 0u, 0u, 0u};
   if (nb != 0) own[wave][rowbase] = (unsigned char)lane;
+  // where the item for output position o sits in the tile's piece of the list; `carry`: owner of the last position of
+  // the row before
   unsigned carry = 0;
-  for (unsigned o0 = 0; o0 < tt; o0 += 64u) {
-    const unsigned o = o0 + lane;
+  auto source_of = [&](unsigned o) -> unsigned {
     unsigned b = wave_incl_max_scan((unsigned)own[wave][o]);
     b = max(b, carry);
     carry = (unsigned)__builtin_amdgcn_readlane((int)b, 63);
-    if (o < tt) {
-      unsigned r = o - rb[wave][b];
-      const unsigned cc = cb[wave][b];
-      unsigned q = 0;                                // the sub-list the r-th item of the block sits in
+    unsigned r = o - rb[wave][b];
+    const unsigned cc = cb[wave][b];
+    unsigned q = 0;                                  // the sub-list the r-th item of the block sits in
 #pragma unroll
-      for (int qq = 0; qq < NQ - 1; qq++) {
-        const unsigned nq = (cc >> (qq * CB)) & CMASK;
-        const bool adv = (q == (unsigned)qq) && r >= nq;
-        r -= adv ? nq : 0u;
-        q += adv ? 1u : 0u;
-      }
-      unsigned so = 0, qstart = 0;
+    for (int qq = 0; qq < NQ - 1; qq++) {
+      const unsigned nq = (cc >> (qq * CB)) & CMASK;
+      const bool adv = (q == (unsigned)qq) && r >= nq;
+      r -= adv ? nq : 0u;
+      q += adv ? 1u : 0u;
+    }
+    unsigned so = 0, qstart = 0;
 #pragma unroll
-      for (int d = 0; d < NPK; d++) {
-        const unsigned e = qb[wave][d][b];
+    for (int d = 0; d < NPK; d++) {
+      const unsigned e = qb[wave][d][b];
 #pragma unroll
-        for (int f = 0; f < FPD; f++) {
-          const int qq = d * FPD + f;
-          if (qq < NQ) {
-            so = (q == (unsigned)qq) ? ((e >> (f * FB)) & FMASK) : so;
-            qstart = (q == (unsigned)qq) ? qoff[qq] : qstart;
-          }
+      for (int f = 0; f < FPD; f++) {
+        const int qq = d * FPD + f;
+        if (qq < NQ) {
+          so = (q == (unsigned)qq) ? ((e >> (f * FB)) & FMASK) : so;
+          qstart = (q == (unsigned)qq) ? qoff[qq] : qstart;
         }
       }
-      p.ac[dst + pre + o] = fetch(src + pre + qstart + so + r);
+    }
+    return qstart + so + r;
+  };
+  // four rows of 64 positions at a time: their items are fetched side by side, then stored (one row at a time the loop is
+  // a chain of load -> store -> load ...: the compiler cannot tell the list from AC_exact)
+  constexpr unsigned RU = 4;
+  for (unsigned o0 = 0; o0 < tt; o0 += 64u * RU) {
+    unsigned at[RU];
+    float v[RU];
+#pragma unroll
+    for (unsigned u = 0; u < RU; u++) {
+      const unsigned o = o0 + 64u * u + lane;
+      at[u] = (o0 + 64u * u < tt) ? source_of(min(o, (unsigned)TILE_ELEMS - 1u)) : 0u;   // (whole rows: the max-scan wants every lane)
+    }
+#pragma unroll
+    for (unsigned u = 0; u < RU; u++) {
+      const unsigned o = o0 + 64u * u + lane;
+      v[u] = (o < tt) ? fetch(src + pre + at[u]) : 0.f;
+    }
+#pragma unroll
+    for (unsigned u = 0; u < RU; u++) {
+      const unsigned o = o0 + 64u * u + lane;
+      if (o < tt) p.ac[dst + pre + o] = v[u];
     }
   }
 }
@@ -1221,7 +1250,7 @@ __device__ __forceinline__ S load_params(const S* src) {
 }
 
 template <typename T, int MODE>
-__global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu((sizeof(T) == 4 && DCTZ_WPE32) ? DCTZ_WPE32 : Phases<T>::C)))
+__global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(compress_waves<T, MODE, Phases<T>::C>())))
 void k_compress_batch(const BatchFwd<T>* items, const unsigned* __restrict__ first, unsigned k) {
   const unsigned i = batch_item_of(first, k, blockIdx.x);
   const FwdParams<T> p = load_params(&items[i].p);
