@@ -628,11 +628,14 @@ __device__ __forceinline__ void compact_ac_body(const FwdParams<T>& p, const dou
   using S = Sub<T, MODE>;
   constexpr int NQ = S::NQ, CB = S::CBITS, FB = S::FB, FPD = S::FPD, NPK = S::NPK;
   constexpr unsigned CMASK = (1u << CB) - 1u, FMASK = (1u << FB) - 1u;
+  constexpr int ROWW = NQ == 4 ? 4 : 8;              // dwords of a block's table row (below)
+  constexpr unsigned HALF = TILE_ELEMS / 2;          // output positions the owner map covers at a time
   __shared__ T qtab[64];
-  __shared__ unsigned rb[COMPACT_TPW][64];           // per wave: first output position of every block of the tile
-  __shared__ unsigned cb[COMPACT_TPW][64];           // ... its counts (k_compress's word)
-  __shared__ unsigned qb[COMPACT_TPW][NPK][64];      // ... the start of its run inside every sub-list (FB bits each)
-  __shared__ __attribute__((aligned(16))) unsigned char own[COMPACT_TPW][TILE_ELEMS];   // ... owner map: block that owns an output position
+  // per wave, per block of its tile: [0] first output position, [1 ..] the ends of its sub-list runs inside the block
+  // (a byte each), then per sub-list 16 bits: (where the run starts in the tile's piece of the list) - (where it starts
+  // in the block) + 64 -- so that the item for the r-th position of the block is found with one table row
+  __shared__ __attribute__((aligned(16))) unsigned tab[COMPACT_TPW][64][ROWW];
+  __shared__ __attribute__((aligned(16))) unsigned char own[COMPACT_TPW][HALF];   // owner map: block that owns an output position
   if (MODE == DCTZHIP_QT) {
     if (threadIdx.x < 64) {
       T v = Traits<T>::from_bits((Bits)p.ctl->qraw[threadIdx.x]);
@@ -684,75 +687,72 @@ __device__ __forceinline__ void compact_ac_body(const FwdParams<T>& p, const dou
     ex[d] = incl - v;
     tot[d] = (unsigned)__builtin_amdgcn_readlane((int)incl, 63);
   }
-  unsigned rowbase = 0, nb = 0, qoff[NQ], acc_q = 0;  // qoff: where every sub-list starts in the tile's piece (uniform)
+  unsigned rowbase = 0, cum = 0, acc_q = 0, row[ROWW];
+#pragma unroll
+  for (int i = 0; i < ROWW; i++) row[i] = 0;
 #pragma unroll
   for (int q = 0; q < NQ; q++) {
-    rowbase += (ex[q / FPD] >> ((q % FPD) * FB)) & FMASK;
-    nb += (c >> (q * CB)) & CMASK;
-    qoff[q] = acc_q;
+    const unsigned qbq = (ex[q / FPD] >> ((q % FPD) * FB)) & FMASK;            // start of the block's run in sub-list q
+    const unsigned nq = (c >> (q * CB)) & CMASK;
+    rowbase += qbq;
+    const unsigned del = acc_q + qbq + 64u - cum;                               // acc_q: where sub-list q starts in the tile's piece (uniform)
+    cum += nq;
+    row[1 + q / 4] |= cum << (8 * (q % 4));
+    row[(NQ == 4 ? 2 : 4) + q / 2] |= del << (16 * (q % 2));
     acc_q += (tot[q / FPD] >> ((q % FPD) * FB)) & FMASK;
   }
-  const unsigned tt = acc_q;                         // == ttot[t]
+  row[0] = rowbase;
+  const unsigned nb = cum, tt = acc_q;               // the block's / the tile's items (tt == ttot[t])
   if (tt == 0) return;
   // (one wave writes and reads its own tables: LDS operations of a wave are in order)
-  rb[wave][lane] = rowbase;
-  cb[wave][lane] = c;
 #pragma unroll
-  for (int d = 0; d < NPK; d++) qb[wave][d][lane] = ex[d];
-  for (unsigned o = lane * 16u; o < tt; o += 1024u) *reinterpret_cast<u32x4*>(&own[wave][o]) = u32x4{0u, 0u, 0u, 0u};
-  if (nb != 0) own[wave][rowbase] = (unsigned char)lane;
-  // where the item for output position o sits in the tile's piece of the list; `carry`: owner of the last position of
-  // the row before
-  unsigned carry = 0;
-  auto source_of = [&](unsigned o) -> unsigned {
-    unsigned b = wave_incl_max_scan((unsigned)own[wave][o]);
-    b = max(b, carry);
-    carry = (unsigned)__builtin_amdgcn_readlane((int)b, 63);
-    unsigned r = o - rb[wave][b];
-    const unsigned cc = cb[wave][b];
-    unsigned q = 0;                                  // the sub-list the r-th item of the block sits in
-#pragma unroll
-    for (int qq = 0; qq < NQ - 1; qq++) {
-      const unsigned nq = (cc >> (qq * CB)) & CMASK;
-      const bool adv = (q == (unsigned)qq) && r >= nq;
-      r -= adv ? nq : 0u;
-      q += adv ? 1u : 0u;
-    }
-    unsigned so = 0, qstart = 0;
-#pragma unroll
-    for (int d = 0; d < NPK; d++) {
-      const unsigned e = qb[wave][d][b];
-#pragma unroll
-      for (int f = 0; f < FPD; f++) {
-        const int qq = d * FPD + f;
-        if (qq < NQ) {
-          so = (q == (unsigned)qq) ? ((e >> (f * FB)) & FMASK) : so;
-          qstart = (q == (unsigned)qq) ? qoff[qq] : qstart;
-        }
+  for (int i = 0; i < ROWW; i += 4) *reinterpret_cast<u32x4*>(&tab[wave][lane][i]) = u32x4{row[i], row[i + 1], row[i + 2], row[i + 3]};
+  unsigned carry = 0;                                // owner of the last position handled so far
+  for (unsigned h0 = 0; h0 < tt; h0 += HALF) {
+    const unsigned hn = min(tt - h0, HALF);
+    for (unsigned o = lane * 16u; o < hn; o += 1024u) *reinterpret_cast<u32x4*>(&own[wave][o]) = u32x4{0u, 0u, 0u, 0u};
+    if (nb != 0 && rowbase - h0 < HALF) own[wave][rowbase - h0] = (unsigned char)lane;       // (unsigned: rowbase >= h0 too)
+    // where the item for output position o (of this half) sits in the tile's piece of the list
+    auto source_of = [&](unsigned o) -> unsigned {
+      unsigned b = wave_incl_max_scan((unsigned)own[wave][o - h0]);
+      b = max(b, carry) & 63u;                       // (& 63: lanes beyond the tile's last position read bytes nobody wrote)
+      carry = (unsigned)__builtin_amdgcn_readlane((int)b, 63);
+      const u32x4 t0 = *reinterpret_cast<const u32x4*>(&tab[wave][b][0]);
+      const unsigned r = o - t0.x;                   // position inside the block (< 64 for a real position)
+      const unsigned R = (r & 63u) * 0x01010101u;
+      unsigned q = (unsigned)__popc(((R | 0x80808080u) - t0.y) & 0x80808080u);   // sub-lists of the block that end at or before r
+      unsigned dw;
+      if constexpr (NQ == 4) {
+        dw = q < 2u ? t0.z : t0.w;
+      } else {
+        q += (unsigned)__popc(((R | 0x80808080u) - t0.z) & 0x80808080u);
+        const u32x4 t1 = *reinterpret_cast<const u32x4*>(&tab[wave][b][4]);
+        const unsigned lo2 = (q & 2u) ? t1.y : t1.x, hi2 = (q & 2u) ? t1.w : t1.z;
+        dw = (q & 4u) ? hi2 : lo2;
       }
-    }
-    return qstart + so + r;
-  };
-  // four rows of 64 positions at a time: their items are fetched side by side, then stored (one row at a time the loop is
-  // a chain of load -> store -> load ...: the compiler cannot tell the list from AC_exact)
-  constexpr unsigned RU = 4;
-  for (unsigned o0 = 0; o0 < tt; o0 += 64u * RU) {
-    unsigned at[RU];
-    float v[RU];
+      return r + ((dw >> ((q & 1u) * 16u)) & 0xFFFFu) - 64u;
+    };
+    // four rows of 64 positions at a time: their items are fetched side by side, then stored (one row at a time the loop
+    // is a chain of load -> store -> load ...: the compiler cannot tell the list from AC_exact)
+    constexpr unsigned RU = 4;
+    for (unsigned o0 = h0; o0 < h0 + hn; o0 += 64u * RU) {
+      unsigned at[RU];
+      float v[RU];
 #pragma unroll
-    for (unsigned u = 0; u < RU; u++) {
-      const unsigned o = o0 + 64u * u + lane;
-      at[u] = (o0 + 64u * u < tt) ? source_of(min(o, (unsigned)TILE_ELEMS - 1u)) : 0u;   // (whole rows: the max-scan wants every lane)
-    }
+      for (unsigned u = 0; u < RU; u++) {
+        const unsigned o = o0 + 64u * u + lane;
+        at[u] = (o0 + 64u * u < h0 + hn) ? source_of(min(o, h0 + HALF - 1u)) : 0u;   // (whole rows: the max-scan wants every lane)
+      }
 #pragma unroll
-    for (unsigned u = 0; u < RU; u++) {
-      const unsigned o = o0 + 64u * u + lane;
-      v[u] = (o < tt) ? fetch(src + pre + at[u]) : 0.f;
-    }
+      for (unsigned u = 0; u < RU; u++) {
+        const unsigned o = o0 + 64u * u + lane;
+        v[u] = (o < h0 + hn) ? fetch(src + pre + at[u]) : 0.f;
+      }
 #pragma unroll
-    for (unsigned u = 0; u < RU; u++) {
-      const unsigned o = o0 + 64u * u + lane;
-      if (o < tt) p.ac[dst + pre + o] = v[u];
+      for (unsigned u = 0; u < RU; u++) {
+        const unsigned o = o0 + 64u * u + lane;
+        if (o < h0 + hn) p.ac[dst + pre + o] = v[u];
+      }
     }
   }
 }
