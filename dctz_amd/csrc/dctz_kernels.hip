@@ -132,6 +132,10 @@ void read_cmp_stamps(unsigned long long* out12) {
 }
 #endif
 
+// A list's entry in tile_cnt[]: its length, and LIST_IN_ORDER when every tile of the workgroup had items in its first
+// sub-list only -- block-major over the first range of j is then the reference's order (a smooth field: what is stored
+// exactly are the lowest frequencies), and k_compact_ac copies the list as it is.
+constexpr unsigned LIST_IN_ORDER = 0x80000000u, LIST_LEN = 0x7FFFFFFFu;
 template <typename T>
 size_t compress_lds_bytes(int mode) {              // tile image + sub-list staging (+ positions, QT); must match k_compress's static arrays
   using G = Geo<T, Phases<T>::C>;
@@ -217,6 +221,7 @@ __device__ __forceinline__ void compress_body(const FwdParams<T>& p, const unsig
   StatAcc<T> acc;
   acc.init();
   unsigned run = 0;                                  // length of the workgroup's list so far (uniform)
+  bool in_order = true;                              // every tile so far has items in its first sub-list only (see LIST_IN_ORDER)
 
   // bin ids, DC and per-block counts of a tile on their way out (those of the previous tile)
   bool pend = false;
@@ -440,6 +445,7 @@ __device__ __forceinline__ void compress_body(const FwdParams<T>& p, const unsig
       }
       run += tot;
       ttot += tot;
+      if (Q != 0 && tot != 0u) in_order = false;
     };
     auto sub = [&](auto qi) {
       if (bwd.ok) { if (p.fast_bw & 2u) sub_list(qi, std::true_type{}, std::false_type{}); else sub_list(qi, std::true_type{}, std::true_type{}); }
@@ -473,7 +479,7 @@ __device__ __forceinline__ void compress_body(const FwdParams<T>& p, const unsig
 #ifdef DCTZ_STAMP
   STAMP_FLUSH(g_cmp_stamps);
 #endif
-  if (lane == 0) p.tile_cnt[wg] = run;
+  if (lane == 0) p.tile_cnt[wg] = run | (in_order ? LIST_IN_ORDER : 0u);
   if (QMAX_HERE) {
     const QBits m = qmax_lds[lane];
     if (m != 0) atomicMax(&p.ctl->qraw[lane], (unsigned long long)m);
@@ -574,7 +580,7 @@ __device__ __forceinline__ void qt_max_body(const FwdParams<T>& p, const unsigne
   __syncthreads();
   const unsigned G = p.nlists_main;
   for (unsigned l = wg; l < nlists; l += nwg) {
-    const unsigned n = p.tile_cnt[l];
+    const unsigned n = p.tile_cnt[l] & LIST_LEN;
     const size_t src = list_slot(l, G, p.ntiles);
     // eight items per thread in flight (a list of some thousand items is a chain of dependent round trips otherwise:
     // 93 us for 22 M items before, fp32 512^3 at p = 17 %)
@@ -664,18 +670,38 @@ __device__ __forceinline__ void compact_ac_body(const FwdParams<T>& p, const dou
     c = blk < p.nfull ? p.qcnt[blk] : 0u;
   }
   unsigned before = 0;
-  for (unsigned i = threadIdx.x; i < l; i += SWG) before += p.tile_cnt[i];
+  for (unsigned i = threadIdx.x; i < l; i += SWG) before += p.tile_cnt[i] & LIST_LEN;
   const unsigned dst = block_sum(before, sh);
-  const unsigned n = p.tile_cnt[l];
+  const unsigned nraw = p.tile_cnt[l], n = nraw & LIST_LEN;
   if (l == nlists - 1 && chunk == 0 && threadIdx.x == 0) p.ctl->cnt_total = dst + n;
   const size_t src = list_slot(l, G, p.ntiles);
-  if (l >= G) {                                      // the remainder block's list: already in order
-    if (chunk == 0)
-      for (unsigned i = threadIdx.x; i < n; i += SWG) p.ac[dst + i] = fetch(src + i);
+  if (l >= G || (nraw & LIST_IN_ORDER)) {            // the remainder block's list, or a list that is in order as it is
+    if (chunk == 0) {
+      for (unsigned i0 = threadIdx.x; i0 < n; i0 += 4 * SWG) {          // (four independent items in flight per thread)
+        float v[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) { const unsigned i = i0 + (unsigned)u * SWG; v[u] = i < n ? fetch(src + i) : 0.f; }
+#pragma unroll
+        for (int u = 0; u < 4; u++) { const unsigned i = i0 + (unsigned)u * SWG; if (i < n) p.ac[dst + i] = v[u]; }
+      }
+    }
     return;
   }
   if (!tile_here) return;
   pre = (unsigned)__builtin_amdgcn_readlane((int)wave_incl_scan(pre), 63);
+  if (!__builtin_amdgcn_ballot_w64((c >> CB) != 0u)) {
+    // only the first sub-list of the tile has items (a smooth field: what is stored exactly are the lowest
+    // frequencies): block-major over its range of j IS the reference's order -- the tile's piece is copied as it is
+    const unsigned tt0 = (unsigned)__builtin_amdgcn_readlane((int)wave_incl_scan(c & CMASK), 63);
+    for (unsigned o0 = 0; o0 < tt0; o0 += 256u) {
+      float v[4];
+#pragma unroll
+      for (unsigned u = 0; u < 4; u++) { const unsigned o = o0 + 64u * u + lane; v[u] = o < tt0 ? fetch(src + pre + o) : 0.f; }
+#pragma unroll
+      for (unsigned u = 0; u < 4; u++) { const unsigned o = o0 + 64u * u + lane; if (o < tt0) p.ac[dst + pre + o] = v[u]; }
+    }
+    return;
+  }
   // prefix sums over the blocks, FPD sub-lists per dword
   unsigned ex[NPK], tot[NPK];
 #pragma unroll
@@ -761,7 +787,7 @@ __global__ __launch_bounds__(SWG) void k_compact_ac(FwdParams<T> p, double eb, u
   __shared__ unsigned sh[SWG / 64];
   if (fin.box != nullptr && blockIdx.x == 0 && blockIdx.y == 0) {
     unsigned all = 0;
-    for (unsigned i = threadIdx.x; i < nlists; i += SWG) all += p.tile_cnt[i];
+    for (unsigned i = threadIdx.x; i < nlists; i += SWG) all += p.tile_cnt[i] & LIST_LEN;
     FinBody f;
     f.ctl = fin.ctl; f.part = fin.part; f.nparts = fin.nparts; f.box = fin.box; f.seq = fin.seq; f.guess = fin.guess;
     f.cnt_known = true; f.cnt_total = block_sum(all, sh);                // tot_AC_exact_count (:478-544)
@@ -1295,7 +1321,7 @@ __device__ __forceinline__ void batch_finish_compress(const BatchFwd<T>* items, 
     const unsigned nl = items[i].nlists;
     if (nl <= SHORT) continue;
     unsigned c = 0;
-    for (unsigned l = lane; l < nl; l += 64u) c += items[i].p.tile_cnt[l];
+    for (unsigned l = lane; l < nl; l += 64u) c += items[i].p.tile_cnt[l] & LIST_LEN;
     c = (unsigned)__builtin_amdgcn_readlane((int)wave_incl_scan(c), 63);
     if (lane == 0) put(i, c);
   }
@@ -1303,7 +1329,7 @@ __device__ __forceinline__ void batch_finish_compress(const BatchFwd<T>* items, 
     const unsigned nl = items[i].nlists;
     if (nl > SHORT) continue;
     unsigned c = 0;
-    for (unsigned l = 0; l < nl; l++) c += items[i].p.tile_cnt[l];
+    for (unsigned l = 0; l < nl; l++) c += items[i].p.tile_cnt[l] & LIST_LEN;
     put(i, c);
   }
   if (qt)
