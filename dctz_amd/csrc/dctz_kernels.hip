@@ -669,10 +669,11 @@ __device__ __forceinline__ void compact_ac_body(const FwdParams<T>& p, const dou
     const unsigned blk = t * (unsigned)TILE_BLKS + lane;
     c = blk < p.nfull ? p.qcnt[blk] : 0u;
   }
+  const unsigned nraw = p.tile_cnt[l], n = nraw & LIST_LEN;
+  if ((l >= G || (nraw & LIST_IN_ORDER)) && chunk != 0) return;     // such a list is copied by its first workgroup alone
   unsigned before = 0;
   for (unsigned i = threadIdx.x; i < l; i += SWG) before += p.tile_cnt[i] & LIST_LEN;
   const unsigned dst = block_sum(before, sh);
-  const unsigned nraw = p.tile_cnt[l], n = nraw & LIST_LEN;
   if (l == nlists - 1 && chunk == 0 && threadIdx.x == 0) p.ctl->cnt_total = dst + n;
   const size_t src = list_slot(l, G, p.ntiles);
   if (l >= G || (nraw & LIST_IN_ORDER)) {            // the remainder block's list, or a list that is in order as it is
