@@ -906,36 +906,58 @@ __device__ __forceinline__ void decompress_body(const InvParams<T>& p, const uns
   u32x4 bw[4];
   float dcv = 0.f;
   unsigned S = 0, total = 0;                          // first exact coefficient of the tile / how many (uniform)
+  unsigned cnts = (tr.lo + (unsigned)lane < tr.hi) ? p.tile_cnt[tr.lo + (unsigned)lane] : 0u;   // k_count_tiles' counts of the first 64 tiles
   unsigned S_next = S_wg;                             // ... of the tile to be prefetched next
   auto prefetch = [&](unsigned tile) {
     const unsigned rel = tile - tr.lo;
-    const int vo = (int)(rel * (unsigned)TILE_ELEMS) + lane * 64;
-#pragma unroll
-    for (int i = 0; i < 4; i++) bw[i] = __builtin_amdgcn_raw_buffer_load_b128(r_bin, vo + i * 16, 0, 0);
-    dcv = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r_dc, (int)(rel * 64u + (unsigned)lane) * 4, 0, 0));
     S = S_next;
-    total = __builtin_amdgcn_readfirstlane(p.tile_cnt[tile]);
+    // (the counts of 64 tiles at a time sit in a register, lane i = tile i of the batch: a load per tile here was a
+    // round trip to wait for in every trip of the loop)
+    if ((rel & 63u) == 0u && rel != 0u) cnts = (tile + (unsigned)lane < tr.hi) ? p.tile_cnt[tile + (unsigned)lane] : 0u;
+    total = (unsigned)__builtin_amdgcn_readlane((int)cnts, (int)(rel & 63u));
     S_next = S + total;
+    // (the DMA first: the loads into registers behind it are what the loop waits for -- `landed` below -- and vector
+    // memory reads come back in the order they were issued)
     if (total <= (unsigned)DEC_EXC_CAP) {
 #pragma unroll
       for (int i = 0; i < DEC_EXC_CAP / 256; i++)
         if ((unsigned)(i * 256) < total)
           DMA16(r_ac, excbuf + i * 256, lane * 16, (int)((S - S_wg + (unsigned)(i * 256)) * 4u), 0);
     }
+    const int vo = (int)(rel * (unsigned)TILE_ELEMS) + lane * 64;
+#pragma unroll
+    for (int i = 0; i < 4; i++) bw[i] = __builtin_amdgcn_raw_buffer_load_b128(r_bin, vo + i * 16, 0, 0);
+    dcv = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r_dc, (int)(rel * 64u + (unsigned)lane) * 4, 0, 0));
+  };
+  // The next tile's inputs are waited for BEFORE this tile's row stores go out (a use of the registers the compiler can
+  // see: it places the wait here).  Reads and writes share one counter and may complete out of order with each other, so
+  // a wait for a read issued in front of stores is a wait for the stores as well: at the top of the next trip -- where
+  // the inputs are needed -- it would sit behind 32 row stores just issued; here the reads have had the whole inverse
+  // transform to land, and the stores in flight are the previous tile's, a tile old.
+  auto landed = [&]() {
+    asm volatile("" :: "v"(bw[0]), "v"(bw[1]), "v"(bw[2]), "v"(bw[3]), "v"(dcv));
   };
 
-  if (tr.lo < tr.hi) prefetch(tr.lo);
+  if (tr.lo < tr.hi) { prefetch(tr.lo); landed(); }
   STAMP_DECL;
   for (unsigned tile = tr.lo; tile < tr.hi; tile++) {
     const unsigned rel = tile - tr.lo;
     const unsigned blks_here = min((unsigned)TILE_BLKS, p.nfull - tile * TILE_BLKS);
     const bool active = (unsigned)lane < blks_here;
     const unsigned S_t = S, total_t = total;
-    const bool in_lds = total_t <= (unsigned)DEC_EXC_CAP;
+    // The tile's exact coefficients AC_exact[S_t, S_t + total_t) are read out of LDS: staged one tile ahead in their own
+    // buffer when they are few (DEC_EXC_CAP: prefetch), and for a dense tile brought into the output image now -- the
+    // image is free until this tile's own rows are written, and up to 4032 floats are half of it.  (Round 2 gathered a
+    // dense tile's coefficients one by one from global memory: 0.52 ms against 0.22 ms for the decode of 512^3 at eb 1e-5.)
+    const bool staged = total_t <= (unsigned)DEC_EXC_CAP;
+    const float* const stage = staged ? excbuf : reinterpret_cast<const float*>(outbuf);
+    const unsigned stage_last = staged ? (unsigned)DEC_EXC_CAP - 1u : (unsigned)TILE_ELEMS - 1u;
     STAMP(0);
-    // this tile's inputs have landed: everything but the previous tile's row stores (the youngest NROW operations)
-    if (tile == tr.lo) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(%0)" :: "n"(G::NROW) : "memory");
+    if (!staged) {
+      for (unsigned i = 0; i * 256u < total_t; i++)
+        DMA16(r_ac, outbuf + i * 1024u, lane * 16, (int)((S_t - S_wg + i * 256u) * 4u), 0);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
     STAMP(1);
     unsigned w[16] = {bw[0].x, bw[0].y, bw[0].z, bw[0].w, bw[1].x, bw[1].y, bw[1].z, bw[1].w,
                       bw[2].x, bw[2].y, bw[2].z, bw[2].w, bw[3].x, bw[3].y, bw[3].z, bw[3].w};
@@ -974,13 +996,8 @@ __device__ __forceinline__ void decompress_body(const InvParams<T>& p, const uns
         at[2] = at[1] + ((m >> 15) & 1u);
         at[3] = at[2] + ((m >> 23) & 1u);
         ptr = at[3] + (m >> 31);
-        if (in_lds) {                                                  // (all lanes read: predicating the reads on the flag measured slower)
 #pragma unroll
-          for (int i = 0; i < 4; i++) e[i] = excbuf[min(at[i], (unsigned)DEC_EXC_CAP - 1u)];
-        } else {
-#pragma unroll
-          for (int i = 0; i < 4; i++) e[i] = (((m >> (8 * i + 7)) & 1u) && S_t + at[i] < p.ac_count) ? p.ac[S_t + at[i]] : 0.f;
-        }
+        for (int i = 0; i < 4; i++) e[i] = stage[min(at[i], stage_last)];      // (all lanes read: predicating the reads on the flag measured slower)
       }
 #pragma unroll
       for (int i = 0; i < 4; i++) {
@@ -1003,9 +1020,7 @@ __device__ __forceinline__ void decompress_body(const InvParams<T>& p, const uns
       const unsigned b = (w[j >> 2] >> (8 * (j & 3))) & 255u;
       T v = bctab[b];                                                  // :416 / :462
       if (b == 255u) {                                                 // :400 / :446
-        float e;
-        if (in_lds) e = excbuf[ptr];
-        else e = (S_t + ptr < p.ac_count) ? p.ac[S_t + ptr] : 0.f;
+        const float e = stage[min(ptr, stage_last)];
         ptr++;
         v = (T)e;
         if (MODE == DCTZHIP_QT) v = qt_restore(v, qt[j], p.eb, T(10), p.range_min, p.range_max);
@@ -1024,6 +1039,7 @@ __device__ __forceinline__ void decompress_body(const InvParams<T>& p, const uns
       for (int j = 0; j < 64; j++) x[j] = x[j] * p.sf;                 // dctz-decomp-lib.c:494-511
     }
     STAMP(6);
+    if (tile + 1 < tr.hi) landed();
     // registers -> LDS image -> HBM, one 1 KiB row (8 whole 128-byte lines) per instruction, a phase at a time; blocks
     // beyond the end fall outside r_out
     const int vbase = (int)(rel * (unsigned)G::TILEB);
