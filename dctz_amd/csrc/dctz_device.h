@@ -25,7 +25,9 @@ constexpr int TILE_ELEMS = TILE_BLKS * 64;   // 4096
 constexpr int WG = 64;                       // threads per workgroup of k_compress / k_decompress
 constexpr int SWG = 256;                     // threads per workgroup of the streaming helpers (stats, count, compact, ...)
 constexpr int EXC_BYTES = 4096;              // k_compress: the lanes' exception strips, then the 64 x 64 bin ids of the tile on their way out
-constexpr int DEC_EXC_CAP = DCTZ_DEC_EXC_CAP;            // decode: exact coefficients of one tile staged in LDS (floats); more -> direct gathers
+constexpr int DEC_EXC_CAP = DCTZ_DEC_EXC_CAP;            // decode: exact coefficients of one tile staged in LDS one tile ahead (floats), fp64
+// fp32 decodes through a half-tile image (8 KiB): with 2048 staged floats behind it the two hold a dense tile's 4032
+template <typename T> struct DecStage { static constexpr int CAP = sizeof(T) == 8 ? DEC_EXC_CAP : 2 * DEC_EXC_CAP; };
 
 template <typename T> struct Traits;
 template <> struct Traits<double> {

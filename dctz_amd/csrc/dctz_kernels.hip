@@ -856,7 +856,7 @@ __global__ __launch_bounds__(SWG) void k_count_tiles(const uint8_t* __restrict__
 // exact coefficients AC_exact[S, S + total) (S from the prefix over the per-tile counts) are staged in LDS by
 // LDS-DMA one tile ahead, like the bin ids / DC (plain loads into registers).
 template <typename T>
-size_t decompress_lds_bytes() { return (size_t)Geo<T, Phases<T>::D>::PHB + 256 * sizeof(T) + DEC_EXC_CAP * 4 + 64 * sizeof(T); }
+size_t decompress_lds_bytes() { return (size_t)Geo<T, Phases<T>::D>::PHB + 256 * sizeof(T) + DecStage<T>::CAP * 4 + 64 * sizeof(T); }
 
 #ifndef DCTZ_WPED32
 #define DCTZ_WPED32 0
@@ -866,9 +866,15 @@ size_t decompress_lds_bytes() { return (size_t)Geo<T, Phases<T>::D>::PHB + 256 *
 template <typename T, int MODE, int PH, int GEOM, typename Handoff>
 __device__ __forceinline__ void decompress_body(const InvParams<T>& p, const unsigned wg, const unsigned nwg, Handoff&& handoff) {
   using G = Geo<T, PH>;
-  __shared__ __attribute__((aligned(1024))) unsigned char outbuf[G::PHB];
+  // ONE array: the output image (a phase of the tile) and, behind it, the buffer the next tile's exact coefficients are
+  // staged in; a dense tile's coefficients (up to 4032 floats) are brought into the front of the whole array when the
+  // tile's turn comes (fp64: half of the image; fp32: the half-tile image and the staging buffer together)
+  constexpr int DEC_CAP = DecStage<T>::CAP;
+  __shared__ __attribute__((aligned(1024))) unsigned char io[G::PHB + DEC_CAP * 4];
+  unsigned char* const outbuf = io;
+  float* const excbuf = reinterpret_cast<float*>(io + G::PHB);
+  static_assert(G::PHB + DEC_CAP * 4 >= TILE_ELEMS * 4, "a dense tile's coefficients fit the array");
   __shared__ __attribute__((aligned(16))) T bctab[256];               // bin_center[] of gen_bins
-  __shared__ __attribute__((aligned(16))) float excbuf[DEC_EXC_CAP];
   __shared__ T qt[64];
   const int lane = threadIdx.x;
   const TileRange tr = tile_range(wg, nwg, p.ntiles);
@@ -918,9 +924,9 @@ __device__ __forceinline__ void decompress_body(const InvParams<T>& p, const uns
     S_next = S + total;
     // (the DMA first: the loads into registers behind it are what the loop waits for -- `landed` below -- and vector
     // memory reads come back in the order they were issued)
-    if (total <= (unsigned)DEC_EXC_CAP) {
+    if (total <= (unsigned)DEC_CAP) {
 #pragma unroll
-      for (int i = 0; i < DEC_EXC_CAP / 256; i++)
+      for (int i = 0; i < DEC_CAP / 256; i++)
         if ((unsigned)(i * 256) < total)
           DMA16(r_ac, excbuf + i * 256, lane * 16, (int)((S - S_wg + (unsigned)(i * 256)) * 4u), 0);
     }
@@ -934,8 +940,10 @@ __device__ __forceinline__ void decompress_body(const InvParams<T>& p, const uns
   // a wait for a read issued in front of stores is a wait for the stores as well: at the top of the next trip -- where
   // the inputs are needed -- it would sit behind 32 row stores just issued; here the reads have had the whole inverse
   // transform to land, and the stores in flight are the previous tile's, a tile old.
+  // (fp64 only: in the fp32 kernel -- two waves per SIMD cover each other -- the statement made the compiler keep half of
+  // the block in scratch across it)
   auto landed = [&]() {
-    asm volatile("" :: "v"(bw[0]), "v"(bw[1]), "v"(bw[2]), "v"(bw[3]), "v"(dcv));
+    if constexpr (sizeof(T) == 8) asm volatile("" :: "v"(dcv));      // (the youngest of the reads: the others came back before it)
   };
 
   if (tr.lo < tr.hi) { prefetch(tr.lo); landed(); }
@@ -946,16 +954,16 @@ __device__ __forceinline__ void decompress_body(const InvParams<T>& p, const uns
     const bool active = (unsigned)lane < blks_here;
     const unsigned S_t = S, total_t = total;
     // The tile's exact coefficients AC_exact[S_t, S_t + total_t) are read out of LDS: staged one tile ahead in their own
-    // buffer when they are few (DEC_EXC_CAP: prefetch), and for a dense tile brought into the output image now -- the
+    // buffer when they are few (DecStage::CAP: prefetch), and for a dense tile brought into the output image now -- the
     // image is free until this tile's own rows are written, and up to 4032 floats are half of it.  (Round 2 gathered a
     // dense tile's coefficients one by one from global memory: 0.52 ms against 0.22 ms for the decode of 512^3 at eb 1e-5.)
-    const bool staged = total_t <= (unsigned)DEC_EXC_CAP;
-    const float* const stage = staged ? excbuf : reinterpret_cast<const float*>(outbuf);
-    const unsigned stage_last = staged ? (unsigned)DEC_EXC_CAP - 1u : (unsigned)TILE_ELEMS - 1u;
+    const bool staged = total_t <= (unsigned)DEC_CAP;
+    const float* const stage = reinterpret_cast<const float*>(io) + (staged ? (unsigned)(G::PHB / 4) : 0u);
+    const unsigned stage_last = staged ? (unsigned)DEC_CAP - 1u : (unsigned)TILE_ELEMS - 1u;
     STAMP(0);
     if (!staged) {
       for (unsigned i = 0; i * 256u < total_t; i++)
-        DMA16(r_ac, outbuf + i * 1024u, lane * 16, (int)((S_t - S_wg + i * 256u) * 4u), 0);
+        DMA16(r_ac, io + i * 1024u, lane * 16, (int)((S_t - S_wg + i * 256u) * 4u), 0);
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     STAMP(1);
@@ -1076,7 +1084,7 @@ __device__ __forceinline__ void decompress_body(const InvParams<T>& p, const uns
 }
 
 template <typename T, int MODE, int PH, int GEOM>
-__global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu((sizeof(T) == 4 && DCTZ_WPED32) ? DCTZ_WPED32 : PH))) void k_decompress(InvParams<T> p, FinArgs fin) {
+__global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu((sizeof(T) == 4 && DCTZ_WPED32) ? DCTZ_WPED32 : PH, (sizeof(T) == 4 && DCTZ_WPED32) ? DCTZ_WPED32 : PH))) void k_decompress(InvParams<T> p, FinArgs fin) {
   decompress_body<T, MODE, PH, GEOM>(p, blockIdx.x, gridDim.x, [&]() {
     if (fin.box != nullptr && blockIdx.x == 0) {
       // the one thing the host waits for on decode: does the stream promise more exact coefficients than the caller
@@ -1419,7 +1427,7 @@ __device__ __forceinline__ void batch_finish_decompress(const BatchInv<T>* items
 }
 
 template <typename T, int MODE>
-__global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu((sizeof(T) == 4 && DCTZ_WPED32) ? DCTZ_WPED32 : Phases<T>::D)))
+__global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu((sizeof(T) == 4 && DCTZ_WPED32) ? DCTZ_WPED32 : Phases<T>::D, (sizeof(T) == 4 && DCTZ_WPED32) ? DCTZ_WPED32 : Phases<T>::D)))
 void k_decompress_batch(const BatchInv<T>* items, const unsigned* __restrict__ first, unsigned k, BatchFin fin) {
   if (blockIdx.x == 0 && fin.res != nullptr) batch_finish_decompress<T>(items, k, fin);
   const unsigned i = batch_item_of(first, k, blockIdx.x);
