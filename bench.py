@@ -59,6 +59,8 @@ def parse(argv=None):
     ap.add_argument("--mode", choices=["ec", "qt"], default=None)
     ap.add_argument("--dtype", choices=["f64", "f32"], default="f64")
     ap.add_argument("--plumbing-only", action="store_true", help="launcher + rendezvous + gather on gloo; no kernels, no value")
+    ap.add_argument("--launch-timeout", type=float, default=480.0, help="the launcher ends all ranks after this many seconds (below the driver's own limit)")
+    ap.add_argument("--plumbing-fail-rank", type=int, default=-1, help="(tests) this rank of a --plumbing-only run exits with code 7 before the rendezvous")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-entropy-stage", action="store_true", help="skip the (untimed) report on the device entropy stage")
     ap.add_argument("--no-speculation", action="store_true", help="always run the separate statistics pass first")
@@ -106,7 +108,15 @@ def workload(a, rank):
 # ------------------------------------------------------------------ launcher --
 def launch(a):
     """Parent of an N-rank run.  Makes NO GPU call (imports neither the array framework nor the library): it only
-    starts the ranks."""
+    starts the ranks -- fresh child processes, never a re-exec -- and watches them: the first rank that exits non-zero
+    (or the deadline, --launch-timeout seconds) ends the others within seconds, so that a rank that dies at start-up
+    cannot leave its peers sitting in the rendezvous until the collective library's own time-out."""
+    pre = " ".join(os.environ.get(k, "") for k in ("LD_PRELOAD", "ROCPROFILER_LIBRARY", "ROCP_TOOL_LIBRARIES", "ROCPROF_ATTACH_TOOL_LIBRARY"))
+    if "rocprofiler" in pre or "rocprof" in pre:
+        # the profiler's preload has initialised the GPU in THIS process: starting children from it is the exec hop the
+        # pool forbids.  Profile one rank: rocprofv3 ... -- python3 bench.py --gpus 1 (tools/README.md)
+        print("bench.py: refusing to launch ranks from under a rocprof preload; profile a single rank instead", file=sys.stderr)
+        return 2
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
@@ -117,19 +127,48 @@ def launch(a):
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0", DCTZ_BENCH_LAUNCHED="1")
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
                                       stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
-    out0, _ = procs[0].communicate()
-    rcs = [procs[0].returncode] + [p.wait() for p in procs[1:]]
-    sys.stdout.write(out0.decode())
-    sys.stdout.flush()
-    if any(rcs):
-        print(f"bench.py: rank exit codes {rcs}", file=sys.stderr)
-        return 1
-    return 0
+    import threading
+    out0 = []
+    reader = threading.Thread(target=lambda: out0.append(procs[0].stdout.read()), daemon=True)
+    reader.start()
+    deadline = time.monotonic() + a.launch_timeout
+    why = None
+    while True:
+        rcs = [p.poll() for p in procs]
+        if all(rc is not None for rc in rcs):
+            break
+        bad = [i for i, rc in enumerate(rcs) if rc not in (None, 0)]
+        if bad:
+            why = f"rank {bad[0]} exited with code {rcs[bad[0]]}"
+        elif time.monotonic() > deadline:
+            why = f"no result after {a.launch_timeout:.0f} s"
+        if why:
+            for p in procs:                                    # the exact children started above, nothing else
+                if p.poll() is None:
+                    p.terminate()
+            t_kill = time.monotonic() + 5.0
+            while any(p.poll() is None for p in procs) and time.monotonic() < t_kill:
+                time.sleep(0.05)
+            for p in procs:
+                if p.poll() is None:
+                    p.kill()
+            break
+        time.sleep(0.05)
+    rcs = [p.wait() for p in procs]
+    reader.join(timeout=5.0)
+    if why is None and not any(rcs):
+        sys.stdout.write((out0[0] if out0 else b"").decode())
+        sys.stdout.flush()
+        return 0
+    print(f"bench.py: {why or 'a rank failed'}; rank exit codes {rcs}", file=sys.stderr)
+    return 1
 
 
 # ------------------------------------------------------------ plumbing only --
 def plumbing(a, rank, world):
     """Rendezvous + the stream gather on gloo with synthetic byte streams: no kernels, no oracle, no GPU."""
+    if rank == a.plumbing_fail_rank:
+        sys.exit(7)                                           # (tests: a rank that dies at start-up)
     import numpy as np
     import torch
     import torch.distributed as dist

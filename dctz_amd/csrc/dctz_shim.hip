@@ -1907,7 +1907,10 @@ struct Rccl {
   bool ok = false;
 };
 Rccl g_rccl;
-constexpr int NCCL_UINT8 = 1, NCCL_UINT64 = 5, NCCL_FLOAT32 = 7;     // ncclDataType_t (rccl.h)
+// ncclDataType_t as /opt/rocm/include/rccl/rccl.h spells it: ncclInt8 = 0, ncclUint8 = 1, ncclInt32 = 2, ncclUint32 = 3,
+// ncclInt64 = 4, ncclUint64 = 5, ncclFloat16 = 6, ncclFloat32 = 7, ncclFloat64 = 8 (the library is loaded with dlopen, so
+// the header is not included; tests/test_abi_cpu.py compares these three with the header's text when it is installed)
+constexpr int NCCL_UINT8 = 1, NCCL_UINT64 = 5, NCCL_FLOAT32 = 7;
 
 bool rccl_load(dctzhip_ctx* c) {
   if (g_rccl.ok) return true;
@@ -1986,29 +1989,42 @@ extern "C" int dctzhip_comm_gather(dctzhip_ctx* c, int root, const void* d_bin, 
   if (!d_bin || !d_dc || (sizes[3 * me + 2] && !d_ac)) return fail(c, DCTZHIP_E_ARG, "null stream buffer");
   HIPCHK(c, hipSetDevice(c->device));
   hipStream_t s = c->stream;
+  // the root's own streams first, OUTSIDE the group: a failure here must not leave a group open
+  if (me == root) {
+    uint64_t ob = 0, od = 0, oa = 0;
+    for (int r = 0; r < me; r++) { ob += sizes[3 * r]; od += sizes[3 * r + 1]; oa += sizes[3 * r + 2]; }
+    const uint64_t n = sizes[3 * me], nb = sizes[3 * me + 1], cn = sizes[3 * me + 2];
+    HIPCHK(c, hipMemcpyAsync((char*)d_bin_all + ob, d_bin, n, hipMemcpyDeviceToDevice, s));
+    HIPCHK(c, hipMemcpyAsync(d_dc_all + od, d_dc, nb * 4, hipMemcpyDeviceToDevice, s));
+    if (cn) HIPCHK(c, hipMemcpyAsync(d_ac_all + oa, d_ac, cn * 4, hipMemcpyDeviceToDevice, s));
+  }
+  // Every exit between GroupStart and GroupEnd closes the group first: a rank that returned with its group open would
+  // never issue its operations while its peers wait in theirs.
   RCCLCHK(c, g_rccl.GroupStart());
+  int bad = 0;
+  const char* what = "";
+#define IN_GROUP(call) do { if (!bad) { bad = (call); if (bad) what = #call; } } while (0)
   if (me == root) {
     uint64_t ob = 0, od = 0, oa = 0;
     for (int r = 0; r < W; r++) {
       const uint64_t n = sizes[3 * r], nb = sizes[3 * r + 1], cn = sizes[3 * r + 2];
-      if (r == me) {
-        HIPCHK(c, hipMemcpyAsync((char*)d_bin_all + ob, d_bin, n, hipMemcpyDeviceToDevice, s));
-        HIPCHK(c, hipMemcpyAsync(d_dc_all + od, d_dc, nb * 4, hipMemcpyDeviceToDevice, s));
-        if (cn) HIPCHK(c, hipMemcpyAsync(d_ac_all + oa, d_ac, cn * 4, hipMemcpyDeviceToDevice, s));
-      } else {
-        RCCLCHK(c, g_rccl.Recv((char*)d_bin_all + ob, n, NCCL_UINT8, r, c->comm, s));
-        RCCLCHK(c, g_rccl.Recv(d_dc_all + od, nb, NCCL_FLOAT32, r, c->comm, s));
-        if (cn) RCCLCHK(c, g_rccl.Recv(d_ac_all + oa, cn, NCCL_FLOAT32, r, c->comm, s));
+      if (r != me) {
+        IN_GROUP(g_rccl.Recv((char*)d_bin_all + ob, n, NCCL_UINT8, r, c->comm, s));
+        IN_GROUP(g_rccl.Recv(d_dc_all + od, nb, NCCL_FLOAT32, r, c->comm, s));
+        if (cn) IN_GROUP(g_rccl.Recv(d_ac_all + oa, cn, NCCL_FLOAT32, r, c->comm, s));
       }
       ob += n; od += nb; oa += cn;
     }
   } else {
     const uint64_t n = sizes[3 * me], nb = sizes[3 * me + 1], cn = sizes[3 * me + 2];
-    RCCLCHK(c, g_rccl.Send(d_bin, n, NCCL_UINT8, root, c->comm, s));
-    RCCLCHK(c, g_rccl.Send(d_dc, nb, NCCL_FLOAT32, root, c->comm, s));
-    if (cn) RCCLCHK(c, g_rccl.Send(d_ac, cn, NCCL_FLOAT32, root, c->comm, s));
+    IN_GROUP(g_rccl.Send(d_bin, n, NCCL_UINT8, root, c->comm, s));
+    IN_GROUP(g_rccl.Send(d_dc, nb, NCCL_FLOAT32, root, c->comm, s));
+    if (cn) IN_GROUP(g_rccl.Send(d_ac, cn, NCCL_FLOAT32, root, c->comm, s));
   }
-  RCCLCHK(c, g_rccl.GroupEnd());
+#undef IN_GROUP
+  const int end = g_rccl.GroupEnd();                  // (always: also after a failed call inside the group)
+  if (bad) return fail(c, DCTZHIP_E_HIP, "%s failed: %s", what, g_rccl.GetErrorString(bad));
+  if (end) return fail(c, DCTZHIP_E_HIP, "ncclGroupEnd failed: %s", g_rccl.GetErrorString(end));
   HIPCHK(c, hipStreamSynchronize(s));
   return DCTZHIP_OK;
 }

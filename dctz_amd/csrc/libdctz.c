@@ -417,8 +417,11 @@ static int read_index(const unsigned char *const sec[3], const unsigned int zlen
   return 1;
 }
 
-/* The three sections of an indexed container inflated chunk by chunk on host threads (sizes / chunk from read_index). */
-static void inflate_indexed(const unsigned char *const sec[3], const unsigned int zlen[3], unsigned char *const dst[3], const size_t raw[3],
+/* The three sections of an indexed container inflated chunk by chunk on host threads (sizes / chunk from read_index).
+ * Returns 1, or 0 when a chunk does not inflate or the content's adler32 is not the stream's: the caller then hands the
+ * sections to the ordinary inflate, which treats damage the way the reference's reader does (dctz-decomp-lib.c:244-322
+ * ignores inflate's return code). */
+static int inflate_indexed(const unsigned char *const sec[3], const unsigned int zlen[3], unsigned char *const dst[3], const size_t raw[3],
                             size_t chunk, uint32_t *const sizes[3]) {
   size_t nch[3], total = 0;
   for (int i = 0; i < 3; i++) { nch[i] = (raw[i] + chunk - 1) / chunk; total += nch[i]; }
@@ -457,7 +460,8 @@ static void inflate_indexed(const unsigned char *const sec[3], const unsigned in
     if (a != want) ok = 0;
   }
   free(chunks);
-  if (!ok) { fprintf(stderr, "libdctz: a chunk of an indexed section does not inflate\n"); exit(1); }
+  if (!ok) fprintf(stderr, "libdctz: a chunk of an indexed section does not inflate; falling back to the one-stream inflate\n");
+  return ok;
 }
 
 /* DCTZ_INFLATE_GPU=1: indexed sections are inflated on the device (one lane per chunk) instead of by host threads.
@@ -771,10 +775,35 @@ int dctz_check_container(const void *z, size_t zbytes, int max_elements, int dee
   if (h.bindex_count != npos) return DCTZ_CHECK_BAD_HEADER;                                     /* :798 */
 #endif
   if (zbytes < want) return DCTZ_CHECK_TRUNCATED;
-  if (!deep) return DCTZ_CHECK_OK;
   const unsigned char *cur = (const unsigned char *)z + sizeof(h);
   const size_t raw[3] = {npos, nblk * sizeof(float), (size_t)h.tot_AC_exact_count * sizeof(float)};
   const unsigned int zs[3] = {h.bindex_sz_compressed, h.DC_sz_compressed, h.AC_exact_sz_compressed};
+  {
+    /* Sections that carry the mark of the GPU entropy stage (78 5E): dctz_decompress will look for the "DZIX" chunk index
+     * BEHIND the container -- it has no size to check that against, this function has.  The index must be there in full
+     * and describe the sections exactly (the same test as the reader's), or the container is refused: a foreign stream
+     * that merely starts 78 5E (zlib at levels 2 .. 5 writes those bytes too) would make the reader look past the buffer. */
+    const unsigned char *sp[3] = {cur, cur + zs[0], cur + (size_t)zs[0] + zs[1]};
+    int marked = 1;
+    for (int i = 0; i < 3; i++) if (zs[i] < 8 || sp[i][0] != 0x78 || sp[i][1] != 0x5E) marked = 0;
+    if (marked) {
+      if (zbytes < want + 20) return DCTZ_CHECK_TRUNCATED;
+      unsigned int hd[5];
+      memcpy(hd, (const unsigned char *)z + want, sizeof(hd));
+      if (hd[0] != DCTZ_IX_MAGIC || hd[1] < 1024 || hd[1] > 65535) return DCTZ_CHECK_BAD_STREAM;
+      size_t entries = 0;
+      for (int i = 0; i < 3; i++) {
+        if (hd[2 + i] != (raw[i] + hd[1] - 1) / hd[1]) return DCTZ_CHECK_BAD_STREAM;
+        entries += hd[2 + i];
+      }
+      if (zbytes < want + 20 + 2 * entries) return DCTZ_CHECK_TRUNCATED;
+      uint32_t *sizes[3];
+      size_t chunk = 0;
+      if (!read_index(sp, zs, raw, (const unsigned char *)z + want, &chunk, sizes)) return DCTZ_CHECK_BAD_STREAM;
+      for (int i = 0; i < 3; i++) free(sizes[i]);
+    }
+  }
+  if (!deep) return DCTZ_CHECK_OK;
   for (int i = 0; i < 3; i++) {
     /* inflate into a small window, counting: the section must end exactly at `raw[i]` bytes */
     z_stream st;
@@ -871,8 +900,7 @@ int dctz_decompress(t_var *var_z, t_var *var_r) {
   AC_exact = (float *)host_buf(2, (size_t)cnt * sizeof(float));
   /* three inflates, in order (dctz-decomp-lib.c:244-322) */
   unsigned char *const rawp[3] = {(unsigned char *)bin_index, (unsigned char *)DC, (unsigned char *)AC_exact};
-  if (indexed) {                                   /* chunks side by side on host threads */
-    inflate_indexed(secp, zl, rawp, rawn, ix_chunk_bytes, ix_sizes);
+  if (indexed && inflate_indexed(secp, zl, rawp, rawn, ix_chunk_bytes, ix_sizes)) {   /* chunks side by side on host threads */
     got = (uLong)npos;
   } else if (zlib_threads() == 0 || zlib_threads() > 3) {   /* the sections are independent streams: inflate them side by side
                                                                (DCTZ_ZLIB_THREADS=1..3 keeps the reference's one-after-the-other) */

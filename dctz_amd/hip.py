@@ -428,10 +428,16 @@ class Context:
         res = None
         ptrs = (None, None, None)
         if rank == root:
-            res = {"bin_index": t.empty(sum(s[0] for s in sz), dtype=t.uint8, device=self.device),
-                   "dc": t.empty(sum(s[1] for s in sz), dtype=t.float32, device=self.device),
-                   "ac_exact": t.empty(max(1, sum(s[2] for s in sz)), dtype=t.float32, device=self.device), "sizes": sz}
-            ptrs = (res["bin_index"].data_ptr(), res["dc"].data_ptr(), res["ac_exact"].data_ptr())
+            # the receive buffers are kept between calls (the same shards every step: 1.3 GB of torch.empty per gather
+            # otherwise) and only grow; the views handed back are valid until the next gather of this context
+            need = (sum(s[0] for s in sz), sum(s[1] for s in sz), max(1, sum(s[2] for s in sz)))
+            keep = getattr(self, "_gather_bufs", None)
+            if keep is None or any(k.numel() < n_ for k, n_ in zip(keep, need)):
+                keep = (t.empty(need[0], dtype=t.uint8, device=self.device), t.empty(need[1], dtype=t.float32, device=self.device),
+                        t.empty(need[2], dtype=t.float32, device=self.device))
+                self._gather_bufs = keep
+            res = {"bin_index": keep[0][:need[0]], "dc": keep[1][:need[1]], "ac_exact": keep[2][:need[2]], "sizes": sz}
+            ptrs = (keep[0].data_ptr(), keep[1].data_ptr(), keep[2].data_ptr())
         self._check(self.lib.dctzhip_comm_gather(self.h, int(root), out["bin_index"].data_ptr(), out["dc"].data_ptr(),
                                                  out["ac_exact"].data_ptr(), sizes, *ptrs), "dctzhip_comm_gather")
         return res

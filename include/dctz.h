@@ -145,7 +145,13 @@ int dctz_set_block_dims(int ndims, const size_t *dims);
  * dctz_decompress here looks for the trailer only when all three sections start 78 5E (zlib itself writes 78 9C at the
  * reference's settings), validates it against the header (chunk counts, sizes that tile each stream exactly up to its
  * 03 00 + adler32) and then inflates the chunks side by side on DCTZ_ZLIB_THREADS host threads (default: the cores) --
- * or on the device with DCTZ_INFLATE_GPU=1; anything inconsistent falls back to the ordinary inflate. */
+ * or on the device with DCTZ_INFLATE_GPU=1; anything inconsistent -- an index that does not describe the sections, a chunk
+ * that does not inflate, content whose adler32 is not the stream's -- falls back to the ordinary one-stream inflate, which
+ * treats damage as the reference's reader does.
+ * dctz_decompress() is not told the size of var_z->buf (dctz.h:127), so it can only TRUST that a container whose three
+ * sections start 78 5E is followed by its index (20 bytes + 2 per chunk): for containers of unknown origin -- zlib at levels
+ * 2 .. 5 writes 78 5E too -- call dctz_check_container(z, zbytes, ...) first, which has the size and refuses a marked
+ * container whose index is missing, cut short or does not tile the sections. */
 #define DCTZ_IX_MAGIC 0x58495A44u   /* "DZIX" little-endian */
 /* Stage timers of the last dctz_compress / dctz_decompress call, seconds
  * (the reference's -DTIME_DEBUG split, dctz-comp-lib.c:762-773). */

@@ -37,3 +37,29 @@ def test_parent_of_a_multi_rank_run_imports_no_gpu_stack():
     src = open(BENCH).read()
     body = src[src.index("def launch(a):"):src.index("# ------------------------------------------------------------ plumbing only --")]
     assert "import torch" not in body and "dctz_amd" not in body and "cuda" not in body
+
+
+def test_a_rank_that_dies_at_start_up_ends_the_run_within_seconds():
+    """rank 1 exits before the rendezvous; rank 0 would sit in init_process_group until the library's own
+    time-out (minutes).  The launcher must end it and exit non-zero, without a JSON line, in seconds."""
+    import time
+    t0 = time.monotonic()
+    r = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--plumbing-only", "--plumbing-fail-rank", "1"], env=_env(),
+                       capture_output=True, text=True, timeout=120)
+    took = time.monotonic() - t0
+    assert r.returncode == 1 and "rank 1 exited with code 7" in r.stderr and r.stdout.strip() == "", (r.returncode, r.stderr[-500:])
+    assert took < 60, took
+
+
+def test_launcher_deadline():
+    """A run that does not finish by --launch-timeout is ended by the launcher itself (the driver's limit is never reached)."""
+    r = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--plumbing-only", "--launch-timeout", "0.01"], env=_env(),
+                       capture_output=True, text=True, timeout=120)
+    assert r.returncode == 1 and "no result after" in r.stderr and r.stdout.strip() == ""
+
+
+def test_launcher_refuses_a_profiler_preload():
+    """under rocprofv3 the parent has already initialised the GPU; spawning ranks from it is forbidden."""
+    r = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--plumbing-only"], env=_env(ROCP_TOOL_LIBRARIES="/opt/rocm/lib/librocprofiler-sdk-tool.so"),
+                       capture_output=True, text=True, timeout=60)
+    assert r.returncode == 2 and "rocprof" in r.stderr and r.stdout.strip() == ""

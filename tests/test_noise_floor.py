@@ -23,15 +23,15 @@ from tests import workloads as W
 from tests.noise import classify_flips
 
 # ceilings on the fraction of differing bin ids (measured values in the comment; seeded inputs, deterministic)
-CEIL = {
+CEIL = {                    # about 1.5 x the measured value: a change of the fast flow's numerics of that size must show
     ("f64", 1e-3): 1e-6,    # 0
     ("f64", 1e-4): 1e-6,    # 0
     ("f64", 1e-5): 1e-6,    # 0
-    ("f64", 1e-6): 1e-5,    # 0
-    ("f32", 1e-3): 5e-5,    # 1.25e-5
-    ("f32", 1e-4): 5e-4,    # 1.08e-4
-    ("f32", 1e-5): 1e-3,    # 1.98e-4 of all = 1.06e-3 of the in-range bin ids
-    ("f32", 1e-6): 1e-3,    # 2.24e-4 of all = 1.18e-2 of the in-range bin ids
+    ("f64", 1e-6): 2e-6,    # 0
+    ("f32", 1e-3): 1.9e-5,  # 1.25e-5
+    ("f32", 1e-4): 1.65e-4, # 1.08e-4
+    ("f32", 1e-5): 3.0e-4,  # 1.98e-4 of all = 1.06e-3 of the in-range bin ids
+    ("f32", 1e-6): 3.4e-4,  # 2.24e-4 of all = 1.18e-2 of the in-range bin ids
 }
 
 

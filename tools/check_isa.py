@@ -1,9 +1,10 @@
 #!/usr/bin/env python3
 """ISA lint of the built gfx950 code object (dctz_amd/lib/libdctzhip.so, or any .so / .o given).
 
-Rule (the round-1 data corruption, reproduced in tools/ubench/probe_r2.hip on MI355X): a MUBUF store of more than
-64 bits of data (buffer_store_dwordx3 / x4) whose soffset operand is an SGPR must not be followed, within two
-instructions, by a VALU instruction that writes one of its data registers.  LLVM's hazard recognizer only inserts the
+Rules (the round-1 data corruption, reproduced in tools/ubench/probe_r2.hip on MI355X): (A) NO vector-memory store of more
+than 64 bits of data -- buffer_ / global_ / flat_ / scratch_, any soffset -- may be followed directly by a VALU
+instruction that writes one of its data registers; (B) a MUBUF store of that width whose soffset operand is an SGPR is
+refused as a form (and must not be followed by such a write within two instructions).  LLVM's hazard recognizer only inserts the
 wait states for the form WITHOUT a register soffset (GCNHazardRecognizer::createsVALUHazard), although the hardware
 needs them for both: with no wait state in between, ~0.7 % of such stores carried the NEW register contents.
 The kernels therefore never use a register soffset on 16-byte buffer stores; this script checks the result.
@@ -53,8 +54,25 @@ def regs(tok):
     return set()
 
 
+WIDE = r"(dwordx3|dwordx4|format_xyzw?|format_d16_xyzw)"
+
+
+def _valu_writes(op, args):
+    """Registers a VALU instruction writes (empty for compares into SGPRs, lane reads, non-VALU)."""
+    if not op.startswith("v_") or op.startswith("v_cmp") or op.startswith("v_readlane") or op.startswith("v_readfirstlane"):
+        return set()
+    return regs(args.split(",")[0].strip())
+
+
 def lint(disasm):
-    """Returns (number of wide buffer stores seen, list of violations)."""
+    """Returns (number of wide VMEM stores seen, list of violations).
+
+    Rule A, every store of more than 64 bits -- buffer_ / global_ / flat_ / scratch_, any soffset: the instruction right
+    behind it must not be a VALU write of one of its data registers (tools/ubench/probe_r2.hip: with soffset = 0 and NO
+    wait state 19 % of such stores carried the new register contents; with one wait state none).  For the forms LLVM's
+    hazard recognizer knows it inserts that wait state itself; this rule verifies the result instead of trusting it.
+    Rule B, buffer stores with a REGISTER soffset: the recognizer does not cover them at all, so the form itself is
+    refused, and a VALU write of a data register within two instructions is reported on top."""
     ins = []
     func = "?"
     for line in disasm.splitlines():
@@ -67,15 +85,24 @@ def lint(disasm):
             ins.append((func, m.group(1), m.group(2)))
     bad, seen = [], 0
     for k, (f, op, args) in enumerate(ins):
-        if not re.fullmatch(r"buffer_store_(dwordx3|dwordx4|format_xyzw?|format_d16_xyzw)", op):
+        m = re.fullmatch(r"(buffer|global|flat|scratch)_store_" + WIDE, op)
+        if not m:
             continue
         seen += 1
         toks = [t.strip() for t in args.split(",")]
-        data = regs(toks[0])
-        # operands: vdata, vaddr|off, srsrc, soffset [modifiers]
+        # operands: buffer: vdata, vaddr|off, srsrc, soffset; global / flat / scratch: vaddr|off, vdata, ...
+        data = regs(toks[0].split()[0]) if m.group(1) == "buffer" else (regs(toks[1].split()[0]) if len(toks) > 1 else set())
+        # Rule A
+        if k + 1 < len(ins) and ins[k + 1][0] == f:
+            op2, args2 = ins[k + 1][1], ins[k + 1][2]
+            if _valu_writes(op2, args2) & data:
+                bad.append(f"{f}: '{op} {args}' followed with no wait state by '{op2} {args2}' (a VALU write of its data registers)")
+        if m.group(1) != "buffer":
+            continue
         soff = toks[3].split()[0] if len(toks) > 3 else ""
         if not re.fullmatch(r"s\d+|m0|vcc_lo|vcc_hi|ttmp\d+", soff):
-            continue                                        # immediate / inline constant: LLVM guards this form
+            continue                                        # immediate / inline constant: covered by rule A
+        # Rule B
         for d in (1, 2):
             if k + d >= len(ins) or ins[k + d][0] != f:
                 break
@@ -85,13 +112,8 @@ def lint(disasm):
                 if n >= 2 or d == 2:
                     break
                 continue
-            if op2.startswith("v_") and not op2.startswith("v_cmp") and not op2.startswith("v_readlane") and not op2.startswith("v_readfirstlane"):
-                dst = regs(args2.split(",")[0].strip())
-                if dst & data:
-                    bad.append(f"{f}: '{op} {args}' followed after {d - 1} instruction(s) by '{op2} {args2}'")
-            if not op2.startswith("s_"):
-                pass
-        # (also flag the form itself, so that new code does not rely on luck)
+            if d == 2 and _valu_writes(op2, args2) & data:  # (d == 1 is rule A's)
+                bad.append(f"{f}: '{op} {args}' followed after 1 instruction(s) by '{op2} {args2}'")
         bad.append(f"{f}: '{op} {args}' uses a register soffset (use soffset = 0 and put the offset into the VGPR / immediate)")
     return seen, bad
 
@@ -118,7 +140,7 @@ def main():
             allbad += bad
     for b in allbad:
         print("VIOLATION:", b)
-    print(f"{total} wide buffer stores checked, {len(allbad)} violation(s)")
+    print(f"{total} wide vector-memory stores checked, {len(allbad)} violation(s)")
     return 1 if allbad else 0
 
 
