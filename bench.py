@@ -288,6 +288,28 @@ def run_rank(a, rank, local_rank, world):
     ms_per_step = elapsed * 1e3 / a.steps
     info = infos[0]
 
+    # ---- the step with the reference's in-place scaling made visible: dctz_compress divides the CALLER's array by sf
+    # (dctz-comp-lib.c:193-216); the device entry point does that on request into d_scaled (a 2 s bytes / element pass of
+    # its own, after the codec kernels, with the verified sf).  `value` is quoted without it ("add s"); this is
+    # the same K steps with it ----
+    with_scaled = None
+    if not many:
+        sc = torch.empty_like(x)
+        def step_scaled():
+            _, inf = ctx.compress(x, ebs[0], mode, out=out, scaled=sc)
+            ctx.decompress(out, inf.cnt, n, tdt[0], ebs[0], inf.sf, mode, qtable=inf.qtable if qt else None, dst=rec)
+        for _ in range(3):
+            step_scaled()
+        barrier()
+        w0 = time.perf_counter()
+        for _ in range(a.steps):
+            step_scaled()
+        barrier()
+        w_ms = shard.max_over_ranks(time.perf_counter() - w0, ctx.device) * 1e3 / a.steps
+        with_scaled = {"ms_per_step": w_ms, "value": in_bytes * world / (w_ms * 1e-3) / 1e9,
+                       "note": "compress writes x / sf into a second buffer as well (the reference's in-place scaling of the caller's array)"}
+        del sc
+
     # ---- a list of arrays: the same list with one call per array (what the batch entry points replace) ----
     looped = None
     if many:
@@ -561,6 +583,8 @@ def run_rank(a, rank, local_rank, world):
         if many:
             line["kernels"]["other_sequence"] = {"element_type": other, **seqs[other]}
             line["looped"] = looped
+        if with_scaled is not None:
+            line["with_scaled_copy"] = with_scaled
         if with_gather is not None:
             line["with_gather"] = with_gather
         print(json.dumps(line), flush=True)

@@ -739,6 +739,12 @@ static int compress_pass(dctzhip_ctx* c, const T* d_in, size_t n, double eb, int
   if (c->grid_c > 0 && (unsigned)c->grid_c < cap) cap = (unsigned)c->grid_c;       // DCTZHIP_GRID_C (experiments)
   const int grid = (int)(cap < ntiles ? cap : ntiles);
   p.nlists_main = (unsigned)grid;
+  // launch-time check of the grid against what it indexes -- list lengths (+ the remainder block's), fused statistics
+  // partials, per-tile words: whatever chose the grid (occupancy query, DCTZHIP_GRID_C / DCTZHIP_WG_PER_CU, a part with
+  // more CUs than the tables were sized for), a grid that does not fit is refused here, not found out by a fault
+  if ((size_t)grid + 2 > c->tile_cap || (fused && grid + 1 > PART_SLOTS) || (size_t)ntiles + 2 > c->qcnt_cap)
+    return fail(c, DCTZHIP_E_INTERNAL, "compress grid of %d workgroups over %u tiles exceeds the scratch tables (%zu list entries, %d partials, %zu tiles)",
+                grid, ntiles, c->tile_cap, PART_SLOTS, c->qcnt_cap);
   if (ntiles) launch_compress<T>(p, mode, fused, grid, geom, s);
   if (c->profiling) HIPCHK(c, hipEventRecord(c->ev[3], s));
   if (rem) launch_compress_rem<T>(p, mode, rem, s);

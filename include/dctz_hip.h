@@ -34,7 +34,8 @@ enum {
   DCTZHIP_E_ARG = -1,        /* bad argument (null, misaligned, n == 0, n > INT_MAX) */
   DCTZHIP_E_BOUND = -2,      /* error_bound < 1e-6: dctz-comp-lib.c:135-138 */
   DCTZHIP_E_HIP = -3,        /* a HIP runtime call failed (no device, OOM, ...) */
-  DCTZHIP_E_INTERNAL = -4    /* in-kernel watchdog tripped (look-back spin bound) */
+  DCTZHIP_E_INTERNAL = -4    /* the library caught itself out: a launch plan that does not fit its scratch tables, a
+                                hand-off that never arrived (10 s), an error flag set by a kernel */
 };
 
 typedef struct dctzhip_ctx dctzhip_ctx;
