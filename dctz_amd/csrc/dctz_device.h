@@ -287,7 +287,6 @@ template <typename T> void launch_sf_batch(const BatchFwd<T>* items, unsigned k,
 template <typename T> void launch_scale_batch(const BatchFwd<T>* items, const unsigned* first, unsigned k, unsigned grid, hipStream_t s);
 template <typename T> void launch_compress_batch(const BatchFwd<T>* items, const unsigned* first, unsigned k, unsigned grid, int mode, hipStream_t s);
 template <typename T> void launch_compress_rem_batch(const BatchFwd<T>* items, const unsigned* rem_items, unsigned nrem, int mode, hipStream_t s);
-template <typename T> void launch_qt_max_batch(const BatchFwd<T>* items, const unsigned* first, unsigned k, unsigned grid, hipStream_t s);
 template <typename T> void launch_compact_batch(const BatchFwd<T>* items, const unsigned* first, unsigned k, unsigned grid, unsigned chunks, int mode,
                                                 const double* bstats, const BatchFin& fin, hipStream_t s);
 template <typename T> void launch_count_batch(const BatchInv<T>* items_src, const unsigned* first_src, unsigned k, unsigned grid,
@@ -312,7 +311,6 @@ template <typename T> void launch_compress(const FwdParams<T>& p, int mode, bool
 template <typename T> void launch_gather_nd(const T* x, T* lin, const NdShape& sh, double* part, int nparts, hipStream_t s);
 template <typename T> void launch_scatter_nd(const T* lin, T* out, const NdShape& sh, int grid, hipStream_t s);
 template <typename T> void launch_compress_rem(const FwdParams<T>& p, int mode, int l, hipStream_t s);
-template <typename T> void launch_qt_max(const FwdParams<T>& p, unsigned nlists, int grid, hipStream_t s);
 template <typename T> void launch_compact_ac(const FwdParams<T>& p, int mode, double eb, unsigned nlists, int grid, const FinArgs& fin, hipStream_t s);
 void launch_count_tiles(const uint8_t* bin, unsigned nfull, unsigned ntiles, unsigned nwg, unsigned* tile_cnt, unsigned* wg_cnt, hipStream_t s);
 template <typename T> void launch_decompress(const InvParams<T>& p, int mode, int grid, const FinArgs& fin, int geom, hipStream_t s);

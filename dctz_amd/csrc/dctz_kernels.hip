@@ -140,7 +140,7 @@ template <typename T>
 size_t compress_lds_bytes(int mode) {              // tile image + sub-list staging (+ positions, QT); must match k_compress's static arrays
   using G = Geo<T, Phases<T>::C>;
   if (mode != DCTZHIP_QT) return (size_t)G::PHB + Sub<T, DCTZHIP_EC>::BYTES;
-  return (size_t)G::PHB + Sub<T, DCTZHIP_QT>::BYTES + (sizeof(T) == 4 ? 256 : 0);   // + fp32: the per-position maxima
+  return (size_t)G::PHB + Sub<T, DCTZHIP_QT>::BYTES + 64 * sizeof(typename Traits<T>::Bits);   // + the per-position maxima
 }
 
 // PH = 1: the whole tile (fp32: 16 KiB) sits in LDS.  PH = 2 (fp64): half a tile at a time (16 KiB), eight single-wave
@@ -172,11 +172,12 @@ __device__ __forceinline__ void compress_body(const FwdParams<T>& p, const unsig
   Item* const items = reinterpret_cast<Item*>(excbuf);
   unsigned char* const jbuf = excbuf + S::ITEM_BYTES;                                // QT: position j of every staged item
   const unsigned exc_at = lds_offset(excbuf);                                        // (stores into it: dctz_kernel_common.h, lds_store_*)
-  // QT, fp32: per-position maximum |coef| over the out-of-range coefficients (dctz-comp-lib.c:371-372 / :396-397), kept
-  // per wave while the sub-lists go out (one LDS atomic per item) and merged into Ctl::qraw at the end -- no pass over
-  // the lists for it.  (fp64 keeps the separate k_qt_max: the kernel is at its register limit.)
+  // QT: per-position maximum |coef| over the out-of-range coefficients (dctz-comp-lib.c:371-372 / :396-397), kept per wave
+  // while the sub-lists go out (one LDS atomic per item) and merged into Ctl::qraw at the end -- no pass over the lists
+  // for it (round 2 needed one for fp64, k_qt_max, 24 us on 512^3: the strip flush had no register to spare; the row
+  // loop of the sub-lists has).
   using QBits = typename Traits<T>::Bits;
-  constexpr bool QMAX_HERE = (MODE == DCTZHIP_QT) && sizeof(T) == 4;
+  constexpr bool QMAX_HERE = (MODE == DCTZHIP_QT);
   __shared__ QBits qmax_lds[QMAX_HERE ? 64 : 1];
   if (QMAX_HERE) qmax_lds[threadIdx.x] = 0;
   const int lane = threadIdx.x;
@@ -555,7 +556,7 @@ __device__ __forceinline__ void compress_rem_body(const FwdParams<T>& p, const i
       if (MODE == DCTZHIP_EC) p.ac_tmp[start + rank] = (float)coef;
       else {
         p.qt_item[start + rank] = coef; p.qt_j[start + rank] = (uint8_t)k;
-        if (sizeof(T) == 4 && fabs(coef) > p.range_max) atomicMax(&p.ctl->qraw[k], (unsigned long long)to_bits(fabs(coef)));   // :371-372 / :396-397 (fp64: k_qt_max)
+        if (fabs(coef) > p.range_max) atomicMax(&p.ctl->qraw[k], (unsigned long long)to_bits(fabs(coef)));   // :371-372 / :396-397
       }
     }
   }
@@ -569,40 +570,6 @@ __global__ __launch_bounds__(64) void k_compress_rem(FwdParams<T> p, int l) { co
 __device__ __forceinline__ size_t list_slot(unsigned l, unsigned G, unsigned ntiles) {
   return (size_t)(l < G ? tile_range(l, G, ntiles).lo : ntiles) * TILE_ELEMS;
 }
-
-// QT: per-position maximum |coef| over the out-of-range coefficients (dctz-comp-lib.c:371-372 / :396-397),
-// taken over the lists k_compress has just written (one workgroup per list).
-template <typename T>
-__device__ __forceinline__ void qt_max_body(const FwdParams<T>& p, const unsigned nlists, const unsigned wg, const unsigned nwg) {
-  using Bits = typename Traits<T>::Bits;
-  __shared__ Bits qmax[64];
-  if (threadIdx.x < 64) qmax[threadIdx.x] = 0;
-  __syncthreads();
-  const unsigned G = p.nlists_main;
-  for (unsigned l = wg; l < nlists; l += nwg) {
-    const unsigned n = p.tile_cnt[l] & LIST_LEN;
-    const size_t src = list_slot(l, G, p.ntiles);
-    // eight items per thread in flight (a list of some thousand items is a chain of dependent round trips otherwise:
-    // 93 us for 22 M items before, fp32 512^3 at p = 17 %)
-    for (unsigned i0 = threadIdx.x; i0 < n; i0 += 8 * SWG) {
-      T a[8];
-      unsigned jj[8];
-#pragma unroll
-      for (int u = 0; u < 8; u++) {
-        const unsigned i = i0 + (unsigned)u * SWG;
-        a[u] = T(0); jj[u] = 0;
-        if (i < n) { a[u] = fabs(p.qt_item[src + i]); jj[u] = p.qt_j[src + i]; }
-      }
-#pragma unroll
-      for (int u = 0; u < 8; u++)
-        if (a[u] > p.range_max) atomicMax(&qmax[jj[u]], to_bits(a[u]));   // positive values order like their bits
-    }
-  }
-  __syncthreads();
-  if (threadIdx.x < 64 && qmax[threadIdx.x] != 0) atomicMax(&p.ctl->qraw[threadIdx.x], (unsigned long long)qmax[threadIdx.x]);
-}
-template <typename T>
-__global__ __launch_bounds__(SWG) void k_qt_max(FwdParams<T> p, unsigned nlists) { qt_max_body<T>(p, nlists, blockIdx.x, gridDim.x); }
 
 // Move every workgroup-local list to its place in AC_exact[], the sub-lists of every tile back in the reference's order
 // (dctz-comp-lib.c:478-544: block after block, j ascending -- k_compress leaves a tile as NQ sub-lists, each block-major
@@ -1226,11 +1193,6 @@ void launch_compress_rem(const FwdParams<T>& p, int mode, int l, hipStream_t s) 
   else hipLaunchKernelGGL((k_compress_rem<T, DCTZHIP_QT>), dim3(1), dim3(64), 0, s, p, l);
 }
 
-template <typename T>
-void launch_qt_max(const FwdParams<T>& p, unsigned nlists, int grid, hipStream_t s) {
-  hipLaunchKernelGGL(k_qt_max<T>, dim3(grid), dim3(SWG), 0, s, p, nlists);
-}
-
 void launch_count_tiles(const uint8_t* bin, unsigned nfull, unsigned ntiles, unsigned nwg, unsigned* tile_cnt, unsigned* wg_cnt, hipStream_t s) {
   hipLaunchKernelGGL(k_count_tiles, dim3(nwg), dim3(SWG), 0, s, bin, nfull, ntiles, nwg, tile_cnt, wg_cnt);
 }
@@ -1313,15 +1275,6 @@ __global__ __launch_bounds__(64) void k_compress_rem_batch(const BatchFwd<T>* it
   const unsigned i = rem_items[blockIdx.x];
   const FwdParams<T> p = load_params(&items[i].p);
   compress_rem_body<T, MODE>(p, (int)items[i].rem);
-}
-
-// one workgroup per list, like k_compact_batch below
-template <typename T>
-__global__ __launch_bounds__(SWG) void k_qt_max_batch(const BatchFwd<T>* items, const unsigned* __restrict__ first, unsigned k) {
-  const unsigned i = batch_item_of(first, k, blockIdx.x);
-  const FwdParams<T> p = load_params(&items[i].p);
-  const unsigned nlists = items[i].nlists;
-  qt_max_body<T>(p, nlists, blockIdx.x - first[i], nlists);
 }
 
 // Hand-off of a whole batch by ONE workgroup (the first of the sequence's last kernel): per array, what the single-array
@@ -1453,10 +1406,6 @@ void launch_compress_rem_batch(const BatchFwd<T>* items, const unsigned* rem_ite
   else hipLaunchKernelGGL((k_compress_rem_batch<T, DCTZHIP_QT>), dim3(nrem), dim3(64), 0, s, items, rem_items);
 }
 template <typename T>
-void launch_qt_max_batch(const BatchFwd<T>* items, const unsigned* first, unsigned k, unsigned grid, hipStream_t s) {
-  hipLaunchKernelGGL(k_qt_max_batch<T>, dim3(grid), dim3(SWG), 0, s, items, first, k);
-}
-template <typename T>
 void launch_compact_batch(const BatchFwd<T>* items, const unsigned* first, unsigned k, unsigned grid, unsigned chunks, int mode, const double* bstats,
                           const BatchFin& fin, hipStream_t s) {
   if (mode == DCTZHIP_EC) hipLaunchKernelGGL((k_compact_batch<T, DCTZHIP_EC>), dim3(grid, chunks), dim3(SWG), 0, s, items, first, k, bstats, fin);
@@ -1489,13 +1438,11 @@ template __global__ void DCTZ_DEV_ONE(DCTZ_DEV_ARGS);
 #define INST(T)                                                                                         \
   template void launch_compress<T>(const FwdParams<T>&, int, bool, int, int, hipStream_t);              \
   template void launch_compress_rem<T>(const FwdParams<T>&, int, int, hipStream_t);                     \
-  template void launch_qt_max<T>(const FwdParams<T>&, unsigned, int, hipStream_t);                      \
   template void launch_compact_ac<T>(const FwdParams<T>&, int, double, unsigned, int, const FinArgs&, hipStream_t); \
   template void launch_decompress<T>(const InvParams<T>&, int, int, const FinArgs&, int, hipStream_t);  \
   template void launch_decompress_rem<T>(const InvParams<T>&, int, bool, int, hipStream_t);             \
   template void launch_compress_batch<T>(const BatchFwd<T>*, const unsigned*, unsigned, unsigned, int, hipStream_t);                        \
   template void launch_compress_rem_batch<T>(const BatchFwd<T>*, const unsigned*, unsigned, int, hipStream_t);                              \
-  template void launch_qt_max_batch<T>(const BatchFwd<T>*, const unsigned*, unsigned, unsigned, hipStream_t);                               \
   template void launch_compact_batch<T>(const BatchFwd<T>*, const unsigned*, unsigned, unsigned, unsigned, int, const double*, const BatchFin&, hipStream_t); \
   template void launch_count_batch<T>(const BatchInv<T>*, const unsigned*, unsigned, unsigned, const void*, void*, size_t, hipStream_t);    \
   template void launch_decompress_batch<T>(const BatchInv<T>*, const unsigned*, unsigned, unsigned, int, const BatchFin&, hipStream_t);     \

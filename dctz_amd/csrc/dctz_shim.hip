@@ -750,9 +750,8 @@ static int compress_pass(dctzhip_ctx* c, const T* d_in, size_t n, double eb, int
   if (rem) launch_compress_rem<T>(p, mode, rem, s);
   // stitch the workgroup-local lists into AC_exact[]
   const unsigned nlists = (unsigned)grid + (rem ? 1u : 0u);
-  // QT: the per-position maxima of :371-372 -- fp32: gathered by k_compress itself while its exceptions go out; fp64:
-  // a pass over the lists (k_compress<double, QT> has no register to spare)
-  if (mode == DCTZHIP_QT && sizeof(T) == 8) launch_qt_max<T>(p, nlists, (int)(nlists < 1024u ? nlists : 1024u), s);
+  // (QT: the per-position maxima of :371-372 are gathered by k_compress / k_compress_rem themselves while their items go
+  // out; round 2 needed a pass over the lists for fp64)
   // (k_compact_ac finds the place of every list itself: no scan kernel.)  With the mailbox its first workgroup hands
   // the call's results to the host as soon as the kernel starts -- all of them are in by then -- so the host is back in
   // the caller, queueing the next call's launches, while the lists are still being moved
@@ -1544,7 +1543,6 @@ static int launch_compress_seq(dctzhip_ctx* c, const dctzhip_batch_citem* items,
   if (q.grid_main) launch_compress_batch<T>(it_d, first_d + (k + 1), (unsigned)k, q.grid_main, mode, s);
   if (prof) HIPCHK(c, hipEventRecord(ev[2], s));
   if (nrem) launch_compress_rem_batch<T>(it_d, first_d + 4 * (k + 1), nrem, mode, s);
-  if (mode == DCTZHIP_QT && sizeof(T) == 8 && q.grid_list) launch_qt_max_batch<T>(it_d, first_d + 2 * (k + 1), (unsigned)k, q.grid_list, s);
   BatchFin fin;
   fin.word = publish ? const_cast<unsigned long long*>(ch.word_dev) : nullptr; fin.seq = seq;
   fin.res = c->b_res_hdev + q.item_off * sizeof(BatchResC);

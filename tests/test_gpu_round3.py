@@ -18,7 +18,7 @@ import pytest
 
 from oracle import oracle as O
 from tests import workloads as W
-from tests.noise import classify_flips
+from tests.noise import block_noise
 
 pytestmark = pytest.mark.gpu
 
@@ -54,11 +54,17 @@ def test_qt_against_the_independent_flow(ctx, dtype, eb):
     mine = _Streams(dtype, x.size, out["bin_index"].cpu().numpy(), coef.cpu().numpy(), scaled.cpu().numpy())
     ref = O.compress(x, eb, O.QT, O.NAIVE, want_coef=True)
     assert info.sf == ref.sf and np.array_equal(mine.scaled.view(np.uint8), ref.scaled.view(np.uint8))
-    flips, illegal = classify_flips(mine, ref, eb)
-    assert illegal == 0, (flips, illegal)
+    # (QT writes the normalised value back into a_x at the out-of-range positions, dctz-comp-lib.c:488-492, and the
+    # oracle's coefficient tap shows that; the kernel's tap shows the transform's output: compared where both are in range)
+    inr = (mine.bin_index != 255) & (ref.bin_index != 255)
+    noise = np.repeat(block_noise(ref.scaled, dtype), 64)[:x.size]
+    assert np.all(np.abs(mine.coef.astype(np.float64) - ref.coef.astype(np.float64))[inr] <= noise[inr] + 1e-300)
+    differ = int((mine.bin_index != ref.bin_index).sum())
     eps = float(np.finfo(dtype).eps)
     if dtype == np.float64:
-        assert flips == 0 and info.cnt == ref.cnt
+        assert differ == 0 and info.cnt == ref.cnt
+    else:
+        assert differ <= (2e-4 if eb >= 1e-4 else 4e-4) * x.size, differ         # (tests/test_noise_floor.py: 1.3e-5 .. 1.1e-4 measured)
     # the table holds max |coef| per position over the out-of-range coefficients: two correct transforms agree to noise
     q_mine, q_ref = np.array(info.qtable[1:]), ref.qtable[1:].astype(np.float64)
     assert np.all(np.abs(q_mine - q_ref) <= 64 * eps * np.maximum(np.abs(q_ref), 1.0)), np.abs(q_mine - q_ref).max()
