@@ -913,6 +913,40 @@ __device__ __forceinline__ void decompress_body(const InvParams<T>& p, const uns
     if constexpr (sizeof(T) == 8) asm volatile("" :: "v"(dcv));      // (the youngest of the reads: the others came back before it)
   };
 
+  // The image's rows -> HBM, one 1 KiB row (8 whole 128-byte lines) per instruction; blocks beyond the end fall outside
+  // r_out.  Build knob DCTZ_SPLIT_ROWS=1 (fp64: one wave per SIMD, 32 rows per tile): the second half of a tile's rows
+  // goes out one stage later, behind the next tile's de-quantisation, so that the 32 stores -- 7 K cycles at the issue
+  // port, the store stream's rate -- come in two bursts.  Measured (round 3, same box, interleaved): 0.227 / 0.235 ms
+  // against 0.229 / 0.227 at p = 5 %, 0.287 against 0.260 at p = 17 %: off.
+#ifndef DCTZ_SPLIT_ROWS
+#define DCTZ_SPLIT_ROWS 0
+#endif
+  constexpr bool SPLIT = DCTZ_SPLIT_ROWS && PH == 1 && sizeof(T) == 8;
+  bool pend_rows = false;
+  unsigned pend_tile = 0;
+  auto store_rows = [&](auto phase, unsigned tile_s, int jg0, int jg1) {
+    constexpr int PHASE = decltype(phase)::value;
+    const int vbase = (int)((tile_s - tr.lo) * (unsigned)G::TILEB);
+#pragma unroll
+    for (int jg = 0; jg < 8; jg++) {
+      if (jg < jg0 || jg >= jg1) continue;
+      unsigned org = 0;
+      int cg = 0;
+      if (GEOM != GEOM_1D && nd_direct) {              // this lane's piece of row (jg, s): a chunk of block 8 jg + beta of the tile
+        const int beta = lane >> 3, gam = lane & 7;
+        org = nd_block_origin<T>(p.nd, tile_s * (unsigned)TILE_BLKS + (unsigned)(8 * jg + beta));
+        cg = gam ^ (beta >> 1) ^ ((jg & 1) << 2);
+      }
+      const int vo = vbase + jg * 8 * G::BLKB + ((jg & 1) ? tm.g_odd : tm.g_even);
+#pragma unroll
+      for (int s = 0; s < G::SEGP; s++) {
+        const u32x4 v = *reinterpret_cast<const u32x4*>(outbuf + (jg * G::SEGP + s) * 1024 + lane * 16);
+        int at = vo + (PHASE * G::SEGP + s) * 128;
+        if (GEOM != GEOM_1D && nd_direct) at = (int)(org >= 0xFFFFFFF0u ? org : org + nd_chunk_offset<T>(p.nd, 8 * (PHASE * G::SEGP + s) + cg));
+        __builtin_amdgcn_raw_buffer_store_b128(v, r_out, at, 0, 2 /* nt */);
+      }
+    }
+  };
   if (tr.lo < tr.hi) { prefetch(tr.lo); landed(); }
   STAMP_DECL;
   for (unsigned tile = tr.lo; tile < tr.hi; tile++) {
@@ -1006,6 +1040,7 @@ __device__ __forceinline__ void decompress_body(const InvParams<T>& p, const uns
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                  // the staged coefficients are consumed: the strip is free
     STAMP(3);
     if (tile + 1 < tr.hi) prefetch(tile + 1);
+    if (SPLIT && pend_rows) { store_rows(std::integral_constant<int, 0>{}, pend_tile, 4, 8); pend_rows = false; }
     STAMP(4);
     block_inv<T, CTab<T>, GEOM, (PH > 1)>(x, tab);
     STAMP(5);
@@ -1017,38 +1052,23 @@ __device__ __forceinline__ void decompress_body(const InvParams<T>& p, const uns
     if (tile + 1 < tr.hi) landed();
     // registers -> LDS image -> HBM, one 1 KiB row (8 whole 128-byte lines) per instruction, a phase at a time; blocks
     // beyond the end fall outside r_out
-    const int vbase = (int)(rel * (unsigned)G::TILEB);
     auto store_phase = [&](auto phase) {
       constexpr int PHASE = decltype(phase)::value;
       write_phase<T, PH, PHASE>(x, outbuf, tm);
-#pragma unroll
-      for (int jg = 0; jg < 8; jg++) {
-        unsigned org = 0;
-        int cg = 0;
-        if (GEOM != GEOM_1D && nd_direct) {            // this lane's piece of row (jg, s): a chunk of block 8 jg + beta of the tile
-          const int beta = lane >> 3, gam = lane & 7;
-          org = nd_block_origin<T>(p.nd, tile * (unsigned)TILE_BLKS + (unsigned)(8 * jg + beta));
-          cg = gam ^ (beta >> 1) ^ ((jg & 1) << 2);
-        }
-        const int vo = vbase + jg * 8 * G::BLKB + ((jg & 1) ? tm.g_odd : tm.g_even);
-#pragma unroll
-        for (int s = 0; s < G::SEGP; s++) {
-          const u32x4 v = *reinterpret_cast<const u32x4*>(outbuf + (jg * G::SEGP + s) * 1024 + lane * 16);
-          int at = vo + (PHASE * G::SEGP + s) * 128;
-          if (GEOM != GEOM_1D && nd_direct) at = (int)(org >= 0xFFFFFFF0u ? org : org + nd_chunk_offset<T>(p.nd, 8 * (PHASE * G::SEGP + s) + cg));
-          __builtin_amdgcn_raw_buffer_store_b128(v, r_out, at, 0, 2 /* nt */);
-        }
-      }
+      store_rows(phase, tile, 0, SPLIT ? 4 : 8);
+      if (SPLIT) { pend_rows = true; pend_tile = tile; }
     };
     store_phase(std::integral_constant<int, 0>{});
     if (PH == 2) store_phase(std::integral_constant<int, PH - 1>{});
     STAMP(7);
   }
+  if (SPLIT && pend_rows) store_rows(std::integral_constant<int, 0>{}, pend_tile, 4, 8);
 #ifdef DCTZ_STAMP
   STAMP_FLUSH(g_dec_stamps);
 #endif
   if (underrun) atomicExch(&p.ctl->error, 2u);
 }
+
 
 template <typename T, int MODE, int PH, int GEOM>
 __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu((sizeof(T) == 4 && DCTZ_WPED32) ? DCTZ_WPED32 : PH, (sizeof(T) == 4 && DCTZ_WPED32) ? DCTZ_WPED32 : PH))) void k_decompress(InvParams<T> p, FinArgs fin) {
