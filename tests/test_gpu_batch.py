@@ -182,3 +182,19 @@ def test_batch_decode_reports_the_short_array(ctx):
     cnts[2] += 1
     dsts, status, _ = ctx.decompress_batch(outs, cnts, [x.size for x in xs], [_tdt(x) for x in xs], 1e-3, [i.sf for i in infos], O.EC)
     assert status == [0, 0, 0, 0]
+
+
+def test_c_program_drives_a_list_through_the_batch_entry_points(tmp_path):
+    """tests/c/batch_list.c (the code INTEGRATION.md section E shows): built with gcc against include/dctz_hip.h alone,
+    the six list-msst19 lengths x four bounds, one call per array against one batch -- byte for byte the same."""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "batch_list")
+    lib = os.path.join(root, "dctz_amd", "lib")
+    subprocess.check_call(["gcc", "-std=gnu99", "-O1", os.path.join(root, "tests", "c", "batch_list.c"), "-I", os.path.join(root, "include"),
+                           "-L", lib, "-ldctzhip", f"-Wl,-rpath,{lib}", "-lm", "-o", exe])
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "BATCH arrays=24 identical" in r.stdout, r.stdout + r.stderr
+    r = subprocess.run([exe, "1", "63", "64", "4097", "70001"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "BATCH arrays=20 identical" in r.stdout, r.stdout + r.stderr
