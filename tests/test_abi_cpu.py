@@ -92,3 +92,18 @@ def test_no_cpu_fallback_without_gpu():
     h = C.c_void_p()
     assert lib.dctzhip_ctx_create(C.byref(h), -1) != 0 and not h.value
     assert b"HIP" in lib.dctzhip_last_error(None) or b"device" in lib.dctzhip_last_error(None)
+
+
+def test_rccl_datatype_values_match_the_header():
+    """the shim calls the dlopen'ed RCCL with hand-written ncclDataType_t values (the header is not
+    included: single-GPU users need no RCCL).  Compared with rccl.h's own text where the header is installed."""
+    hdr = "/opt/rocm/include/rccl/rccl.h"
+    if not os.path.exists(hdr):
+        pytest.skip("rccl.h not installed")
+    txt = open(hdr).read()
+    src = open(os.path.join(ROOT, "dctz_amd", "csrc", "dctz_shim.hip")).read()
+    m = re.search(r"constexpr int NCCL_UINT8 = (\d+), NCCL_UINT64 = (\d+), NCCL_FLOAT32 = (\d+);", src)
+    assert m, "the shim's ncclDataType_t constants moved"
+    for name, val in zip(("ncclUint8", "ncclUint64", "ncclFloat32"), m.groups()):
+        h = re.search(name + r"\s*=\s*(\d+)", txt)
+        assert h and h.group(1) == val, (name, val, h and h.group(1))
