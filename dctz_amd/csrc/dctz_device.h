@@ -85,11 +85,17 @@ template <typename T, int MODE> struct Sub {
 #endif
   static constexpr int QW = sizeof(T) == 8 ? DCTZ_QW64 : 16;                        // coefficients per sub-list
   static constexpr int NQ = 64 / QW;                                                // sub-lists per tile
-  static constexpr int SLOTS = EXC_BYTES / (int)sizeof(Item);                       // 1024 floats | 512 doubles
+  // QT, fp64: items (8 B), positions (1 B) AND the wave's per-position maxima of the tile (64 x 8 B, QMAX_AT) share the
+  // 4 KiB the tile's bin ids need on their way out anyway -- with anything more the kernel loses its eighth workgroup
+  // per CU (20 KiB each): 384 slots.  Otherwise the buffer holds 4 KiB of items, the positions (QT, fp32) behind them.
+  static constexpr bool PACKED = (MODE == DCTZHIP_QT) && sizeof(T) == 8;
+  static constexpr int SLOTS = PACKED ? 384 : EXC_BYTES / (int)sizeof(Item);        // 1024 floats | 384 doubles
   static constexpr int CAP = SLOTS - 64;
-  static constexpr int ITEM_BYTES = SLOTS * (int)sizeof(Item);                      // 4 KiB: what the tile's bin ids need on their way out too
+  static constexpr int ITEM_BYTES = SLOTS * (int)sizeof(Item);
   static constexpr int POS_BYTES = (MODE == DCTZHIP_QT) ? SLOTS : 0;
-  static constexpr int BYTES = ITEM_BYTES + POS_BYTES;
+  static constexpr int QMAX_AT = EXC_BYTES - 512;                                   // (PACKED only)
+  static constexpr int BYTES = PACKED ? EXC_BYTES : ITEM_BYTES + POS_BYTES;
+  static_assert(!PACKED || ITEM_BYTES + POS_BYTES <= QMAX_AT, "items and positions end in front of the maxima");
   static constexpr int CBITS = 32 / NQ;                                             // bits per count in a block's word (counts <= QW)
   // k_compact_ac: the counts of two sub-lists share a dword for the prefix sums over the blocks of a tile (sums <= 1024)
   static constexpr int FB = 16;

@@ -52,6 +52,16 @@ __device__ __forceinline__ void lds_store_b32(unsigned, unsigned) {}
 __device__ __forceinline__ void lds_store_b64(unsigned, u32x2) {}
 __device__ __forceinline__ void lds_store_b128(unsigned, u32x4) {}
 #endif
+// (the same for LDS atomics without a return value: a store as far as the wait insertion is concerned)
+#if defined(__HIP_DEVICE_COMPILE__)
+__device__ __forceinline__ void lds_max_u32(unsigned at, unsigned v) { asm volatile("ds_max_u32 %0, %1" :: "v"(at), "v"(v) : "memory"); }
+__device__ __forceinline__ void lds_max_u64(unsigned at, unsigned long long v) { asm volatile("ds_max_u64 %0, %1" :: "v"(at), "v"(v) : "memory"); }
+#else
+__device__ __forceinline__ void lds_max_u32(unsigned, unsigned) {}
+__device__ __forceinline__ void lds_max_u64(unsigned, unsigned long long) {}
+#endif
+__device__ __forceinline__ void lds_max_bits(unsigned at, unsigned v) { lds_max_u32(at, v); }
+__device__ __forceinline__ void lds_max_bits(unsigned at, unsigned long long v) { lds_max_u64(at, v); }
 __device__ __forceinline__ void lds_store_item(unsigned at, float v) { lds_store_b32(at, __builtin_bit_cast(unsigned, v)); }
 __device__ __forceinline__ void lds_store_item(unsigned at, double v) { lds_store_b64(at, __builtin_bit_cast(u32x2, v)); }
 

@@ -140,7 +140,7 @@ template <typename T>
 size_t compress_lds_bytes(int mode) {              // tile image + sub-list staging (+ positions, QT); must match k_compress's static arrays
   using G = Geo<T, Phases<T>::C>;
   if (mode != DCTZHIP_QT) return (size_t)G::PHB + Sub<T, DCTZHIP_EC>::BYTES;
-  return (size_t)G::PHB + Sub<T, DCTZHIP_QT>::BYTES + 64 * sizeof(typename Traits<T>::Bits);   // + the per-position maxima
+  return (size_t)G::PHB + Sub<T, DCTZHIP_QT>::BYTES + (Sub<T, DCTZHIP_QT>::PACKED ? 0 : 64 * sizeof(typename Traits<T>::Bits));   // + the per-position maxima
 }
 
 // PH = 1: the whole tile (fp32: 16 KiB) sits in LDS.  PH = 2 (fp64): half a tile at a time (16 KiB), eight single-wave
@@ -175,11 +175,15 @@ __device__ __forceinline__ void compress_body(const FwdParams<T>& p, const unsig
   // QT: per-position maximum |coef| over the out-of-range coefficients (dctz-comp-lib.c:371-372 / :396-397), kept per wave
   // while the sub-lists go out (one LDS atomic per item) and merged into Ctl::qraw at the end -- no pass over the lists
   // for it (round 2 needed one for fp64, k_qt_max, 24 us on 512^3: the strip flush had no register to spare; the row
-  // loop of the sub-lists has).
+  // loop of the sub-lists has).  fp32: an LDS array of its own for the whole kernel; fp64 (S::PACKED): the tail of the
+  // staging buffer for the time of a tile's sub-lists, collected into lane j's register for position j at the tile's end
+  // (the buffer serves the bin ids' way out between two tiles).
   using QBits = typename Traits<T>::Bits;
   constexpr bool QMAX_HERE = (MODE == DCTZHIP_QT);
-  __shared__ QBits qmax_lds[QMAX_HERE ? 64 : 1];
-  if (QMAX_HERE) qmax_lds[threadIdx.x] = 0;
+  __shared__ QBits qmax_lds[(QMAX_HERE && !S::PACKED) ? 64 : 1];
+  if (QMAX_HERE && !S::PACKED) qmax_lds[threadIdx.x] = 0;
+  const unsigned qmax_at = S::PACKED ? exc_at + (unsigned)S::QMAX_AT : lds_offset(qmax_lds);
+  QBits qreg = 0;
   const int lane = threadIdx.x;
   const TileRange tr = tile_range(wg, nwg, p.ntiles);
   const unsigned list_base = tr.lo * TILE_ELEMS;     // this workgroup's list lives in its tiles' slots
@@ -352,6 +356,7 @@ __device__ __forceinline__ void compress_body(const FwdParams<T>& p, const unsig
       if (p.last_is_full && tile * TILE_BLKS + lane == p.nfull - 1) p.ctl->q0 = (unsigned long long)to_bits(x[0]);   // :355-360
     }
 
+    if (S::PACKED) lds_store_b64(qmax_at + (unsigned)lane * 8u, u32x2{0u, 0u});     // this tile's maxima (the flush has been through the buffer)
     unsigned w[16];
     unsigned qc = 0;                                 // this block's counts, one field per sub-list
     unsigned ttot = 0;                               // "stored exactly" coefficients of the tile (uniform)
@@ -439,7 +444,7 @@ __device__ __forceinline__ void compress_body(const FwdParams<T>& p, const unsig
             __builtin_amdgcn_raw_buffer_store_b8(jj, r_listj, in ? at : 0x7FFFFFF0, 0, 0);
             if (QMAX_HERE && in) {
               const T a = fabs((T)v);
-              if (a > rmax) atomicMax(&qmax_lds[jj], to_bits(a));               // positive values order like their bits
+              if (a > rmax) lds_max_bits(qmax_at + (unsigned)jj * (unsigned)sizeof(QBits), to_bits(a));   // positive values order like their bits
             }
           }
         }
@@ -470,6 +475,10 @@ __device__ __forceinline__ void compress_body(const FwdParams<T>& p, const unsig
     if constexpr (NQ >= 8) { sub(std::integral_constant<int, 6>{}); sub(std::integral_constant<int, 7>{}); }
     STAMP(10);
     w[0] |= 0xFFu;                                   // :361 DC slot
+    if (S::PACKED) {
+      const QBits m = *reinterpret_cast<const QBits*>(excbuf + S::QMAX_AT + lane * (int)sizeof(QBits));
+      qreg = m > qreg ? m : qreg;
+    }
     if (lane == 0) p.ttot[tile] = ttot;
     pend = true; p_rel = rel; p_qc = qc; p_dc = (float)x[0];
 #pragma unroll
@@ -482,7 +491,7 @@ __device__ __forceinline__ void compress_body(const FwdParams<T>& p, const unsig
 #endif
   if (lane == 0) p.tile_cnt[wg] = run | (in_order ? LIST_IN_ORDER : 0u);
   if (QMAX_HERE) {
-    const QBits m = qmax_lds[lane];
+    const QBits m = S::PACKED ? qreg : qmax_lds[lane];
     if (m != 0) atomicMax(&p.ctl->qraw[lane], (unsigned long long)m);
   }
   if (STATS) {
