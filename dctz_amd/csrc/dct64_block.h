@@ -20,6 +20,7 @@
 // (-ffp-contract=off).  The file compiles under hipcc (device + host) and under g++ (tests/emu),
 // and the CPU checker under tests/ restates the same sequence of operations as its pinned "fast" flow.
 #pragma once
+#include <type_traits>
 
 #if defined(__HIPCC__)
 #define DCTZ_HD __host__ __device__ __forceinline__
@@ -88,6 +89,19 @@ DCTZ_HD void fft8(T (&xr)[8], T (&xi)[8], T r) {
   }
 }
 
+// A caller's hook inside the forward transform: called with a compile-time index at the points where the schedule is
+// fenced anyway (k_compress issues pieces of the next tile's LDS-DMA there instead of one burst in front of the
+// transform).  The default does nothing.
+struct NoHook { template <typename I> DCTZ_HD void operator()(I) const {} };
+template <int I, typename Hook> DCTZ_HD void hook_const(Hook& h) { h(std::integral_constant<int, I>{}); }
+template <typename Hook> DCTZ_HD void hook_at(Hook& h, int i) {
+  switch (i) {
+    case 0: hook_const<0>(h); break; case 1: hook_const<1>(h); break; case 2: hook_const<2>(h); break; case 3: hook_const<3>(h); break;
+    case 4: hook_const<4>(h); break; case 5: hook_const<5>(h); break; case 6: hook_const<6>(h); break; case 7: hook_const<7>(h); break;
+    case 8: hook_const<8>(h); break; case 9: hook_const<9>(h); break; case 10: hook_const<10>(h); break; default: hook_const<11>(h); break;
+  }
+}
+
 // c0 p + c1 q + c2 r + c3 s, accumulated left to right: one product, three fused multiply-adds
 template <typename T, typename TabPtr>
 DCTZ_HD T lin4(TabPtr c, T p, T q, T r, T s) {
@@ -102,8 +116,8 @@ DCTZ_HD constexpr int pack_pos(int m, int c) { return (m < 16) ? (4 * m + 2 * c)
 // x[0..63]: one block (already scaled) in, its 64 DCT-II coefficients out (dct.c:55-103).
 // TabPtr: const T* on the host; on the GPU a pointer into the CONSTANT address space, so that the (wave-uniform)
 // table reads become scalar loads.
-template <typename T, typename TabPtr, bool FENCED = false>
-DCTZ_HD void dct64_fwd(T (&x)[64], TabPtr tab) {
+template <typename T, typename TabPtr, bool FENCED = false, typename Hook = NoHook>
+DCTZ_HD void dct64_fwd(T (&x)[64], TabPtr tab, Hook hook = Hook{}) {
   T Yr[4][8], Yi[4][8];
   const T r = tab[TB_R];
 #pragma unroll
@@ -121,6 +135,7 @@ DCTZ_HD void dct64_fwd(T (&x)[64], TabPtr tab) {
       Yi[n2][k1] = fma_(-yr[k1], wi, yi[k1] * wr);
     }
     DCT64_FENCE();
+    hook_at(hook, n2);
   }
   T Zr[32], Zi[32];
 #pragma unroll
@@ -133,6 +148,7 @@ DCTZ_HD void dct64_fwd(T (&x)[64], TabPtr tab) {
     Zr[k1 + 24] = br - di; Zi[k1 + 24] = bi + dr;    // b + i d
   }
   DCT64_FENCE();
+  hook_const<4>(hook);
   // split + twiddle, merged (header comment); the two self-paired bins are exact scalings:
   // b[0] = (Re Z[0] + Im Z[0]) / 8  (= sum of the block / 8), b[32] = (Re Z[0] - Im Z[0]) / 8
   x[0] = (Zr[0] + Zi[0]) * T(0.125);
@@ -146,7 +162,7 @@ DCTZ_HD void dct64_fwd(T (&x)[64], TabPtr tab) {
     x[64 - k] = lin4<T, TabPtr>(c + 4, Zr[k], Zi[k], Zr[32 - k], Zi[32 - k]);
     x[32 - k] = lin4<T, TabPtr>(c + 8, Zr[k], Zi[k], Zr[32 - k], Zi[32 - k]);
     x[32 + k] = lin4<T, TabPtr>(c + 12, Zr[k], Zi[k], Zr[32 - k], Zi[32 - k]);
-    if (k % 2 == 0) DCT64_FENCE();
+    if (k % 2 == 0) { DCT64_FENCE(); hook_at(hook, 4 + k / 2); }
   }
 }
 

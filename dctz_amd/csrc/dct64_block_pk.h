@@ -75,8 +75,8 @@ DCTZ_HD pk2 pk_lin4(TabPtr c, float p, float q, float r, float s) {
 }
 
 // forward: dct64_fwd<float> of dct64_block.h
-template <typename TabPtr, bool FENCED = false>
-DCTZ_HD void dct64_fwd_pk(float (&x)[64], TabPtr tab) {
+template <typename TabPtr, bool FENCED = false, typename Hook = NoHook>
+DCTZ_HD void dct64_fwd_pk(float (&x)[64], TabPtr tab, Hook hook = Hook{}) {
   pk2 Y[4][8];
   const float r = tab[TB_R];
 #pragma unroll
@@ -93,6 +93,7 @@ DCTZ_HD void dct64_fwd_pk(float (&x)[64], TabPtr tab) {
       Y[n2][k1] = pk_fma(pk_swap(y[k1]), pk_mk(wi, -wi), y[k1] * pk_bc(wr));      // times exp(-i 2 pi n2 k1 / 32)
     }
     DCT64_FENCE();
+    hook_at(hook, n2);
   }
   pk2 Z[32];
 #pragma unroll
@@ -102,6 +103,7 @@ DCTZ_HD void dct64_fwd_pk(float (&x)[64], TabPtr tab) {
     Z[k1 + 8] = b + pk_J(d); Z[k1 + 24] = b - pk_J(d);
   }
   DCT64_FENCE();
+  hook_const<4>(hook);
   {
     const pk2 e = (pk_bc(Z[0][0]) + pk_mk(Z[0][1], -Z[0][1])) * pk_bc(0.125f);      // b[0], b[32]
     x[0] = e[0]; x[32] = e[1];
@@ -114,7 +116,7 @@ DCTZ_HD void dct64_fwd_pk(float (&x)[64], TabPtr tab) {
     const pk2 u = pk_lin4<TabPtr>(c, Z[k][0], Z[k][1], Z[32 - k][0], Z[32 - k][1]);
     const pk2 v = pk_lin4<TabPtr>(c + 8, Z[k][0], Z[k][1], Z[32 - k][0], Z[32 - k][1]);
     x[k] = u[0]; x[64 - k] = u[1]; x[32 - k] = v[0]; x[32 + k] = v[1];
-    if (k % 2 == 0) DCT64_FENCE();
+    if (k % 2 == 0) { DCT64_FENCE(); hook_at(hook, 4 + k / 2); }
   }
 }
 
@@ -165,12 +167,12 @@ DCTZ_HD void dct64_inv_pk(float (&x)[64], TabPtr tab) {
 #ifndef DCTZ_PK32
 #define DCTZ_PK32 1
 #endif
-template <typename T, typename TabPtr, int GEOM, bool FENCED>
-DCTZ_HD void block_fwd(T (&x)[64], TabPtr tab) {
-  if constexpr (GEOM == GEOM_2D) dct8x8_fwd<T, TabPtr>(x, tab);
+template <typename T, typename TabPtr, int GEOM, bool FENCED, typename Hook = NoHook>
+DCTZ_HD void block_fwd(T (&x)[64], TabPtr tab, Hook hook = Hook{}) {
+  if constexpr (GEOM == GEOM_2D) dct8x8_fwd<T, TabPtr>(x, tab);                 // (no hook points: the caller does not ask for any there)
   else if constexpr (GEOM == GEOM_3D) dct4x4x4_fwd<T, TabPtr>(x, tab);
-  else if constexpr (sizeof(T) == 4 && DCTZ_PK32) dct64_fwd_pk<TabPtr, FENCED>(x, tab);
-  else dct64_fwd<T, TabPtr, FENCED>(x, tab);
+  else if constexpr (sizeof(T) == 4 && DCTZ_PK32) dct64_fwd_pk<TabPtr, FENCED, Hook>(x, tab, hook);
+  else dct64_fwd<T, TabPtr, FENCED, Hook>(x, tab, hook);
 }
 template <typename T, typename TabPtr, int GEOM, bool FENCED>
 DCTZ_HD void block_inv(T (&x)[64], TabPtr tab) {

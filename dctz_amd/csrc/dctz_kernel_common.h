@@ -212,12 +212,13 @@ struct TileMap {
 
 // HBM -> LDS, one phase of a tile, no registers.  rsrc covers the workgroup's input range; the range check
 // zero-fills whatever lies beyond the last whole block.
-template <typename T, int PH>
+// (JG0, JG1: the rows of block groups [JG0, JG1) only -- k_compress issues a phase in pieces, between its other work)
+template <typename T, int PH, int JG0 = 0, int JG1 = 8>
 __device__ __forceinline__ void issue_phase_dma(__amdgpu_buffer_rsrc_t rsrc, unsigned rel, int phase, unsigned char* tilebuf, const TileMap<T, PH>& tm) {
   using G = Geo<T, PH>;
   const int base = (int)(rel * (unsigned)G::TILEB) + phase * G::SEGP * 128;
 #pragma unroll
-  for (int jg = 0; jg < 8; jg++)
+  for (int jg = JG0; jg < JG1; jg++)
 #pragma unroll
     for (int s = 0; s < G::SEGP; s++)
       DMA16(rsrc, tilebuf + (jg * G::SEGP + s) * 1024, (jg & 1) ? tm.g_odd : tm.g_even, base + jg * 8 * G::BLKB + s * 128, 2 /* nt */);

@@ -155,6 +155,10 @@ size_t compress_lds_bytes(int mode) {              // tile image + sub-list stag
 #ifndef DCTZ_WPE32
 #define DCTZ_WPE32 3
 #endif
+#ifndef DCTZ_DMA_SPREAD
+#define DCTZ_DMA_SPREAD 1
+#endif
+template <int I> using IC = std::integral_constant<int, I>;
 template <typename T, int MODE, int PH> constexpr int compress_waves() { return (sizeof(T) == 4 && MODE == DCTZHIP_EC && DCTZ_WPE32) ? DCTZ_WPE32 : PH; }
 // The body is shared by two launch shapes: k_compress (one array per launch: workgroup wg = blockIdx.x of nwg = gridDim.x)
 // and k_compress_batch (many arrays per launch: the workgroup looks its array up and is workgroup wg of the nwg that array
@@ -196,6 +200,13 @@ __device__ __forceinline__ void compress_body(const FwdParams<T>& p, const unsig
   const __amdgpu_buffer_rsrc_t r_in = nd_direct
       ? __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(p.x), 0, (int)p.nd.bytes, 0x00020000)
       : __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(p.x + first_el), 0, range_el * (int)sizeof(T), 0x00020000);
+  // The same in pieces (flat geometry): 16 (fp64) / 8 (fp32) DMA instructions issued back to back stall the wave for
+  // ~270 cycles each behind the CU's full memory queue (4.3 K cycles per phase, stamped); spread over the work that
+  // follows they find the queue drained.  SPREAD: build knob DCTZ_DMA_SPREAD.
+  constexpr bool SPREAD = DCTZ_DMA_SPREAD != 0 && PH == 2 && GEOM == GEOM_1D;
+  auto issue_rows = [&](unsigned rel, int phase, const TileMap<T, PH>& tmx, auto jg0, auto jg1) {
+    issue_phase_dma<T, PH, decltype(jg0)::value, decltype(jg1)::value>(r_in, rel, phase, tilebuf, tmx);
+  };
   auto issue_dma = [&](unsigned rel, int phase, const TileMap<T, PH>& tmx) {
     if (GEOM != GEOM_1D && nd_direct) {
       int l = lane;
@@ -320,6 +331,12 @@ __device__ __forceinline__ void compress_body(const FwdParams<T>& p, const unsig
     const unsigned blks_here = min((unsigned)TILE_BLKS, p.nfull - tile * TILE_BLKS);
     const bool active = (unsigned)lane < blks_here;
     const TileMap<T, PH> tm = tile_map();
+    const bool more = tile + 1 < tr.hi;
+    // (pieces are issued without a branch -- a branch inside the transform splits its scheduling regions --: behind the
+    // last tile they ask for addresses beyond the descriptor's range, which move no data)
+    TileMap<T, PH> tmn = tm;
+    if (SPREAD && !more) tmn.g_even = tmn.g_odd = 0x7FFF0000;
+    const unsigned reln = (SPREAD && !more) ? 0u : rel + 1;
     T x[64];
     if (PH == 2) {
 #pragma unroll
@@ -330,11 +347,21 @@ __device__ __forceinline__ void compress_body(const FwdParams<T>& p, const unsig
       read_phase<T, PH, PH - 1>(x, tilebuf, tm);
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");        // ... and is in registers: the buffer is free
       STAMP(2);
-      if (tile + 1 < tr.hi) issue_dma(rel + 1, 0, tm);
-      STAMP(3);
-      if (pend) flush();
-      STAMP(4);
-      stats_scale(x, std::integral_constant<int, PH - 1>{}, active, false);
+      if constexpr (SPREAD) {
+        issue_rows(reln, 0, tmn, IC<0>{}, IC<1>{});
+        STAMP(3);
+        if (pend) flush();
+        STAMP(4);
+        issue_rows(reln, 0, tmn, IC<1>{}, IC<2>{});
+        stats_scale(x, std::integral_constant<int, PH - 1>{}, active, false);
+        issue_rows(reln, 0, tmn, IC<2>{}, IC<3>{});
+      } else {
+        if (more) issue_dma(rel + 1, 0, tm);
+        STAMP(3);
+        if (pend) flush();
+        STAMP(4);
+        stats_scale(x, std::integral_constant<int, PH - 1>{}, active, false);
+      }
       STAMP(5);
     } else {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // the DMA has landed (and everything older is done)
@@ -345,7 +372,15 @@ __device__ __forceinline__ void compress_body(const FwdParams<T>& p, const unsig
       stats_scale(x, std::integral_constant<int, 0>{}, active, tile == 0);
     }
     __builtin_amdgcn_sched_barrier(0);
-    block_fwd<T, CTab<T>, GEOM, (PH > 1)>(x, tab);
+    if constexpr (SPREAD) {
+      auto hook = [&](auto idx) {                      // rows 3 .. 7 at the transform's first five fences
+        constexpr int I = decltype(idx)::value;
+        if constexpr (I < 5) issue_rows(reln, 0, tmn, IC<3 + I>{}, IC<4 + I>{});
+      };
+      block_fwd<T, CTab<T>, GEOM, (PH > 1), decltype(hook)>(x, tab, hook);
+    } else {
+      block_fwd<T, CTab<T>, GEOM, (PH > 1)>(x, tab);
+    }
     STAMP(6);
     if (p.coef != nullptr && active) {               // test tap: the coefficients as computed
 #pragma unroll
@@ -466,12 +501,20 @@ __device__ __forceinline__ void compress_body(const FwdParams<T>& p, const unsig
       STAMP(8);
       read_phase<T, PH, 0>(xn, tilebuf, tm);
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      issue_dma(rel + 1, 1, tm);
-      stats_scale(xn, std::integral_constant<int, 0>{}, (unsigned)lane < min((unsigned)TILE_BLKS, p.nfull - (tile + 1) * TILE_BLKS), false);
+      if constexpr (SPREAD) {
+        issue_rows(rel + 1, 1, tm, IC<0>{}, IC<2>{});
+        stats_scale(xn, std::integral_constant<int, 0>{}, (unsigned)lane < min((unsigned)TILE_BLKS, p.nfull - (tile + 1) * TILE_BLKS), false);
+        issue_rows(rel + 1, 1, tm, IC<2>{}, IC<4>{});
+      } else {
+        issue_dma(rel + 1, 1, tm);
+        stats_scale(xn, std::integral_constant<int, 0>{}, (unsigned)lane < min((unsigned)TILE_BLKS, p.nfull - (tile + 1) * TILE_BLKS), false);
+      }
       STAMP(9);
     }
     sub(std::integral_constant<int, NQ / 2>{});
+    if constexpr (SPREAD) issue_rows(reln, 1, tmn, IC<4>{}, IC<6>{});
     if constexpr (NQ >= 4) sub(std::integral_constant<int, NQ / 2 + 1>{});
+    if constexpr (SPREAD) issue_rows(reln, 1, tmn, IC<6>{}, IC<8>{});
     if constexpr (NQ >= 8) { sub(std::integral_constant<int, 6>{}); sub(std::integral_constant<int, 7>{}); }
     STAMP(10);
     w[0] |= 0xFFu;                                   // :361 DC slot
@@ -839,6 +882,24 @@ size_t decompress_lds_bytes() { return (size_t)Geo<T, Phases<T>::D>::PHB + 256 *
 #endif
 // (body shared by k_decompress and k_decompress_batch, like compress_body; `handoff` runs where the single-array kernel
 // hands the call's result to the host)
+#ifndef DCTZ_BC_ARITH
+#define DCTZ_BC_ARITH 1
+#endif
+// bin_center[b] of gen_bins / gen_bins_f (binning.c:17-23 / :37-43) = (T)(b odd ? b/2 + 1 : -(b/2)) * bin_width, computed
+// instead of looked up, in the fp64 kernel (a table in LDS is 63 reads per block with bank conflicts wherever the bin ids
+// of a position spread over the 64 blocks of a tile: 36 % of the kernel's LDS cycles, profiles/r02_pmc.txt, r03_pmc.txt).  `w1` holds the four
+// magnitudes (b + 1) >> 1 of a dword of bin ids as bytes, `nw` the dword's complement (bit 0 of a byte set <=> b even
+// <=> the centre is negative).  The magnitude goes byte -> float in one instruction, the sign is or-ed in, and the
+// product passes through "+ (+0)": -0 * bin_width + 0 = +0, the table's value for b = 0.
+template <typename T>
+__device__ __forceinline__ T bin_centre(const unsigned w1, const unsigned nw, const int i, const T bin_width) {
+  const float mag = (float)((w1 >> (8 * i)) & 255u);
+  const unsigned sgn = (nw << (31 - 8 * i)) & 0x80000000u;
+  const float t = __builtin_bit_cast(float, __builtin_bit_cast(unsigned, mag) | sgn);
+  if constexpr (sizeof(T) == 8) return __builtin_fma((double)t, bin_width, 0.0);
+  else return __builtin_fmaf(t, bin_width, 0.0f);
+}
+
 template <typename T, int MODE, int PH, int GEOM, typename Handoff>
 __device__ __forceinline__ void decompress_body(const InvParams<T>& p, const unsigned wg, const unsigned nwg, Handoff&& handoff) {
   using G = Geo<T, PH>;
@@ -850,7 +911,10 @@ __device__ __forceinline__ void decompress_body(const InvParams<T>& p, const uns
   unsigned char* const outbuf = io;
   float* const excbuf = reinterpret_cast<float*>(io + G::PHB);
   static_assert(G::PHB + DEC_CAP * 4 >= TILE_ELEMS * 4, "a dense tile's coefficients fit the array");
-  __shared__ __attribute__((aligned(16))) T bctab[256];               // bin_center[] of gen_bins
+  // fp64 (one wave per SIMD, every LDS round trip exposed): computed, 0.233 -> 0.230 ms at p = 5 %, 0.267 -> 0.262 at
+  // p = 17 %; fp32 (VALU-bound, two waves per SIMD hide the reads): the table, computing measured 6 % slower
+  constexpr bool BC_ARITH = DCTZ_BC_ARITH != 0 && sizeof(T) == 8;
+  __shared__ __attribute__((aligned(16))) T bctab[BC_ARITH ? 1 : 256]; // bin_center[] of gen_bins
   __shared__ T qt[64];
   const int lane = threadIdx.x;
   const TileRange tr = tile_range(wg, nwg, p.ntiles);
@@ -875,10 +939,11 @@ __device__ __forceinline__ void decompress_body(const InvParams<T>& p, const uns
   tm.init(lane);
   const CTab<T> tab = as_ctab<T>(p.tab);
   // gen_bins / gen_bins_f (binning.c:17-23 / :37-43): bin_center[b] = (b odd ? b/2 + 1 : -(b/2)) * bin_width
-  for (int b = lane; b < 256; b += WG) {
-    const int ti = (b & 1) ? (b >> 1) + 1 : -(b >> 1);
-    bctab[b] = (T)ti * p.bin_width;
-  }
+  if (!BC_ARITH)
+    for (int b = lane; b < 256; b += WG) {
+      const int ti = (b & 1) ? (b >> 1) + 1 : -(b >> 1);
+      bctab[b] = (T)ti * p.bin_width;
+    }
   if (MODE == DCTZHIP_QT) qt[lane] = p.qtab[lane];
   const bool scale = (p.sf != T(1));                 // dctz-decomp-lib.c:496 / :505
   bool underrun = false;
@@ -1006,6 +1071,7 @@ __device__ __forceinline__ void decompress_body(const InvParams<T>& p, const uns
       const unsigned nv = ~wg;                                         // a zero byte of nv <=> bin id 255
       unsigned m = ~(((nv & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | nv) & 0x80808080u;
       if (g == 0) m &= ~0x80u;                                         // j = 0 is the DC slot (:392 / :438)
+      const unsigned w1 = ((wg >> 1) & 0x7F7F7F7Fu) + (wg & 0x01010101u);   // four magnitudes (b + 1) >> 1
       float e[4] = {0.f, 0.f, 0.f, 0.f};
       if (__builtin_amdgcn_ballot_w64(m != 0u)) {                      // :400 / :446 somewhere in the wave
         unsigned at[4];
@@ -1021,8 +1087,9 @@ __device__ __forceinline__ void decompress_body(const InvParams<T>& p, const uns
       for (int i = 0; i < 4; i++) {
         const int j = 4 * g + i;
         if (j == 0) { x[0] = (T)dc_t; continue; }                      // :392 / :438
-        const unsigned b = (wg >> (8 * i)) & 255u;
-        T v = bctab[b];                                                // :416 / :462
+        T v;
+        if constexpr (BC_ARITH) v = bin_centre<T>(w1, nv, i, p.bin_width);
+        else v = bctab[(wg >> (8 * i)) & 255u];                        // :416 / :462
         if ((m >> (8 * i + 7)) & 1u) {
           v = (T)e[i];
           if (MODE == DCTZHIP_QT) v = qt_restore(v, qt[j], p.eb, T(10), p.range_min, p.range_max);
@@ -1036,7 +1103,11 @@ __device__ __forceinline__ void decompress_body(const InvParams<T>& p, const uns
 #pragma unroll
     for (int j = 1; j < 64; j++) {
       const unsigned b = (w[j >> 2] >> (8 * (j & 3))) & 255u;
-      T v = bctab[b];                                                  // :416 / :462
+      T v;
+      if constexpr (BC_ARITH) {
+        const unsigned wj = w[j >> 2];
+        v = bin_centre<T>(((wj >> 1) & 0x7F7F7F7Fu) + (wj & 0x01010101u), ~wj, j & 3, p.bin_width);
+      } else v = bctab[b];                                             // :416 / :462
       if (b == 255u) {                                                 // :400 / :446
         const float e = stage[min(ptr, stage_last)];
         ptr++;

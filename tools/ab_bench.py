@@ -20,6 +20,7 @@ def main():
     ap.add_argument("--dtype", default="f64")
     ap.add_argument("--mode", default="ec")
     ap.add_argument("--eb", type=float, default=1e-3)
+    ap.add_argument("--data", default="c3")
     ap.add_argument("--variants", default="fd=2;fd=1;fd=0;fd=2,wg=4")
     a = ap.parse_args()
     import numpy as np
@@ -30,6 +31,8 @@ def main():
     tdt = torch.float64 if a.dtype == "f64" else torch.float32
     mode = dctz_amd.QT if a.mode == "qt" else dctz_amd.EC
     xh = W.c3(a.n, dtype=npdt)
+    if a.data == "tileconst":      # one value per tile of 4096 elements: any permutation inside a tile leaves the data as it is
+        xh = np.repeat(xh.reshape(-1)[::4096], 4096).astype(npdt)
     x = torch.from_numpy(xh).cuda()
     n = x.numel()
     ctxs = []
