@@ -106,32 +106,6 @@ __device__ __forceinline__ float bin_value(T item, T q, T range_max) {
   return h;
 }
 
-// diagnostic phase timers (-DDCTZ_STAMP builds only): cycles of thread 0 of every workgroup per phase of the tile loop
-#ifdef DCTZ_STAMP
-#define STAMP_DECL unsigned long long st_last = __builtin_amdgcn_s_memtime(), st_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}
-#define STAMP(i) do { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); st_acc[i] += t_ - st_last; st_last = t_; } while (0)
-#define STAMP_FLUSH(ptr) do { if (threadIdx.x == 0) for (int i_ = 0; i_ < 12; i_++) atomicAdd(reinterpret_cast<unsigned long long*>(ptr) + i_, st_acc[i_]); } while (0)
-#else
-#define STAMP_DECL ((void)0)
-#define STAMP(i) ((void)0)
-#define STAMP_FLUSH(ptr) ((void)0)
-#endif
-
-#ifdef DCTZ_STAMP
-__device__ unsigned long long g_dec_stamps[12];      // k_decompress's phase timers (diagnostic builds)
-__device__ unsigned long long g_cmp_stamps[12];      // k_compress's
-void read_dec_stamps(unsigned long long* out12) {
-  (void)hipMemcpyFromSymbol(out12, HIP_SYMBOL(g_dec_stamps), 96);
-  unsigned long long z[12] = {0};
-  (void)hipMemcpyToSymbol(HIP_SYMBOL(g_dec_stamps), z, 96);
-}
-void read_cmp_stamps(unsigned long long* out12) {
-  (void)hipMemcpyFromSymbol(out12, HIP_SYMBOL(g_cmp_stamps), 96);
-  unsigned long long z[12] = {0};
-  (void)hipMemcpyToSymbol(HIP_SYMBOL(g_cmp_stamps), z, 96);
-}
-#endif
-
 // A list's entry in tile_cnt[]: its length, and LIST_IN_ORDER when every tile of the workgroup had items in its first
 // sub-list only -- block-major over the first range of j is then the reference's order (a smooth field: what is stored
 // exactly are the lowest frequencies), and k_compact_ac copies the list as it is.
@@ -325,7 +299,6 @@ __device__ __forceinline__ void compress_body(const FwdParams<T>& p, const unsig
       stats_scale(xn, std::integral_constant<int, 0>{}, (unsigned)lane < min((unsigned)TILE_BLKS, p.nfull - tr.lo * TILE_BLKS), tr.lo == 0);
     }
   }
-  STAMP_DECL;
   for (unsigned tile = tr.lo; tile < tr.hi; tile++) {
     const unsigned rel = tile - tr.lo;
     const unsigned blks_here = min((unsigned)TILE_BLKS, p.nfull - tile * TILE_BLKS);
@@ -341,28 +314,20 @@ __device__ __forceinline__ void compress_body(const FwdParams<T>& p, const unsig
     if (PH == 2) {
 #pragma unroll
       for (int j = 0; j < 32; j++) x[j] = xn[j];
-      STAMP(0);
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // the second half has landed (and everything older is done)
-      STAMP(1);
       read_phase<T, PH, PH - 1>(x, tilebuf, tm);
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");        // ... and is in registers: the buffer is free
-      STAMP(2);
       if constexpr (SPREAD) {
         issue_rows(reln, 0, tmn, IC<0>{}, IC<1>{});
-        STAMP(3);
         if (pend) flush();
-        STAMP(4);
         issue_rows(reln, 0, tmn, IC<1>{}, IC<2>{});
         stats_scale(x, std::integral_constant<int, PH - 1>{}, active, false);
         issue_rows(reln, 0, tmn, IC<2>{}, IC<3>{});
       } else {
         if (more) issue_dma(rel + 1, 0, tm);
-        STAMP(3);
         if (pend) flush();
-        STAMP(4);
         stats_scale(x, std::integral_constant<int, PH - 1>{}, active, false);
       }
-      STAMP(5);
     } else {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // the DMA has landed (and everything older is done)
       read_phase<T, PH, 0>(x, tilebuf, tm);
@@ -381,7 +346,6 @@ __device__ __forceinline__ void compress_body(const FwdParams<T>& p, const unsig
     } else {
       block_fwd<T, CTab<T>, GEOM, (PH > 1)>(x, tab);
     }
-    STAMP(6);
     if (p.coef != nullptr && active) {               // test tap: the coefficients as computed
 #pragma unroll
       for (int j = 0; j < 64; j++) p.coef[((size_t)tile * TILE_BLKS + lane) * 64 + j] = x[j];
@@ -495,10 +459,8 @@ __device__ __forceinline__ void compress_body(const FwdParams<T>& p, const unsig
     sub(std::integral_constant<int, 0>{});
     if constexpr (NQ >= 4) sub(std::integral_constant<int, 1>{});
     if constexpr (NQ >= 8) { sub(std::integral_constant<int, 2>{}); sub(std::integral_constant<int, 3>{}); }
-    STAMP(7);
     if (PH == 2 && tile + 1 < tr.hi) {               // the next tile's first half (see above)
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      STAMP(8);
       read_phase<T, PH, 0>(xn, tilebuf, tm);
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       if constexpr (SPREAD) {
@@ -509,14 +471,12 @@ __device__ __forceinline__ void compress_body(const FwdParams<T>& p, const unsig
         issue_dma(rel + 1, 1, tm);
         stats_scale(xn, std::integral_constant<int, 0>{}, (unsigned)lane < min((unsigned)TILE_BLKS, p.nfull - (tile + 1) * TILE_BLKS), false);
       }
-      STAMP(9);
     }
     sub(std::integral_constant<int, NQ / 2>{});
     if constexpr (SPREAD) issue_rows(reln, 1, tmn, IC<4>{}, IC<6>{});
     if constexpr (NQ >= 4) sub(std::integral_constant<int, NQ / 2 + 1>{});
     if constexpr (SPREAD) issue_rows(reln, 1, tmn, IC<6>{}, IC<8>{});
     if constexpr (NQ >= 8) { sub(std::integral_constant<int, 6>{}); sub(std::integral_constant<int, 7>{}); }
-    STAMP(10);
     w[0] |= 0xFFu;                                   // :361 DC slot
     if (S::PACKED) {
       const QBits m = *reinterpret_cast<const QBits*>(excbuf + S::QMAX_AT + lane * (int)sizeof(QBits));
@@ -528,10 +488,6 @@ __device__ __forceinline__ void compress_body(const FwdParams<T>& p, const unsig
     for (int i = 0; i < 16; i++) pw[i] = w[i];
   }
   if (pend) flush();
-  STAMP(11);
-#ifdef DCTZ_STAMP
-  STAMP_FLUSH(g_cmp_stamps);
-#endif
   if (lane == 0) p.tile_cnt[wg] = run | (in_order ? LIST_IN_ORDER : 0u);
   if (QMAX_HERE) {
     const QBits m = S::PACKED ? qreg : qmax_lds[lane];
@@ -988,22 +944,14 @@ __device__ __forceinline__ void decompress_body(const InvParams<T>& p, const uns
   };
 
   // The image's rows -> HBM, one 1 KiB row (8 whole 128-byte lines) per instruction; blocks beyond the end fall outside
-  // r_out.  Build knob DCTZ_SPLIT_ROWS=1 (fp64: one wave per SIMD, 32 rows per tile): the second half of a tile's rows
-  // goes out one stage later, behind the next tile's de-quantisation, so that the 32 stores -- 7 K cycles at the issue
-  // port, the store stream's rate -- come in two bursts.  Measured (round 3, same box, interleaved): 0.227 / 0.235 ms
-  // against 0.229 / 0.227 at p = 5 %, 0.287 against 0.260 at p = 17 %: off.
-#ifndef DCTZ_SPLIT_ROWS
-#define DCTZ_SPLIT_ROWS 0
-#endif
-  constexpr bool SPLIT = DCTZ_SPLIT_ROWS && PH == 1 && sizeof(T) == 8;
-  bool pend_rows = false;
-  unsigned pend_tile = 0;
-  auto store_rows = [&](auto phase, unsigned tile_s, int jg0, int jg1) {
+  // r_out.  (Sending the second half of a tile's rows one stage later, behind the next tile's de-quantisation, so that
+  // the 32 stores -- 7 K cycles at the issue port -- come in two bursts, measured slower: 0.287 against 0.260 ms at
+  // p = 17 %, no gain at 5 %.)
+  auto store_rows = [&](auto phase, unsigned tile_s) {
     constexpr int PHASE = decltype(phase)::value;
     const int vbase = (int)((tile_s - tr.lo) * (unsigned)G::TILEB);
 #pragma unroll
     for (int jg = 0; jg < 8; jg++) {
-      if (jg < jg0 || jg >= jg1) continue;
       unsigned org = 0;
       int cg = 0;
       if (GEOM != GEOM_1D && nd_direct) {              // this lane's piece of row (jg, s): a chunk of block 8 jg + beta of the tile
@@ -1022,7 +970,6 @@ __device__ __forceinline__ void decompress_body(const InvParams<T>& p, const uns
     }
   };
   if (tr.lo < tr.hi) { prefetch(tr.lo); landed(); }
-  STAMP_DECL;
   for (unsigned tile = tr.lo; tile < tr.hi; tile++) {
     const unsigned rel = tile - tr.lo;
     const unsigned blks_here = min((unsigned)TILE_BLKS, p.nfull - tile * TILE_BLKS);
@@ -1035,13 +982,11 @@ __device__ __forceinline__ void decompress_body(const InvParams<T>& p, const uns
     const bool staged = total_t <= (unsigned)DEC_CAP;
     const float* const stage = reinterpret_cast<const float*>(io) + (staged ? (unsigned)(G::PHB / 4) : 0u);
     const unsigned stage_last = staged ? (unsigned)DEC_CAP - 1u : (unsigned)TILE_ELEMS - 1u;
-    STAMP(0);
     if (!staged) {
       for (unsigned i = 0; i * 256u < total_t; i++)
         DMA16(r_ac, io + i * 1024u, lane * 16, (int)((S_t - S_wg + i * 256u) * 4u), 0);
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
-    STAMP(1);
     unsigned w[16] = {bw[0].x, bw[0].y, bw[0].z, bw[0].w, bw[1].x, bw[1].y, bw[1].z, bw[1].w,
                       bw[2].x, bw[2].y, bw[2].z, bw[2].w, bw[3].x, bw[3].y, bw[3].z, bw[3].w};
     const float dc_t = dcv;
@@ -1057,7 +1002,6 @@ __device__ __forceinline__ void decompress_body(const InvParams<T>& p, const uns
     }
     if (!active) n = 0;
     unsigned ptr = wave_incl_scan(n) - n;                              // index inside the tile's piece of AC_exact
-    STAMP(2);
     if (S_t + total_t > p.ac_count) underrun = true;                  // the stream promises more than the caller provides
     T x[64];
     if constexpr (sizeof(T) == 8) {
@@ -1118,34 +1062,23 @@ __device__ __forceinline__ void decompress_body(const InvParams<T>& p, const uns
     }
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                  // the staged coefficients are consumed: the strip is free
-    STAMP(3);
     if (tile + 1 < tr.hi) prefetch(tile + 1);
-    if (SPLIT && pend_rows) { store_rows(std::integral_constant<int, 0>{}, pend_tile, 4, 8); pend_rows = false; }
-    STAMP(4);
     block_inv<T, CTab<T>, GEOM, (PH > 1)>(x, tab);
-    STAMP(5);
     if (scale) {
 #pragma unroll
       for (int j = 0; j < 64; j++) x[j] = x[j] * p.sf;                 // dctz-decomp-lib.c:494-511
     }
-    STAMP(6);
     if (tile + 1 < tr.hi) landed();
     // registers -> LDS image -> HBM, one 1 KiB row (8 whole 128-byte lines) per instruction, a phase at a time; blocks
     // beyond the end fall outside r_out
     auto store_phase = [&](auto phase) {
       constexpr int PHASE = decltype(phase)::value;
       write_phase<T, PH, PHASE>(x, outbuf, tm);
-      store_rows(phase, tile, 0, SPLIT ? 4 : 8);
-      if (SPLIT) { pend_rows = true; pend_tile = tile; }
+      store_rows(phase, tile);
     };
     store_phase(std::integral_constant<int, 0>{});
     if (PH == 2) store_phase(std::integral_constant<int, PH - 1>{});
-    STAMP(7);
   }
-  if (SPLIT && pend_rows) store_rows(std::integral_constant<int, 0>{}, pend_tile, 4, 8);
-#ifdef DCTZ_STAMP
-  STAMP_FLUSH(g_dec_stamps);
-#endif
   if (underrun) atomicExch(&p.ctl->error, 2u);
 }
 

@@ -2033,19 +2033,3 @@ extern "C" int dctzhip_comm_gather(dctzhip_ctx* c, int root, const void* d_bin, 
   return DCTZHIP_OK;
 }
 
-#ifdef DCTZ_STAMP
-namespace dctz { void read_dec_stamps(unsigned long long* out12); void read_cmp_stamps(unsigned long long* out12); }
-extern "C" int dctzhip_debug_stamps_dec(dctzhip_ctx* c, unsigned long long* out12) {
-  if (!c) return DCTZHIP_E_ARG;
-  HIPCHK(c, hipStreamSynchronize(c->stream));
-  dctz::read_dec_stamps(out12);
-  return DCTZHIP_OK;
-}
-// diagnostic builds only: the 12 phase-cycle sums of k_compress (dctz_kernels.hip, STAMP), read and reset
-extern "C" int dctzhip_debug_stamps(dctzhip_ctx* c, unsigned long long* out12) {
-  if (!c) return DCTZHIP_E_ARG;
-  HIPCHK(c, hipStreamSynchronize(c->stream));
-  dctz::read_cmp_stamps(out12);
-  return DCTZHIP_OK;
-}
-#endif
