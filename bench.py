@@ -60,6 +60,9 @@ def parse(argv=None):
     ap.add_argument("--dtype", choices=["f64", "f32"], default="f64")
     ap.add_argument("--plumbing-only", action="store_true", help="launcher + rendezvous + gather on gloo; no kernels, no value")
     ap.add_argument("--launch-timeout", type=float, default=480.0, help="the launcher ends all ranks after this many seconds (below the driver's own limit)")
+    ap.add_argument("--rehearse-one-gpu", action="store_true",
+                    help="N > 1 ranks that SHARE cuda:0 (gloo for the barriers, tests/c/librccl_double.so in RCCL's place): the whole "
+                         "multi-rank code path on a one-GPU box; the line says so and its number is not a scaling measurement")
     ap.add_argument("--plumbing-fail-rank", type=int, default=-1, help="(tests) this rank of a --plumbing-only run exits with code 7 before the rendezvous")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-entropy-stage", action="store_true", help="skip the (untimed) report on the device entropy stage")
@@ -125,6 +128,8 @@ def launch(a):
     for r in range(a.gpus):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(a.gpus), LOCAL_WORLD_SIZE=str(a.gpus),
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0", DCTZ_BENCH_LAUNCHED="1")
+        if a.rehearse_one_gpu:
+            env["DCTZHIP_RCCL_LIBRARY"] = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tests", "c", "librccl_double.so")
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
                                       stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
     import threading
@@ -216,8 +221,15 @@ def run_rank(a, rank, local_rank, world):
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if a.rehearse_one_gpu:
+            if world > 6:
+                print("bench.py: --rehearse-one-gpu takes at most 6 ranks (processes on one card)", file=sys.stderr)
+                sys.exit(2)
+            local_rank = 0
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
     seen_world = dist.get_world_size() if dist is not None else 1
     if seen_world != a.gpus:
         print(f"bench.py: world size {seen_world} != --gpus {a.gpus}: refusing to report a scaled number", file=sys.stderr)
@@ -284,7 +296,8 @@ def run_rank(a, rank, local_rank, world):
     for _ in range(a.steps):
         infos = step()
     barrier()
-    elapsed = shard.max_over_ranks(time.perf_counter() - t0, ctx.device)
+    red_dev = "cpu" if a.rehearse_one_gpu else ctx.device   # (gloo reduces host tensors)
+    elapsed = shard.max_over_ranks(time.perf_counter() - t0, red_dev)
     ms_per_step = elapsed * 1e3 / a.steps
     info = infos[0]
 
@@ -305,7 +318,7 @@ def run_rank(a, rank, local_rank, world):
         for _ in range(a.steps):
             step_scaled()
         barrier()
-        w_ms = shard.max_over_ranks(time.perf_counter() - w0, ctx.device) * 1e3 / a.steps
+        w_ms = shard.max_over_ranks(time.perf_counter() - w0, red_dev) * 1e3 / a.steps
         with_scaled = {"ms_per_step": w_ms, "value": in_bytes * world / (w_ms * 1e-3) / 1e9,
                        "note": "compress writes x / sf into a second buffer as well (the reference's in-place scaling of the caller's array)"}
         del sc
@@ -324,7 +337,7 @@ def run_rank(a, rank, local_rank, world):
         for _ in range(k_loop):
             loop_step()
         barrier()
-        l_ms = shard.max_over_ranks(time.perf_counter() - l0, ctx.device) * 1e3 / k_loop
+        l_ms = shard.max_over_ranks(time.perf_counter() - l0, red_dev) * 1e3 / k_loop
         looped = {"ms_per_step": l_ms, "value": in_bytes * world / (l_ms * 1e-3) / 1e9, "steps": k_loop, "speedup_of_the_batch": l_ms / ms_per_step,
                   "note": "the same arrays, one dctzhip_compress + one dctzhip_decompress call per array"}
 
@@ -374,7 +387,7 @@ def run_rank(a, rank, local_rank, world):
             info = step()[0]
             ctx.comm_gather(out, info.cnt, n, root=0)
         barrier()
-        g_ms = shard.max_over_ranks(time.perf_counter() - g0, ctx.device) * 1e3 / a.steps
+        g_ms = shard.max_over_ranks(time.perf_counter() - g0, red_dev) * 1e3 / a.steps
         with_gather = {"ms_per_step": g_ms, "value": n * es * world / (g_ms * 1e-3) / 1e9,
                        "note": "compress + decompress + RCCL gather of bin_index / DC / AC_exact of every shard to rank 0 per step"}
 
@@ -587,6 +600,10 @@ def run_rank(a, rank, local_rank, world):
             line["with_scaled_copy"] = with_scaled
         if with_gather is not None:
             line["with_gather"] = with_gather
+        if a.rehearse_one_gpu:
+            line["rehearsal"] = (f"{world} ranks SHARE one GPU (gloo barriers; the gather runs through the RCCL test double of "
+                                 "tests/c/rccl_double.cpp): the N > 1 code path end to end, NOT a scaling measurement")
+            line["scaling"] = "none (rehearsal)"
         print(json.dumps(line), flush=True)
     if dist is not None:
         dist.barrier()

@@ -1918,9 +1918,14 @@ constexpr int NCCL_UINT8 = 1, NCCL_UINT64 = 5, NCCL_FLOAT32 = 7;
 
 bool rccl_load(dctzhip_ctx* c) {
   if (g_rccl.ok) return true;
-  const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
-  for (const char* n : names) { g_rccl.h = dlopen(n, RTLD_NOW | RTLD_GLOBAL); if (g_rccl.h) break; }
-  if (!g_rccl.h) { fail(c, DCTZHIP_E_HIP, "RCCL not found (dlopen librccl.so): %s", dlerror()); return false; }
+  // DCTZHIP_RCCL_LIBRARY: an RCCL build outside the loader's path -- or the test double of tests/c/rccl_double.cpp
+  const char* names[] = {getenv("DCTZHIP_RCCL_LIBRARY"), "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+  for (const char* n : names) {
+    if (!n || !*n) continue;
+    g_rccl.h = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
+    if (g_rccl.h || n == names[0]) break;            // (a library that was asked for by name is not silently replaced)
+  }
+  if (!g_rccl.h) { fail(c, DCTZHIP_E_HIP, "RCCL not found (dlopen %s): %s", names[0] && *names[0] ? names[0] : "librccl.so", dlerror()); return false; }
 #define SYM(field, name) *(void**)(&g_rccl.field) = dlsym(g_rccl.h, name); if (!g_rccl.field) { fail(c, DCTZHIP_E_HIP, "RCCL symbol %s missing", name); return false; }
   SYM(GetUniqueId, "ncclGetUniqueId") SYM(CommInitRank, "ncclCommInitRank") SYM(CommDestroy, "ncclCommDestroy")
   SYM(AllGather, "ncclAllGather") SYM(Send, "ncclSend") SYM(Recv, "ncclRecv") SYM(GroupStart, "ncclGroupStart")
