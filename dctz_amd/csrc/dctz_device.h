@@ -70,20 +70,31 @@ template <typename T, int PHASES = 1> struct Geo {
   static constexpr int PHB = TILEB / PH;                 // bytes of a phase image
   static_assert(NSEG % PH == 0, "a phase is a whole number of 128-byte segments");
 };
-// The "stored exactly" coefficients of a tile leave k_compress as NQ = 4 SUB-LISTS: the coefficients j in [16 q, 16 q + 16)
-// of all 64 blocks, block after block, compacted in LDS by the whole wave (one prefix sum over the lanes' counts per
-// sub-list) and written out in whole rows of 64 items.  The staging buffer holds SLOTS items, of which the last 64 are
-// the lanes' dump slots (a coefficient that is not stored exactly is written there); a sub-list with more than CAP items
-// goes out in several rounds.  k_compact_ac puts the sub-lists of a tile back into the reference's order
+// The "stored exactly" coefficients of a tile leave k_compress as NQ SUB-LISTS of QW positions each: the coefficients j in
+// [QW q, QW q + QW) of all 64 blocks, block after block, compacted in LDS by the whole wave (one prefix sum over the
+// lanes' counts per sub-list) and written out in whole rows of 64 items.  The staging buffer holds SLOTS items, of which
+// the last 64 are the lanes' dump slots (a coefficient that is not stored exactly is written there); a sub-list with more
+// than CAP items goes out in several rounds.  k_compact_ac puts the sub-lists of a tile back into the reference's order
 // (dctz-comp-lib.c:478-544: block-major, j ascending) from the per-block counts k_compress leaves: one word per block,
-// a byte per sub-list.  An item is a float (EC: what AC_exact stores) or the coefficient in full precision plus its
+// CBITS bits per sub-list.  An item is a float (EC: what AC_exact stores) or the coefficient in full precision plus its
 // position (QT: the normalisation needs the table of the whole array first).
+// QW = 16 (four sub-lists), except QT on fp64 (8).  Wider sub-lists mean fewer prefix sums, lists that are more often in
+// the reference's order as they stand (nothing beyond position QW stored exactly: a flat copy for k_compact_ac) and fewer
+// runs to merge otherwise -- and more coefficient registers pinned while a sub-list is staged.  Measured on 512^3,
+// k_compress + k_compact_ac in ms at p = 5 % / 17 % / 69 %: fp64 EC  QW 8: 0.289 / 0.366 / 0.577, 16: 0.274 / 0.363 / 0.550,
+// 32 (spills): 0.335 / 0.392 / 0.625; fp64 QT  8: 0.332 / 0.456 / 0.910, 16 (20 spilled registers): 0.327 / 0.470 / 0.887.
 template <typename T, int MODE> struct Sub {
   using Item = typename std::conditional<MODE == DCTZHIP_EC, float, T>::type;
 #ifndef DCTZ_QW64
-#define DCTZ_QW64 8
+#define DCTZ_QW64 16
 #endif
-  static constexpr int QW = sizeof(T) == 8 ? DCTZ_QW64 : 16;                        // coefficients per sub-list
+#ifndef DCTZ_QW64_QT
+#define DCTZ_QW64_QT 8
+#endif
+#ifndef DCTZ_QW32
+#define DCTZ_QW32 16
+#endif
+  static constexpr int QW = sizeof(T) == 8 ? (MODE == DCTZHIP_QT ? DCTZ_QW64_QT : DCTZ_QW64) : DCTZ_QW32;   // coefficients per sub-list
   static constexpr int NQ = 64 / QW;                                                // sub-lists per tile
   // QT, fp64: items (8 B), positions (1 B) AND the wave's per-position maxima of the tile (64 x 8 B, QMAX_AT) share the
   // 4 KiB the tile's bin ids need on their way out anyway -- with anything more the kernel loses its eighth workgroup

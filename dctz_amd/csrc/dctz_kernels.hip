@@ -368,8 +368,7 @@ __device__ __forceinline__ void compress_body(const FwdParams<T>& p, const unsig
     //     go to the lane's dump slot) and the sub-list leaves in whole rows of 64 items.
     auto sub_list = [&](auto qi, auto fast, auto safe) {
       constexpr int Q = decltype(qi)::value, J0 = Q * QW;
-      Item fq[QW];
-      unsigned m = 0;
+      unsigned m = 0;                                // bit i: coefficient J0 + i of this block is stored exactly
 #pragma unroll
       for (int gg = 0; gg < QW / 4; gg++) {
         const int g = J0 / 4 + gg;
@@ -401,11 +400,8 @@ __device__ __forceinline__ void compress_body(const FwdParams<T>& p, const unsig
         // has such a coefficient in it (the high-frequency groups of a smooth field never do)
         const unsigned nw = ~wgd;
         const unsigned mm = ~(((nw & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | nw) & 0x80808080u;
-        if (__builtin_amdgcn_ballot_w64(mm != 0u)) {
-#pragma unroll
-          for (int i = 0; i < 4; i++) fq[4 * gg + i] = (Item)x[4 * g + i];       // :496-497 / :535-537 USE_TRUNCATE (EC); QT: full precision
+        if (__builtin_amdgcn_ballot_w64(mm != 0u))
           m |= (((mm >> 7) | (mm >> 14) | (mm >> 21) | (mm >> 28)) & 0xFu) << (4 * gg);
-        }
         __builtin_amdgcn_sched_barrier(0);           // keep the groups apart: hoisting all 64 quotients first costs 128 registers
       }
       if (!active) m = 0;
@@ -416,17 +412,26 @@ __device__ __forceinline__ void compress_body(const FwdParams<T>& p, const unsig
       const unsigned base = incl - n;                // this block's place in the sub-list
       for (unsigned lo = 0; lo < tot; lo += (unsigned)S::CAP) {      // (one round unless most coefficients are stored exactly)
         unsigned pos = base - lo;                    // (wraps for blocks in front of the round's window: never < CAP then)
-        // (QT: the positions J0 + i come from ONE register the compiler cannot see through -- as 16 constants per
+        // The items are taken from the coefficient registers here (:496-497 / :535-537 USE_TRUNCATE for EC; QT: full
+        // precision), four positions at a time and only where some lane of the wave has one: a smooth field pays for
+        // its lowest frequencies, not for the width of the sub-list.
+        // (QT: the positions J0 + i come from ONE register the compiler cannot see through -- as constants per
         // sub-list they are hoisted out of the tile loop and cost 64 registers, i.e. 60 spilled ones)
         unsigned jv = (unsigned)J0;
         if (MODE == DCTZHIP_QT) asm volatile("" : "+v"(jv));
 #pragma unroll
-        for (int i = 0; i < QW; i++) {
-          const bool f = ((m >> i) & 1u) != 0u;
-          const unsigned at = (f && pos < (unsigned)S::CAP) ? pos : (unsigned)(S::CAP + lane);
-          lds_store_item(exc_at + at * (unsigned)sizeof(Item), fq[i]);
-          if (MODE == DCTZHIP_QT) lds_store_b8(exc_at + (unsigned)S::ITEM_BYTES + at, jv + (unsigned)i);
-          pos += f ? 1u : 0u;
+        for (int gg = 0; gg < QW / 4; gg++) {
+          if (__builtin_amdgcn_ballot_w64(((m >> (4 * gg)) & 0xFu) != 0u)) {
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+              const int i = 4 * gg + k;
+              const bool f = ((m >> i) & 1u) != 0u;
+              const unsigned at = (f && pos < (unsigned)S::CAP) ? pos : (unsigned)(S::CAP + lane);
+              lds_store_item(exc_at + at * (unsigned)sizeof(Item), (Item)x[J0 + i]);
+              if (MODE == DCTZHIP_QT) lds_store_b8(exc_at + (unsigned)S::ITEM_BYTES + at, jv + (unsigned)i);
+              pos += f ? 1u : 0u;
+            }
+          }
         }
         const unsigned cnt = min(tot - lo, (unsigned)S::CAP);
         for (unsigned r = 0; r * 64u < cnt; r++) {   // whole rows -> the workgroup's list; lanes beyond the end fall outside the descriptor
@@ -609,7 +614,8 @@ __device__ __forceinline__ void compact_ac_body(const FwdParams<T>& p, const dou
   using S = Sub<T, MODE>;
   constexpr int NQ = S::NQ, CB = S::CBITS, FB = S::FB, FPD = S::FPD, NPK = S::NPK;
   constexpr unsigned CMASK = (1u << CB) - 1u, FMASK = (1u << FB) - 1u;
-  constexpr int ROWW = NQ == 4 ? 4 : 8;              // dwords of a block's table row (below)
+  static_assert(NQ == 2 || NQ == 4 || NQ == 8, "table rows are laid out for 2, 4 or 8 sub-lists");
+  constexpr int ROWW = NQ <= 4 ? 4 : 8;              // dwords of a block's table row (below)
   constexpr unsigned HALF = TILE_ELEMS / 2;          // output positions the owner map covers at a time
   __shared__ T qtab[64];
   // per wave, per block of its tile: [0] first output position, [1 ..] the ends of its sub-list runs inside the block
@@ -700,10 +706,11 @@ __device__ __forceinline__ void compact_ac_body(const FwdParams<T>& p, const dou
     const unsigned del = acc_q + qbq + 64u - cum;                               // acc_q: where sub-list q starts in the tile's piece (uniform)
     cum += nq;
     row[1 + q / 4] |= cum << (8 * (q % 4));
-    row[(NQ == 4 ? 2 : 4) + q / 2] |= del << (16 * (q % 2));
+    row[(NQ <= 4 ? 2 : 4) + q / 2] |= del << (16 * (q % 2));
     acc_q += (tot[q / FPD] >> ((q % FPD) * FB)) & FMASK;
   }
   row[0] = rowbase;
+  if (NQ == 2) row[1] |= 0x7F7F0000u;                // (bytes of sub-lists that do not exist: ends no position reaches)
   const unsigned nb = cum, tt = acc_q;               // the block's / the tile's items (tt == ttot[t])
   if (tt == 0) return;
   // (one wave writes and reads its own tables: LDS operations of a wave are in order)
@@ -724,7 +731,7 @@ __device__ __forceinline__ void compact_ac_body(const FwdParams<T>& p, const dou
       const unsigned R = (r & 63u) * 0x01010101u;
       unsigned q = (unsigned)__popc(((R | 0x80808080u) - t0.y) & 0x80808080u);   // sub-lists of the block that end at or before r
       unsigned dw;
-      if constexpr (NQ == 4) {
+      if constexpr (NQ <= 4) {
         dw = q < 2u ? t0.z : t0.w;
       } else {
         q += (unsigned)__popc(((R | 0x80808080u) - t0.z) & 0x80808080u);
