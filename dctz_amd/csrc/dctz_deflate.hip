@@ -32,6 +32,7 @@ constexpr int NSYM = NLIT + NDIST + NCL;               // the three alphabets si
 constexpr uint32_t ADLER_M = 65521u;
 
 __device__ __forceinline__ int pad(int i) { return i + ((i >> SEG_SHIFT) << 2); }   // 4 bytes of padding per segment
+__device__ __forceinline__ int pad16(int i) { return i + ((i >> SEG_SHIFT) << 1); } // the same for 16-bit entries: lanes at the same offset of their segments hit different banks
 
 constexpr int META_SYMS = 320;                         // NLIT + NDIST rounded up
 constexpr int HDR_WORDS = 160;                         // >= (17 + 3 * 19 + 316 * 14) / 32 + 1
@@ -61,7 +62,9 @@ __device__ __forceinline__ uint32_t wave_sum_u32(uint32_t v) {
 // ------------------------------------------------------------------ parse --
 struct LdsParse {
   uint8_t in[CHUNK + (CHUNK >> SEG_SHIFT) * 4 + 16];
-  uint8_t tok[CHUNK + (CHUNK >> SEG_SHIFT) * 4 + 16];
+  // per position: during the parse its entry of parse_segment_dwords (best length | candidate << 8), afterwards -- low
+  // byte -- the token record (deflate_chunk.h: tok)
+  uint16_t tok[CHUNK + (CHUNK >> SEG_SHIFT) * 2 + 8];
   uint32_t freq[META_SYMS];
   unsigned long long adler_b;
   uint32_t adler_a;
@@ -101,20 +104,30 @@ __global__ __launch_bounds__(NTHR) void k_dfl_parse(const uint8_t* __restrict__ 
 
   auto in = [&](int i) -> int { return s.in[pad(i)]; };
   const int p0 = tid * SEG, p1 = (p0 + SEG < len) ? p0 + SEG : len;
+  auto in4 = [&](int i) -> uint32_t { return *(const uint32_t*)&s.in[pad(i)]; };     // i a multiple of four
   if (p0 < len) {
     uint32_t a = 0, b = 0;                                // adler32 pieces of this segment: sum d, sum (seglen - j) d_j
-    for (int p = p0; p < p1; p++) { a += (uint32_t)in(p); b += a; }
+    if (p1 - p0 == SEG) {
+      for (int w = p0; w < p1; w += 4) {
+        const uint32_t x = in4(w);
+        a += x & 255u; b += a; a += (x >> 8) & 255u; b += a; a += (x >> 16) & 255u; b += a; a += x >> 24; b += a;
+      }
+    } else
+      for (int p = p0; p < p1; p++) { a += (uint32_t)in(p); b += a; }
     atomicAdd(&s.adler_a, a);
     atomicAdd(&s.adler_b, (unsigned long long)b + (unsigned long long)a * (unsigned long long)(len - p1));
     if (MATCH) {
       int fc = -1, fl = 0, lc = -1, ll = 0, lp = p0, nt = 0;
-      parse_segment(in, [&](int p, int v) { s.tok[pad(p)] = (uint8_t)v; }, p0, p1, 0,
-                    [&](int sym) { atomicAdd(&s.freq[sym], 1u); }, [&](int sym) { atomicAdd(&s.freq[NLIT + sym], 1u); },
-                    [&](int p, int l, int c) { if (nt == 0) { fc = c; fl = l; } lc = c; ll = l; lp = p; nt++; });
+      parse_segment_dwords(in, in4,
+                           [&](int i, uint32_t lo, uint32_t hi) { uint32_t* t = (uint32_t*)&s.tok[pad16(i)]; t[0] = lo; t[1] = hi; },
+                           [&](int p) -> uint32_t { return s.tok[pad16(p)]; },
+                           [&](int p, int v) { s.tok[pad16(p)] = (uint16_t)v; }, p0, p1,
+                           [&](int sym) { atomicAdd(&s.freq[sym], 1u); }, [&](int sym) { atomicAdd(&s.freq[NLIT + sym], 1u); },
+                           [&](int p, int l, int c) { if (nt == 0) { fc = c; fl = l; } lc = c; ll = l; lp = p; nt++; });
       s.first_c[tid] = (int16_t)fc; s.first_len[tid] = (uint16_t)fl; s.last_c[tid] = (int16_t)lc; s.last_len[tid] = (uint16_t)ll;
       s.last_p[tid] = (uint16_t)lp; s.ntok[tid] = (uint16_t)nt;
     } else
-      for (int p = p0; p < p1; p++) { s.tok[pad(p)] = 0; atomicAdd(&s.freq[in(p)], 1u); }
+      for (int p = p0; p < p1; p++) { s.tok[pad16(p)] = 0; atomicAdd(&s.freq[in(p)], 1u); }
   } else if (MATCH) { s.first_c[tid] = -1; s.last_c[tid] = -1; s.ntok[tid] = 0; s.first_len[tid] = 0; s.last_len[tid] = 0; s.last_p[tid] = 0; }
   __syncthreads();
   if (MATCH && p0 < len) {
@@ -125,7 +138,7 @@ __global__ __launch_bounds__(NTHR) void k_dfl_parse(const uint8_t* __restrict__ 
       const int lc = s.last_c[tid], ll = s.last_len[tid], lp = s.last_p[tid];
       const int fc = s.first_c[tid + 1], fl = s.first_len[tid + 1];
       if (lc >= 0 && lp + ll == p0 + SEG && fc == lc && ll + fl <= MAXMATCH && merge_allowed(tid, s.ntok[tid] == 1, s.ntok[tid + 1] == 1)) {
-        s.tok[pad(lp + 1)] = (uint8_t)(ll + fl - 3);
+        s.tok[pad16(lp + 1)] = (uint16_t)(ll + fl - 3);
         int sa, sb, sc, eb, ev;
         len_code(ll, sa, eb, ev); len_code(fl, sb, eb, ev); len_code(ll + fl, sc, eb, ev);
         atomicSub(&s.freq[sa], 1u); atomicSub(&s.freq[sb], 1u); atomicAdd(&s.freq[sc], 1u);
@@ -136,11 +149,15 @@ __global__ __launch_bounds__(NTHR) void k_dfl_parse(const uint8_t* __restrict__ 
       const int lc = s.last_c[tid - 1], ll = s.last_len[tid - 1], lp = s.last_p[tid - 1];
       const int fc = s.first_c[tid], fl = s.first_len[tid];
       if (lc >= 0 && lp + ll == p0 && fc == lc && ll + fl <= MAXMATCH && merge_allowed(tid - 1, s.ntok[tid - 1] == 1, s.ntok[tid] == 1))
-        s.tok[pad(p0)] = (uint8_t)TOK_ABSORBED;
+        s.tok[pad16(p0)] = (uint16_t)TOK_ABSORBED;
     }
   }
   __syncthreads();
-  for (int i = tid * 4; i < CHUNK; i += NTHR * 4) *(uint32_t*)(tok_g + off + i) = *(const uint32_t*)&s.tok[pad(i)];   // (scratch is a whole number of chunks)
+  for (int i = tid * 4; i < CHUNK; i += NTHR * 4) {       // the low bytes of four entries = four token bytes (scratch is a whole number of chunks)
+    const uint32_t* t = (const uint32_t*)&s.tok[pad16(i)];
+    const uint32_t d0 = t[0], d1 = t[1];
+    *(uint32_t*)(tok_g + off + i) = (d0 & 255u) | ((d0 >> 8) & 0xFF00u) | ((d1 & 255u) << 16) | ((d1 << 8) & 0xFF000000u);
+  }
   for (int i = tid; i < META_SYMS; i += NTHR) freq_g[(size_t)blockIdx.x * META_SYMS + i] = s.freq[i];
   if (tid == 0) {
     // this chunk's share of the section's adler32: S1 = sum d, S2 = sum (n - i) d_i  (mod 65521)
