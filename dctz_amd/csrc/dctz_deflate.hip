@@ -62,7 +62,7 @@ __device__ __forceinline__ uint32_t wave_sum_u32(uint32_t v) {
 // ------------------------------------------------------------------ parse --
 struct LdsParse {
   uint8_t in[CHUNK + (CHUNK >> SEG_SHIFT) * 4 + 16];
-  // per position: during the parse its entry of parse_segment_dwords (best length | candidate << 8), afterwards -- low
+  // per position: during the parse its entry of parse_segment_dwords (length and candidate of the best match from there), afterwards -- low
   // byte -- the token record (deflate_chunk.h: tok)
   uint16_t tok[CHUNK + (CHUNK >> SEG_SHIFT) * 2 + 8];
   uint32_t freq[META_SYMS];

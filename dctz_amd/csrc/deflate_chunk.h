@@ -167,56 +167,67 @@ DFL_HD void parse_segment(In in, TokW tokw, int p0, int p1, int avail, CountL li
 //     for every candidate distance the bytes d positions back (aligned dwords for multiples of four, two dwords and a
 //     byte shift otherwise) are compared four at a time, and a running count per candidate -- "this position and how many
 //     behind it repeat at distance d" = the length the walk above would find from here -- is kept; the longest (first
-//     candidate on a tie, as above) goes into a 16-bit entry per position: length | candidate << 8, 0 = nothing of 3+;
+//     candidate on a tie, as above) goes into a 16-bit entry per position: (length << 2) | (NCAND - 1 - candidate);
 //   pass B, forwards: the greedy walk itself, one entry per TOKEN.
 // in4(i): the four input bytes at chunk offset i (i a multiple of four, >= 0; bytes beyond the chunk's end read as anything:
 // they are masked); tmpw(i, lo, hi): entries of positions i .. i + 3 (two per word); tmpr(p): entry of position p.
 template <class In, class In4, class TmpW, class TmpR, class TokW, class CountL, class CountD, class Info = NoTokInfo>
 DFL_HD void parse_segment_dwords(In in, In4 in4, TmpW tmpw, TmpR tmpr, TokW tokw, int p0, int p1, CountL lit, CountD dst, Info info = Info()) {
   static_assert(HIST == 0, "candidates never reach in front of the chunk");
-  int rl[NCAND];
+  static_assert(NCAND <= 4 && SEG <= 128, "an entry is (length << 2) | (NCAND - 1 - candidate)");
+  // R[c] = (running length << 2) | (NCAND - 1 - c): the maximum over the candidates is the longest run, the FIRST
+  // candidate on a tie -- and is the position's entry as it stands
+  uint32_t R[NCAND];
 #pragma unroll
-  for (int c = 0; c < NCAND; c++) rl[c] = 0;
+  for (int c = 0; c < NCAND; c++) R[c] = (uint32_t)(NCAND - 1 - c);
   const int pe = (p1 + 3) & ~3;
+  // positions of the segment's last dword that lie inside it (all four but for the section's last segment)
+  uint32_t inside = (p1 & 3) ? (0x80808080u >> (8 * (4 - (p1 & 3)))) : 0x80808080u;
   uint32_t cur = in4(pe - 4);
   for (int w = pe - 4; w >= p0; w -= 4) {
-    const uint32_t prev = w >= 4 ? in4(w - 4) : 0u;
-    const int left = p1 - w;                               // positions of this dword inside the segment (4 but for the section's last one)
-    const uint32_t inside = left >= 4 ? 0x80808080u : (0x80808080u >> (8 * (4 - left)));
+    // every load of the trip up front, from clamped offsets; what lies in front of the chunk is replaced by bytes that
+    // cannot compare equal (the complement of what they are compared with)
+    const uint32_t prev = in4(w >= 4 ? w - 4 : 0);
+    uint32_t hi[NCAND], lo[NCAND];
+#pragma unroll
+    for (int c = 0; c < NCAND; c++) {
+      const int d = cand_dist(c), a = d >> 2, r = d & 3;
+      hi[c] = a == 0 ? cur : in4(w >= 4 * a ? w - 4 * a : 0);
+      lo[c] = r == 0 ? 0u : (a == 0 ? prev : in4(w >= 4 * a + 4 ? w - 4 * a - 4 : 0));
+    }
     uint32_t z[NCAND];
 #pragma unroll
     for (int c = 0; c < NCAND; c++) {
       const int d = cand_dist(c), a = d >> 2, r = d & 3;
       uint32_t ref;
-      if (r == 0) ref = w >= d ? in4(w - d) : ~cur;
+      if (r == 0) ref = w >= d ? hi[c] : ~cur;
       else {
-        const uint32_t hi = a == 0 ? cur : (w >= 4 * a ? in4(w - 4 * a) : 0u);
-        const uint32_t lo = a == 0 ? prev : (w >= 4 * a + 4 ? in4(w - 4 * a - 4) : 0u);
-        ref = (hi << (8 * r)) | (lo >> (32 - 8 * r));
+        const uint32_t h = w >= 4 * a ? hi[c] : ~(cur >> (8 * r));                 // (bytes r .. 3 of ref)
+        const uint32_t l = w >= 4 * a + 4 ? lo[c] : ~(cur << (32 - 8 * r));        // (bytes 0 .. r - 1 of ref)
+        ref = (h << (8 * r)) | (l >> (32 - 8 * r));
       }
-      const int need = d - w;                              // positions w + k with k >= need have their candidate byte inside the chunk
-      const uint32_t there = need <= 0 ? 0x80808080u : (need >= 4 ? 0u : (0x80808080u << (8 * need)));
       const uint32_t x = cur ^ ref;
-      z[c] = ~(((x & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | x) & inside & there;      // bit 7 of byte k: position w + k repeats at distance d
+      z[c] = ~(((x & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | x) & inside;                      // bit 7 of byte k: position w + k repeats at distance d
     }
+    inside = 0x80808080u;
     uint32_t e[4];
 #pragma unroll
     for (int k = 3; k >= 0; k--) {
-      int b = 0, bc = 0;
+      uint32_t key = 0;
 #pragma unroll
       for (int c = 0; c < NCAND; c++) {
-        rl[c] = ((z[c] >> (8 * k + 7)) & 1u) ? rl[c] + 1 : 0;
-        if (rl[c] > b) { b = rl[c]; bc = c; }
+        R[c] = ((z[c] >> (8 * k + 7)) & 1u) ? R[c] + 4u : (uint32_t)(NCAND - 1 - c);
+        key = R[c] > key ? R[c] : key;
       }
-      e[k] = b >= MINMATCH ? (uint32_t)(b | (bc << 8)) : 0u;
+      e[k] = key;
     }
     tmpw(w, e[0] | (e[1] << 16), e[2] | (e[3] << 16));
     cur = prev;
   }
   for (int p = p0; p < p1;) {
     const uint32_t en = tmpr(p);
-    const int best = (int)(en & 0xFFu), bc = (int)(en >> 8);
-    if (best) {
+    const int best = (int)(en >> 2), bc = NCAND - 1 - (int)(en & 3u);
+    if (best >= MINMATCH) {
       tokw(p, 1 + bc);
       tokw(p + 1, best - 3);
       int s, eb, v;
