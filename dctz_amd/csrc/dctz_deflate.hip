@@ -444,8 +444,7 @@ struct LdsEmit {
   uint8_t in[CHUNK + (CHUNK >> SEG_SHIFT) * 4 + 16];
   uint8_t tok[CHUNK + (CHUNK >> SEG_SHIFT) * 4 + 16];
   uint32_t out[CHUNK / 4 + 8];
-  uint16_t code[META_SYMS];
-  uint8_t len[META_SYMS];
+  uint32_t cl[META_SYMS];                              // code | length << 16: one look-up per symbol
   uint32_t scan[NTHR / 64 + 1];
 };
 
@@ -483,7 +482,7 @@ __global__ __launch_bounds__(NTHR) void k_dfl_emit(const uint8_t* __restrict__ s
   }
   load_chunk(s.in, src + off, len, (((uintptr_t)src) & 3) == 0);
   load_chunk(s.tok, tok_g + off, CHUNK, true);
-  for (int i = tid; i < META_SYMS; i += NTHR) { s.code[i] = m->code[i]; s.len[i] = m->len[i]; }
+  for (int i = tid; i < META_SYMS; i += NTHR) s.cl[i] = (uint32_t)m->code[i] | ((uint32_t)m->len[i] << 16);
   const uint32_t hbits = m->hbits, hwords = (hbits + 31) / 32;
   for (int i = tid; i < CHUNK / 4 + 8; i += NTHR) s.out[i] = i < (int)hwords ? m->hdr[i] : 0u;
   __syncthreads();
@@ -493,15 +492,17 @@ __global__ __launch_bounds__(NTHR) void k_dfl_emit(const uint8_t* __restrict__ s
   uint32_t mybits = 0;
   // (a segment whose first token was merged into the previous segment's last one starts behind it: deflate_chunk.h)
   const int pstart = (p0 < len && s.tok[pad(p0)] == TOK_ABSORBED) ? p0 + s.tok[pad(p0 + 1)] + 3 : p0;
+  // (a token's three bytes -- record, length, literal -- are asked for together, then its code(s): two round trips through
+  // LDS per token instead of three or four; the walk is a chain of them)
   if (p0 < len) {
     for (int p = pstart; p < p1;) {
-      const int t = s.tok[pad(p)];
-      if (t == 0) { mybits += s.len[in(p)]; p++; }
+      const int t = s.tok[pad(p)], t1 = s.tok[pad(p + 1)], b = in(p);
+      if (t == 0) { mybits += s.cl[b] >> 16; p++; }
       else {
-        const int l = s.tok[pad(p + 1)] + 3;
+        const int l = t1 + 3;
         int sym, eb, ev;
         len_code(l, sym, eb, ev);
-        mybits += s.len[sym] + eb + s.len[NLIT + cand_dsym_rt(t - 1)] + cand_deb_rt(t - 1);
+        mybits += (s.cl[sym] >> 16) + eb + (s.cl[NLIT + cand_dsym_rt(t - 1)] >> 16) + cand_deb_rt(t - 1);
         p += l;
       }
     }
@@ -512,23 +513,24 @@ __global__ __launch_bounds__(NTHR) void k_dfl_emit(const uint8_t* __restrict__ s
   uint32_t wave_base = 0, total = 0;
   for (int w = 0; w < NTHR / 64; w++) { if (w < (tid >> 6)) wave_base += s.scan[w]; total += s.scan[w]; }
   const uint32_t excl = wave_base + incl - mybits;
-  const uint32_t body_bits = hbits + total + s.len[256];
+  const uint32_t body_bits = hbits + total + (s.cl[256] >> 16);
   const uint32_t dyn_bytes = (body_bits + 3 + 7) / 8 + 4;       // == sizes[chunk]
 
   auto orw = [&](uint32_t w, uint32_t v) { atomicOr(&s.out[w], v); };
   if (p0 < len) {
     BitW<decltype(orw)> bw(orw, (uint64_t)hbits + excl);
     for (int p = pstart; p < p1;) {
-      const int t = s.tok[pad(p)];
-      if (t == 0) { const int b = in(p); bw.put(s.code[b], s.len[b]); p++; }
+      const int t = s.tok[pad(p)], t1 = s.tok[pad(p + 1)], b = in(p);
+      if (t == 0) { const uint32_t e = s.cl[b]; bw.put(e & 0xFFFFu, (int)(e >> 16)); p++; }
       else {
-        const int l = s.tok[pad(p + 1)] + 3;
+        const int l = t1 + 3;
         int sym, eb, ev;
         len_code(l, sym, eb, ev);
-        bw.put(s.code[sym], s.len[sym]);
-        if (eb) bw.put((uint32_t)ev, eb);
         const int c = t - 1, ds = cand_dsym_rt(c), de = cand_deb_rt(c);
-        bw.put(s.code[NLIT + ds], s.len[NLIT + ds]);
+        const uint32_t el = s.cl[sym], ed = s.cl[NLIT + ds];
+        bw.put(el & 0xFFFFu, (int)(el >> 16));
+        if (eb) bw.put((uint32_t)ev, eb);
+        bw.put(ed & 0xFFFFu, (int)(ed >> 16));
         if (de) bw.put((uint32_t)cand_dev_rt(c), de);
         p += l;
       }
@@ -538,7 +540,7 @@ __global__ __launch_bounds__(NTHR) void k_dfl_emit(const uint8_t* __restrict__ s
   const uint32_t end_byte = (body_bits + 3 + 7) / 8;     // where LEN = 0 of the empty stored block starts
   if (tid == 0) {
     BitW<decltype(orw)> bw(orw, (uint64_t)hbits + total);
-    bw.put(s.code[256], s.len[256]);                     // end of block; the 3 header bits 000 and the padding are zeros already
+    bw.put(s.cl[256] & 0xFFFFu, (int)(s.cl[256] >> 16));   // end of block; the 3 header bits 000 and the padding are zeros already
     bw.flush();
     BitW<decltype(orw)> tail(orw, (uint64_t)(end_byte + 2) * 8);
     tail.put(0xFFFFu, 16);
