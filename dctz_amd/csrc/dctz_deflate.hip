@@ -494,17 +494,30 @@ __global__ __launch_bounds__(NTHR) void k_dfl_emit(const uint8_t* __restrict__ s
   const int pstart = (p0 < len && s.tok[pad(p0)] == TOK_ABSORBED) ? p0 + s.tok[pad(p0 + 1)] + 3 : p0;
   // (a token's three bytes -- record, length, literal -- are asked for together, then its code(s): two round trips through
   // LDS per token instead of three or four; the walk is a chain of them)
+  // Literals and matches go through ONE sequence of instructions (a literal is a token without length-extra, distance and
+  // distance-extra bits): with 64 lanes at 64 different places of their token streams nearly every trip of a two-branch
+  // loop ran both branches.
+  auto token = [&](int p, uint32_t& e1, int& eb, int& ev, uint32_t& e2, int& de, int& dv) -> int {
+    const int t = s.tok[pad(p)], t1 = s.tok[pad(p + 1)], b = in(p);
+    const bool m = t != 0;
+    const int l = m ? t1 + 3 : 3;
+    int sym;
+    len_code(l, sym, eb, ev);
+    const int c = m ? t - 1 : 0;
+    e1 = s.cl[m ? sym : b];
+    e2 = m ? s.cl[NLIT + cand_dsym_rt(c)] : 0u;
+    eb = m ? eb : 0;
+    de = m ? cand_deb_rt(c) : 0;
+    dv = m ? cand_dev_rt(c) : 0;
+    return m ? l : 1;
+  };
   if (p0 < len) {
     for (int p = pstart; p < p1;) {
-      const int t = s.tok[pad(p)], t1 = s.tok[pad(p + 1)], b = in(p);
-      if (t == 0) { mybits += s.cl[b] >> 16; p++; }
-      else {
-        const int l = t1 + 3;
-        int sym, eb, ev;
-        len_code(l, sym, eb, ev);
-        mybits += (s.cl[sym] >> 16) + eb + (s.cl[NLIT + cand_dsym_rt(t - 1)] >> 16) + cand_deb_rt(t - 1);
-        p += l;
-      }
+      uint32_t e1, e2;
+      int eb, ev, de, dv;
+      const int adv = token(p, e1, eb, ev, e2, de, dv);
+      mybits += (e1 >> 16) + (uint32_t)eb + (e2 >> 16) + (uint32_t)de;
+      p += adv;
     }
   }
   const uint32_t incl = wave_incl_scan_u32(mybits);
@@ -520,20 +533,14 @@ __global__ __launch_bounds__(NTHR) void k_dfl_emit(const uint8_t* __restrict__ s
   if (p0 < len) {
     BitW<decltype(orw)> bw(orw, (uint64_t)hbits + excl);
     for (int p = pstart; p < p1;) {
-      const int t = s.tok[pad(p)], t1 = s.tok[pad(p + 1)], b = in(p);
-      if (t == 0) { const uint32_t e = s.cl[b]; bw.put(e & 0xFFFFu, (int)(e >> 16)); p++; }
-      else {
-        const int l = t1 + 3;
-        int sym, eb, ev;
-        len_code(l, sym, eb, ev);
-        const int c = t - 1, ds = cand_dsym_rt(c), de = cand_deb_rt(c);
-        const uint32_t el = s.cl[sym], ed = s.cl[NLIT + ds];
-        bw.put(el & 0xFFFFu, (int)(el >> 16));
-        if (eb) bw.put((uint32_t)ev, eb);
-        bw.put(ed & 0xFFFFu, (int)(ed >> 16));
-        if (de) bw.put((uint32_t)cand_dev_rt(c), de);
-        p += l;
-      }
+      uint32_t e1, e2;
+      int eb, ev, de, dv;
+      const int adv = token(p, e1, eb, ev, e2, de, dv);
+      const int n1 = (int)(e1 >> 16), n2 = (int)(e2 >> 16);
+      // code + its extra bits (<= 15 + 5), distance code + its extra bits (<= 15 + 13; nothing for a literal)
+      bw.put((e1 & 0xFFFFu) | ((uint32_t)ev << n1), n1 + eb);
+      bw.put((e2 & 0xFFFFu) | ((uint32_t)dv << n2), n2 + de);
+      p += adv;
     }
     bw.flush();
   }

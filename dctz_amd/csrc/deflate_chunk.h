@@ -330,7 +330,7 @@ struct BitW {
   int nbits;
   uint32_t wpos;
   DFL_HD BitW(OrW o, uint64_t bit_offset) : orw(o), acc(0), nbits((int)(bit_offset & 31)), wpos((uint32_t)(bit_offset >> 5)) {}
-  DFL_HD void put(uint32_t v, int n) {          // n <= 16
+  DFL_HD void put(uint32_t v, int n) {          // n <= 32 (v has no bits above n; n = 0 writes nothing)
     acc |= (uint64_t)v << nbits;
     nbits += n;
     if (nbits >= 32) { orw(wpos++, (uint32_t)acc); acc >>= 32; nbits -= 32; }
