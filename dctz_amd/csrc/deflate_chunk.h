@@ -224,24 +224,21 @@ DFL_HD void parse_segment_dwords(In in, In4 in4, TmpW tmpw, TmpR tmpr, TokW tokw
     tmpw(w, e[0] | (e[1] << 16), e[2] | (e[3] << 16));
     cur = prev;
   }
+  // (one sequence of instructions for both kinds of token: lanes of a wave are at different places of their streams, and
+  // a loop with a branch per kind runs both branches nearly every trip)
   for (int p = p0; p < p1;) {
     const uint32_t en = tmpr(p);
+    const int byte = in(p);
     const int best = (int)(en >> 2), bc = NCAND - 1 - (int)(en & 3u);
-    if (best >= MINMATCH) {
-      tokw(p, 1 + bc);
-      tokw(p + 1, best - 3);
-      int s, eb, v;
-      len_code(best, s, eb, v);
-      lit(s);
-      dst(cand_dsym_rt(bc));
-      info(p, best, bc);
-      p += best;
-    } else {
-      tokw(p, 0);
-      lit(in(p));
-      info(p, 1, -1);
-      p++;
-    }
+    const bool m = best >= MINMATCH;
+    int s, eb, v;
+    len_code(m ? best : MINMATCH, s, eb, v);
+    tokw(p, m ? 1 + bc : 0);
+    if (m) tokw(p + 1, best - 3);
+    lit(m ? s : byte);
+    if (m) dst(cand_dsym_rt(bc));
+    info(p, m ? best : 1, m ? bc : -1);
+    p += m ? best : 1;
   }
 }
 
