@@ -58,6 +58,8 @@ def parse(argv=None):
     ap.add_argument("--eb", type=float, default=None)
     ap.add_argument("--mode", choices=["ec", "qt"], default=None)
     ap.add_argument("--dtype", choices=["f64", "f32"], default="f64")
+    ap.add_argument("--settle-ms", type=float, default=25.0,
+                    help="untimed steps of the same workload for this long before the warm-up steps (allocations, clocks); 0 = none")
     ap.add_argument("--plumbing-only", action="store_true", help="launcher + rendezvous + gather on gloo; no kernels, no value")
     ap.add_argument("--launch-timeout", type=float, default=480.0, help="the launcher ends all ranks after this many seconds (below the driver's own limit)")
     ap.add_argument("--rehearse-one-gpu", action="store_true",
@@ -278,7 +280,19 @@ def run_rank(a, rank, local_rank, world):
             ctx.decompress_batch(None, None, None, None, None, None, mode, prepared=state["dp"])
         return infos
 
+    # Settling, in front of the W warm-up steps the caller asked for: the first call allocates (5 ms), and the part's power
+    # management answers sustained load with a dip -- steps 4 to 12 of a fresh process run 12 % slower than steps 1 to 3 and
+    # than everything from step 15 on (tools/warm_probe.py: 0.51 / 0.60 / 0.52 ms; host time follows the GPU's, it is not
+    # the library).  A 20-step window behind 5 warm-up steps would measure that dip.  --settle-ms 0 switches this off.
     infos = None
+    settle_steps = 0
+    if a.settle_ms > 0:
+        torch.cuda.synchronize()
+        s0 = time.perf_counter()
+        while (time.perf_counter() - s0) * 1e3 < a.settle_ms or settle_steps < 2:
+            infos = step()
+            torch.cuda.synchronize()
+            settle_steps += 1
     for _ in range(a.warmup):
         infos = step()
     if infos is None:
@@ -562,6 +576,8 @@ def run_rank(a, rank, local_rank, world):
                       else f"compress+decompress GB/s (input bytes), config {a.config}: {a.dtype if not many else 'fp64+fp32 list'} "
                            f"{a.mode.upper()}" + ("" if many else f" eb={a.eb:g}"),
             "value": value, "unit": "GB/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "settle": {"ms": a.settle_ms, "steps": settle_steps, "note": "untimed, in front of the warm-up steps: first-call allocations and the "
+                       "power management's dip under fresh load (steps 4-12 of a process run 12 % slow, tools/warm_probe.py)"},
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": a.dtype if not many else "f64+f32", "data": "synthetic",
             "config": {"workload": wl_name + ("; step = dctzhip_compress + dctzhip_decompress" if not many else "") + ", inputs resident in HBM",

@@ -17,6 +17,8 @@ mkdir -p $O
 cd $R
 B="python3 bench.py"
 timeout -k 10 300 $B --steps 20 --warmup 5 > $O/bench_driver_form.json 2> $O/bench_driver_form.err
+timeout -k 10 300 $B --steps 20 --warmup 5 --settle-ms 0 --no-cpu-baseline --no-entropy-stage > $O/bench_driver_form_unsettled.json 2> $O/bench_driver_form_unsettled.err
+python3 tools/warm_probe.py 80 > $O/warm_probe.json 2> $O/warm_probe.err
 rocprofv3 --kernel-trace --stats -d $O/kt -o kt -- $B --no-cpu-baseline > $O/kt_bench.json 2> $O/kt.err
 python3 tools/pmc_summary.py $O/kt > $O/kernel_stats.csv 2>&1
 rocprofv3 --pmc FETCH_SIZE -d $O/pf -o pf -- $B --no-cpu-baseline --no-entropy-stage --steps 5 --warmup 2 > /dev/null 2> $O/pf.err
