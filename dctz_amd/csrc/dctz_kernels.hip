@@ -642,8 +642,15 @@ __device__ __forceinline__ void compact_ac_body(const FwdParams<T>& p, const dou
   // (the tile's own words are asked for first: they do not depend on the list's place, and a workgroup's life is a chain
   // of round trips -- list lengths, tile totals, block counts, items)
   const TileRange tr = tile_range(l < G ? l : 0u, G ? G : 1u, p.ntiles);
-  const unsigned t = tr.lo + chunk * (unsigned)COMPACT_TPW + wave;
-  const bool tile_here = l < G && t < tr.hi;
+  // A chunk with fewer tiles than waves -- small arrays: a list is one or two tiles -- shares every tile among `share`
+  // waves: each builds the tile's tables for itself (they are per wave anyway) and takes every share-th group of rows.
+  // A dense single-tile list was one wave walking 63 rows (C1: k_compact_ac 23 us of a 62 us step).
+  const unsigned first_t = tr.lo + chunk * (unsigned)COMPACT_TPW;
+  const unsigned m_here = (l < G && first_t < tr.hi) ? min((unsigned)COMPACT_TPW, tr.hi - first_t) : 0u;
+  const unsigned share = m_here == 1u ? 4u : (m_here == 2u ? 2u : 1u), part = wave % share;
+  static_assert(COMPACT_TPW == 4, "the sharing above is written for four waves");
+  const unsigned t = first_t + wave / share;
+  const bool tile_here = wave / share < m_here;
   unsigned pre = 0, c = 0;                           // items of this list in front of tile t; block `lane`'s counts
   if (tile_here) {
     for (unsigned u = tr.lo + lane; u < t; u += 64u) pre += p.ttot[u];
@@ -675,7 +682,7 @@ __device__ __forceinline__ void compact_ac_body(const FwdParams<T>& p, const dou
     // only the first sub-list of the tile has items (a smooth field: what is stored exactly are the lowest
     // frequencies): block-major over its range of j IS the reference's order -- the tile's piece is copied as it is
     const unsigned tt0 = (unsigned)__builtin_amdgcn_readlane((int)wave_incl_scan(c & CMASK), 63);
-    for (unsigned o0 = 0; o0 < tt0; o0 += 256u) {
+    for (unsigned o0 = part * 256u; o0 < tt0; o0 += 256u * share) {
       float v[4];
 #pragma unroll
       for (unsigned u = 0; u < 4; u++) { const unsigned o = o0 + 64u * u + lane; v[u] = o < tt0 ? fetch(src + pre + o) : 0.f; }
@@ -717,15 +724,19 @@ __device__ __forceinline__ void compact_ac_body(const FwdParams<T>& p, const dou
 #pragma unroll
   for (int i = 0; i < ROWW; i += 4) *reinterpret_cast<u32x4*>(&tab[wave][lane][i]) = u32x4{row[i], row[i + 1], row[i + 2], row[i + 3]};
   unsigned carry = 0;                                // owner of the last position handled so far
+  unsigned grp = 0;                                  // row groups seen so far (this wave takes those with grp % share == part)
   for (unsigned h0 = 0; h0 < tt; h0 += HALF) {
     const unsigned hn = min(tt - h0, HALF);
     for (unsigned o = lane * 16u; o < hn; o += 1024u) *reinterpret_cast<u32x4*>(&own[wave][o]) = u32x4{0u, 0u, 0u, 0u};
     if (nb != 0 && rowbase - h0 < HALF) own[wave][rowbase - h0] = (unsigned char)lane;       // (unsigned: rowbase >= h0 too)
     // where the item for output position o (of this half) sits in the tile's piece of the list
-    auto source_of = [&](unsigned o) -> unsigned {
+    auto owner_of = [&](unsigned o) -> unsigned {      // (every wave of a shared tile walks ALL rows here: the running maximum is a chain)
       unsigned b = wave_incl_max_scan((unsigned)own[wave][o - h0]);
       b = max(b, carry) & 63u;                       // (& 63: lanes beyond the tile's last position read bytes nobody wrote)
       carry = (unsigned)__builtin_amdgcn_readlane((int)b, 63);
+      return b;
+    };
+    auto source_of = [&](unsigned o, unsigned b) -> unsigned {
       const u32x4 t0 = *reinterpret_cast<const u32x4*>(&tab[wave][b][0]);
       const unsigned r = o - t0.x;                   // position inside the block (< 64 for a real position)
       const unsigned R = (r & 63u) * 0x01010101u;
@@ -744,13 +755,19 @@ __device__ __forceinline__ void compact_ac_body(const FwdParams<T>& p, const dou
     // four rows of 64 positions at a time: their items are fetched side by side, then stored (one row at a time the loop
     // is a chain of load -> store -> load ...: the compiler cannot tell the list from AC_exact)
     constexpr unsigned RU = 4;
-    for (unsigned o0 = h0; o0 < h0 + hn; o0 += 64u * RU) {
+    for (unsigned o0 = h0; o0 < h0 + hn; o0 += 64u * RU, grp++) {
       unsigned at[RU];
       float v[RU];
 #pragma unroll
       for (unsigned u = 0; u < RU; u++) {
         const unsigned o = o0 + 64u * u + lane;
-        at[u] = (o0 + 64u * u < h0 + hn) ? source_of(min(o, h0 + HALF - 1u)) : 0u;   // (whole rows: the max-scan wants every lane)
+        at[u] = (o0 + 64u * u < h0 + hn) ? owner_of(min(o, h0 + HALF - 1u)) : 0u;    // (whole rows: the max-scan wants every lane)
+      }
+      if (grp % share != part) continue;
+#pragma unroll
+      for (unsigned u = 0; u < RU; u++) {
+        const unsigned o = o0 + 64u * u + lane;
+        at[u] = (o0 + 64u * u < h0 + hn) ? source_of(min(o, h0 + HALF - 1u), at[u]) : 0u;
       }
 #pragma unroll
       for (unsigned u = 0; u < RU; u++) {
