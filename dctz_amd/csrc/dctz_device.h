@@ -218,6 +218,7 @@ struct FwdParams {
   float* dc;                       // DC out
   float* ac;                       // AC_exact out
   T* coef;                         // optional coefficient tap (tests)
+  T* scaled;                       // optional: x / sf of every full block written here by k_compress itself (dctz-comp-lib.c:193-216); never x
   float* ac_tmp;                   // workgroup-local AC_exact lists, list of workgroup b starts at the slot of its first tile
   unsigned* tile_cnt;              // list lengths, one per workgroup (+1 for the remainder block)
   T* qt_item;                      // QT scratch: flagged coefficients, full precision (same list layout as ac_tmp)
@@ -343,7 +344,7 @@ size_t deflate_bound(size_t n);
 hipError_t launch_deflate(const void* src, size_t n, void* dst, void* scratch, unsigned long long* box_len, uint32_t* host_sizes, bool literals_only,
                           hipStream_t st);
 hipError_t launch_inflate(const void* sec, const uint32_t* offs, size_t nch, size_t n, void* dst, unsigned long long* adler, uint32_t* status, hipStream_t st);
-template <typename T> int compress_occupancy(int mode, bool stats, int geom);
+template <typename T> int compress_occupancy(int mode, bool stats, int geom, bool scaled = false);
 template <typename T> int decompress_occupancy(int mode, int geom);
 template <typename T> size_t compress_lds_bytes(int mode);
 template <typename T> size_t decompress_lds_bytes();

@@ -137,7 +137,12 @@ template <typename T, int MODE, int PH> constexpr int compress_waves() { return 
 // The body is shared by two launch shapes: k_compress (one array per launch: workgroup wg = blockIdx.x of nwg = gridDim.x)
 // and k_compress_batch (many arrays per launch: the workgroup looks its array up and is workgroup wg of the nwg that array
 // got).
-template <typename T, int MODE, bool STATS, int PH, int GEOM>
+// SC: the scaled values x / sf go back out as well (FwdParams::scaled: the reference's in-place division of the caller's
+// array, dctz-comp-lib.c:193-216, which otherwise is a 2 s bytes / element pass of its own, k_scale): each half of a
+// tile takes the way k_decompress's output takes -- registers -> the transposed image -> 1 KiB rows -- through the one
+// image there is, in the window where it is free (the half is in registers, the next DMA not yet issued); that DMA
+// therefore starts ~3 K cycles later than in the plain kernel, which is why this is a variant and not the kernel.
+template <typename T, int MODE, bool STATS, int PH, int GEOM, bool SC = false>
 __device__ __forceinline__ void compress_body(const FwdParams<T>& p, const unsigned wg, const unsigned nwg) {
   using G = Geo<T, PH>;
   using S = Sub<T, MODE>;
@@ -177,7 +182,8 @@ __device__ __forceinline__ void compress_body(const FwdParams<T>& p, const unsig
   // The same in pieces (flat geometry): 16 (fp64) / 8 (fp32) DMA instructions issued back to back stall the wave for
   // ~270 cycles each behind the CU's full memory queue (4.3 K cycles per phase, stamped); spread over the work that
   // follows they find the queue drained.  SPREAD: build knob DCTZ_DMA_SPREAD.
-  constexpr bool SPREAD = DCTZ_DMA_SPREAD != 0 && PH == 2 && GEOM == GEOM_1D;
+  static_assert(!SC || (PH == 2 && GEOM == GEOM_1D), "the scaled write-back exists for the flat two-phase kernels");
+  constexpr bool SPREAD = DCTZ_DMA_SPREAD != 0 && PH == 2 && GEOM == GEOM_1D && !SC;
   auto issue_rows = [&](unsigned rel, int phase, const TileMap<T, PH>& tmx, auto jg0, auto jg1) {
     issue_phase_dma<T, PH, decltype(jg0)::value, decltype(jg1)::value>(r_in, rel, phase, tilebuf, tmx);
   };
@@ -193,6 +199,24 @@ __device__ __forceinline__ void compress_body(const FwdParams<T>& p, const unsig
   const __amdgpu_buffer_rsrc_t r_bin = __builtin_amdgcn_make_buffer_rsrc(p.bin + first_el, 0, range_el, 0x00020000);
   const __amdgpu_buffer_rsrc_t r_dc = __builtin_amdgcn_make_buffer_rsrc(p.dc + first_el / 64, 0, range_el / 64 * 4, 0x00020000);
   const __amdgpu_buffer_rsrc_t r_qc = __builtin_amdgcn_make_buffer_rsrc(p.qcnt + first_el / 64, 0, range_el / 64 * 4, 0x00020000);
+  const __amdgpu_buffer_rsrc_t r_sc = __builtin_amdgcn_make_buffer_rsrc(SC ? p.scaled + first_el : nullptr, 0, SC ? range_el * (int)sizeof(T) : 0, 0x00020000);
+  // SC: one phase of a tile, scaled, registers -> image -> HBM (the rows of k_decompress's store_rows); ends with the image
+  // read out, i.e. free for the next DMA
+  auto put_scaled = [&](const T (&v)[64], auto phase, unsigned rel_s, const TileMap<T, PH>& tmx) {
+    constexpr int PHASE = decltype(phase)::value;
+    write_phase<T, PH, PHASE>(v, tilebuf, tmx);
+    const int vbase = (int)(rel_s * (unsigned)G::TILEB);
+#pragma unroll
+    for (int jg = 0; jg < 8; jg++) {
+      const int vo = vbase + jg * 8 * G::BLKB + ((jg & 1) ? tmx.g_odd : tmx.g_even);
+#pragma unroll
+      for (int sg = 0; sg < G::SEGP; sg++) {
+        const u32x4 r = *reinterpret_cast<const u32x4*>(tilebuf + (jg * G::SEGP + sg) * 1024 + lane * 16);
+        __builtin_amdgcn_raw_buffer_store_b128(r, r_sc, vo + (PHASE * G::SEGP + sg) * 128, 0, 2 /* nt */);
+      }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  };
   // the workgroup's list(s) behind descriptors too: 32-bit offsets, no 64-bit pointers to keep alive (or spill)
   const int list_slots = (int)((tr.hi - tr.lo) * (unsigned)TILE_ELEMS);
   const __amdgpu_buffer_rsrc_t r_list = (MODE == DCTZHIP_EC)
@@ -295,8 +319,14 @@ __device__ __forceinline__ void compress_body(const FwdParams<T>& p, const unsig
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       read_phase<T, PH, 0>(xn, tilebuf, tm0);
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      issue_dma(0u, 1, tm0);
-      stats_scale(xn, std::integral_constant<int, 0>{}, (unsigned)lane < min((unsigned)TILE_BLKS, p.nfull - tr.lo * TILE_BLKS), tr.lo == 0);
+      if constexpr (SC) {
+        stats_scale(xn, std::integral_constant<int, 0>{}, (unsigned)lane < min((unsigned)TILE_BLKS, p.nfull - tr.lo * TILE_BLKS), tr.lo == 0);
+        put_scaled(xn, IC<0>{}, 0u, tm0);
+        issue_dma(0u, 1, tm0);
+      } else {
+        issue_dma(0u, 1, tm0);
+        stats_scale(xn, std::integral_constant<int, 0>{}, (unsigned)lane < min((unsigned)TILE_BLKS, p.nfull - tr.lo * TILE_BLKS), tr.lo == 0);
+      }
     }
   }
   for (unsigned tile = tr.lo; tile < tr.hi; tile++) {
@@ -323,6 +353,11 @@ __device__ __forceinline__ void compress_body(const FwdParams<T>& p, const unsig
         issue_rows(reln, 0, tmn, IC<1>{}, IC<2>{});
         stats_scale(x, std::integral_constant<int, PH - 1>{}, active, false);
         issue_rows(reln, 0, tmn, IC<2>{}, IC<3>{});
+      } else if constexpr (SC) {
+        stats_scale(x, std::integral_constant<int, PH - 1>{}, active, false);
+        put_scaled(x, IC<PH - 1>{}, rel, tm);
+        if (more) issue_dma(rel + 1, 0, tm);
+        if (pend) flush();
       } else {
         if (more) issue_dma(rel + 1, 0, tm);
         if (pend) flush();
@@ -472,6 +507,10 @@ __device__ __forceinline__ void compress_body(const FwdParams<T>& p, const unsig
         issue_rows(rel + 1, 1, tm, IC<0>{}, IC<2>{});
         stats_scale(xn, std::integral_constant<int, 0>{}, (unsigned)lane < min((unsigned)TILE_BLKS, p.nfull - (tile + 1) * TILE_BLKS), false);
         issue_rows(rel + 1, 1, tm, IC<2>{}, IC<4>{});
+      } else if constexpr (SC) {
+        stats_scale(xn, std::integral_constant<int, 0>{}, (unsigned)lane < min((unsigned)TILE_BLKS, p.nfull - (tile + 1) * TILE_BLKS), false);
+        put_scaled(xn, IC<0>{}, rel + 1, tm);
+        issue_dma(rel + 1, 1, tm);
       } else {
         issue_dma(rel + 1, 1, tm);
         stats_scale(xn, std::integral_constant<int, 0>{}, (unsigned)lane < min((unsigned)TILE_BLKS, p.nfull - (tile + 1) * TILE_BLKS), false);
@@ -504,9 +543,9 @@ __device__ __forceinline__ void compress_body(const FwdParams<T>& p, const unsig
   }
 }
 
-template <typename T, int MODE, bool STATS, int PH, int GEOM>
+template <typename T, int MODE, bool STATS, int PH, int GEOM, bool SC = false>
 __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(compress_waves<T, MODE, PH>()))) void k_compress(FwdParams<T> p) {
-  compress_body<T, MODE, STATS, PH, GEOM>(p, blockIdx.x, gridDim.x);
+  compress_body<T, MODE, STATS, PH, GEOM, SC>(p, blockIdx.x, gridDim.x);
 }
 
 // The last, short block (length l = N % 64): the reference re-plans a length-l
@@ -534,6 +573,7 @@ __device__ __forceinline__ void compress_rem_body(const FwdParams<T>& p, const i
   if (k < l) {
     T a = p.x[base + k];
     if (SCALE) a = sfd.div(a);
+    if (p.scaled != nullptr) p.scaled[base + k] = a;               // (dctz-comp-lib.c:193-216, when k_compress writes the scaled copy)
     if (l & 1) { v[k] = a; v[l + (l - 1 - k)] = a; }               // dct.c:61-64
     else if (k & 1) v[l - 1 - (k >> 1)] = a;                       // dct.c:75-83
     else v[k >> 1] = a;
@@ -1192,7 +1232,15 @@ void launch_finish(Ctl* ctl, const double* part, int nparts, HostBox* box, unsig
 
 template <typename T>
 void launch_compress(const FwdParams<T>& p, int mode, bool stats, int grid, int geom, hipStream_t s) {
-  if (geom == GEOM_1D) {
+  if (geom == GEOM_1D && p.scaled != nullptr) {        // the variant that writes x / sf back as well
+    if (mode == DCTZHIP_EC) {
+      if (stats) hipLaunchKernelGGL((k_compress<T, DCTZHIP_EC, true, Phases<T>::C, GEOM_1D, true>), dim3(grid), dim3(WG), 0, s, p);
+      else hipLaunchKernelGGL((k_compress<T, DCTZHIP_EC, false, Phases<T>::C, GEOM_1D, true>), dim3(grid), dim3(WG), 0, s, p);
+    } else {
+      if (stats) hipLaunchKernelGGL((k_compress<T, DCTZHIP_QT, true, Phases<T>::C, GEOM_1D, true>), dim3(grid), dim3(WG), 0, s, p);
+      else hipLaunchKernelGGL((k_compress<T, DCTZHIP_QT, false, Phases<T>::C, GEOM_1D, true>), dim3(grid), dim3(WG), 0, s, p);
+    }
+  } else if (geom == GEOM_1D) {
     if (mode == DCTZHIP_EC) {
       if (stats) hipLaunchKernelGGL((k_compress<T, DCTZHIP_EC, true, Phases<T>::C, GEOM_1D>), dim3(grid), dim3(WG), 0, s, p);
       else hipLaunchKernelGGL((k_compress<T, DCTZHIP_EC, false, Phases<T>::C, GEOM_1D>), dim3(grid), dim3(WG), 0, s, p);
@@ -1222,14 +1270,17 @@ void launch_compress(const FwdParams<T>& p, int mode, bool stats, int grid, int 
 // Resident workgroups per CU of the k_compress instantiation a launch would pick (registers AND LDS: the persistent
 // grid must not exceed what is resident at once, or its tail runs as a second round)
 template <typename T>
-int compress_occupancy(int mode, bool stats, int geom) {
+int compress_occupancy(int mode, bool stats, int geom, bool scaled) {
   int n = 0;
   hipError_t e;
 #define OCC(M, S, G) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, (const void*)k_compress<T, M, S, Phases<T>::C, G>, WG, 0)
-  if (geom == GEOM_1D) { if (mode == DCTZHIP_EC) { if (stats) OCC(DCTZHIP_EC, true, GEOM_1D); else OCC(DCTZHIP_EC, false, GEOM_1D); } else { if (stats) OCC(DCTZHIP_QT, true, GEOM_1D); else OCC(DCTZHIP_QT, false, GEOM_1D); } }
+#define OCCS(M, S) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, (const void*)k_compress<T, M, S, Phases<T>::C, GEOM_1D, true>, WG, 0)
+  if (geom == GEOM_1D && scaled) { if (mode == DCTZHIP_EC) { if (stats) OCCS(DCTZHIP_EC, true); else OCCS(DCTZHIP_EC, false); } else { if (stats) OCCS(DCTZHIP_QT, true); else OCCS(DCTZHIP_QT, false); } }
+  else if (geom == GEOM_1D) { if (mode == DCTZHIP_EC) { if (stats) OCC(DCTZHIP_EC, true, GEOM_1D); else OCC(DCTZHIP_EC, false, GEOM_1D); } else { if (stats) OCC(DCTZHIP_QT, true, GEOM_1D); else OCC(DCTZHIP_QT, false, GEOM_1D); } }
   else if (geom == GEOM_2D) { if (mode == DCTZHIP_EC) { if (stats) OCC(DCTZHIP_EC, true, GEOM_2D); else OCC(DCTZHIP_EC, false, GEOM_2D); } else { if (stats) OCC(DCTZHIP_QT, true, GEOM_2D); else OCC(DCTZHIP_QT, false, GEOM_2D); } }
   else { if (mode == DCTZHIP_EC) { if (stats) OCC(DCTZHIP_EC, true, GEOM_3D); else OCC(DCTZHIP_EC, false, GEOM_3D); } else { if (stats) OCC(DCTZHIP_QT, true, GEOM_3D); else OCC(DCTZHIP_QT, false, GEOM_3D); } }
 #undef OCC
+#undef OCCS
   return e == hipSuccess ? n : 0;
 }
 template <typename T>
@@ -1504,7 +1555,7 @@ template __global__ void DCTZ_DEV_ONE(DCTZ_DEV_ARGS);
   template void launch_count_batch<T>(const BatchInv<T>*, const unsigned*, unsigned, unsigned, const void*, void*, size_t, hipStream_t);    \
   template void launch_decompress_batch<T>(const BatchInv<T>*, const unsigned*, unsigned, unsigned, int, const BatchFin&, hipStream_t);     \
   template void launch_decompress_rem_batch<T>(const BatchInv<T>*, const unsigned*, unsigned, int, hipStream_t);                            \
-  template int compress_occupancy<T>(int, bool, int);                                                      \
+  template int compress_occupancy<T>(int, bool, int, bool);                                                      \
   template int decompress_occupancy<T>(int, int);                                                          \
   template size_t compress_lds_bytes<T>(int);                                                              \
   template size_t decompress_lds_bytes<T>();

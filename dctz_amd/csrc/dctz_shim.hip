@@ -87,6 +87,7 @@ struct dctzhip_ctx {
   int handoff = 1;                  // 1: mailbox + spin; 0: D2H copy + hipStreamSynchronize (DCTZHIP_HANDOFF)
   int ctl_dirty = 1;                // control block may be non-zero: memset it before the next call
   // profiling
+  int fuse_scaled = 1;              // d_scaled (out of place, flat blocks) written by k_compress itself instead of a k_scale pass (DCTZHIP_FUSE_SCALED)
   int fastdiv = 2;                  // hoisted-reciprocal division: 0 off, 1 per-tile window test, 2 + skip the test when k_stats proves it (DCTZHIP_FASTDIV)
   int stats_grid = 2048;            // workgroups of the statistics kernel (DCTZHIP_STATS_GRID, <= 2048)
   int wg_per_cu = 0;                // grid = CUs * this; 0 = as many single-wave workgroups as a CU's LDS admits (DCTZHIP_WG_PER_CU)
@@ -175,6 +176,7 @@ extern "C" int dctzhip_ctx_create(dctzhip_ctx** out, int device) {
   HIPCHK(nullptr, hipGetDeviceProperties(&prop, device));
   c->num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
   if (const char* e = getenv("DCTZHIP_FASTDIV")) c->fastdiv = atoi(e);
+  if (const char* e = getenv("DCTZHIP_FUSE_SCALED")) c->fuse_scaled = atoi(e);
   if (const char* e = getenv("DCTZHIP_STATS_GRID")) { int v = atoi(e); if (v >= 1 && v <= STATS_GRID_MAX) c->stats_grid = v; }
   if (const char* e = getenv("DCTZHIP_WG_PER_CU")) { int v = atoi(e); if (v >= 1 && v <= WG_PER_CU_MAX) c->wg_per_cu = v; }
   if (const char* e = getenv("DCTZHIP_SPECULATE")) c->speculate = atoi(e) != 0;
@@ -692,7 +694,7 @@ template <typename T>
 static int compress_pass(dctzhip_ctx* c, const T* d_in, size_t n, double eb, int mode, uint8_t* d_bin, float* d_dc,
                          float* d_ac, T* d_coef, const HostStats& st, bool fused, double* sf_out, T* sf_t_out,
                          unsigned* fast_sf_out, unsigned long long seq, int geom, bool device_sf = false,
-                         const NdDirect* nd = nullptr) {
+                         const NdDirect* nd = nullptr, T* d_scaled = nullptr) {
   const int dtype = sizeof(T) == 8 ? DCTZHIP_F64 : DCTZHIP_F32;
   hipStream_t s = c->stream;
   const unsigned nfull = (unsigned)(n / 64);
@@ -705,6 +707,7 @@ static int compress_pass(dctzhip_ctx* c, const T* d_in, size_t n, double eb, int
   const int half = DCTZHIP_NBINS / 2;
   FwdParams<T> p;
   p.x = d_in; p.bin = d_bin; p.dc = d_dc; p.ac = d_ac; p.coef = d_coef;
+  p.scaled = d_scaled;                               // (k_compress writes x / sf there itself: compress_impl)
   p.qt_item = reinterpret_cast<T*>(c->qt_item); p.qt_j = c->qt_j;
   p.qcnt = c->qcnt; p.ttot = c->ttot;
   p.ac_tmp = c->ac_tmp;
@@ -845,10 +848,15 @@ static int compress_impl(dctzhip_ctx* c, const T* d_in, size_t n, double eb, int
   unsigned fast_sf = 0;
   unsigned flags = 0;
   bool respin = false;                              // second pass of a call: the host's own statistics and scaling factor
+  // The scaled copy (dctz-comp-lib.c:193-216) is written by k_compress itself when it goes to a buffer of its own and the
+  // blocks are flat (DCTZHIP_FUSE_SCALED=0: always the separate pass); a pass with a wrong guess of sf is run again with
+  // the right one and writes it again.  In place (d_scaled == d_in) a wrong first pass would have destroyed the input:
+  // there, and for multi-dimensional blocks, x / sf stays a pass of its own behind the kernels.
+  T* const scaled_by_kernel = (d_scaled && (const void*)d_scaled != (const void*)d_in && geom == GEOM_1D && !nd && c->fuse_scaled) ? d_scaled : nullptr;
   // one pass of the kernels + the hand-off of its results into *hc / hs[4..6]
   auto run = [&](const HostStats& stats, bool fused) -> int {
     const bool dev = dsf && !respin;
-    int rc = compress_pass<T>(c, d_in, n, eb, mode, d_bin, d_dc, d_ac, d_coef, stats, fused, &sf, &sf_t, &fast_sf, seq, geom, dev, nd);
+    int rc = compress_pass<T>(c, d_in, n, eb, mode, d_bin, d_dc, d_ac, d_coef, stats, fused, &sf, &sf_t, &fast_sf, seq, geom, dev, nd, scaled_by_kernel);
     if (rc) return rc;
     if (box) {
       rc = wait_seq(c, &hb->seq_done, seq, "compress");
@@ -894,7 +902,7 @@ static int compress_impl(dctzhip_ctx* c, const T* d_in, size_t n, double eb, int
   }
   // dctz-comp-lib.c:193-216: the reference divides the caller's array by sf in place; here on request, into
   // d_scaled (which may be d_in itself), once sf is final
-  if (d_scaled) {
+  if (d_scaled && !scaled_by_kernel) {
     if (sf_t != (T)1.0) launch_scale<T>(d_in, d_scaled, n, sf_t, c->num_cu * 8, s);
     else if ((const void*)d_scaled != (const void*)d_in) HIPCHK(c, hipMemcpyAsync(d_scaled, d_in, n * sizeof(T), hipMemcpyDeviceToDevice, s));
     HIPCHK(c, hipGetLastError());
@@ -1489,7 +1497,7 @@ static int launch_compress_seq(dctzhip_ctx* c, const dctzhip_batch_citem* items,
     BatchFwd<T>& b = hi[j];
     memset(&b, 0, sizeof(b));
     FwdParams<T>& p = b.p;
-    p.x = (const T*)it.d_in; p.bin = (uint8_t*)it.d_bin_index; p.dc = it.d_dc; p.ac = it.d_ac_exact; p.coef = nullptr;
+    p.x = (const T*)it.d_in; p.bin = (uint8_t*)it.d_bin_index; p.dc = it.d_dc; p.ac = it.d_ac_exact; p.coef = nullptr; p.scaled = nullptr;
     const size_t slot0 = (ch.tile_off + (size_t)q.tile_base[j]) * TILE_ELEMS;
     p.ac_tmp = c->ac_tmp ? c->ac_tmp + slot0 : nullptr;
     // (the chain's region starts at a byte offset that is right for either element type)

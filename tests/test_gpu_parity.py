@@ -59,7 +59,15 @@ def _compress_both(ctx, x, eb, mode):
     xd = _dev(ctx, x)
     coef = torch.empty_like(xd)
     scaled = torch.empty_like(xd)
+    # Twice: without a scaled copy (the plain k_compress) and with one in a buffer of its own (the variant of k_compress
+    # that writes x / sf back itself, dctz_kernels.hip: SC) -- the streams of the two must be the same bytes.
+    plain, pinfo = ctx.compress(xd, eb, mode)
+    keep = {k: plain[k].clone() for k in ("bin_index", "dc")}
+    keep["ac_exact"] = plain["ac_exact"][:pinfo.cnt].clone()
     out, info = ctx.compress(xd, eb, mode, scaled=scaled, coef=coef)
+    assert (pinfo.cnt, pinfo.sf) == (info.cnt, info.sf)
+    assert torch.equal(keep["bin_index"], out["bin_index"]) and torch.equal(keep["dc"].view(torch.int32), out["dc"].view(torch.int32))
+    assert torch.equal(keep["ac_exact"].view(torch.int32), out["ac_exact"][:info.cnt].view(torch.int32))
     c = O.compress(x, eb, mode, O.FAST, want_coef=True)
     return xd, out, info, coef, scaled, c
 
