@@ -12,9 +12,14 @@ import sys
 txt, key = sys.argv[1], sys.argv[2]
 vals = {}
 for line in open(txt):
-    m = re.match(r"(?:void )?dctz::(k_\w+).*dispatches \d+ \{'(FETCH_SIZE|WRITE_SIZE)': (\d+)\}", line)
+    m = re.search(r"dctz::(k_\w+)(<[^>]*>)?.*dispatches \d+ \{'(FETCH_SIZE|WRITE_SIZE)': (\d+)\}", line)
     if m:
-        vals.setdefault(m.group(1), {})[m.group(2)] = int(m.group(3))
+        name = m.group(1)
+        # k_compress<T, MODE, STATS, PH, GEOM, SC>: the SC = true variant also writes the scaled copy (a different kernel for
+        # this purpose: 8 bytes per element more)
+        if name == "k_compress" and m.group(2) and m.group(2).rstrip(">").split(",")[-1].strip() == "true" and m.group(2).count(",") == 5:
+            name = "k_compress_scaled"
+        vals.setdefault(name, {})[m.group(3)] = int(m.group(4))
 out = {}
 for k, v in vals.items():
     if "FETCH_SIZE" in v and "WRITE_SIZE" in v:
