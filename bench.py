@@ -65,6 +65,7 @@ def parse(argv=None):
     ap.add_argument("--rehearse-one-gpu", action="store_true",
                     help="N > 1 ranks that SHARE cuda:0 (gloo for the barriers, tests/c/librccl_double.so in RCCL's place): the whole "
                          "multi-rank code path on a one-GPU box; the line says so and its number is not a scaling measurement")
+    ap.add_argument("--gather-timeout", type=float, default=150.0, help="N > 1: seconds the (last) gather phase may take before the line is printed without it")
     ap.add_argument("--plumbing-fail-rank", type=int, default=-1, help="(tests) this rank of a --plumbing-only run exits with code 7 before the rendezvous")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-entropy-stage", action="store_true", help="skip the (untimed) report on the device entropy stage")
@@ -131,7 +132,8 @@ def launch(a):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(a.gpus), LOCAL_WORLD_SIZE=str(a.gpus),
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0", DCTZ_BENCH_LAUNCHED="1")
         if a.rehearse_one_gpu:
-            env["DCTZHIP_RCCL_LIBRARY"] = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tests", "c", "librccl_double.so")
+            env["DCTZHIP_RCCL_LIBRARY"] = os.environ.get("DCTZ_BENCH_RCCL_OVERRIDE") or \
+                os.path.join(os.path.dirname(os.path.abspath(__file__)), "tests", "c", "librccl_double.so")   # (the override: tests of the failure path)
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
                                       stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
     import threading
@@ -388,23 +390,6 @@ def run_rank(a, rank, local_rank, world):
         c2_like = [j for j in range(len(xs)) if xs_host[j].itemsize == 4 and ebs[j] == 1e-4][:1]
         looped["subsets"] = {"msst19_24_small_fp64": sub(small), "msst19_24_plus_one_fp32_field_at_1e-4": sub(small + c2_like)}
 
-    # ---- N > 1: the same K steps with the gather of the streams to rank 0 inside the step ----
-    with_gather = None
-    if dist is not None and not many:
-        ids = [dctz_amd.Context.comm_unique_id() if rank == 0 else None]
-        dist.broadcast_object_list(ids, src=0)
-        ctx.comm_create(rank, world, ids[0])
-        ctx.comm_gather(out, info.cnt, n, root=0)              # warm-up (communicator set-up, receive buffers)
-        barrier()
-        g0 = time.perf_counter()
-        for _ in range(a.steps):
-            info = step()[0]
-            ctx.comm_gather(out, info.cnt, n, root=0)
-        barrier()
-        g_ms = shard.max_over_ranks(time.perf_counter() - g0, red_dev) * 1e3 / a.steps
-        with_gather = {"ms_per_step": g_ms, "value": n * es * world / (g_ms * 1e-3) / 1e9,
-                       "note": "compress + decompress + RCCL gather of bin_index / DC / AC_exact of every shard to rank 0 per step"}
-
     # ---- per-kernel durations (HIP events on the launch stream), same K steps --
     ctx.set_profiling(True)
     acc = {"c_stats": 0.0, "c_main": 0.0, "c_tail": 0.0, "d_pre": 0.0, "d_main": 0.0, "d_tail": 0.0}
@@ -614,12 +599,69 @@ def run_rank(a, rank, local_rank, world):
             line["looped"] = looped
         if with_scaled is not None:
             line["with_scaled_copy"] = with_scaled
-        if with_gather is not None:
-            line["with_gather"] = with_gather
         if a.rehearse_one_gpu:
             line["rehearsal"] = (f"{world} ranks SHARE one GPU (gloo barriers; the gather runs through the RCCL test double of "
                                  "tests/c/rccl_double.cpp): the N > 1 code path end to end, NOT a scaling measurement")
             line["scaling"] = "none (rehearsal)"
+    else:
+        line = None
+
+    # ---- N > 1, LAST: the same K steps with the gather of the streams to rank 0 inside the step.  Everything the line
+    # reports has been measured by now.  This is the one phase that talks to a second collective library instance (RCCL
+    # through the C ABI's own dlopen) and that no box of this project could ever run on N GPUs: if it fails on any rank, or
+    # does not finish in --gather-timeout seconds, the line goes out without it (with the reason) instead of not at all.
+    if dist is not None and not many:
+        import threading
+        barrier()                                             # (rank 0 comes from its CPU baseline: the timers below start together)
+
+        def bail():
+            if rank == 0:
+                line["with_gather"] = {"error": f"the gather phase did not finish within {a.gather_timeout:.0f} s"}
+                print(json.dumps(line), flush=True)
+            os._exit(0)
+        watchdog = threading.Timer(a.gather_timeout, bail)
+        watchdog.daemon = True
+        watchdog.start()
+        with_gather = None
+        try:
+            ids = [(None, "")]
+            if rank == 0:
+                try:
+                    ids = [(dctz_amd.Context.comm_unique_id(), "")]
+                except Exception as e:                          # e.g. RCCL not found by the library's own loader
+                    ids = [(None, str(e))]
+            dist.broadcast_object_list(ids, src=0)
+            mine_ok, why = 1, ""
+            if ids[0][0] is None:
+                mine_ok, why = 0, ids[0][1] if rank == 0 else "no id from rank 0"
+            else:
+                try:
+                    ctx.comm_create(rank, world, ids[0][0])
+                except Exception as e:
+                    mine_ok, why = 0, str(e)
+            flags = [None] * world
+            dist.all_gather_object(flags, (mine_ok, why))
+            if all(f[0] for f in flags):
+                ctx.comm_gather(out, info.cnt, n, root=0)          # warm-up (communicator set-up, receive buffers)
+                barrier()
+                g0 = time.perf_counter()
+                for _ in range(a.steps):
+                    info = step()[0]
+                    ctx.comm_gather(out, info.cnt, n, root=0)
+                barrier()
+                g_ms = shard.max_over_ranks(time.perf_counter() - g0, red_dev) * 1e3 / a.steps
+                with_gather = {"ms_per_step": g_ms, "value": n * es * world / (g_ms * 1e-3) / 1e9,
+                               "note": "compress + decompress + RCCL gather of bin_index / DC / AC_exact of every shard to rank 0 per step"}
+            else:
+                if mine_ok:
+                    ctx.lib.dctzhip_comm_destroy(ctx.h)
+                with_gather = {"error": "no communicator: " + "; ".join(f"rank {i}: {f[1]}" for i, f in enumerate(flags) if not f[0])}
+        except Exception as e:
+            with_gather = {"error": f"rank {rank}: {e}"}
+        watchdog.cancel()
+        if rank == 0:
+            line["with_gather"] = with_gather
+    if rank == 0:
         print(json.dumps(line), flush=True)
     if dist is not None:
         dist.barrier()

@@ -84,3 +84,17 @@ def test_bench_multi_rank_path_rehearsed_on_one_gpu():
     assert line["n_gpus"] == 2 and line["ranks_seen"] == 2 and [d["rank"] for d in line["devices"]] == [0, 1]
     assert "rehearsal" in line and line["scaling"].startswith("none")
     assert line["with_gather"]["ms_per_step"] > line["ms_per_step"] > 0
+
+
+def test_bench_line_survives_a_gather_that_cannot_start():
+    """The gather is the last phase of an N-rank bench run, and the one nobody could run on N GPUs: when the library finds no
+    RCCL to load (here: a name that does not exist) the line must still go out, with the reason in `with_gather`."""
+    import json
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env["DCTZ_BENCH_RCCL_OVERRIDE"] = "/nonexistent/librccl.so"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--rehearse-one-gpu", "--n", "256", "--steps", "3",
+                        "--warmup", "1", "--no-cpu-baseline", "--no-entropy-stage"], env=env, capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    assert line["n_gpus"] == 2 and line["value"] > 0
+    assert "error" in line["with_gather"] and "no communicator" in line["with_gather"]["error"]
