@@ -46,9 +46,14 @@ def main():
         c = O.compress(x, eb, mode, O.FAST)
         ref = O.decompress(c, O.FAST)
         xd = torch.from_numpy(x).cuda()
-        out, info = ctx.compress(xd, eb, mode)
+        # every other case also asks for the scaled copy in a buffer of its own: the variant of k_compress that writes x / sf back
+        sc = torch.empty_like(xd) if k % 2 else None
+        out, info = ctx.compress(xd, eb, mode, scaled=sc)
         flags_seen[info.flags] = flags_seen.get(info.flags, 0) + 1
         it = np.uint64 if dtype == np.float64 else np.uint32
+        if sc is not None and not np.array_equal(sc.cpu().numpy().view(it), c.scaled.view(it)):
+            print(f"MISMATCH (scaled copy) case {k}: n={n} dtype={dtype.__name__} mode={mode} eb={eb} amp={amp:g}")
+            sys.exit(1)
         ok = (info.sf == c.sf and info.cnt == c.cnt and np.array_equal(out["bin_index"].cpu().numpy(), c.bin_index)
               and np.array_equal(out["dc"].cpu().numpy().view(np.uint32), c.dc.view(np.uint32))
               and np.array_equal(out["ac_exact"][:c.cnt].cpu().numpy().view(np.uint32), c.ac_exact.view(np.uint32)))
