@@ -284,19 +284,20 @@ def test_speculation_window_violation_is_detected(spec_ctx, dtype):
 
 
 def test_in_place_scaling_under_speculation_and_small_inputs(spec_ctx):
-    """d_scaled may alias d_in (the reference's in-place division, dctz-comp-lib.c:193-216): the scaled copy is
-    written last, with the verified sf, so a wrong guess cannot destroy the input."""
+    """d_scaled may alias d_in (the reference's in-place division, dctz-comp-lib.c:193-216): such a call leaves the
+    speculative path (k_compress writes x / sf over the input itself, which needs the verified sf), so a spike the sample
+    cannot see does no harm; and everything else about the call is what the oracle says."""
     import torch
     x = W.ragged(1 << 20, np.float64, scale=37.0)
     c = O.compress(x, 1e-3, O.EC, O.FAST)
     for spike in (False, True):
         z = x.copy()
         if spike:
-            z[12345] = 4.0e4                                         # the sample cannot see it: wrong decade, re-run
+            z[12345] = 4.0e4                                         # a sample would not see it (wrong decade)
         cz = O.compress(z, 1e-3, O.EC, O.FAST)
         xd = _dev(spec_ctx, z)
         out, info = spec_ctx.compress(xd, 1e-3, O.EC, scaled=xd)    # d_scaled aliases d_in
-        assert info.flags in ((H.INFO_RESPUN,) if spike else (H.INFO_STATS_FUSED,))
+        assert info.flags == 0                                      # neither speculated nor run twice
         assert info.sf == cz.sf and info.cnt == cz.cnt
         assert _same(xd.cpu().numpy(), cz.scaled)
         assert np.array_equal(out["bin_index"].cpu().numpy(), cz.bin_index)
