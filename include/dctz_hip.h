@@ -97,7 +97,11 @@ int dctzhip_set_profiling(dctzhip_ctx *ctx, int on);
 /* Speculative fused statistics (see DCTZHIP_INFO_*): on != 0 enables it for inputs of
  * at least min_elements (0 keeps the current threshold, default 2^22); on == 0 always
  * runs the separate statistics pass first.  Default: on (env DCTZHIP_SPECULATE=0 turns
- * it off).  d_scaled (which may alias d_in) is written last, with the verified sf. */
+ * it off).  d_scaled holds x / sf for the verified sf when the call returns: k_compress
+ * writes it while it runs (a pass with a wrong guess is run again and writes it again); a
+ * call whose d_scaled aliases d_in does not speculate (the input would not survive a wrong
+ * guess) and takes the full statistics pass first.  DCTZHIP_FUSE_SCALED=0: a pass of its
+ * own behind the kernels, as before round 3. */
 int dctzhip_set_speculation(dctzhip_ctx *ctx, int on, size_t min_elements);
 int dctzhip_last_timings(dctzhip_ctx *ctx, dctzhip_timings *t);
 /* on != 0: every compress / decompress call ends with a synchronisation of the context's stream, i.e. its outputs are
@@ -128,7 +132,8 @@ int dctzhip_host_unregister(dctzhip_ctx *ctx, void *ptr);
  *   d_ac_exact  capacity n floats out; info->cnt of them are valid, block-major,
  *               j ascending -- byte-identical to the reference's AC_exact[]
  *   d_scaled    optional: receives x/sf (the reference's in-place scaling of the
- *               caller's buffer, :193-216); may be NULL, may alias d_in
+ *               caller's buffer, :193-216); may be NULL, may alias d_in (then the
+ *               call runs on verified statistics: see dctzhip_set_speculation)
  *   d_coef      optional debug tap: the DCT coefficients a_x after pass 1
  *               (= dct_result.bin under -DDCT_FILE_DEBUG, :422-428); may be NULL
  * On return *info is filled (the host has waited for it); the last kernels of the
