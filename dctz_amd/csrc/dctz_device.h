@@ -313,6 +313,51 @@ template <typename T> void launch_decompress_batch(const BatchInv<T>* items, con
                                                    const BatchFin& fin, hipStream_t s);
 template <typename T> void launch_decompress_rem_batch(const BatchInv<T>* items, const unsigned* rem_items, unsigned nrem, int mode, hipStream_t s);
 
+// ---- one launch per call (dctz_kernels_one.hip): arrays whose tiles are all resident at once --------------------
+// One WAVE per tile, ONE_TW tiles per workgroup (+ one workgroup for the short last block): calc_data_stat, scaling,
+// transform, binning AND the ordered placement of AC_exact in a single kernel; on decode the flag counts, their prefix
+// and the reconstruction.  What the chain of kernels hands over at kernel boundaries travels through the BOARD here: one
+// 8-byte {tag = epoch, value} granule per workgroup and step, written by one agent-scope store and swept with agent-scope
+// loads by the first wave of every workgroup (every workgroup of the launch is resident: the grid is at most what the
+// chip holds at once).  Several tiles per workgroup because a sweep reads a granule per WORKGROUP: with single-wave
+// workgroups the sweeps of a 2000-tile array would move 2000 x 2000 x 8 bytes past the caches.
+constexpr int ONE_TW = 4;
+struct OneBoard {
+  unsigned long long* ga;          // per workgroup: decade index of its max|x| (+ "outside FastDiv's window"), compress only
+  unsigned long long* gb;          // per workgroup: its "stored exactly" coefficients (tot_AC_exact_count of the tile)
+  double* rec;                     // per workgroup: max|x|, min|x|, sum (what the host is told; never on the critical path)
+  unsigned epoch;                  // tag of this launch's granules (never 0; older launches left other tags)
+  unsigned nwg;                    // workgroups of the launch = ceil(ntiles / ONE_TW) + (rem ? 1 : 0)
+  unsigned long long* dbg;         // NULL, or 16 time stamps (100 MHz clock) per workgroup: DCTZHIP_ONE_STAMPS, tools/one_stamps.py
+};
+template <typename T>
+struct OneFwd {
+  FwdParams<T> p;                  // x, bin, dc, ac, coef, scaled, tab, rtab, ctl, nfull, ntiles, last_is_full, fast_bw, bin_width, range_*
+  OneBoard b;
+  SfTable sft;
+  HostBox* box;                    // hand-off by the launch's last workgroup
+  unsigned long long seq;
+  Ctl* ctl_next;                   // the control block of the NEXT one-launch call: zeroed by the hand-off workgroup
+  double eb;
+  unsigned rem;                    // N % 64
+  unsigned pad;
+};
+template <typename T>
+struct OneInv {
+  InvParams<T> p;                  // bin, dc, ac, out, tab, rtab, qtab, ctl, nfull, ntiles, ac_count, sf, bin_width, range_*, eb
+  OneBoard b;
+  HostBox* box;
+  unsigned long long seq;
+  unsigned rem;
+  unsigned pad;
+  T qtab[64];                      // QT: the clamped table (dctz-decomp-lib.c:193-199), in the kernel's arguments
+};
+constexpr unsigned ONE_ERR_TIMEOUT = 3u;   // Ctl::error / HostBox::error: a sweep of the board gave up (a workgroup was not resident)
+template <typename T> void launch_compress_one(const OneFwd<T>& a, int mode, bool scaled, hipStream_t s);
+template <typename T> void launch_decompress_one(const OneInv<T>& a, int mode, hipStream_t s);
+template <typename T> int compress_one_occupancy(int mode, bool scaled);
+template <typename T> int decompress_one_occupancy(int mode);
+
 template <typename T> void launch_stats(const T* x, size_t n, double* part, int nparts, double* out, hipStream_t s,
                                         HostBox* box = nullptr, unsigned long long seq = 0, Ctl* zero = nullptr,
                                         const SfTable* tab = nullptr, SfGuess* guess = nullptr);

@@ -90,22 +90,7 @@ __global__ __launch_bounds__(SWG) void k_finish(FinArgs a) {
 // dct.c:55-103) -> DC (:350-351) -> pass-1 binning (:361-414) -> ordered exception stream (:478-544),
 // full 64-element blocks only.
 //
-// Binning of one coefficient (:363-414; conv_tbl :27-43) in floating point:
-//   q = (item - range_min) / bin_width  (the reference's own expression, exact division),  f = floor(q)
-//   (== the (t_bin_id) truncation for q >= 0),  conv_tbl[f] = |254.5 - 2 f| - 0.5  for f = 0..254, and
-//   >= 255 for f >= 255 or f <= -1, which v_cvt_pk_u8_f32 saturates to 255 = "stored exactly" while it
-//   packs the byte.  SAFE = false relies on  item > range_max  =>  q >= 255, which the host verifies
-//   for the launch constants ((2 range_max) / bin_width >= 255 in T arithmetic); otherwise the
-//   reference's range test is applied explicitly (one compare + one select more per coefficient).
-template <typename T, bool SAFE>
-__device__ __forceinline__ float bin_value(T item, T q, T range_max) {
-  const T f = floor(q);
-  const T g = fma_(T(-2), f, T(254.5));
-  float h = (float)(fabs(g) - T(0.5));
-  if (SAFE) h = (fabs(item) > range_max) ? 255.0f : h;       // == (item < range_min || item > range_max): range_min = -range_max
-  return h;
-}
-
+// (bin_value -- the binning of one coefficient in floating point -- lives in dctz_kernel_common.h: k_compress_one shares it)
 // A list's entry in tile_cnt[]: its length, and LIST_IN_ORDER when every tile of the workgroup had items in its first
 // sub-list only -- block-major over the first range of j is then the reference's order (a smooth field: what is stored
 // exactly are the lowest frequencies), and k_compact_ac copies the list as it is.
@@ -905,21 +890,7 @@ size_t decompress_lds_bytes() { return (size_t)Geo<T, Phases<T>::D>::PHB + 256 *
 #ifndef DCTZ_BC_ARITH
 #define DCTZ_BC_ARITH 1
 #endif
-// bin_center[b] of gen_bins / gen_bins_f (binning.c:17-23 / :37-43) = (T)(b odd ? b/2 + 1 : -(b/2)) * bin_width, computed
-// instead of looked up, in the fp64 kernel (a table in LDS is 63 reads per block with bank conflicts wherever the bin ids
-// of a position spread over the 64 blocks of a tile: 36 % of the kernel's LDS cycles, profiles/r02_pmc.txt, r03_pmc.txt).  `w1` holds the four
-// magnitudes (b + 1) >> 1 of a dword of bin ids as bytes, `nw` the dword's complement (bit 0 of a byte set <=> b even
-// <=> the centre is negative).  The magnitude goes byte -> float in one instruction, the sign is or-ed in, and the
-// product passes through "+ (+0)": -0 * bin_width + 0 = +0, the table's value for b = 0.
-template <typename T>
-__device__ __forceinline__ T bin_centre(const unsigned w1, const unsigned nw, const int i, const T bin_width) {
-  const float mag = (float)((w1 >> (8 * i)) & 255u);
-  const unsigned sgn = (nw << (31 - 8 * i)) & 0x80000000u;
-  const float t = __builtin_bit_cast(float, __builtin_bit_cast(unsigned, mag) | sgn);
-  if constexpr (sizeof(T) == 8) return __builtin_fma((double)t, bin_width, 0.0);
-  else return __builtin_fmaf(t, bin_width, 0.0f);
-}
-
+// (bin_centre: dctz_kernel_common.h)
 template <typename T, int MODE, int PH, int GEOM, typename Handoff>
 __device__ __forceinline__ void decompress_body(const InvParams<T>& p, const unsigned wg, const unsigned nwg, Handoff&& handoff) {
   using G = Geo<T, PH>;

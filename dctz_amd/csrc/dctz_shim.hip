@@ -120,6 +120,18 @@ struct dctzhip_ctx {
   unsigned char* b_res_hdev = nullptr;
   size_t b_res_cap = 0;
   void* rtab_cache[2][64] = {};     // remainder-block tables per (dtype, length), device
+  // one launch per call (dctz_kernels_one.hip): the board of granules, the control blocks of this and the next such call
+  unsigned long long* one_ga = nullptr;
+  unsigned long long* one_gb = nullptr;
+  double* one_rec = nullptr;
+  Ctl* one_ctl = nullptr;           // three blocks: compress calls alternate between [0] and [1] (a call's hand-off zeroes the other one); [2]: decode's error word
+  unsigned one_cslot = 0;
+  unsigned long long* one_dbg = nullptr;   // DCTZHIP_ONE_STAMPS=1: 16 time stamps per workgroup of the last one-launch kernel
+  unsigned one_epoch = 0;
+  int one = 1;                      // 0: always the chain of kernels (DCTZHIP_ONE)
+  int one_cooldown = 0;             // calls left on the chain after a launch whose workgroups were not all resident
+  int one_occ[2][2][2][2] = {};     // resident workgroups per CU [f64][decode][qt][scaled], 0 = not asked yet
+  unsigned long long one_calls = 0, one_fallbacks = 0;
   hipStream_t b_stream = nullptr;   // a mixed batch runs its fp32 sequences here, beside the fp64 ones on the context's stream
   hipEvent_t b_fork = nullptr, b_join = nullptr;
   hipEvent_t b_ev[2][5] = {};       // profiling: per element-type sequence of the last batch call
@@ -133,6 +145,8 @@ static int build_sf_tables(dctzhip_ctx* c);
 static constexpr int STATS_GRID_MAX = 2048;
 static constexpr int PART_SLOTS = 256 * 16 + 64;       // >= largest k_compress grid + 1 (fused statistics partials), >= 4/3 of the PSNR grid
 static constexpr int SPEC_COOLDOWN = 8;
+static constexpr int ONE_BOARD = 256 * 8 + 64;         // granules of the one-launch path: workgroups of ONE_TW waves, at most 8 per CU
+static constexpr int ONE_COOLDOWN = 64;
 static constexpr int WG_PER_CU_MAX = 12;               // single-wave workgroups per CU: three per SIMD (k_compress<float>: 160 VGPRs, 12 KiB of LDS)
 static constexpr size_t PIN_STATS = 0, PIN_CTL = 64, PIN_TAB = 64 + sizeof(Ctl);
 static constexpr size_t PIN_BYTES = PIN_TAB + sizeof(double) * RTAB_SIZE + sizeof(double) * 64;
@@ -222,6 +236,15 @@ extern "C" int dctzhip_ctx_create(dctzhip_ctx** out, int device) {
   if (const char* e = getenv("DCTZHIP_STAGED_D2H")) c->staged_d2h = atoi(e) != 0;
   if (const char* e = getenv("DCTZHIP_DEFLATE_SIDE")) c->dfl_side = atoi(e) != 0;
   if (int rc = build_sf_tables(c)) return rc;
+  if (const char* e = getenv("DCTZHIP_ONE")) c->one = atoi(e) != 0;
+  HIPCHK(nullptr, hipMalloc(&c->one_ga, sizeof(unsigned long long) * ONE_BOARD));
+  HIPCHK(nullptr, hipMalloc(&c->one_gb, sizeof(unsigned long long) * ONE_BOARD));
+  HIPCHK(nullptr, hipMalloc(&c->one_rec, sizeof(double) * 3 * ONE_BOARD));
+  HIPCHK(nullptr, hipMalloc(&c->one_ctl, sizeof(Ctl) * 3));
+  HIPCHK(nullptr, hipMemset(c->one_ga, 0, sizeof(unsigned long long) * ONE_BOARD));
+  HIPCHK(nullptr, hipMemset(c->one_gb, 0, sizeof(unsigned long long) * ONE_BOARD));
+  HIPCHK(nullptr, hipMemset(c->one_ctl, 0, sizeof(Ctl) * 3));
+  if (const char* e = getenv("DCTZHIP_ONE_STAMPS")) if (atoi(e)) { HIPCHK(nullptr, hipMalloc(&c->one_dbg, sizeof(unsigned long long) * 16 * ONE_BOARD)); HIPCHK(nullptr, hipMemset(c->one_dbg, 0, sizeof(unsigned long long) * 16 * ONE_BOARD)); }
   *out = c;
   return DCTZHIP_OK;
 }
@@ -233,7 +256,7 @@ extern "C" void dctzhip_ctx_destroy(dctzhip_ctx* c) {
   (void)dctzhip_comm_destroy(c);
   (void)hipStreamSynchronize(c->stream);
   if (c->side_stream) { (void)hipStreamSynchronize(c->side_stream); (void)hipStreamDestroy(c->side_stream); }
-  void* bufs[] = {c->qcnt, c->ttot, c->ac_tmp, c->tile_cnt, c->wg_cnt, c->serial_out, c->tab_f64, c->tab_f32, c->rtab, c->qtab, c->ctl, c->part, c->stats_out, c->qt_item, c->qt_j, c->nd_buf, c->dfl_buf, c->sf_thr[0], c->sf_thr[1], c->sf_pw[0], c->sf_pw[1], c->sf_guess};
+  void* bufs[] = {c->one_dbg, c->one_ga, c->one_gb, c->one_rec, c->one_ctl, c->qcnt, c->ttot, c->ac_tmp, c->tile_cnt, c->wg_cnt, c->serial_out, c->tab_f64, c->tab_f32, c->rtab, c->qtab, c->ctl, c->part, c->stats_out, c->qt_item, c->qt_j, c->nd_buf, c->dfl_buf, c->sf_thr[0], c->sf_thr[1], c->sf_pw[0], c->sf_pw[1], c->sf_guess};
   for (void* b : bufs) if (b) (void)hipFree(b);
   if (c->h_pin) (void)hipHostFree(c->h_pin);
   if (c->box) (void)hipHostFree(c->box);
@@ -287,6 +310,19 @@ extern "C" int dctzhip_set_speculation(dctzhip_ctx* c, int on, size_t min_elemen
   c->speculate = on != 0;
   c->spec_cooldown = 0;
   if (min_elements) c->spec_min = min_elements;
+  return DCTZHIP_OK;
+}
+extern "C" int dctzhip_set_one_launch(dctzhip_ctx* c, int on) {
+  if (!c) return DCTZHIP_E_ARG;
+  c->one = on != 0;
+  c->one_cooldown = 0;
+  return DCTZHIP_OK;
+}
+// (development: the time stamps of the last one-launch kernel, 16 per workgroup; DCTZHIP_ONE_STAMPS=1 at context creation)
+extern "C" int dctzhip_debug_one_stamps(dctzhip_ctx* c, unsigned long long* host, size_t nwg) {
+  if (!c || !host || !c->one_dbg || nwg > (size_t)ONE_BOARD) return DCTZHIP_E_ARG;
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  HIPCHK(c, hipMemcpy(host, c->one_dbg, sizeof(unsigned long long) * 16 * nwg, hipMemcpyDeviceToHost));
   return DCTZHIP_OK;
 }
 extern "C" int dctzhip_last_timings(dctzhip_ctx* c, dctzhip_timings* t) {
@@ -687,6 +723,178 @@ static int wg_per_cu(dctzhip_ctx* c, bool decode, int mode, bool stats = false, 
   return slot;
 }
 
+// *info of a compress call from what came back from the device (shared by the chain of kernels and the one-launch path)
+static void fill_cinfo(dctzhip_cinfo* info, int dtype, int mode, double sf, const HostStats& st, size_t nm, unsigned cnt, unsigned nblk,
+                       unsigned flags, const unsigned long long* qraw, unsigned long long q0bits) {
+  memset(info, 0, sizeof(*info));
+  info->sf = sf;
+  // util.c:28 / :41: sum / N over the caller's array
+  info->mean = (dtype == DCTZHIP_F64) ? st.sum / (double)(int)nm : (double)((float)st.sum / (float)(int)nm);
+  info->max_abs = st.max_abs; info->min_abs = st.min_abs;
+  info->cnt = cnt; info->nblk = nblk;
+  info->flags = flags;
+  if (mode == DCTZHIP_QT) {
+    for (int j = 0; j < 64; j++) {
+      double v;
+      if (dtype == DCTZHIP_F64) { unsigned long long b = qraw[j]; memcpy(&v, &b, 8); }
+      else { unsigned int b = (unsigned int)qraw[j]; float f; memcpy(&f, &b, 4); v = f; }
+      info->qtable_raw[j] = v;
+      info->qtable[j] = (j >= 1 && v < 1.0) ? 1.0 : v;          // :450-461
+    }
+    double q0;
+    if (dtype == DCTZHIP_F64) { unsigned long long b = q0bits; memcpy(&q0, &b, 8); }
+    else { unsigned int b = (unsigned int)q0bits; float f; memcpy(&f, &b, 4); q0 = f; }
+    info->qtable[0] = info->qtable_raw[0] = q0;                 // :355-360
+  }
+}
+
+// ---- one launch per call (dctz_kernels_one.hip) ----------------------------------------------------------------------
+// Arrays whose tiles are all resident at once -- ONE_TW tiles per workgroup, as many workgroups as the chip holds -- go
+// through ONE kernel per call; everything else, and any call for which that kernel reports that its workgroups were not
+// all resident (ONE_ERR_TIMEOUT: the occupancy query is advisory, another process may share the GPU), takes the chain.
+static constexpr int ONE_DECLINED = 1;               // (positive: not an error code) the caller runs the chain of kernels
+template <typename T>
+static unsigned one_capacity(dctzhip_ctx* c, bool decode, int mode, bool scaled) {
+  int& slot = c->one_occ[sizeof(T) == 8][decode ? 1 : 0][mode == DCTZHIP_QT][scaled ? 1 : 0];
+  if (slot == 0) {
+    const int v = decode ? decompress_one_occupancy<T>(mode) : compress_one_occupancy<T>(mode, scaled);
+    slot = v < 1 ? -1 : (v > 8 ? 8 : v);
+  }
+  return slot > 0 ? (unsigned)(slot * c->num_cu) : 0u;
+}
+static unsigned one_next_epoch(dctzhip_ctx* c) {
+  if (++c->one_epoch == 0u) c->one_epoch = 1u;
+  return c->one_epoch;
+}
+// a launch gave up (or never reported): back to a known state, and the chain for a while
+static int one_gave_up(dctzhip_ctx* c) {
+  c->one_fallbacks++;
+  c->one_cooldown = ONE_COOLDOWN;
+  HIPCHK(c, hipMemsetAsync(c->one_ctl, 0, sizeof(Ctl) * 3, c->stream));
+  return DCTZHIP_OK;
+}
+
+template <typename T>
+static int compress_one(dctzhip_ctx* c, const T* d_in, size_t n, double eb, int mode, uint8_t* d_bin, float* d_dc, float* d_ac,
+                        T* d_scaled, T* d_coef, dctzhip_cinfo* info) {
+  const int dtype = sizeof(T) == 8 ? DCTZHIP_F64 : DCTZHIP_F32;
+  if (!c->one || !c->handoff || !c->dev_sf || c->sf_nk[dtype] <= 0 || c->sf_nk[dtype] > 64 * (dtype == DCTZHIP_F64 ? 10 : 2)) return ONE_DECLINED;
+  const unsigned nfull = (unsigned)(n / 64);
+  const int rem = (int)(n % 64);
+  const unsigned ntiles = (nfull + TILE_BLKS - 1) / TILE_BLKS;
+  const unsigned nwg = (ntiles + ONE_TW - 1) / ONE_TW + (rem ? 1u : 0u);
+  if (nwg > (unsigned)ONE_BOARD || nwg > one_capacity<T>(c, false, mode, d_scaled != nullptr)) return ONE_DECLINED;
+  if (c->one_cooldown > 0) { c->one_cooldown--; return ONE_DECLINED; }
+  hipStream_t s = c->stream;
+  if (rem) { int rc = upload_rtab<T>(c, rem); if (rc) return rc; }
+  const unsigned epoch = one_next_epoch(c);
+  OneFwd<T> a;
+  memset(&a, 0, sizeof(a));
+  FwdParams<T>& p = a.p;
+  p.x = d_in; p.bin = d_bin; p.dc = d_dc; p.ac = d_ac; p.coef = d_coef; p.scaled = d_scaled;
+  p.tab = tab_of<T>(c); p.rtab = reinterpret_cast<const T*>(c->rtab);
+  const unsigned slot = c->one_cslot;
+  c->one_cslot ^= 1u;
+  p.ctl = c->one_ctl + slot;
+  p.nfull = nfull; p.ntiles = ntiles; p.last_is_full = rem ? 0u : 1u;
+  // bin ranges, dctz-comp-lib.c:271-281 (computed in double, stored in T)
+  const int half = DCTZHIP_NBINS / 2;
+  p.sf = (T)1;
+  p.bin_width = (T)(eb * 2.0 * 1.0);
+  p.range_min = (T)(-(half * 2 + 1) * (eb * 1.0));
+  p.range_max = (T)((half * 2 + 1) * (eb * 1.0));
+  p.fast_bw = c->fastdiv ? divisor_in_window(dtype, (double)p.bin_width) : 0u;
+  {
+    volatile T u = (T)(p.range_max - p.range_min);      // (bit 1: see compress_pass)
+    volatile T q = (T)(u / p.bin_width);
+    if (p.fast_bw && c->fastdiv >= 2 && q >= (T)255) p.fast_bw |= 2u;
+  }
+  a.b.ga = c->one_ga; a.b.gb = c->one_gb; a.b.rec = c->one_rec; a.b.epoch = epoch; a.b.nwg = nwg; a.b.dbg = c->one_dbg;
+  a.sft = {c->sf_thr[dtype], c->sf_pw[dtype], c->sf_nk[dtype], c->fastdiv, dtype};
+  a.box = c->box_dev;
+  const unsigned long long seq = ++c->seq;
+  a.seq = seq;
+  a.ctl_next = c->one_ctl + (slot ^ 1u);
+  a.eb = eb; a.rem = (unsigned)rem;
+  if (c->profiling) { HIPCHK(c, hipEventRecord(c->ev[0], s)); HIPCHK(c, hipEventRecord(c->ev[1], s)); HIPCHK(c, hipEventRecord(c->ev[2], s)); }
+  launch_compress_one<T>(a, mode, d_scaled != nullptr, s);
+  if (c->profiling) { HIPCHK(c, hipEventRecord(c->ev[3], s)); HIPCHK(c, hipEventRecord(c->ev[4], s)); }
+  HIPCHK(c, hipGetLastError());
+  c->one_calls++;
+  HostBox* hb = c->box;
+  int rc = wait_seq(c, &hb->seq_done, seq, "compress (one launch)");
+  if (rc) { (void)one_gave_up(c); return rc; }
+  if (hb->error == ONE_ERR_TIMEOUT) {
+    // (nothing the caller owns is lost unless the scaled copy went over the input)
+    if (d_scaled && (const void*)d_scaled == (const void*)d_in)
+      return fail(c, DCTZHIP_E_INTERNAL, "one-launch compress gave up after its in-place scaling had begun (workgroups not all resident)");
+    rc = one_gave_up(c);
+    return rc ? rc : ONE_DECLINED;
+  }
+  if (hb->error) { (void)one_gave_up(c); return fail(c, DCTZHIP_E_INTERNAL, "in-kernel error flag set (code %u)", hb->error); }
+  if (c->profiling) { HIPCHK(c, hipEventSynchronize(c->ev[4])); rc = read_timings(c, 2); if (rc) return rc; }
+  // the scaling factor the device chose from its decade tables against the host's own expression on the true statistics
+  const HostStats st = {hb->fstats[0], hb->fstats[1], hb->fstats[2]};
+  const double sf = hb->sf_used, true_sf = scaling_factor(dtype, st.max_abs);
+  const bool window_ok = hb->fast_used != 2 || (value_in_window(dtype, st.min_abs) && value_in_window(dtype, st.max_abs));
+  if (!((T)true_sf == (T)sf && window_ok)) {
+    c->one = 0;                                     // (a table bug: never seen; the chain has the host in its loop)
+    if (d_scaled && (const void*)d_scaled == (const void*)d_in)
+      return fail(c, DCTZHIP_E_INTERNAL, "scaling factor %g chosen on the device differs from the host's %g after an in-place pass", sf, true_sf);
+    rc = one_gave_up(c);
+    return rc ? rc : ONE_DECLINED;
+  }
+  if (info) fill_cinfo(info, dtype, mode, true_sf, st, n, hb->cnt_total, nfull + (rem ? 1u : 0u), DCTZHIP_INFO_STATS_FUSED | DCTZHIP_INFO_ONE_LAUNCH,
+                       const_cast<const unsigned long long*>(hb->qraw), hb->q0);
+  return DCTZHIP_OK;
+}
+
+template <typename T>
+static int decompress_one(dctzhip_ctx* c, const uint8_t* d_bin, const float* d_dc, const float* d_ac, uint32_t ac_count,
+                          const void* qtable_host, size_t n, double eb, double sf, int mode, T* d_out) {
+  if (!c->one || !c->handoff) return ONE_DECLINED;
+  const unsigned nfull = (unsigned)(n / 64);
+  const int rem = (int)(n % 64);
+  const unsigned ntiles = (nfull + TILE_BLKS - 1) / TILE_BLKS;
+  const unsigned nwg = (ntiles + ONE_TW - 1) / ONE_TW + (rem ? 1u : 0u);
+  if (nwg > (unsigned)ONE_BOARD || nwg > one_capacity<T>(c, true, mode, false)) return ONE_DECLINED;
+  if (c->one_cooldown > 0) { c->one_cooldown--; return ONE_DECLINED; }
+  hipStream_t s = c->stream;
+  if (rem) { int rc = upload_rtab<T>(c, rem); if (rc) return rc; }
+  const unsigned epoch = one_next_epoch(c);
+  OneInv<T> a;
+  memset(&a, 0, sizeof(a));
+  InvParams<T>& p = a.p;
+  p.bin = d_bin; p.dc = d_dc; p.ac = d_ac; p.out = d_out;
+  p.tab = tab_of<T>(c); p.rtab = reinterpret_cast<const T*>(c->rtab);
+  p.ctl = c->one_ctl + 2;
+  p.nfull = nfull; p.ntiles = ntiles; p.ac_count = ac_count;
+  p.sf = (T)sf;
+  p.bin_width = (T)((T)eb * 2 * 1.0);             // gen_bins / gen_bins_f (binning.c:17 / :37), as decompress_impl
+  p.range_max = (T)(eb * DCTZHIP_NBINS);          // dctz-decomp-lib.c:372-381
+  p.range_min = (T)(-eb * DCTZHIP_NBINS);
+  p.eb = eb;
+  if (mode == DCTZHIP_QT) memcpy(a.qtab, qtable_host, sizeof(T) * 64);      // (the table rides in the kernel's arguments: no copy in front of the launch)
+  a.b.ga = c->one_ga; a.b.gb = c->one_gb; a.b.rec = c->one_rec; a.b.epoch = epoch; a.b.nwg = nwg; a.b.dbg = c->one_dbg;
+  a.box = c->box_dev;
+  const unsigned long long seq = ++c->seq;
+  a.seq = seq;
+  a.rem = (unsigned)rem;
+  if (c->profiling) { HIPCHK(c, hipEventRecord(c->ev[0], s)); HIPCHK(c, hipEventRecord(c->ev[1], s)); HIPCHK(c, hipEventRecord(c->ev[2], s)); }
+  launch_decompress_one<T>(a, mode, s);
+  if (c->profiling) { HIPCHK(c, hipEventRecord(c->ev[3], s)); HIPCHK(c, hipEventRecord(c->ev[4], s)); }
+  HIPCHK(c, hipGetLastError());
+  c->one_calls++;
+  int rc = wait_seq(c, &c->box->seq_done, seq, "decompress (one launch)");
+  if (rc) { (void)one_gave_up(c); return rc; }
+  const unsigned err = c->box->error;
+  if (err == ONE_ERR_TIMEOUT) { rc = one_gave_up(c); return rc ? rc : ONE_DECLINED; }
+  if (c->profiling) { HIPCHK(c, hipEventSynchronize(c->ev[4])); rc = read_timings(c, 2); if (rc) return rc; }
+  if (err == 2) return fail(c, DCTZHIP_E_ARG, "bin_index flags more exact coefficients than ac_count provides");
+  if (err) return fail(c, DCTZHIP_E_INTERNAL, "in-kernel error flag set (code %u)", err);
+  return DCTZHIP_OK;
+}
+
 // One pass of the compress kernels for a given set of statistics.  `fused`: the
 // statistics are a guess (from a sample); k_compress recomputes the true ones on
 // the way and leaves them in stats_out for the caller to check.
@@ -781,6 +989,11 @@ static int compress_impl(dctzhip_ctx* c, const T* d_in, size_t n, double eb, int
   const unsigned nblk = nfull + (rem ? 1 : 0);
   double* hs = reinterpret_cast<double*>(c->h_pin + PIN_STATS);    // [0..2] first statistics, [4..6] fused ones
   Ctl* hc = reinterpret_cast<Ctl*>(c->h_pin + PIN_CTL);
+  // arrays whose tiles are all resident at once: the whole call is one kernel (dctz_kernels_one.hip)
+  if (geom == GEOM_1D && !nd && pre_parts == 0) {
+    const int rc1 = compress_one<T>(c, d_in, n, eb, mode, d_bin, d_dc, d_ac, d_scaled, d_coef, info);
+    if (rc1 != ONE_DECLINED) return rc1;
+  }
 
   // Speculation: calc_data_stat needs the whole array before the first division, i.e. a second
   // read of the input.  Only the DECADE of max|x| matters (util.c:29), so guess it from a sample,
@@ -916,28 +1129,7 @@ static int compress_impl(dctzhip_ctx* c, const T* d_in, size_t n, double eb, int
     HIPCHK(c, hipGetLastError());
   }
 
-  if (info) {
-    memset(info, 0, sizeof(*info));
-    info->sf = sf;
-    const size_t nm = n_orig ? n_orig : n;          // util.c:28 / :41: sum / N over the caller's array
-    info->mean = (dtype == DCTZHIP_F64) ? st.sum / (double)(int)nm : (double)((float)st.sum / (float)(int)nm);
-    info->max_abs = st.max_abs; info->min_abs = st.min_abs;
-    info->cnt = hc->cnt_total; info->nblk = nblk;
-    info->flags = flags;
-    if (mode == DCTZHIP_QT) {
-      for (int j = 0; j < 64; j++) {
-        double v;
-        if (dtype == DCTZHIP_F64) { unsigned long long b = hc->qraw[j]; memcpy(&v, &b, 8); }
-        else { unsigned int b = (unsigned int)hc->qraw[j]; float f; memcpy(&f, &b, 4); v = f; }
-        info->qtable_raw[j] = v;
-        info->qtable[j] = (j >= 1 && v < 1.0) ? 1.0 : v;          // :450-461
-      }
-      double q0;
-      if (dtype == DCTZHIP_F64) { unsigned long long b = hc->q0; memcpy(&q0, &b, 8); }
-      else { unsigned int b = (unsigned int)hc->q0; float f; memcpy(&f, &b, 4); q0 = f; }
-      info->qtable[0] = info->qtable_raw[0] = q0;                 // :355-360
-    }
-  }
+  if (info) fill_cinfo(info, dtype, mode, sf, st, n_orig ? n_orig : n, hc->cnt_total, nblk, flags, hc->qraw, hc->q0);
   return DCTZHIP_OK;
 }
 
@@ -1057,6 +1249,10 @@ static int decompress_impl(dctzhip_ctx* c, const uint8_t* d_bin, const float* d_
   const int rem = (int)(n % 64);
   const unsigned ntiles = (nfull + TILE_BLKS - 1) / TILE_BLKS;
   const bool box = c->handoff != 0;                 // mailbox + spin instead of D2H copy + stream sync
+  if (geom == GEOM_1D && !nd) {                     // arrays whose tiles are all resident at once: one kernel
+    const int rc1 = decompress_one<T>(c, d_bin, d_dc, d_ac, ac_count, qtable_host, n, eb, sf, mode, d_out);
+    if (rc1 != ONE_DECLINED) return rc1;
+  }
   if (!box || c->ctl_dirty) HIPCHK(c, hipMemsetAsync(c->ctl, 0, sizeof(Ctl), s));      // (a good call leaves `error` at zero)
   c->ctl_dirty = 1;
   if (mode == DCTZHIP_QT) {

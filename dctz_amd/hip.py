@@ -31,6 +31,7 @@ class CompressInfo(C.Structure):
 
 INFO_STATS_FUSED = 1   # sampled guess of sf verified: the separate statistics pass was saved
 INFO_RESPUN = 2        # guess wrong: the compress kernels ran a second time with the true statistics
+INFO_ONE_LAUNCH = 4    # the whole call was one kernel (arrays whose tiles are all resident at once: dctz_kernels_one.hip)
 
 
 class Timings(C.Structure):
@@ -63,6 +64,7 @@ _PROTOS = {
     "dctzhip_set_profiling": (C.c_int, [C.c_void_p, C.c_int]),
     "dctzhip_last_timings": (C.c_int, [C.c_void_p, C.POINTER(Timings)]),
     "dctzhip_set_speculation": (C.c_int, [C.c_void_p, C.c_int, C.c_size_t]),
+    "dctzhip_set_one_launch": (C.c_int, [C.c_void_p, C.c_int]),
     "dctzhip_malloc": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.c_size_t]),
     "dctzhip_free": (C.c_int, [C.c_void_p, C.c_void_p]),
     "dctzhip_memcpy_h2d": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
@@ -193,6 +195,10 @@ class Context:
     def set_speculation(self, on=True, min_elements=0):
         """Fused statistics behind a sampled guess of sf (include/dctz_hip.h, DCTZHIP_INFO_*)."""
         self._check(self.lib.dctzhip_set_speculation(self.h, int(on), int(min_elements)), "set_speculation")
+
+    def set_one_launch(self, on=True):
+        """One kernel per call for arrays whose tiles are all resident at once (include/dctz_hip.h); off: the chain of kernels."""
+        self._check(self.lib.dctzhip_set_one_launch(self.h, int(on)), "set_one_launch")
 
     def set_blocking(self, on=True):
         """Calls return only when their outputs are complete for any observer (default: complete in stream order)."""

@@ -65,6 +65,7 @@ typedef struct {
  * the true statistics. */
 #define DCTZHIP_INFO_STATS_FUSED 1u   /* guess verified: the separate statistics pass was saved */
 #define DCTZHIP_INFO_RESPUN 2u        /* guess wrong: compress kernels were run a second time    */
+#define DCTZHIP_INFO_ONE_LAUNCH 4u    /* the whole call was one kernel (arrays whose tiles are all resident at once)         */
 
 /* Per-kernel device time of the last compress / decompress call, milliseconds,
  * measured with HIP events on the context's stream (only when profiling is on). */
@@ -104,6 +105,14 @@ int dctzhip_set_profiling(dctzhip_ctx *ctx, int on);
  * own behind the kernels, as before round 3. */
 int dctzhip_set_speculation(dctzhip_ctx *ctx, int on, size_t min_elements);
 int dctzhip_last_timings(dctzhip_ctx *ctx, dctzhip_timings *t);
+/* One launch per call.  An array whose tiles are all resident on the chip at once (up to about 8 M fp32 / 4 M fp64 elements:
+ * 2048 / 1024 tiles of 64 blocks) is compressed -- and decompressed -- by ONE kernel: calc_data_stat, scaling, transform,
+ * binning and the ordered placement of AC_exact (decode: flag counts, their prefix, reconstruction) exchange what the chain
+ * of kernels hands over at kernel boundaries through 8-byte tagged words in device memory instead.  The outputs are bit for
+ * bit the chain's (DCTZHIP_INFO_ONE_LAUNCH in info->flags tells which ran); a launch that finds its workgroups not all
+ * resident (another process on the GPU) gives up after 20 ms and the call is run through the chain.  Default: on (env
+ * DCTZHIP_ONE=0 turns it off); on == 0 always takes the chain of kernels. */
+int dctzhip_set_one_launch(dctzhip_ctx *ctx, int on);
 /* on != 0: every compress / decompress call ends with a synchronisation of the context's stream, i.e. its outputs are
  * complete for ANY observer when it returns (default off: complete in stream order, see the two calls below; env
  * DCTZHIP_BLOCKING=1 does the same).  For callers that read the buffers from another stream or from the host without

@@ -70,6 +70,21 @@ def _compress_both(ctx, x, eb, mode):
     assert (pinfo.cnt, pinfo.sf) == (info.cnt, info.sf)
     assert torch.equal(keep["bin_index"], out["bin_index"]) and torch.equal(keep["dc"].view(torch.int32), out["dc"].view(torch.int32))
     assert torch.equal(keep["ac_exact"].view(torch.int32), out["ac_exact"][:info.cnt].view(torch.int32))
+    # ... and a third time through the chain of kernels (arrays of this size take ONE kernel by default,
+    # dctz_kernels_one.hip): the same bytes, the same header scalars
+    assert pinfo.flags & H.INFO_ONE_LAUNCH and info.flags & H.INFO_ONE_LAUNCH
+    ctx.set_one_launch(False)
+    try:
+        sc2, cf2 = torch.empty_like(xd), torch.empty_like(xd)
+        chain, cinfo = ctx.compress(xd, eb, mode, scaled=sc2, coef=cf2)
+    finally:
+        ctx.set_one_launch(True)
+    assert not (cinfo.flags & H.INFO_ONE_LAUNCH)
+    assert (cinfo.cnt, cinfo.sf, cinfo.max_abs, cinfo.min_abs) == (info.cnt, info.sf, info.max_abs, info.min_abs)
+    assert torch.equal(chain["bin_index"], out["bin_index"]) and torch.equal(chain["dc"].view(torch.int32), out["dc"].view(torch.int32))
+    assert torch.equal(chain["ac_exact"][:info.cnt].view(torch.int32), out["ac_exact"][:info.cnt].view(torch.int32))
+    assert torch.equal(sc2.view(torch.uint8), scaled.view(torch.uint8)) and torch.equal(cf2.view(torch.uint8), coef.view(torch.uint8))
+    assert list(cinfo.qtable) == list(info.qtable) and list(cinfo.qtable_raw) == list(info.qtable_raw)
     c = O.compress(x, eb, mode, O.FAST, want_coef=True)
     return xd, out, info, coef, scaled, c
 
@@ -111,6 +126,12 @@ def test_decompress_bit_exact(ctx, dtype, mode, n):
     tdt = torch.float64 if dtype == np.float64 else torch.float32
     r = ctx.decompress(out, c.cnt, n, tdt, eb, c.sf, mode, qtable=c.qtable).cpu().numpy()
     assert _same(r, ref), f"maxdiff={np.abs(r - ref).max()}"
+    ctx.set_one_launch(False)                          # ... and through the chain of kernels
+    try:
+        r2 = ctx.decompress(out, c.cnt, n, tdt, eb, c.sf, mode, qtable=c.qtable).cpu().numpy()
+    finally:
+        ctx.set_one_launch(True)
+    assert _same(r2, ref)
 
 
 @pytest.mark.parametrize("eb", [1e-3, 1e-4, 1e-5, 1e-6])
@@ -220,6 +241,7 @@ def spec_ctx():
     import dctz_amd
     c = dctz_amd.Context(0)
     c.set_speculation(True, 1 << 18)
+    c.set_one_launch(False)                 # (these tests are about the chain's speculative statistics)
     yield c
     c.close()
 
@@ -312,6 +334,34 @@ def test_in_place_scaling_under_speculation_and_small_inputs(spec_ctx):
     spec_ctx.set_speculation(False)
     out, info = spec_ctx.compress(_dev(spec_ctx, x), 1e-3, O.EC)
     assert info.flags == 0 and info.cnt == c.cnt
+
+
+@pytest.mark.parametrize("one", [True, False])
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+@pytest.mark.parametrize("mode", [O.EC, O.QT])
+@pytest.mark.parametrize("n", [64 * 64 * 3 + 64 * 9 + 21, 64 * 5 + 7, 1 << 20, 40])
+@pytest.mark.parametrize("sf_one", [False, True])
+def test_in_place_scaling_every_layout(ctx, one, dtype, mode, n, sf_one):
+    """d_scaled == d_in (what the reference does to its caller's array, dctz-comp-lib.c:193-216) for both element types and
+    modes, whole tiles, a partial last tile, a remainder block, an array shorter than a block, and sf == 1 -- through the
+    one-launch kernel and through the chain (only fp64 / EC / whole tiles were pinned)."""
+    x = W.ragged(n, dtype, scale=(5.0 if sf_one else 37.0))
+    c = O.compress(x, 1e-3, mode, O.FAST)
+    assert (c.sf == 1.0) == sf_one
+    xd = _dev(ctx, x)
+    ctx.set_one_launch(one)
+    try:
+        out, info = ctx.compress(xd, 1e-3, mode, scaled=xd)
+    finally:
+        ctx.set_one_launch(True)
+    assert bool(info.flags & H.INFO_ONE_LAUNCH) == one
+    assert info.sf == c.sf and info.cnt == c.cnt
+    assert _same(xd.cpu().numpy(), c.scaled)
+    assert np.array_equal(out["bin_index"].cpu().numpy(), c.bin_index)
+    assert _same(out["dc"].cpu().numpy(), c.dc)
+    assert _same(out["ac_exact"][:c.cnt].cpu().numpy(), c.ac_exact)
+    if mode == O.QT:
+        assert _same(np.array(info.qtable[:], dtype=dtype), c.qtable)
 
 
 @pytest.mark.parametrize("dtype", [np.float64, np.float32])
