@@ -340,7 +340,7 @@ struct OneFwd {
   Ctl* ctl_next;                   // the control block of the NEXT one-launch call: zeroed by the hand-off workgroup
   double eb;
   unsigned rem;                    // N % 64
-  unsigned pad;
+  unsigned bad_guess;              // (tests) the first guess of the array's decade is made wrong on purpose: every tile runs twice
 };
 template <typename T>
 struct OneInv {

@@ -49,6 +49,7 @@ constexpr unsigned long long ONE_SPIN_TICKS = 2000000ull;   // 20 ms of the 100 
 constexpr unsigned ONE_EXC_MAX = 63u * 64u;                  // "stored exactly" coefficients of a tile at most
 constexpr unsigned ONE_GAVE_UP = 0xFFFFFFFFu;                // what a sweep that timed out leaves for the other waves
 constexpr int OTW = ONE_TW;
+constexpr int ONE_SPEC_MIN_WG = 128;                         // workgroups from which k_compress_one scales on a guess (see there)
 
 // Development aid: time stamps of the first wave of every workgroup at the phases of the kernels (OneBoard::dbg != NULL)
 __device__ __forceinline__ void one_stamp(const OneBoard& b, int k) {
@@ -146,6 +147,7 @@ __device__ __forceinline__ unsigned one_stat_word(const SfTable& t, double mx, d
 // What the waves of a workgroup tell each other (and its first wave the board)
 struct OneShared {
   unsigned word[OTW];              // statistics words of the waves' tiles
+  unsigned gword[OTW];             // ... and their guesses of the ARRAY's decade (own tile and a sample)
   unsigned tot[OTW];               // "stored exactly" coefficients of the waves' tiles
   double mx[OTW], mn[OTW], sum[OTW];
   unsigned res_stats, res_prefix;  // the sweeps' answers (ONE_GAVE_UP: timed out)
@@ -220,12 +222,17 @@ __global__ __launch_bounds__(OTW * 64) void k_compress_one(const OneFwd<T> a) {
   FastDiv<T> bwd;
   bwd.init(p.bin_width, (p.fast_bw & 1u) != 0);
 
+  // Scaling on a guess of the array's decade (below) pays where the first sweep is long: many workgroups (C2: 397; with the
+  // 65 of C1 the sweep ends 1.3 us after the last post, and the sample costs as much).  Never with SC: x / sf goes to the
+  // caller's memory before the transform.
+  const bool speculate = !SC && (nwg >= (unsigned)ONE_SPEC_MIN_WG || a.bad_guess != 0u);
+
   // ---- phase 1: the data, and calc_data_stat over it (util.c:18-25) ---------------------------------------------------
   one_stamp(a.b, 0);
   T x[64];
-  T raw = T(0), x0raw = T(0);
+  T raw = T(0);
   double mx = 0.0, mn = 1.79769313486231570815e308, rsum = 0.0;
-  unsigned word = 0;
+  unsigned word = 0, gword = 0;
   if (tile_wave) {
     if (MODE == DCTZHIP_QT) qmax_lds[lane] = 0;
     const __amdgpu_buffer_rsrc_t r_in = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(p.x + first_el), 0, range_el * (int)sizeof(T), 0x00020000);
@@ -234,6 +241,16 @@ __global__ __launch_bounds__(OTW * 64) void k_compress_one(const OneFwd<T> a) {
     double thr[NT];
 #pragma unroll
     for (int i = 0; i < NT; i++) thr[i] = (lane + 64 * i < a.sft.nk) ? a.sft.thr[lane + 64 * i] : __builtin_inf();
+    // (and this wave's quarter of the sample behind the guess of the array's decade: 64 whole blocks spread evenly over the
+    // array, the same for every workgroup -- coalesced rows that the caches serve after the first reader)
+    constexpr int NS = 16;
+    T smp[NS];
+#pragma unroll
+    for (int i = 0; i < NS; i++) smp[i] = T(0);
+    if (speculate) {
+#pragma unroll
+      for (int i = 0; i < NS; i++) smp[i] = p.x[(((size_t)(wv * NS + i) * p.nfull) >> 6) * 64 + lane];
+    }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     read_phase<T, 1, 0>(x, tilebuf, tm);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -243,13 +260,34 @@ __global__ __launch_bounds__(OTW * 64) void k_compress_one(const OneFwd<T> a) {
 #pragma unroll
       for (int j = 0; j < 64; j++) acc.minmax(x[j]);
     }
-    x0raw = x[0];
+    // (the sum of util.c:18-28 -- never x[0] -- over the raw values, here and now: everything the hand-off reports about
+    // the statistics is on the board before the first sweep, and nothing has to be drained in front of the counts later)
+    {
+      double s0 = 0.0, s1 = 0.0;
+      if (active) {
+#pragma unroll
+        for (int j = 0; j < 64; j += 2) { s0 += (double)x[j]; s1 += (double)x[j + 1]; }
+        if (tile == 0 && lane == 0) s0 -= (double)x[0];
+      }
+      rsum = wave_sum_f64(s0 + s1);
+    }
     mx = wave_minmax<true>((double)acc.mx);
     mn = wave_minmax<false>((double)acc.mn);
     unsigned below = 0;
 #pragma unroll
     for (int i = 0; i < NT; i++) below += (unsigned)__popcll(__builtin_amdgcn_ballot_w64(thr[i] < mx));
     word = one_stat_word(a.sft, mx, mn, below);
+    {
+      StatAcc<T> sacc;
+      sacc.init();
+#pragma unroll
+      for (int i = 0; i < NS; i++) sacc.minmax(smp[i]);
+      const double gmx = fmax(mx, wave_minmax<true>((double)sacc.mx));
+      unsigned gb = 0;
+#pragma unroll
+      for (int i = 0; i < NT; i++) gb += (unsigned)__popcll(__builtin_amdgcn_ballot_w64(thr[i] < gmx));
+      gword = gmx == 0.0 ? 0u : gb + 1u;
+    }
   } else if (rem_wave) {
     raw = lane < l ? p.x[rbase + lane] : T(0);
     StatAcc<T> acc;
@@ -262,146 +300,229 @@ __global__ __launch_bounds__(OTW * 64) void k_compress_one(const OneFwd<T> a) {
     for (int i0 = 0; i0 < a.sft.nk; i0 += 64) below += (unsigned)__popcll(__builtin_amdgcn_ballot_w64(i0 + lane < a.sft.nk && a.sft.thr[i0 + lane] < mx));
     word = one_stat_word(a.sft, mx, mn, below);
   }
-  if (lane == 0) { sh.word[wv] = word; sh.mx[wv] = mx; sh.mn[wv] = mn; }
+  if (lane == 0) { sh.word[wv] = word; sh.gword[wv] = gword; sh.mx[wv] = mx; sh.mn[wv] = mn; sh.sum[wv] = rsum; }
   one_stamp(a.b, 1);
   __syncthreads();
   one_stamp(a.b, 2);
   if (wv == 0) {
-    // the workgroup's statistics -> its record and its granule; then the largest decade of the whole array
+    // the workgroup's statistics -> its record and its granule
     unsigned kw = 0, vw = 0;
-    double wmx = 0.0, wmn = 1.79769313486231570815e308;
+    double wmx = 0.0, wmn = 1.79769313486231570815e308, wsum = 0.0;
 #pragma unroll
-    for (int i = 0; i < OTW; i++) { kw = max(kw, sh.word[i] & 0xFFFFu); vw |= sh.word[i] >> 16; wmx = fmax(wmx, sh.mx[i]); wmn = fmin(wmn, sh.mn[i]); }
+    for (int i = 0; i < OTW; i++) { kw = max(kw, sh.word[i] & 0xFFFFu); vw |= sh.word[i] >> 16; wmx = fmax(wmx, sh.mx[i]); wmn = fmin(wmn, sh.mn[i]); wsum += sh.sum[i]; }
     if (lane == 0) {
       st_agent_f64(a.b.rec + 3 * (size_t)wg, wmx);
       st_agent_f64(a.b.rec + 3 * (size_t)wg + 1, wmn);
+      st_agent_f64(a.b.rec + 3 * (size_t)wg + 2, wsum);
       st_agent(a.b.ga + wg, granule(epoch, kw | (vw << 16)));
     }
+  }
+  // The largest decade of the whole array -- all that the scaling factor depends on (util.c:29) -- is what the FIRST SWEEP
+  // of the board brings back; it is complete only when the slowest workgroup has posted, ~4 us after this one is ready to
+  // scale.  So the tile is scaled, transformed and binned on a GUESS -- the largest decade among the workgroup's own
+  // tiles and a sample of the array (64 blocks, the same for every workgroup: cache hits) -- and the sweep, which by
+  // then finds every granule in place, only verifies it; a wrong guess (a spike the sample did not see) runs the tile
+  // again from its image in LDS, which nothing has touched yet.  The outputs never depend on the guess.
+  // (The short last block is cheap: its workgroup waits.  bad_guess: 1 = every first guess wrong, 3 = guess whatever the
+  // grid; tests.)
+  auto sweep_stats = [&]() {                         // wave 0; the other waves meet it at the barrier behind
     unsigned kmax = 0, viol = 0;
     const bool ok = sweep_granules(a.b.ga, nwg, epoch, [&](unsigned v, unsigned) { kmax = max(kmax, v & 0xFFFFu); viol |= v >> 16; });
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (the record's stores are done as well: they went out in front of the sweep's loads)
     kmax = wave_max_u32(kmax);
     const bool vany = __builtin_amdgcn_ballot_w64(viol != 0u) != 0ull;
     if (lane == 0) sh.res_stats = ok ? (kmax | (vany ? 0x10000u : 0u)) : ONE_GAVE_UP;
-  }
-  one_stamp(a.b, 3);
-  __syncthreads();
-  const unsigned rs = sh.res_stats;
-  if (rs == ONE_GAVE_UP) {                           // (every wave of the workgroup leaves here)
+  };
+  auto gave_up = [&]() {                             // (every wave of the workgroup leaves)
     if (threadIdx.x == 0) atomicExch(&p.ctl->error, ONE_ERR_TIMEOUT);
     if (last_wg && wv == 0) one_handoff_compress<T, MODE>(a, 0u, ONE_ERR_TIMEOUT, 1.0, 0u, 0ull);
-    return;
+  };
+  unsigned kk_use = 0;
+  bool verified = false, replay = false;
+  unsigned rs = 0;                                   // the sweep's answer: the array's decade word
+  if (!speculate || rem_wg) {
+    if (wv == 0) sweep_stats();
+    one_stamp(a.b, 3);
+    __syncthreads();
+    rs = sh.res_stats;
+    if (rs == ONE_GAVE_UP) { gave_up(); return; }
+    kk_use = rs & 0xFFFFu;
+    verified = true;
+  } else {
+#pragma unroll
+    for (int i = 0; i < OTW; i++) kk_use = max(kk_use, sh.gword[i]);
+    if (a.bad_guess == 1u) kk_use += 1u;
   }
-  const OneSf osf = one_sf(a.sft, rs & 0xFFFFu, (rs >> 16) != 0u);
-  const T sf = (T)osf.sf;
-  const bool scale = (sf != T(1));                   // dctz-comp-lib.c:193 / :208
+  const bool own_inwin = (word >> 16) == 0u;         // FastDiv needs no per-element test for THIS tile (the same quotients either way)
 
   // ---- phase 2: scale, transform, bin -----------------------------------------------------------------------------------
   unsigned w[16];
   unsigned mlo = 0, mhi = 0;                         // tile: bit j: coefficient j of this block is stored exactly
   unsigned tot = 0, base = 0;                        // the tile's count, this block's place in the tile's piece of AC_exact
-  double sumpart = 0.0;
   T rcoef = T(0);                                    // remainder block: this lane's coefficient
   bool rexc = false;
   unsigned rbin = 0, rrank = 0;
-  if (tile_wave) {
-    if (scale) {
+  OneSf osf = {1.0, 0u};
+  T sf = T(1);
+#pragma clang loop unroll(disable)
+  for (;;) {
+    osf = one_sf(a.sft, kk_use, !own_inwin);
+    sf = (T)osf.sf;
+    const bool scale = (sf != T(1));                 // dctz-comp-lib.c:193 / :208
+    if (tile_wave) {
+      if (replay) {
+        read_phase<T, 1, 0>(x, tilebuf, tm);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        mlo = 0; mhi = 0;
+      }
+      if (scale) {
+        FastDiv<T> sfd;
+        sfd.init(sf, osf.fast != 0u);
+        if (osf.fast == 2u) {
+          if constexpr (!F64) {
+  #pragma unroll
+            for (int j = 0; j < 64; j += 2) {
+              const f32x2 v = fastdiv_core2(sfd, f32x2{(float)x[j], (float)x[j + 1]});
+              x[j] = v.x; x[j + 1] = v.y;
+            }
+          } else {
+  #pragma unroll
+            for (int j = 0; j < 64; j++) x[j] = sfd.core(x[j]);
+          }
+        } else if (osf.fast == 1u) {
+  #pragma unroll
+          for (int j = 0; j < 64; j++) x[j] = sfd.div(x[j]);
+        } else {
+  #pragma unroll
+          for (int j = 0; j < 64; j++) x[j] = x[j] / sfd.d;
+        }
+      }
+      if constexpr (SC) {
+        // the reference's in-place x / sf of the caller's array (:193-216), into p.scaled (which may be the input itself: the
+        // tile is in registers): registers -> the image -> 1 KiB rows, as k_decompress writes its output
+        const __amdgpu_buffer_rsrc_t r_sc = __builtin_amdgcn_make_buffer_rsrc(p.scaled + first_el, 0, range_el * (int)sizeof(T), 0x00020000);
+        write_phase<T, 1, 0>(x, tilebuf, tm);
+  #pragma unroll
+        for (int jg = 0; jg < 8; jg++) {
+          const int vo = jg * 8 * G::BLKB + ((jg & 1) ? tm.g_odd : tm.g_even);
+  #pragma unroll
+          for (int sg = 0; sg < G::SEGP; sg++) {
+            const u32x4 r = *reinterpret_cast<const u32x4*>(tilebuf + (jg * G::SEGP + sg) * 1024 + lane * 16);
+            __builtin_amdgcn_raw_buffer_store_b128(r, r_sc, vo + sg * 128, 0, 2 /* nt */);
+          }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      block_fwd<T, CTab<T>, GEOM_1D, true>(x, as_ctab<T>(p.tab));
+      if (p.coef != nullptr && active) {               // test tap: the coefficients as computed
+  #pragma unroll
+        for (int j = 0; j < 64; j++) p.coef[((size_t)tile * TILE_BLKS + lane) * 64 + j] = x[j];
+      }
+      if (p.last_is_full && tile == p.ntiles - 1u) {   // :355-360
+        const T dc_last = (T)__shfl(x[0], (int)((p.nfull - 1u) & 63u));
+        if (lane == 0) sh.q0 = (unsigned long long)to_bits(dc_last);
+      }
+      // pass-1 binning (:363-414), four coefficients = one dword of bin ids at a time
+      __builtin_amdgcn_sched_barrier(0);
+      auto bin_tile = [&](auto fast, auto safe) {
+  #pragma unroll
+        for (int g = 0; g < 16; g++) {
+          float h[4];
+          if constexpr (!F64 && decltype(fast)::value) {
+  #pragma unroll
+            for (int i = 0; i < 4; i += 2) {
+              const int j = 4 * g + i;
+              const f32x2 q = fastdiv_core2(bwd, f32x2{(float)x[j], (float)x[j + 1]} - f32x2{(float)rmin, (float)rmin});   // :377 / :402
+              h[i] = bin_value<T, decltype(safe)::value>(x[j], q.x, rmax);
+              h[i + 1] = bin_value<T, decltype(safe)::value>(x[j + 1], q.y, rmax);
+            }
+          } else {
+  #pragma unroll
+            for (int i = 0; i < 4; i++) {
+              const int j = 4 * g + i;
+              const T u = x[j] - rmin;                 // :377 / :402
+              const T q = decltype(fast)::value ? bwd.core(u) : u / bwd.d;
+              h[i] = bin_value<T, decltype(safe)::value>(x[j], q, rmax);
+            }
+          }
+          if (g == 0) h[0] = 0.0f;                     // j = 0 is the DC slot (:361): never stored exactly, its id is set below
+          unsigned wgd = 0u;
+  #pragma unroll
+          for (int i = 0; i < 4; i++) wgd = __builtin_amdgcn_cvt_pk_u8_f32(h[i], i, wgd);
+          asm volatile("" : "+v"(wgd));
+          w[g] = wgd;
+          const unsigned nw = ~wgd;                    // "stored exactly" = id 255: bit 7 of byte i of mm
+          const unsigned mm = ~(((nw & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | nw) & 0x80808080u;
+          const unsigned m4 = ((mm >> 7) | (mm >> 14) | (mm >> 21) | (mm >> 28)) & 0xFu;
+          if (g < 8) mlo |= m4 << (4 * g); else mhi |= m4 << (4 * (g - 8));
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      };
+      if (bwd.ok) { if (p.fast_bw & 2u) bin_tile(std::true_type{}, std::false_type{}); else bin_tile(std::true_type{}, std::true_type{}); }
+      else bin_tile(std::false_type{}, std::true_type{});
+      w[0] |= 0xFFu;                                   // :361 DC slot
+      if (!active) { mlo = 0; mhi = 0; }
+      const unsigned n = (unsigned)(__popc(mlo) + __popc(mhi));
+      const unsigned incl = wave_incl_scan(n);
+      tot = (unsigned)__builtin_amdgcn_readlane((int)incl, 63);
+      base = incl - n;
+    } else if (rem_wave) {
+      // the short last block (length l = N % 64): the reference re-plans a length-l (l even) or 2l (l odd) FFT for it
+      // (dctz-comp-lib.c:326-340, dct.c:59-72); definition-order DFT with host-built roots, lane k = output k
+      T* const v = reinterpret_cast<T*>(tilebuf);
+      const T* rt = p.rtab;
+      const int N = (l & 1) ? 2 * l : l;
+      const int k = lane;
       FastDiv<T> sfd;
       sfd.init(sf, osf.fast != 0u);
-      if (osf.fast == 2u) {
-        if constexpr (!F64) {
-#pragma unroll
-          for (int j = 0; j < 64; j += 2) {
-            const f32x2 v = fastdiv_core2(sfd, f32x2{(float)x[j], (float)x[j + 1]});
-            x[j] = v.x; x[j + 1] = v.y;
-          }
-        } else {
-#pragma unroll
-          for (int j = 0; j < 64; j++) x[j] = sfd.core(x[j]);
-        }
-      } else if (osf.fast == 1u) {
-#pragma unroll
-        for (int j = 0; j < 64; j++) x[j] = sfd.div(x[j]);
-      } else {
-#pragma unroll
-        for (int j = 0; j < 64; j++) x[j] = x[j] / sfd.d;
+      if (k < l) {
+        T e = raw;
+        if (scale) e = sfd.div(e);
+        if (p.scaled != nullptr) p.scaled[rbase + k] = e;
+        if (l & 1) { v[k] = e; v[l + (l - 1 - k)] = e; }             // dct.c:61-64
+        else if (k & 1) v[l - 1 - (k >> 1)] = e;                     // dct.c:75-83
+        else v[k >> 1] = e;
       }
-    }
-    if constexpr (SC) {
-      // the reference's in-place x / sf of the caller's array (:193-216), into p.scaled (which may be the input itself: the
-      // tile is in registers): registers -> the image -> 1 KiB rows, as k_decompress writes its output
-      const __amdgpu_buffer_rsrc_t r_sc = __builtin_amdgcn_make_buffer_rsrc(p.scaled + first_el, 0, range_el * (int)sizeof(T), 0x00020000);
-      write_phase<T, 1, 0>(x, tilebuf, tm);
-#pragma unroll
-      for (int jg = 0; jg < 8; jg++) {
-        const int vo = jg * 8 * G::BLKB + ((jg & 1) ? tm.g_odd : tm.g_even);
-#pragma unroll
-        for (int sg = 0; sg < G::SEGP; sg++) {
-          const u32x4 r = *reinterpret_cast<const u32x4*>(tilebuf + (jg * G::SEGP + sg) * 1024 + lane * 16);
-          __builtin_amdgcn_raw_buffer_store_b128(r, r_sc, vo + sg * 128, 0, 2 /* nt */);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");             // (one wave: its LDS operations are in order)
+      if (k < l) {
+        T sr = T(0), si = T(0);
+        for (int j = 0; j < N; j++) {
+          const int tt = (j * k) % N;
+          sr = sr + v[j] * rt[RTAB_WR + tt];
+          si = si + v[j] * rt[RTAB_WI + tt];
         }
+        rcoef = rt[RTAB_AS + k] * sr + rt[RTAB_AX + k] * si;         // dct.c:100-102 (Im V = -si)
       }
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    }
-    __builtin_amdgcn_sched_barrier(0);
-    block_fwd<T, CTab<T>, GEOM_1D, true>(x, as_ctab<T>(p.tab));
-    if (p.coef != nullptr && active) {               // test tap: the coefficients as computed
-#pragma unroll
-      for (int j = 0; j < 64; j++) p.coef[((size_t)tile * TILE_BLKS + lane) * 64 + j] = x[j];
-    }
-    // the sum (util.c:18-28: never x[0]) from the DC coefficients: orthonormal 64-point DCT, DC = (sum of the block) / 8
-    {
-      double dcs = active ? (double)x[0] : 0.0;
-      if (tile == 0 && lane == 0) dcs -= (double)x0raw / (scale ? 8.0 * (double)sf : 8.0);
-      sumpart = wave_sum_f64(dcs) * (scale ? 8.0 * (double)sf : 8.0);
-    }
-    if (p.last_is_full && tile == p.ntiles - 1u) {   // :355-360
-      const T dc_last = (T)__shfl(x[0], (int)((p.nfull - 1u) & 63u));
-      if (lane == 0) sh.q0 = (unsigned long long)to_bits(dc_last);
-    }
-    // pass-1 binning (:363-414), four coefficients = one dword of bin ids at a time
-    __builtin_amdgcn_sched_barrier(0);
-    auto bin_tile = [&](auto fast, auto safe) {
-#pragma unroll
-      for (int g = 0; g < 16; g++) {
-        float h[4];
-        if constexpr (!F64 && decltype(fast)::value) {
-#pragma unroll
-          for (int i = 0; i < 4; i += 2) {
-            const int j = 4 * g + i;
-            const f32x2 q = fastdiv_core2(bwd, f32x2{(float)x[j], (float)x[j + 1]} - f32x2{(float)rmin, (float)rmin});   // :377 / :402
-            h[i] = bin_value<T, decltype(safe)::value>(x[j], q.x, rmax);
-            h[i + 1] = bin_value<T, decltype(safe)::value>(x[j + 1], q.y, rmax);
-          }
-        } else {
-#pragma unroll
-          for (int i = 0; i < 4; i++) {
-            const int j = 4 * g + i;
-            const T u = x[j] - rmin;                 // :377 / :402
-            const T q = decltype(fast)::value ? bwd.core(u) : u / bwd.d;
-            h[i] = bin_value<T, decltype(safe)::value>(x[j], q, rmax);
-          }
-        }
-        if (g == 0) h[0] = 0.0f;                     // j = 0 is the DC slot (:361): never stored exactly, its id is set below
-        unsigned wgd = 0u;
-#pragma unroll
-        for (int i = 0; i < 4; i++) wgd = __builtin_amdgcn_cvt_pk_u8_f32(h[i], i, wgd);
-        asm volatile("" : "+v"(wgd));
-        w[g] = wgd;
-        const unsigned nw = ~wgd;                    // "stored exactly" = id 255: bit 7 of byte i of mm
-        const unsigned mm = ~(((nw & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | nw) & 0x80808080u;
-        const unsigned m4 = ((mm >> 7) | (mm >> 14) | (mm >> 21) | (mm >> 28)) & 0xFu;
-        if (g < 8) mlo |= m4 << (4 * g); else mhi |= m4 << (4 * (g - 8));
-        __builtin_amdgcn_sched_barrier(0);
+      // pass-1 binning, the reference's own form (:363-414)
+      const bool out = fabs(rcoef) > rmax;                           // == (item < range_min || item > range_max)
+      const T u = rcoef - rmin;
+      const T q = bwd.ok ? bwd.core(u) : u / bwd.d;
+      const int t = (int)q;                                          // (t_bin_id) cast: truncation
+      rbin = out ? 255u : (unsigned)(t <= 127 ? 254 - 2 * t : 2 * t - 255);   // conv_tbl :27-43 (t == 255 -> 255)
+      if (k == 0) rbin = 255u; else rexc = (rbin == 255u);
+      if (k >= l) rexc = false;
+      const unsigned long long m = __builtin_amdgcn_ballot_w64(rexc);
+      rrank = (unsigned)__popcll(m & ((1ull << k) - 1ull));
+      tot = (unsigned)__popcll(m);
+      if (MODE == DCTZHIP_QT) {
+        if (rexc && fabs(rcoef) > rmax) atomicMax(&p.ctl->qraw[k], (unsigned long long)to_bits(fabs(rcoef)));   // :371-372 / :396-397
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       }
-    };
-    if (bwd.ok) { if (p.fast_bw & 2u) bin_tile(std::true_type{}, std::false_type{}); else bin_tile(std::true_type{}, std::true_type{}); }
-    else bin_tile(std::false_type{}, std::true_type{});
-    w[0] |= 0xFFu;                                   // :361 DC slot
-    if (!active) { mlo = 0; mhi = 0; }
-    const unsigned n = (unsigned)(__popc(mlo) + __popc(mhi));
-    const unsigned incl = wave_incl_scan(n);
-    tot = (unsigned)__builtin_amdgcn_readlane((int)incl, 63);
-    base = incl - n;
+      if (k == 0) sh.q0 = (unsigned long long)to_bits(rcoef);        // :355-360
+    }
+    if (verified) break;
+    if (wv == 0) sweep_stats();
+    one_stamp(a.b, 3);
+    __syncthreads();
+    rs = sh.res_stats;
+    if (rs == ONE_GAVE_UP) { gave_up(); return; }
+    verified = true;
+    if ((rs & 0xFFFFu) == kk_use) break;
+    kk_use = rs & 0xFFFFu;                           // (uniform over the workgroup: every wave runs its tile again)
+    replay = true;
+  }
+  if (tile_wave) {
     if (MODE == DCTZHIP_QT) {
       // per-position maximum |coef| over the out-of-range coefficients (:371-372 / :396-397): merged in LDS, then one device
       // atomic per position that has one; drained before the count is posted (the table is read behind ALL counts)
@@ -422,66 +543,16 @@ __global__ __launch_bounds__(OTW * 64) void k_compress_one(const OneFwd<T> a) {
       if (qm != 0) atomicMax(&p.ctl->qraw[lane], (unsigned long long)qm);
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
-  } else if (rem_wave) {
-    // the short last block (length l = N % 64): the reference re-plans a length-l (l even) or 2l (l odd) FFT for it
-    // (dctz-comp-lib.c:326-340, dct.c:59-72); definition-order DFT with host-built roots, lane k = output k
-    T* const v = reinterpret_cast<T*>(tilebuf);
-    const T* rt = p.rtab;
-    const int N = (l & 1) ? 2 * l : l;
-    const int k = lane;
-    FastDiv<T> sfd;
-    sfd.init(sf, osf.fast != 0u);
-    if (k < l) {
-      T e = raw;
-      if (scale) e = sfd.div(e);
-      if (p.scaled != nullptr) p.scaled[rbase + k] = e;
-      if (l & 1) { v[k] = e; v[l + (l - 1 - k)] = e; }             // dct.c:61-64
-      else if (k & 1) v[l - 1 - (k >> 1)] = e;                     // dct.c:75-83
-      else v[k >> 1] = e;
-    }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");             // (one wave: its LDS operations are in order)
-    if (k < l) {
-      T sr = T(0), si = T(0);
-      for (int j = 0; j < N; j++) {
-        const int tt = (j * k) % N;
-        sr = sr + v[j] * rt[RTAB_WR + tt];
-        si = si + v[j] * rt[RTAB_WI + tt];
-      }
-      rcoef = rt[RTAB_AS + k] * sr + rt[RTAB_AX + k] * si;         // dct.c:100-102 (Im V = -si)
-    }
-    // pass-1 binning, the reference's own form (:363-414)
-    const bool out = fabs(rcoef) > rmax;                           // == (item < range_min || item > range_max)
-    const T u = rcoef - rmin;
-    const T q = bwd.ok ? bwd.core(u) : u / bwd.d;
-    const int t = (int)q;                                          // (t_bin_id) cast: truncation
-    rbin = out ? 255u : (unsigned)(t <= 127 ? 254 - 2 * t : 2 * t - 255);   // conv_tbl :27-43 (t == 255 -> 255)
-    if (k == 0) rbin = 255u; else rexc = (rbin == 255u);
-    if (k >= l) rexc = false;
-    const unsigned long long m = __builtin_amdgcn_ballot_w64(rexc);
-    rrank = (unsigned)__popcll(m & ((1ull << k) - 1ull));
-    tot = (unsigned)__popcll(m);
-    sumpart = rsum;
-    if (MODE == DCTZHIP_QT) {
-      if (rexc && fabs(rcoef) > rmax) atomicMax(&p.ctl->qraw[k], (unsigned long long)to_bits(fabs(rcoef)));   // :371-372 / :396-397
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    }
-    if (k == 0) sh.q0 = (unsigned long long)to_bits(rcoef);        // :355-360
   }
-  if (lane == 0) { sh.tot[wv] = tot; sh.sum[wv] = sumpart; }
+  if (lane == 0) sh.tot[wv] = tot;
   one_stamp(a.b, 4);
   __syncthreads();
   one_stamp(a.b, 5);
   unsigned wg_tot = 0;
 #pragma unroll
   for (int i = 0; i < OTW; i++) wg_tot += sh.tot[i];
-  if (wv == 0 && lane == 0) {
-    double s = 0.0;
-#pragma unroll
-    for (int i = 0; i < OTW; i++) s += sh.sum[i];
-    st_agent_f64(a.b.rec + 3 * (size_t)wg + 2, s);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the record is done (the waves' table atomics were drained in front of the barrier)
-    st_agent(a.b.gb + wg, granule(epoch, wg_tot));
-  }
+  // (the record was drained behind the first sweep, the waves' table atomics in front of the barrier)
+  if (wv == 0 && lane == 0) st_agent(a.b.gb + wg, granule(epoch, wg_tot));
 
   // ---- phase 3a: what does not need the place in AC_exact ------------------------------------------------------------
   const unsigned exc_at = lds_offset(tilebuf);
@@ -548,7 +619,7 @@ __global__ __launch_bounds__(OTW * 64) void k_compress_one(const OneFwd<T> a) {
   unsigned E = pre;                                  // this wave's first coefficient in AC_exact[]
 #pragma unroll
   for (int i = 0; i < OTW; i++) E += i < wv ? sh.tot[i] : 0u;
-  if (last_wg && wv == 0) one_handoff_compress<T, MODE>(a, pre + wg_tot, 0u, osf.sf, osf.fast, sh.q0);
+  if (last_wg && wv == 0) one_handoff_compress<T, MODE>(a, pre + wg_tot, 0u, osf.sf, one_sf(a.sft, rs & 0xFFFFu, (rs >> 16) != 0u).fast, sh.q0);
   if (tile_wave) {
     if (MODE == DCTZHIP_QT) {
       // the table is final: clamp (:450-461), normalise this tile's coefficients (:488-518) on their way into the image

@@ -126,6 +126,7 @@ struct dctzhip_ctx {
   double* one_rec = nullptr;
   Ctl* one_ctl = nullptr;           // three blocks: compress calls alternate between [0] and [1] (a call's hand-off zeroes the other one); [2]: decode's error word
   unsigned one_cslot = 0;
+  int one_bad_guess = 0;            // DCTZHIP_ONE_BADGUESS (tests): 1 = the replay path of k_compress_one on every call, 3 = it guesses whatever the grid
   unsigned long long* one_dbg = nullptr;   // DCTZHIP_ONE_STAMPS=1: 16 time stamps per workgroup of the last one-launch kernel
   unsigned one_epoch = 0;
   int one = 1;                      // 0: always the chain of kernels (DCTZHIP_ONE)
@@ -237,6 +238,7 @@ extern "C" int dctzhip_ctx_create(dctzhip_ctx** out, int device) {
   if (const char* e = getenv("DCTZHIP_DEFLATE_SIDE")) c->dfl_side = atoi(e) != 0;
   if (int rc = build_sf_tables(c)) return rc;
   if (const char* e = getenv("DCTZHIP_ONE")) c->one = atoi(e) != 0;
+  if (const char* e = getenv("DCTZHIP_ONE_BADGUESS")) c->one_bad_guess = atoi(e);
   HIPCHK(nullptr, hipMalloc(&c->one_ga, sizeof(unsigned long long) * ONE_BOARD));
   HIPCHK(nullptr, hipMalloc(&c->one_gb, sizeof(unsigned long long) * ONE_BOARD));
   HIPCHK(nullptr, hipMalloc(&c->one_rec, sizeof(double) * 3 * ONE_BOARD));
@@ -815,7 +817,7 @@ static int compress_one(dctzhip_ctx* c, const T* d_in, size_t n, double eb, int 
   const unsigned long long seq = ++c->seq;
   a.seq = seq;
   a.ctl_next = c->one_ctl + (slot ^ 1u);
-  a.eb = eb; a.rem = (unsigned)rem;
+  a.eb = eb; a.rem = (unsigned)rem; a.bad_guess = (unsigned)c->one_bad_guess;
   if (c->profiling) { HIPCHK(c, hipEventRecord(c->ev[0], s)); HIPCHK(c, hipEventRecord(c->ev[1], s)); HIPCHK(c, hipEventRecord(c->ev[2], s)); }
   launch_compress_one<T>(a, mode, d_scaled != nullptr, s);
   if (c->profiling) { HIPCHK(c, hipEventRecord(c->ev[3], s)); HIPCHK(c, hipEventRecord(c->ev[4], s)); }

@@ -364,6 +364,34 @@ def test_in_place_scaling_every_layout(ctx, one, dtype, mode, n, sf_one):
         assert _same(np.array(info.qtable[:], dtype=dtype), c.qtable)
 
 
+@pytest.mark.parametrize("forced", [False, True])
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+@pytest.mark.parametrize("mode", [O.EC, O.QT])
+def test_one_launch_wrong_guess_of_the_decade_is_replayed(dtype, mode, forced, monkeypatch):
+    """k_compress_one scales on a guess of the array's decade (own tiles + a 1024-element sample) and verifies it against
+    the board afterwards; a wrong guess runs the tile again from its image in LDS.  forced: the library makes every first
+    guess wrong (DCTZHIP_ONE_BADGUESS); else a spike between the sample's positions, which only its own workgroup sees."""
+    import dctz_amd
+    monkeypatch.setenv("DCTZHIP_ONE_BADGUESS", "1" if forced else "3")    # (3: guess whatever the grid, not only from 128 workgroups on)
+    c = dctz_amd.Context(0)
+    try:
+        for n in ((1 << 20) + 64 * 3 + 9, 64 * 64 * 7 + 5):
+            x = W.ragged(n, dtype, scale=37.0)
+            if not forced:
+                x[12345 + 64 * 7] = 4.0e4              # (the sample reads 64 whole blocks: block k nfull / 64)
+            ref = O.compress(x, 1e-3, mode, O.FAST)
+            out, info = c.compress(_dev(c, x), 1e-3, mode)
+            assert info.flags & H.INFO_ONE_LAUNCH
+            assert info.sf == ref.sf and info.cnt == ref.cnt and info.max_abs == float(np.abs(x).max())
+            assert np.array_equal(out["bin_index"].cpu().numpy(), ref.bin_index)
+            assert _same(out["dc"].cpu().numpy(), ref.dc)
+            assert _same(out["ac_exact"][:ref.cnt].cpu().numpy(), ref.ac_exact)
+            if mode == O.QT:
+                assert _same(np.array(info.qtable[:], dtype=dtype), ref.qtable)
+    finally:
+        c.close()
+
+
 @pytest.mark.parametrize("dtype", [np.float64, np.float32])
 @pytest.mark.parametrize("mode", [O.EC, O.QT])
 def test_multi_tile_workgroup_ranges_bit_exact(ctx, dtype, mode):
