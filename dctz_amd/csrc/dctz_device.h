@@ -287,11 +287,11 @@ struct BatchInv {
 struct BatchResC {
   double sf_used;                  // scaling factor the device chose (k_sf_batch), verified by the host afterwards
   double stats[3];                 // max|x|, min|x|, sum
-  unsigned cnt, error, fast_used, pad;
+  unsigned cnt, error, fast_used, pad;   // pad: one-launch batches write their tag here, last
   unsigned long long q0;           // bits of the last block's DC (qtable[0])
 };
 struct BatchResQ { unsigned long long qraw[64]; };        // QT: per-position maxima, raw bits of T
-struct BatchResD { unsigned total, error; };              // decode: flags found / 2 = more than ac_count provides
+struct BatchResD { unsigned total, error, tag, pad; };    // decode: flags found / 2 = more than ac_count provides; tag: one-launch batches (written last)
 struct BatchFin {
   unsigned long long* word;        // mailbox word (device view) this sequence publishes `seq` into; NULL: it does not publish
                                    // (a later sequence of its chain does)
@@ -338,6 +338,9 @@ struct OneFwd {
   HostBox* box;                    // hand-off by the launch's last workgroup
   unsigned long long seq;
   Ctl* ctl_next;                   // the control block of the NEXT one-launch call: zeroed by the hand-off workgroup
+  struct BatchResC* bres;          // batch: the array's entry of the result table instead of the mailbox (box == NULL then)
+  struct BatchResQ* bresq;
+  unsigned tag, pad_tag;
   double eb;
   unsigned rem;                    // N % 64
   unsigned bad_guess;              // (tests) the first guess of the array's decade is made wrong on purpose: every tile runs twice
@@ -349,12 +352,58 @@ struct OneInv {
   HostBox* box;
   unsigned long long seq;
   unsigned rem;
-  unsigned pad;
+  unsigned tag;
+  struct BatchResD* bres;          // batch: the array's entry of the result table instead of the mailbox
+  const T* qtab_ptr;               // QT, batch: the array's table in memory; NULL: qtab[] below
   T qtab[64];                      // QT: the clamped table (dctz-decomp-lib.c:193-199), in the kernel's arguments
+};
+// A BATCH through the one-launch kernels: the arrays of one element type share a launch, every array with its own
+// workgroups, its own stretch of the board and its own entry of the result table.  A workgroup finds everything about its
+// array in ONE 128-byte record indexed by its number (pinned host memory the kernel reads once, with scalar loads: one trip
+// over PCIe per workgroup instead of a copy in front of the launch); what the arrays share rides in the kernel's arguments.
+struct OneRecC {
+  const void* x; void* bin; float* dc; float* ac; void* scaled; const void* rtab;
+  double bin_width, range_min, range_max, eb;      // values of the element type, widened
+  unsigned nfull, ntiles, rem, fast_bw;
+  unsigned wg_local, nwg, board_base, item;        // this workgroup among those of its array; first granule of the array; array
+  unsigned pad[4];
+};
+struct OneRecD {
+  const void* bin; const float* dc; const float* ac; void* out; const void* rtab; const void* qtab;
+  double sf, bin_width, range_min, range_max, eb;
+  unsigned nfull, ntiles, rem, ac_count;
+  unsigned wg_local, nwg, board_base, item;
+  unsigned pad[2];
+};
+static_assert(sizeof(OneRecC) == 128 && sizeof(OneRecD) == 128, "one record = two 64-byte scalar loads");
+template <typename T>
+struct OneBatchC {
+  const OneRecC* recs;
+  const T* tab;
+  Ctl* ctl;                        // per array: this call's control blocks ...
+  Ctl* ctl_next;                   // ... and the next call's (zeroed by every array's hand-off)
+  OneBoard b;                      // base pointers and the epoch (nwg: per record)
+  SfTable sft;
+  struct BatchResC* res;           // per array (device view of the host table); `pad` receives `tag` last
+  struct BatchResQ* resq;          // QT
+  unsigned tag;
+  unsigned bad_guess;
+};
+template <typename T>
+struct OneBatchD {
+  const OneRecD* recs;
+  const T* tab;
+  Ctl* ctl;
+  OneBoard b;
+  struct BatchResD* res;
+  unsigned tag;
+  unsigned pad;
 };
 constexpr unsigned ONE_ERR_TIMEOUT = 3u;   // Ctl::error / HostBox::error: a sweep of the board gave up (a workgroup was not resident)
 template <typename T> void launch_compress_one(const OneFwd<T>& a, int mode, bool scaled, hipStream_t s);
 template <typename T> void launch_decompress_one(const OneInv<T>& a, int mode, hipStream_t s);
+template <typename T> void launch_compress_one_batch(const OneBatchC<T>& cm, unsigned grid, int mode, bool scaled, hipStream_t s);
+template <typename T> void launch_decompress_one_batch(const OneBatchD<T>& cm, unsigned grid, int mode, hipStream_t s);
 template <typename T> int compress_one_occupancy(int mode, bool scaled);
 template <typename T> int decompress_one_occupancy(int mode);
 

@@ -55,6 +55,19 @@ constexpr int ONE_SPEC_MIN_WG = 128;                         // workgroups from 
 __device__ __forceinline__ void one_stamp(const OneBoard& b, int k) {
   if (b.dbg != nullptr && threadIdx.x == 0) b.dbg[(size_t)blockIdx.x * 16 + k] = __builtin_amdgcn_s_memrealtime();
 }
+// a record of a batch launch, dword by dword through the constant address space (scalar loads: the index is uniform)
+template <typename S>
+__device__ __forceinline__ S one_load_rec(const S* src) {
+  static_assert(sizeof(S) % 4 == 0, "records are whole dwords");
+  constexpr int W = (int)(sizeof(S) / 4);
+  const __attribute__((address_space(4))) unsigned* w = (const __attribute__((address_space(4))) unsigned*)(src);
+  unsigned buf[W];
+#pragma unroll
+  for (int i = 0; i < W; i++) buf[i] = w[i];
+  S v;
+  __builtin_memcpy(&v, buf, sizeof(S));
+  return v;
+}
 
 // Sweep granules g[0 .. count) by ONE wave: use(value, index) once per granule, by the lane that read it; false: gave up
 // (a tag never came).  Up to eight granules per lane in flight; a pass that finds a foreign tag is repeated after a
@@ -170,23 +183,35 @@ __device__ __forceinline__ void one_handoff_compress(const OneFwd<T>& a, unsigne
   dmx = wave_minmax<true>(dmx);
   dmn = wave_minmax<false>(dmn);
   sum = wave_sum_f64(sum);
+  // the other control block is the next call's: all-zero when that call starts (kernel boundary)
+  unsigned long long* w = reinterpret_cast<unsigned long long*>(a.ctl_next);
+  for (unsigned i = lane; i < (unsigned)(sizeof(Ctl) / 8); i += 64u) w[i] = 0ull;
+  const unsigned long long qr = (MODE == DCTZHIP_QT && error == 0u) ? ld_agent(&a.p.ctl->qraw[lane]) : 0ull;
+  if (a.bres != nullptr) {                           // one array of a batch: its entry of the result table, the tag last
+    if (MODE == DCTZHIP_QT) a.bresq->qraw[lane] = qr;
+    if (lane == 0) {
+      BatchResC* r = a.bres;
+      r->sf_used = sf; r->stats[0] = dmx; r->stats[1] = dmn; r->stats[2] = sum;
+      r->cnt = cnt_total; r->error = error; r->fast_used = fast; r->q0 = q0bits;
+    }
+    __threadfence_system();
+    if (lane == 0) __hip_atomic_store(&a.bres->pad, a.tag, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    return;
+  }
   HostBox* box = a.box;
-  box->qraw[lane] = (MODE == DCTZHIP_QT && error == 0u) ? ld_agent(&a.p.ctl->qraw[lane]) : 0ull;
+  box->qraw[lane] = qr;
   if (lane == 0) {
     box->fstats[0] = dmx; box->fstats[1] = dmn; box->fstats[2] = sum;
     box->cnt_total = cnt_total; box->error = error; box->q0 = q0bits;
     box->sf_used = sf; box->fast_used = fast;
   }
-  // the other control block is the next call's: all-zero when that call starts (kernel boundary)
-  unsigned long long* w = reinterpret_cast<unsigned long long*>(a.ctl_next);
-  for (unsigned i = lane; i < (unsigned)(sizeof(Ctl) / 8); i += 64u) w[i] = 0ull;
   __threadfence_system();
   if (lane == 0) box_publish(&box->seq_done, a.seq);
 }
 
 // ================================================================= compress ==
 template <typename T, int MODE, bool SC>
-__global__ __launch_bounds__(OTW * 64) void k_compress_one(const OneFwd<T> a) {
+__device__ __forceinline__ void compress_one_body(const OneFwd<T>& a, const unsigned wg) {
   using G = Geo<T, 1>;
   using Bits = typename Traits<T>::Bits;
   constexpr bool F64 = sizeof(T) == 8;
@@ -199,7 +224,7 @@ __global__ __launch_bounds__(OTW * 64) void k_compress_one(const OneFwd<T> a) {
   __shared__ OneShared sh;
   static_assert(G::TILEB >= (int)(ONE_EXC_MAX + 64u) * 4, "a dense tile's coefficients and the dump slots fit the image");
   const FwdParams<T>& p = a.p;
-  const unsigned wg = blockIdx.x, epoch = a.b.epoch, nwg = a.b.nwg;
+  const unsigned epoch = a.b.epoch, nwg = a.b.nwg;
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   unsigned char* const tilebuf = tile_all[wv];
   Bits* const qmax_lds = reinterpret_cast<Bits*>(qt_all[MODE == DCTZHIP_QT ? wv : 0]);
@@ -397,7 +422,7 @@ __global__ __launch_bounds__(OTW * 64) void k_compress_one(const OneFwd<T> a) {
           for (int j = 0; j < 64; j++) x[j] = x[j] / sfd.d;
         }
       }
-      if constexpr (SC) {
+      if (SC && p.scaled != nullptr) {               // (an array of a batch may not ask for it)
         // the reference's in-place x / sf of the caller's array (:193-216), into p.scaled (which may be the input itself: the
         // tile is in registers): registers -> the image -> 1 KiB rows, as k_decompress writes its output
         const __amdgpu_buffer_rsrc_t r_sc = __builtin_amdgcn_make_buffer_rsrc(p.scaled + first_el, 0, range_el * (int)sizeof(T), 0x00020000);
@@ -659,10 +684,40 @@ __global__ __launch_bounds__(OTW * 64) void k_compress_one(const OneFwd<T> a) {
   one_stamp(a.b, 9);
 }
 
+template <typename T, int MODE, bool SC>
+__global__ __launch_bounds__(OTW * 64) void k_compress_one(const OneFwd<T> a) {
+  compress_one_body<T, MODE, SC>(a, blockIdx.x);
+}
+// a batch: the workgroup's record says which array it works for and as which of that array's workgroups
+template <typename T, int MODE, bool SC>
+__global__ __launch_bounds__(OTW * 64) void k_compress_one_batch(const OneBatchC<T> cm) {
+  const OneRecC r = one_load_rec(&cm.recs[blockIdx.x]);
+  OneFwd<T> a;
+  FwdParams<T>& p = a.p;
+  p.x = (const T*)r.x; p.bin = (uint8_t*)r.bin; p.dc = r.dc; p.ac = r.ac; p.coef = nullptr; p.scaled = (T*)r.scaled;
+  p.tab = cm.tab; p.rtab = (const T*)r.rtab; p.ctl = cm.ctl + r.item;
+  p.nfull = r.nfull; p.ntiles = r.ntiles; p.last_is_full = r.rem ? 0u : 1u; p.fast_bw = r.fast_bw;
+  p.bin_width = (T)r.bin_width; p.range_min = (T)r.range_min; p.range_max = (T)r.range_max;
+  a.b.ga = cm.b.ga + r.board_base; a.b.gb = cm.b.gb + r.board_base; a.b.rec = cm.b.rec + 3 * (size_t)r.board_base;
+  a.b.epoch = cm.b.epoch; a.b.nwg = r.nwg; a.b.dbg = cm.b.dbg;
+  a.sft = cm.sft;
+  a.box = nullptr; a.seq = 0;
+  a.ctl_next = cm.ctl_next + r.item;
+  a.bres = cm.res + r.item; a.bresq = cm.resq ? cm.resq + r.item : nullptr; a.tag = cm.tag;
+  a.eb = r.eb; a.rem = r.rem; a.bad_guess = cm.bad_guess;
+  compress_one_body<T, MODE, SC>(a, r.wg_local);
+}
+
 // =============================================================== decompress ==
 template <typename T>
 __device__ __forceinline__ void one_handoff_decompress(const OneInv<T>& a, unsigned total, unsigned error) {
   const unsigned lane = threadIdx.x & 63u;
+  if (a.bres != nullptr) {                           // one array of a batch
+    if (lane == 0) { a.bres->total = total; a.bres->error = error; }
+    __threadfence_system();
+    if (lane == 0) __hip_atomic_store(&a.bres->tag, a.tag, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    return;
+  }
   HostBox* box = a.box;
   if (lane == 0) { box->cnt_total = total; box->error = error; }
   __threadfence_system();
@@ -670,7 +725,7 @@ __device__ __forceinline__ void one_handoff_decompress(const OneInv<T>& a, unsig
 }
 
 template <typename T, int MODE>
-__global__ __launch_bounds__(OTW * 64) void k_decompress_one(const OneInv<T> a) {
+__device__ __forceinline__ void decompress_one_body(const OneInv<T>& a, const unsigned wg) {
   using G = Geo<T, 1>;
   // per wave ONE array: the tile's exact coefficients (up to 4032 floats, staged by LDS-DMA), then the output image
   __shared__ __attribute__((aligned(1024))) unsigned char io_all[OTW][G::TILEB];
@@ -679,7 +734,7 @@ __global__ __launch_bounds__(OTW * 64) void k_decompress_one(const OneInv<T> a) 
   __shared__ T qt[64];
   __shared__ unsigned sh_tot[OTW], sh_prefix;
   const InvParams<T>& p = a.p;
-  const unsigned wg = blockIdx.x, epoch = a.b.epoch, nwg = a.b.nwg;
+  const unsigned epoch = a.b.epoch, nwg = a.b.nwg;
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   unsigned char* const io = io_all[wv];
   const unsigned ntw = (p.ntiles + (unsigned)OTW - 1u) / (unsigned)OTW;
@@ -699,7 +754,7 @@ __global__ __launch_bounds__(OTW * 64) void k_decompress_one(const OneInv<T> a) 
       const int ti = (b & 1) ? (b >> 1) + 1 : -(b >> 1);
       bctab[b] = (T)ti * p.bin_width;
     }
-  if (MODE == DCTZHIP_QT && threadIdx.x < 64) qt[threadIdx.x] = a.qtab[threadIdx.x];
+  if (MODE == DCTZHIP_QT && threadIdx.x < 64) qt[threadIdx.x] = a.qtab_ptr ? a.qtab_ptr[threadIdx.x] : a.qtab[threadIdx.x];
   // ---- the flags of the tile (dctz-decomp-lib.c:400 / :446) -------------------------------------------------------------
   one_stamp(a.b, 0);
   unsigned w[16];
@@ -893,7 +948,44 @@ __global__ __launch_bounds__(OTW * 64) void k_decompress_one(const OneInv<T> a) 
   one_stamp(a.b, 9);
 }
 
+template <typename T, int MODE>
+__global__ __launch_bounds__(OTW * 64) void k_decompress_one(const OneInv<T> a) {
+  decompress_one_body<T, MODE>(a, blockIdx.x);
+}
+template <typename T, int MODE>
+__global__ __launch_bounds__(OTW * 64) void k_decompress_one_batch(const OneBatchD<T> cm) {
+  const OneRecD r = one_load_rec(&cm.recs[blockIdx.x]);
+  OneInv<T> a;
+  InvParams<T>& p = a.p;
+  p.bin = (const uint8_t*)r.bin; p.dc = r.dc; p.ac = r.ac; p.out = (T*)r.out;
+  p.tab = cm.tab; p.rtab = (const T*)r.rtab; p.qtab = nullptr; p.ctl = cm.ctl + r.item;
+  p.nfull = r.nfull; p.ntiles = r.ntiles; p.ac_count = r.ac_count;
+  p.sf = (T)r.sf; p.bin_width = (T)r.bin_width; p.range_min = (T)r.range_min; p.range_max = (T)r.range_max; p.eb = r.eb;
+  a.b.ga = nullptr; a.b.gb = cm.b.gb + r.board_base; a.b.rec = nullptr; a.b.epoch = cm.b.epoch; a.b.nwg = r.nwg; a.b.dbg = cm.b.dbg;
+  a.box = nullptr; a.seq = 0; a.rem = r.rem; a.tag = cm.tag;
+  a.bres = cm.res + r.item;
+  a.qtab_ptr = (const T*)r.qtab;
+  decompress_one_body<T, MODE>(a, r.wg_local);
+}
+
 // ================================================================= launchers ==
+template <typename T>
+void launch_compress_one_batch(const OneBatchC<T>& cm, unsigned grid, int mode, bool scaled, hipStream_t s) {
+  const dim3 g(grid), blk(OTW * 64);
+  if (mode == DCTZHIP_EC) {
+    if (scaled) hipLaunchKernelGGL((k_compress_one_batch<T, DCTZHIP_EC, true>), g, blk, 0, s, cm);
+    else hipLaunchKernelGGL((k_compress_one_batch<T, DCTZHIP_EC, false>), g, blk, 0, s, cm);
+  } else {
+    if (scaled) hipLaunchKernelGGL((k_compress_one_batch<T, DCTZHIP_QT, true>), g, blk, 0, s, cm);
+    else hipLaunchKernelGGL((k_compress_one_batch<T, DCTZHIP_QT, false>), g, blk, 0, s, cm);
+  }
+}
+template <typename T>
+void launch_decompress_one_batch(const OneBatchD<T>& cm, unsigned grid, int mode, hipStream_t s) {
+  const dim3 g(grid), blk(OTW * 64);
+  if (mode == DCTZHIP_EC) hipLaunchKernelGGL((k_decompress_one_batch<T, DCTZHIP_EC>), g, blk, 0, s, cm);
+  else hipLaunchKernelGGL((k_decompress_one_batch<T, DCTZHIP_QT>), g, blk, 0, s, cm);
+}
 template <typename T>
 void launch_compress_one(const OneFwd<T>& a, int mode, bool scaled, hipStream_t s) {
   const dim3 grid(a.b.nwg), blk(OTW * 64);
@@ -932,6 +1024,8 @@ int decompress_one_occupancy(int mode) {
 #define INST_ONE(T)                                                                   \
   template void launch_compress_one<T>(const OneFwd<T>&, int, bool, hipStream_t);     \
   template void launch_decompress_one<T>(const OneInv<T>&, int, hipStream_t);         \
+  template void launch_compress_one_batch<T>(const OneBatchC<T>&, unsigned, int, bool, hipStream_t); \
+  template void launch_decompress_one_batch<T>(const OneBatchD<T>&, unsigned, int, hipStream_t);     \
   template int compress_one_occupancy<T>(int, bool);                                  \
   template int decompress_one_occupancy<T>(int);
 INST_ONE(double)

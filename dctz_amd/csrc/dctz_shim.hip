@@ -133,6 +133,10 @@ struct dctzhip_ctx {
   int one_cooldown = 0;             // calls left on the chain after a launch whose workgroups were not all resident
   int one_occ[2][2][2][2] = {};     // resident workgroups per CU [f64][decode][qt][scaled], 0 = not asked yet
   unsigned long long one_calls = 0, one_fallbacks = 0;
+  Ctl* one_bctl = nullptr;          // batches through the one-launch kernels: two halves of one_bctl_cap control blocks (this call's, the next call's)
+  size_t one_bctl_cap = 0;
+  unsigned one_bslot = 0, one_bdirty[2] = {0, 0};   // half of the next call; leading entries of a half that may be non-zero
+  int b_one_seen[2] = {0, 0};       // element types of the current batch call that went through the one-launch kernels (profiling)
   hipStream_t b_stream = nullptr;   // a mixed batch runs its fp32 sequences here, beside the fp64 ones on the context's stream
   hipEvent_t b_fork = nullptr, b_join = nullptr;
   hipEvent_t b_ev[2][5] = {};       // profiling: per element-type sequence of the last batch call
@@ -258,7 +262,7 @@ extern "C" void dctzhip_ctx_destroy(dctzhip_ctx* c) {
   (void)dctzhip_comm_destroy(c);
   (void)hipStreamSynchronize(c->stream);
   if (c->side_stream) { (void)hipStreamSynchronize(c->side_stream); (void)hipStreamDestroy(c->side_stream); }
-  void* bufs[] = {c->one_dbg, c->one_ga, c->one_gb, c->one_rec, c->one_ctl, c->qcnt, c->ttot, c->ac_tmp, c->tile_cnt, c->wg_cnt, c->serial_out, c->tab_f64, c->tab_f32, c->rtab, c->qtab, c->ctl, c->part, c->stats_out, c->qt_item, c->qt_j, c->nd_buf, c->dfl_buf, c->sf_thr[0], c->sf_thr[1], c->sf_pw[0], c->sf_pw[1], c->sf_guess};
+  void* bufs[] = {c->one_bctl, c->one_dbg, c->one_ga, c->one_gb, c->one_rec, c->one_ctl, c->qcnt, c->ttot, c->ac_tmp, c->tile_cnt, c->wg_cnt, c->serial_out, c->tab_f64, c->tab_f32, c->rtab, c->qtab, c->ctl, c->part, c->stats_out, c->qt_item, c->qt_j, c->nd_buf, c->dfl_buf, c->sf_thr[0], c->sf_thr[1], c->sf_pw[0], c->sf_pw[1], c->sf_guess};
   for (void* b : bufs) if (b) (void)hipFree(b);
   if (c->h_pin) (void)hipHostFree(c->h_pin);
   if (c->box) (void)hipHostFree(c->box);
@@ -1792,6 +1796,307 @@ extern "C" int dctzhip_last_batch_timings(dctzhip_ctx* c, dctzhip_timings t[2]) 
   return DCTZHIP_OK;
 }
 
+// ---- batches through the one-launch kernels ---------------------------------------------------------------------------
+// The arrays of one element type whose workgroups all fit the chip at once -- ONE_TW tiles per workgroup, as in
+// compress_one -- share ONE launch: every array has its own workgroups, its own stretch of the board and its own entry of
+// the result table, and the host waits for every entry's tag.  A mixed batch is two launches one after the other on the
+// context's stream (two kernels that both need all their workgroups resident must not share the chip).  Arrays that do
+// not fit, and every array when such a launch gives up, go through the chain of batch kernels below, as before.
+static int wait_tags(dctzhip_ctx* c, const volatile unsigned* first, size_t stride_bytes, size_t k, unsigned tag, const char* what) {
+  const auto t0 = std::chrono::steady_clock::now();
+  size_t at = 0;
+  for (unsigned long long spins = 1; at < k; spins++) {
+    const volatile unsigned* w = reinterpret_cast<const volatile unsigned*>(reinterpret_cast<const volatile char*>(first) + at * stride_bytes);
+    if (__atomic_load_n(w, __ATOMIC_ACQUIRE) == tag) { at++; continue; }
+    __builtin_ia32_pause();
+    if ((spins & 0xFFFF) == 0) {
+      const hipError_t q = hipStreamQuery(c->stream);
+      if (q == hipSuccess) {
+        if (__atomic_load_n(w, __ATOMIC_ACQUIRE) == tag) continue;
+        return fail(c, DCTZHIP_E_INTERNAL, "%s: stream drained without publishing its results", what);
+      }
+      if (q != hipErrorNotReady) return fail(c, DCTZHIP_E_HIP, "%s: %s", what, hipGetErrorString(q));
+      if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(10)) return fail(c, DCTZHIP_E_INTERNAL, "%s: no result after 10 s", what);
+    }
+  }
+  return DCTZHIP_OK;
+}
+namespace {
+struct OnePlan { std::vector<int> idx; std::vector<unsigned> nwg; unsigned grid = 0; bool scaled = false; size_t item_off = 0, rec_off = 0; };
+}
+static unsigned one_wgs_of(size_t n) {
+  const unsigned nfull = (unsigned)(n / 64), ntiles = (nfull + TILE_BLKS - 1) / TILE_BLKS;
+  return (ntiles + ONE_TW - 1) / ONE_TW + ((n % 64) ? 1u : 0u);
+}
+static int ensure_one_bctl(dctzhip_ctx* c, size_t K) {
+  if (K <= c->one_bctl_cap) return DCTZHIP_OK;
+  const size_t cap = K + K / 2 + 16;
+  if (c->one_bctl) HIPCHK(c, hipFree(c->one_bctl));
+  c->one_bctl = nullptr; c->one_bctl_cap = 0;
+  HIPCHK(c, hipMalloc(&c->one_bctl, 2 * cap * sizeof(Ctl)));
+  HIPCHK(c, hipMemset(c->one_bctl, 0, 2 * cap * sizeof(Ctl)));
+  c->one_bctl_cap = cap; c->one_bdirty[0] = c->one_bdirty[1] = 0;
+  return DCTZHIP_OK;
+}
+
+template <typename T>
+static int fill_one_recs_c(dctzhip_ctx* c, const dctzhip_batch_citem* items, const OnePlan& pl, OneRecC* recs) {
+  const int dtype = sizeof(T) == 8 ? DCTZHIP_F64 : DCTZHIP_F32;
+  const int half = DCTZHIP_NBINS / 2;
+  unsigned base = 0;
+  size_t at = 0;
+  for (size_t j = 0; j < pl.idx.size(); j++) {
+    const dctzhip_batch_citem& it = items[pl.idx[j]];
+    const double eb = it.error_bound;
+    OneRecC r;
+    memset(&r, 0, sizeof(r));
+    r.x = it.d_in; r.bin = it.d_bin_index; r.dc = it.d_dc; r.ac = it.d_ac_exact; r.scaled = it.d_scaled;
+    r.nfull = (unsigned)(it.n / 64); r.rem = (unsigned)(it.n % 64); r.ntiles = (r.nfull + TILE_BLKS - 1) / TILE_BLKS;
+    if (r.rem) { const T* rt = nullptr; int rc = rtab_for<T>(c, (int)r.rem, &rt); if (rc) return rc; r.rtab = rt; }
+    const T bw = (T)(eb * 2.0 * 1.0), rmin = (T)(-(half * 2 + 1) * (eb * 1.0)), rmax = (T)((half * 2 + 1) * (eb * 1.0));   // dctz-comp-lib.c:271-281
+    r.bin_width = (double)bw; r.range_min = (double)rmin; r.range_max = (double)rmax; r.eb = eb;
+    r.fast_bw = c->fastdiv ? divisor_in_window(dtype, (double)bw) : 0u;
+    {
+      volatile T u = (T)(rmax - rmin);
+      volatile T q = (T)(u / bw);
+      if (r.fast_bw && c->fastdiv >= 2 && q >= (T)255) r.fast_bw |= 2u;
+    }
+    r.nwg = pl.nwg[j]; r.board_base = base; r.item = (unsigned)(pl.item_off + j);
+    for (unsigned w = 0; w < pl.nwg[j]; w++) { r.wg_local = w; recs[at++] = r; }
+    base += pl.nwg[j];
+  }
+  return DCTZHIP_OK;
+}
+
+static int batch_one_compress(dctzhip_ctx* c, int k, const dctzhip_batch_citem* items, int mode, dctzhip_cinfo* infos, std::vector<char>& done) {
+  c->b_one_seen[0] = c->b_one_seen[1] = 0;
+  if (!c->one || !c->handoff || !c->dev_sf) return DCTZHIP_OK;
+  if (c->one_cooldown > 0) { c->one_cooldown--; return DCTZHIP_OK; }
+  OnePlan pl[2];
+  size_t K = 0, nrec = 0;
+  for (int dt = 1; dt >= 0; dt--) {
+    OnePlan& q = pl[dt];
+    if (c->sf_nk[dt] <= 0 || c->sf_nk[dt] > 64 * (dt == DCTZHIP_F64 ? 10 : 2)) continue;
+    for (int i = 0; i < k; i++) {
+      if (items[i].dtype != dt || items[i].n >= BATCH_BIG) continue;
+      q.idx.push_back(i); q.nwg.push_back(one_wgs_of(items[i].n)); q.grid += q.nwg.back();
+      q.scaled = q.scaled || items[i].d_scaled != nullptr;
+    }
+    const unsigned cap = dt == DCTZHIP_F64 ? one_capacity<double>(c, false, mode, q.scaled) : one_capacity<float>(c, false, mode, q.scaled);
+    if (q.idx.empty() || q.grid > cap || q.grid > (unsigned)ONE_BOARD) { q.idx.clear(); q.nwg.clear(); q.grid = 0; continue; }
+    q.item_off = K; K += q.idx.size();
+    q.rec_off = nrec; nrec += q.grid;
+  }
+  if (K == 0) return DCTZHIP_OK;
+  int rc = ensure_batch(c, K, nrec * sizeof(OneRecC), 0);
+  if (rc) return rc;
+  rc = ensure_batch(c, K, nrec * sizeof(OneRecC), c->b_cap * (sizeof(BatchResC) + (mode == DCTZHIP_QT ? sizeof(BatchResQ) : 0)));
+  if (rc) return rc;
+  rc = ensure_one_bctl(c, K);
+  if (rc) return rc;
+  hipStream_t s = c->stream;
+  const unsigned h = c->one_bslot;
+  c->one_bslot ^= 1u;
+  if (c->one_bdirty[h] > 0) {                        // (entries a call with more arrays than its successor left behind)
+    HIPCHK(c, hipMemsetAsync(c->one_bctl + h * c->one_bctl_cap, 0, c->one_bctl_cap * sizeof(Ctl), s));
+    c->one_bdirty[h] = 0;
+  }
+  const unsigned tag = (unsigned)(++c->seq) | 0x80000000u;
+  BatchResC* res = reinterpret_cast<BatchResC*>(c->b_res);
+  BatchResQ* resq_h = reinterpret_cast<BatchResQ*>(c->b_res + c->b_cap * sizeof(BatchResC));
+  for (size_t i = 0; i < K; i++) res[i].pad = 0;
+  OneRecC* recs = reinterpret_cast<OneRecC*>(c->b_blob);
+  for (int dt = 1; dt >= 0; dt--) {
+    if (pl[dt].idx.empty()) continue;
+    rc = dt == DCTZHIP_F64 ? fill_one_recs_c<double>(c, items, pl[dt], recs + pl[dt].rec_off) : fill_one_recs_c<float>(c, items, pl[dt], recs + pl[dt].rec_off);
+    if (rc) return rc;
+  }
+  __atomic_thread_fence(__ATOMIC_SEQ_CST);             // records and cleared tags are in host memory before the launches read them
+  for (int dt = 1; dt >= 0; dt--) {
+    const OnePlan& q = pl[dt];
+    if (q.idx.empty()) continue;
+    const unsigned epoch = one_next_epoch(c);
+    const bool prof = c->profiling != 0;
+    hipEvent_t* ev = c->b_ev[dt];
+    if (prof) { for (int i = 0; i < 5; i++) if (!ev[i]) HIPCHK(c, hipEventCreate(&ev[i])); HIPCHK(c, hipEventRecord(ev[0], s)); HIPCHK(c, hipEventRecord(ev[1], s)); }
+    OneBoard b;
+    b.ga = c->one_ga; b.gb = c->one_gb; b.rec = c->one_rec; b.epoch = epoch; b.nwg = 0; b.dbg = nullptr;
+    const SfTable sft = {c->sf_thr[dt], c->sf_pw[dt], c->sf_nk[dt], c->fastdiv, dt};
+    BatchResC* res_d = reinterpret_cast<BatchResC*>(c->b_res_hdev);
+    BatchResQ* resq_d = mode == DCTZHIP_QT ? reinterpret_cast<BatchResQ*>(c->b_res_hdev + c->b_cap * sizeof(BatchResC)) : nullptr;
+    const OneRecC* recs_d = reinterpret_cast<const OneRecC*>(c->b_blob_hdev) + q.rec_off;
+    Ctl* ctl = c->one_bctl + h * c->one_bctl_cap;
+    Ctl* ctl_next = c->one_bctl + (h ^ 1u) * c->one_bctl_cap;
+    if (dt == DCTZHIP_F64) {
+      OneBatchC<double> cm = {recs_d, c->tab_f64, ctl, ctl_next, b, sft, res_d, resq_d, tag, (unsigned)c->one_bad_guess};
+      launch_compress_one_batch<double>(cm, q.grid, mode, q.scaled, s);
+    } else {
+      OneBatchC<float> cm = {recs_d, c->tab_f32, ctl, ctl_next, b, sft, res_d, resq_d, tag, (unsigned)c->one_bad_guess};
+      launch_compress_one_batch<float>(cm, q.grid, mode, q.scaled, s);
+    }
+    if (prof) { HIPCHK(c, hipEventRecord(ev[2], s)); HIPCHK(c, hipEventRecord(ev[3], s)); HIPCHK(c, hipEventRecord(ev[4], s)); }
+    HIPCHK(c, hipGetLastError());
+    c->one_calls++;
+    c->b_one_seen[dt] = 1;
+  }
+  // this call's half: dirty where QT maxima were merged (EC leaves it clean); the other half: its first K entries are zeroed
+  if (mode == DCTZHIP_QT) c->one_bdirty[h] = (unsigned)K;
+  if (c->one_bdirty[h ^ 1u] <= K) c->one_bdirty[h ^ 1u] = 0;
+  rc = wait_tags(c, &res[0].pad, sizeof(BatchResC), K, tag, "compress batch (one launch)");
+  if (rc) { (void)one_gave_up(c); c->one_bdirty[0] = c->one_bdirty[1] = (unsigned)c->one_bctl_cap; return rc; }
+  if (c->profiling) {
+    c->b_last[0] = dctzhip_timings{0, 0, 0, 0}; c->b_last[1] = dctzhip_timings{0, 0, 0, 0};
+    for (int dt = 0; dt < 2; dt++) if (c->b_one_seen[dt]) { rc = batch_timings(c, dt); if (rc) return rc; }
+    c->b_have_timings = 1;
+  }
+  bool gave_up = false;
+  for (int dt = 1; dt >= 0; dt--) {
+    const OnePlan& q = pl[dt];
+    for (size_t j = 0; j < q.idx.size(); j++) {
+      const int i = q.idx[j];
+      const BatchResC& r = res[q.item_off + j];
+      const bool in_place = items[i].d_scaled && items[i].d_scaled == items[i].d_in;
+      if (r.error == ONE_ERR_TIMEOUT) {
+        gave_up = true;
+        if (in_place) return fail(c, DCTZHIP_E_INTERNAL, "array %d: one-launch batch gave up after its in-place scaling had begun", i);
+        continue;
+      }
+      if (r.error) return fail(c, DCTZHIP_E_INTERNAL, "array %d: in-kernel error flag set (code %u)", i, r.error);
+      const double true_sf = scaling_factor(dt, r.stats[0]);
+      const bool same = dt == DCTZHIP_F64 ? true_sf == r.sf_used : (float)true_sf == (float)r.sf_used;
+      const bool window_ok = r.fast_used != 2 || (value_in_window(dt, r.stats[1]) && value_in_window(dt, r.stats[0]));
+      if (!same || !window_ok) {                     // (a table bug: never seen; the array is done again by the chain)
+        if (in_place) return fail(c, DCTZHIP_E_INTERNAL, "array %d: scaling factor chosen on the device differs from the host's after an in-place pass", i);
+        c->one = 0;
+        continue;
+      }
+      done[i] = 1;
+      if (!infos) continue;
+      const HostStats st = {r.stats[0], r.stats[1], r.stats[2]};
+      fill_cinfo(&infos[i], dt, mode, true_sf, st, items[i].n, r.cnt, (unsigned)((items[i].n + 63) / 64), DCTZHIP_INFO_STATS_FUSED | DCTZHIP_INFO_ONE_LAUNCH,
+                 resq_h[q.item_off + j].qraw, r.q0);
+    }
+  }
+  if (gave_up) { rc = one_gave_up(c); c->one_bdirty[0] = c->one_bdirty[1] = (unsigned)c->one_bctl_cap; if (rc) return rc; }
+  return DCTZHIP_OK;
+}
+
+template <typename T>
+static int fill_one_recs_d(dctzhip_ctx* c, const dctzhip_batch_ditem* items, const OnePlan& pl, OneRecD* recs, int mode, unsigned char* qt_host,
+                           const unsigned char* qt_dev) {
+  unsigned base = 0;
+  size_t at = 0;
+  for (size_t j = 0; j < pl.idx.size(); j++) {
+    const dctzhip_batch_ditem& it = items[pl.idx[j]];
+    OneRecD r;
+    memset(&r, 0, sizeof(r));
+    r.bin = it.d_bin_index; r.dc = it.d_dc; r.ac = it.d_ac_exact; r.out = it.d_out;
+    r.nfull = (unsigned)(it.n / 64); r.rem = (unsigned)(it.n % 64); r.ntiles = (r.nfull + TILE_BLKS - 1) / TILE_BLKS;
+    r.ac_count = it.ac_count;
+    if (r.rem) { const T* rt = nullptr; int rc = rtab_for<T>(c, (int)r.rem, &rt); if (rc) return rc; r.rtab = rt; }
+    if (mode == DCTZHIP_QT) {
+      memcpy(qt_host + (pl.item_off + j) * 64 * sizeof(double), it.qtable_host, sizeof(T) * 64);
+      r.qtab = qt_dev + (pl.item_off + j) * 64 * sizeof(double);
+    }
+    r.sf = (double)(T)it.sf;
+    r.bin_width = (double)(T)((T)it.error_bound * 2 * 1.0);      // gen_bins / gen_bins_f (binning.c:17 / :37), as decompress_impl
+    r.range_max = (double)(T)(it.error_bound * DCTZHIP_NBINS);   // dctz-decomp-lib.c:372-381
+    r.range_min = (double)(T)(-it.error_bound * DCTZHIP_NBINS);
+    r.eb = it.error_bound;
+    r.nwg = pl.nwg[j]; r.board_base = base; r.item = (unsigned)(pl.item_off + j);
+    for (unsigned w = 0; w < pl.nwg[j]; w++) { r.wg_local = w; recs[at++] = r; }
+    base += pl.nwg[j];
+  }
+  return DCTZHIP_OK;
+}
+
+static int batch_one_decompress(dctzhip_ctx* c, int k, const dctzhip_batch_ditem* items, int mode, int* status, std::vector<char>& done, int* worst) {
+  c->b_one_seen[0] = c->b_one_seen[1] = 0;
+  if (!c->one || !c->handoff) return DCTZHIP_OK;
+  if (c->one_cooldown > 0) { c->one_cooldown--; return DCTZHIP_OK; }
+  OnePlan pl[2];
+  size_t K = 0, nrec = 0;
+  for (int dt = 1; dt >= 0; dt--) {
+    OnePlan& q = pl[dt];
+    for (int i = 0; i < k; i++) {
+      if (items[i].dtype != dt || items[i].n >= BATCH_BIG) continue;
+      q.idx.push_back(i); q.nwg.push_back(one_wgs_of(items[i].n)); q.grid += q.nwg.back();
+    }
+    const unsigned cap = dt == DCTZHIP_F64 ? one_capacity<double>(c, true, mode, false) : one_capacity<float>(c, true, mode, false);
+    if (q.idx.empty() || q.grid > cap || q.grid > (unsigned)ONE_BOARD) { q.idx.clear(); q.nwg.clear(); q.grid = 0; continue; }
+    q.item_off = K; K += q.idx.size();
+    q.rec_off = nrec; nrec += q.grid;
+  }
+  if (K == 0) return DCTZHIP_OK;
+  const size_t qt_off = (nrec * sizeof(OneRecD) + 255) & ~(size_t)255;
+  const size_t blob = qt_off + (mode == DCTZHIP_QT ? K * 64 * sizeof(double) : 0);
+  int rc = ensure_batch(c, K, blob, 0);
+  if (rc) return rc;
+  rc = ensure_batch(c, K, blob, c->b_cap * sizeof(BatchResD));
+  if (rc) return rc;
+  rc = ensure_one_bctl(c, K);
+  if (rc) return rc;
+  hipStream_t s = c->stream;
+  const unsigned tag = (unsigned)(++c->seq) | 0x80000000u;
+  BatchResD* res = reinterpret_cast<BatchResD*>(c->b_res);
+  for (size_t i = 0; i < K; i++) res[i].tag = 0;
+  OneRecD* recs = reinterpret_cast<OneRecD*>(c->b_blob);
+  for (int dt = 1; dt >= 0; dt--) {
+    if (pl[dt].idx.empty()) continue;
+    rc = dt == DCTZHIP_F64 ? fill_one_recs_d<double>(c, items, pl[dt], recs + pl[dt].rec_off, mode, c->b_blob + qt_off, c->b_blob_hdev + qt_off)
+                           : fill_one_recs_d<float>(c, items, pl[dt], recs + pl[dt].rec_off, mode, c->b_blob + qt_off, c->b_blob_hdev + qt_off);
+    if (rc) return rc;
+  }
+  __atomic_thread_fence(__ATOMIC_SEQ_CST);
+  for (int dt = 1; dt >= 0; dt--) {
+    const OnePlan& q = pl[dt];
+    if (q.idx.empty()) continue;
+    const unsigned epoch = one_next_epoch(c);
+    const bool prof = c->profiling != 0;
+    hipEvent_t* ev = c->b_ev[dt];
+    if (prof) { for (int i = 0; i < 5; i++) if (!ev[i]) HIPCHK(c, hipEventCreate(&ev[i])); HIPCHK(c, hipEventRecord(ev[0], s)); HIPCHK(c, hipEventRecord(ev[1], s)); }
+    OneBoard b;
+    b.ga = c->one_ga; b.gb = c->one_gb; b.rec = c->one_rec; b.epoch = epoch; b.nwg = 0; b.dbg = nullptr;
+    const OneRecD* recs_d = reinterpret_cast<const OneRecD*>(c->b_blob_hdev) + q.rec_off;
+    // (decode only ever sets `error` in its control block: any of this context's blocks will do)
+    if (dt == DCTZHIP_F64) {
+      OneBatchD<double> cm = {recs_d, c->tab_f64, c->one_bctl, b, reinterpret_cast<BatchResD*>(c->b_res_hdev), tag, 0u};
+      launch_decompress_one_batch<double>(cm, q.grid, mode, s);
+    } else {
+      OneBatchD<float> cm = {recs_d, c->tab_f32, c->one_bctl, b, reinterpret_cast<BatchResD*>(c->b_res_hdev), tag, 0u};
+      launch_decompress_one_batch<float>(cm, q.grid, mode, s);
+    }
+    if (prof) { HIPCHK(c, hipEventRecord(ev[2], s)); HIPCHK(c, hipEventRecord(ev[3], s)); HIPCHK(c, hipEventRecord(ev[4], s)); }
+    HIPCHK(c, hipGetLastError());
+    c->one_calls++;
+    c->b_one_seen[dt] = 1;
+  }
+  rc = wait_tags(c, &res[0].tag, sizeof(BatchResD), K, tag, "decompress batch (one launch)");
+  if (rc) { (void)one_gave_up(c); return rc; }
+  if (c->profiling) {
+    c->b_last[0] = dctzhip_timings{0, 0, 0, 0}; c->b_last[1] = dctzhip_timings{0, 0, 0, 0};
+    for (int dt = 0; dt < 2; dt++) if (c->b_one_seen[dt]) { rc = batch_timings(c, dt); if (rc) return rc; }
+    c->b_have_timings = 1;
+  }
+  bool gave_up = false;
+  for (int dt = 1; dt >= 0; dt--) {
+    const OnePlan& q = pl[dt];
+    for (size_t j = 0; j < q.idx.size(); j++) {
+      const int i = q.idx[j];
+      const BatchResD& r = res[q.item_off + j];
+      if (r.error == ONE_ERR_TIMEOUT) { gave_up = true; continue; }
+      done[i] = 1;
+      if (r.error == 2) {
+        *worst = DCTZHIP_E_ARG;
+        if (status) status[i] = DCTZHIP_E_ARG;
+        fail(c, DCTZHIP_E_ARG, "array %d: bin_index flags more exact coefficients than ac_count provides", i);
+      } else if (r.error) return fail(c, DCTZHIP_E_INTERNAL, "array %d: in-kernel error flag set (code %u)", i, r.error);
+    }
+  }
+  if (gave_up) { c->one_bdirty[0] = c->one_bdirty[1] = (unsigned)c->one_bctl_cap; rc = one_gave_up(c); if (rc) return rc; }
+  return DCTZHIP_OK;
+}
+
 extern "C" int dctzhip_compress_batch(dctzhip_ctx* c, int k, const dctzhip_batch_citem* items, int mode, dctzhip_cinfo* infos) {
   if (!c) return DCTZHIP_E_ARG;
   if (k < 0 || (k && !items)) return fail(c, DCTZHIP_E_ARG, "dctzhip_compress_batch: bad arguments");
@@ -1807,6 +2112,9 @@ extern "C" int dctzhip_compress_batch(dctzhip_ctx* c, int k, const dctzhip_batch
   }
   HIPCHK(c, hipSetDevice(c->device));
   const bool box = c->handoff != 0 && c->dev_sf && c->sf_nk[0] > 0 && c->sf_nk[1] > 0;
+  // arrays whose workgroups all fit the chip at once: one launch per element type (dctz_kernels_one.hip)
+  std::vector<char> done((size_t)k, 0);
+  { int rc = batch_one_compress(c, k, items, mode, infos, done); if (rc) return rc; }
   // arrays that gain nothing from a batch (launch cost is noise beside their kernels, and the single-array path saves
   // them the statistics pass) -- and every array when the platform has no mailbox -- take the single-array path
   std::vector<int> single;
@@ -1814,7 +2122,7 @@ extern "C" int dctzhip_compress_batch(dctzhip_ctx* c, int k, const dctzhip_batch
   for (int dt = 1; dt >= 0; dt--) {                   // fp64 sequences first, then fp32
     SeqC cur; cur.dtype = dt;
     for (int i = 0; i < k; i++) {
-      if (items[i].dtype != dt) continue;
+      if (items[i].dtype != dt || done[i]) continue;
       if (!box || items[i].n >= BATCH_BIG) { if (dt == items[i].dtype) single.push_back(i); continue; }
       cur.idx.push_back(i);
       if ((int)cur.idx.size() == BATCH_MAX) { seqs.push_back(cur); cur = SeqC(); cur.dtype = dt; }
@@ -1865,7 +2173,7 @@ extern "C" int dctzhip_compress_batch(dctzhip_ctx* c, int k, const dctzhip_batch
     if (rc) return rc;
     if (two) { rc = wait_seq(c, ch[1].word, seq, "compress batch (second chain)"); if (rc) return rc; }
     if (c->profiling) {
-      c->b_last[0] = dctzhip_timings{0, 0, 0, 0}; c->b_last[1] = dctzhip_timings{0, 0, 0, 0};
+      for (int dt = 0; dt < 2; dt++) if (!c->b_one_seen[dt]) c->b_last[dt] = dctzhip_timings{0, 0, 0, 0};
       for (int dt = 0; dt < 2; dt++) if (seen[dt]) { rc = batch_timings(c, dt); if (rc) return rc; }
       c->b_have_timings = 1;
     }
@@ -2017,12 +2325,15 @@ extern "C" int dctzhip_decompress_batch(dctzhip_ctx* c, int k, const dctzhip_bat
   }
   HIPCHK(c, hipSetDevice(c->device));
   const bool box = c->handoff != 0;
+  int worst = DCTZHIP_OK;
+  std::vector<char> done((size_t)k, 0);
+  { int rc = batch_one_decompress(c, k, items, mode, status, done, &worst); if (rc) return rc; }
   std::vector<int> single;
   std::vector<SeqD> seqs;
   for (int dt = 1; dt >= 0; dt--) {
     SeqD cur; cur.dtype = dt;
     for (int i = 0; i < k; i++) {
-      if (items[i].dtype != dt) continue;
+      if (items[i].dtype != dt || done[i]) continue;
       // (an array with tiles but no mailbox, or without any full tile, keeps the single-array path: the batch hands off in
       // the first workgroup of k_decompress_batch)
       if (!box || items[i].n >= BATCH_BIG) { single.push_back(i); continue; }
@@ -2031,7 +2342,6 @@ extern "C" int dctzhip_decompress_batch(dctzhip_ctx* c, int k, const dctzhip_bat
     }
     if (!cur.idx.empty()) seqs.push_back(cur);
   }
-  int worst = DCTZHIP_OK;
   size_t K = 0, blob = 0;
   // a sequence whose arrays have no full tile at all has no k_decompress_batch launch to hand off from: single path
   // (planned once to find out: the grid does not depend on the chains)
@@ -2082,7 +2392,7 @@ extern "C" int dctzhip_decompress_batch(dctzhip_ctx* c, int k, const dctzhip_bat
     if (rc) return rc;
     if (two) { rc = wait_seq(c, ch[1].word, seq, "decompress batch (second chain)"); if (rc) return rc; }
     if (c->profiling) {
-      c->b_last[0] = dctzhip_timings{0, 0, 0, 0}; c->b_last[1] = dctzhip_timings{0, 0, 0, 0};
+      for (int dt = 0; dt < 2; dt++) if (!c->b_one_seen[dt]) c->b_last[dt] = dctzhip_timings{0, 0, 0, 0};
       for (int dt = 0; dt < 2; dt++) if (seen[dt]) { rc = batch_timings(c, dt); if (rc) return rc; }
       c->b_have_timings = 1;
     }
