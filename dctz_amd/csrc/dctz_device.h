@@ -337,7 +337,14 @@ struct OneFwd {
   SfTable sft;
   HostBox* box;                    // hand-off by the launch's last workgroup
   unsigned long long seq;
-  Ctl* ctl_next;                   // the control block of the NEXT one-launch call: zeroed by the hand-off workgroup
+  // QT: the per-position maxima of the whole array (dctz-comp-lib.c:371-372), merged with device atomics -- one per
+  // workgroup and position -- in a table of qt_shards x 64 words, qt_stride words apart: a word per 256 bytes and four shards
+  // for a single array (a few memory channels serialise the atomics on neighbouring words: 1582 waves on two lines of a
+  // contiguous table took 30 us), contiguous and unsharded for the small arrays of a batch.  qt_next: the next call's
+  // table, zeroed by the hand-off.
+  unsigned long long* qt;
+  unsigned long long* qt_next;
+  unsigned qt_stride, qt_shards;
   struct BatchResC* bres;          // batch: the array's entry of the result table instead of the mailbox (box == NULL then)
   struct BatchResQ* bresq;
   unsigned tag, pad_tag;
@@ -354,7 +361,6 @@ struct OneInv {
   unsigned rem;
   unsigned tag;
   struct BatchResD* bres;          // batch: the array's entry of the result table instead of the mailbox
-  const T* qtab_ptr;               // QT, batch: the array's table in memory; NULL: qtab[] below
   T qtab[64];                      // QT: the clamped table (dctz-decomp-lib.c:193-199), in the kernel's arguments
 };
 // A BATCH through the one-launch kernels: the arrays of one element type share a launch, every array with its own
@@ -380,8 +386,9 @@ template <typename T>
 struct OneBatchC {
   const OneRecC* recs;
   const T* tab;
-  Ctl* ctl;                        // per array: this call's control blocks ...
-  Ctl* ctl_next;                   // ... and the next call's (zeroed by every array's hand-off)
+  Ctl* ctl;                        // per array: control blocks (only `error` is used)
+  unsigned long long* qt;          // QT, per array: 64 words of this call's table of maxima ...
+  unsigned long long* qt_next;     // ... and of the next call's (zeroed by every array's hand-off)
   OneBoard b;                      // base pointers and the epoch (nwg: per record)
   SfTable sft;
   struct BatchResC* res;           // per array (device view of the host table); `pad` receives `tag` last

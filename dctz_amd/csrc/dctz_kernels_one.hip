@@ -49,6 +49,8 @@ constexpr unsigned long long ONE_SPIN_TICKS = 2000000ull;   // 20 ms of the 100 
 constexpr unsigned ONE_EXC_MAX = 63u * 64u;                  // "stored exactly" coefficients of a tile at most
 constexpr unsigned ONE_GAVE_UP = 0xFFFFFFFFu;                // what a sweep that timed out leaves for the other waves
 constexpr int OTW = ONE_TW;
+// waves per SIMD the register allocation aims at: fp32 two (two workgroups of 64 KiB of LDS per CU), fp64 one (128 KiB)
+template <typename T> constexpr int one_waves() { return sizeof(T) == 4 ? 2 : 1; }
 constexpr int ONE_SPEC_MIN_WG = 128;                         // workgroups from which k_compress_one scales on a guess (see there)
 
 // Development aid: time stamps of the first wave of every workgroup at the phases of the kernels (OneBoard::dbg != NULL)
@@ -120,6 +122,17 @@ __device__ __forceinline__ double wave_minmax(double v) {           // MAX: valu
 #undef DCTZ_MM_STEP
   return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), 63), __builtin_amdgcn_readlane(__double2loint(v), 63));
 }
+// (the same for one non-negative value of the element type per lane)
+__device__ __forceinline__ double wave_max_pos(double v) { return wave_minmax<true>(v); }
+__device__ __forceinline__ float wave_max_pos(float v) {
+  v = fmaxf(v, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x111, 0xf, 0xf, true)));
+  v = fmaxf(v, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x112, 0xf, 0xf, true)));
+  v = fmaxf(v, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x114, 0xf, 0xf, true)));
+  v = fmaxf(v, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x118, 0xf, 0xf, true)));
+  v = fmaxf(v, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x142, 0xa, 0xf, false)));
+  v = fmaxf(v, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x143, 0xc, 0xf, false)));
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+}
 __device__ __forceinline__ unsigned wave_max_u32(unsigned v) {
   v = max(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, true));
   v = max(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, true));
@@ -165,7 +178,19 @@ struct OneShared {
   double mx[OTW], mn[OTW], sum[OTW];
   unsigned res_stats, res_prefix;  // the sweeps' answers (ONE_GAVE_UP: timed out)
   unsigned long long q0;           // bits of the last block's DC (qtable[0], :355-360)
+  unsigned long long qm[OTW][64];  // QT: the waves' per-position maxima (raw bits)
 };
+
+// QT: position j's maximum over the table's shards (raw bits of T: positive values order like their bits)
+template <typename T>
+__device__ __forceinline__ unsigned long long one_qt_read(const OneFwd<T>& a, unsigned j) {
+  unsigned long long m = 0ull;
+  for (unsigned sd = 0; sd < a.qt_shards; sd++) {
+    const unsigned long long v = ld_agent(a.qt + (size_t)(sd * 64u + j) * a.qt_stride);
+    m = v > m ? v : m;
+  }
+  return m;
+}
 
 // Hand-off of the call's results by the first wave of the launch's LAST workgroup (it has seen every other workgroup's
 // count granule, and every workgroup drained its record and its table atomics in front of that granule).
@@ -183,10 +208,12 @@ __device__ __forceinline__ void one_handoff_compress(const OneFwd<T>& a, unsigne
   dmx = wave_minmax<true>(dmx);
   dmn = wave_minmax<false>(dmn);
   sum = wave_sum_f64(sum);
-  // the other control block is the next call's: all-zero when that call starts (kernel boundary)
-  unsigned long long* w = reinterpret_cast<unsigned long long*>(a.ctl_next);
-  for (unsigned i = lane; i < (unsigned)(sizeof(Ctl) / 8); i += 64u) w[i] = 0ull;
-  const unsigned long long qr = (MODE == DCTZHIP_QT && error == 0u) ? ld_agent(&a.p.ctl->qraw[lane]) : 0ull;
+  // the other table of maxima is the next call's: all-zero when that call starts (kernel boundary)
+  unsigned long long qr = 0ull;
+  if (MODE == DCTZHIP_QT) {
+    for (unsigned sd = 0; sd < a.qt_shards; sd++) a.qt_next[(size_t)(sd * 64u + lane) * a.qt_stride] = 0ull;
+    if (error == 0u) qr = one_qt_read(a, lane);
+  }
   if (a.bres != nullptr) {                           // one array of a batch: its entry of the result table, the tag last
     if (MODE == DCTZHIP_QT) a.bresq->qraw[lane] = qr;
     if (lane == 0) {
@@ -218,17 +245,16 @@ __device__ __forceinline__ void compress_one_body(const OneFwd<T>& a, const unsi
   constexpr int NT = F64 ? 10 : 2;                   // decade thresholds per lane (host: nk <= 64 NT)
   // per wave ONE array: the tile's image (DMA target), then -- SC -- the scaled tile on its way out, then the tile's bin ids
   // on their way out, then the tile's exact coefficients in the reference's order (fp32: two workgroups per CU, 64 KiB each);
-  // QT: the wave's per-position maxima and the clamped table
+  // QT: the clamped table
   __shared__ __attribute__((aligned(1024))) unsigned char tile_all[OTW][G::TILEB];
-  __shared__ __attribute__((aligned(16))) T qt_all[MODE == DCTZHIP_QT ? OTW : 1][MODE == DCTZHIP_QT ? 128 : 1];
+  __shared__ __attribute__((aligned(16))) T qt_all[MODE == DCTZHIP_QT ? OTW : 1][MODE == DCTZHIP_QT ? 64 : 1];
   __shared__ OneShared sh;
   static_assert(G::TILEB >= (int)(ONE_EXC_MAX + 64u) * 4, "a dense tile's coefficients and the dump slots fit the image");
   const FwdParams<T>& p = a.p;
   const unsigned epoch = a.b.epoch, nwg = a.b.nwg;
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   unsigned char* const tilebuf = tile_all[wv];
-  Bits* const qmax_lds = reinterpret_cast<Bits*>(qt_all[MODE == DCTZHIP_QT ? wv : 0]);
-  T* const qt_lds = qt_all[MODE == DCTZHIP_QT ? wv : 0] + (MODE == DCTZHIP_QT ? 64 : 0);
+  T* const qt_lds = qt_all[MODE == DCTZHIP_QT ? wv : 0];
   const unsigned ntw = (p.ntiles + (unsigned)OTW - 1u) / (unsigned)OTW;    // workgroups that hold tiles; workgroup ntw: the short last block
   const bool rem_wg = wg == ntw;
   const unsigned tile = wg * (unsigned)OTW + (unsigned)wv;
@@ -259,7 +285,6 @@ __device__ __forceinline__ void compress_one_body(const OneFwd<T>& a, const unsi
   double mx = 0.0, mn = 1.79769313486231570815e308, rsum = 0.0;
   unsigned word = 0, gword = 0;
   if (tile_wave) {
-    if (MODE == DCTZHIP_QT) qmax_lds[lane] = 0;
     const __amdgpu_buffer_rsrc_t r_in = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(p.x + first_el), 0, range_el * (int)sizeof(T), 0x00020000);
     issue_phase_dma<T, 1>(r_in, 0u, 0, tilebuf, tm);
     // (under the DMA: the decade thresholds this lane compares the tile's maximum with)
@@ -387,6 +412,7 @@ __device__ __forceinline__ void compress_one_body(const OneFwd<T>& a, const unsi
   T rcoef = T(0);                                    // remainder block: this lane's coefficient
   bool rexc = false;
   unsigned rbin = 0, rrank = 0;
+  unsigned long long qmbits = 0ull;                  // QT: position `lane`'s maximum |coef| over this wave's out-of-range coefficients
   OneSf osf = {1.0, 0u};
   T sf = T(1);
 #pragma clang loop unroll(disable)
@@ -530,10 +556,7 @@ __device__ __forceinline__ void compress_one_body(const OneFwd<T>& a, const unsi
       const unsigned long long m = __builtin_amdgcn_ballot_w64(rexc);
       rrank = (unsigned)__popcll(m & ((1ull << k) - 1ull));
       tot = (unsigned)__popcll(m);
-      if (MODE == DCTZHIP_QT) {
-        if (rexc && fabs(rcoef) > rmax) atomicMax(&p.ctl->qraw[k], (unsigned long long)to_bits(fabs(rcoef)));   // :371-372 / :396-397
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      }
+      if (MODE == DCTZHIP_QT) qmbits = (rexc && fabs(rcoef) > rmax) ? (unsigned long long)to_bits(fabs(rcoef)) : 0ull;   // :371-372 / :396-397
       if (k == 0) sh.q0 = (unsigned long long)to_bits(rcoef);        // :355-360
     }
     if (verified) break;
@@ -549,26 +572,26 @@ __device__ __forceinline__ void compress_one_body(const OneFwd<T>& a, const unsi
   }
   if (tile_wave) {
     if (MODE == DCTZHIP_QT) {
-      // per-position maximum |coef| over the out-of-range coefficients (:371-372 / :396-397): merged in LDS, then one device
-      // atomic per position that has one; drained before the count is posted (the table is read behind ALL counts)
-      const unsigned qmax_at = lds_offset(qmax_lds);
+      // per-position maximum |coef| over the out-of-range coefficients (:371-372 / :396-397): one wave reduction per position
+    // that has one somewhere in the tile (LDS atomics of 64 lanes on ONE word ran the dense C1 tile at 23 us for this step),
+    // lane j keeps position j's; the workgroup's waves merge theirs behind the barrier below
+    T qmv = T(0);
 #pragma unroll
-      for (int g = 0; g < 16; g++) {
-        const unsigned mg = ((g < 8 ? mlo >> (4 * g) : mhi >> (4 * (g - 8)))) & 0xFu;
-        if (__builtin_amdgcn_ballot_w64(mg != 0u)) {
+    for (int g = 0; g < 16; g++) {
+      const unsigned mg = ((g < 8 ? mlo >> (4 * g) : mhi >> (4 * (g - 8)))) & 0xFu;
+      if (__builtin_amdgcn_ballot_w64(mg != 0u)) {
 #pragma unroll
-          for (int i = 0; i < 4; i++) {
-            const T av = fabs(x[4 * g + i]);
-            if (((mg >> i) & 1u) && av > rmax) lds_max_bits(qmax_at + (unsigned)(4 * g + i) * (unsigned)sizeof(Bits), to_bits(av));
-          }
+        for (int i = 0; i < 4; i++) {
+          const T av = fabs(x[4 * g + i]);
+          const T mxv = wave_max_pos((((mg >> i) & 1u) && av > rmax) ? av : T(0));
+          if (lane == 4 * g + i) qmv = mxv;
         }
       }
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      const Bits qm = qmax_lds[lane];
-      if (qm != 0) atomicMax(&p.ctl->qraw[lane], (unsigned long long)qm);
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+      qmbits = (unsigned long long)to_bits(qmv);
     }
   }
+  if (MODE == DCTZHIP_QT) sh.qm[wv][lane] = qmbits;
   if (lane == 0) sh.tot[wv] = tot;
   one_stamp(a.b, 4);
   __syncthreads();
@@ -576,8 +599,19 @@ __device__ __forceinline__ void compress_one_body(const OneFwd<T>& a, const unsi
   unsigned wg_tot = 0;
 #pragma unroll
   for (int i = 0; i < OTW; i++) wg_tot += sh.tot[i];
-  // (the record was drained behind the first sweep, the waves' table atomics in front of the barrier)
-  if (wv == 0 && lane == 0) st_agent(a.b.gb + wg, granule(epoch, wg_tot));
+  if (wv == 0) {
+    if (MODE == DCTZHIP_QT) {
+      // the workgroup's maxima -> the array's table: one device atomic per position that has one, drained before the count
+      // is posted (the table is read behind ALL counts)
+      unsigned long long m = 0ull;
+#pragma unroll
+      for (int i = 0; i < OTW; i++) m = sh.qm[i][lane] > m ? sh.qm[i][lane] : m;
+      if (m != 0ull) atomicMax(a.qt + (size_t)((wg % a.qt_shards) * 64u + (unsigned)lane) * a.qt_stride, m);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    // (the record was drained behind the first sweep)
+    if (lane == 0) st_agent(a.b.gb + wg, granule(epoch, wg_tot));
+  }
 
   // ---- phase 3a: what does not need the place in AC_exact ------------------------------------------------------------
   const unsigned exc_at = lds_offset(tilebuf);
@@ -648,7 +682,7 @@ __device__ __forceinline__ void compress_one_body(const OneFwd<T>& a, const unsi
   if (tile_wave) {
     if (MODE == DCTZHIP_QT) {
       // the table is final: clamp (:450-461), normalise this tile's coefficients (:488-518) on their way into the image
-      T qv = Traits<T>::from_bits((Bits)ld_agent(&p.ctl->qraw[lane]));
+      T qv = Traits<T>::from_bits((Bits)one_qt_read(a, (unsigned)lane));
       if (qv < T(1)) qv = T(1);
       qt_lds[lane] = qv;
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -674,7 +708,7 @@ __device__ __forceinline__ void compress_one_body(const OneFwd<T>& a, const unsi
     if (rexc) {
       T item = rcoef;
       if (MODE == DCTZHIP_QT) {
-        T qv = Traits<T>::from_bits((Bits)ld_agent(&p.ctl->qraw[lane]));
+        T qv = Traits<T>::from_bits((Bits)one_qt_read(a, (unsigned)lane));
         if (qv < T(1)) qv = T(1);                                  // :450-461
         item = qt_normalise(item, qv, a.eb, T(10), rmin, rmax);    // :488-518
       }
@@ -685,12 +719,12 @@ __device__ __forceinline__ void compress_one_body(const OneFwd<T>& a, const unsi
 }
 
 template <typename T, int MODE, bool SC>
-__global__ __launch_bounds__(OTW * 64) void k_compress_one(const OneFwd<T> a) {
+__global__ __launch_bounds__(OTW * 64) __attribute__((amdgpu_waves_per_eu(one_waves<T>(), one_waves<T>()))) void k_compress_one(const OneFwd<T> a) {
   compress_one_body<T, MODE, SC>(a, blockIdx.x);
 }
 // a batch: the workgroup's record says which array it works for and as which of that array's workgroups
 template <typename T, int MODE, bool SC>
-__global__ __launch_bounds__(OTW * 64) void k_compress_one_batch(const OneBatchC<T> cm) {
+__global__ __launch_bounds__(OTW * 64) __attribute__((amdgpu_waves_per_eu(one_waves<T>(), one_waves<T>()))) void k_compress_one_batch(const OneBatchC<T> cm) {
   const OneRecC r = one_load_rec(&cm.recs[blockIdx.x]);
   OneFwd<T> a;
   FwdParams<T>& p = a.p;
@@ -702,7 +736,7 @@ __global__ __launch_bounds__(OTW * 64) void k_compress_one_batch(const OneBatchC
   a.b.epoch = cm.b.epoch; a.b.nwg = r.nwg; a.b.dbg = cm.b.dbg;
   a.sft = cm.sft;
   a.box = nullptr; a.seq = 0;
-  a.ctl_next = cm.ctl_next + r.item;
+  a.qt = cm.qt + (size_t)r.item * 64; a.qt_next = cm.qt_next + (size_t)r.item * 64; a.qt_stride = 1u; a.qt_shards = 1u;
   a.bres = cm.res + r.item; a.bresq = cm.resq ? cm.resq + r.item : nullptr; a.tag = cm.tag;
   a.eb = r.eb; a.rem = r.rem; a.bad_guess = cm.bad_guess;
   compress_one_body<T, MODE, SC>(a, r.wg_local);
@@ -725,7 +759,7 @@ __device__ __forceinline__ void one_handoff_decompress(const OneInv<T>& a, unsig
 }
 
 template <typename T, int MODE>
-__device__ __forceinline__ void decompress_one_body(const OneInv<T>& a, const unsigned wg) {
+__device__ __forceinline__ void decompress_one_body(const OneInv<T>& a, const unsigned wg, const T* qtab_src) {
   using G = Geo<T, 1>;
   // per wave ONE array: the tile's exact coefficients (up to 4032 floats, staged by LDS-DMA), then the output image
   __shared__ __attribute__((aligned(1024))) unsigned char io_all[OTW][G::TILEB];
@@ -754,22 +788,21 @@ __device__ __forceinline__ void decompress_one_body(const OneInv<T>& a, const un
       const int ti = (b & 1) ? (b >> 1) + 1 : -(b >> 1);
       bctab[b] = (T)ti * p.bin_width;
     }
-  if (MODE == DCTZHIP_QT && threadIdx.x < 64) qt[threadIdx.x] = a.qtab_ptr ? a.qtab_ptr[threadIdx.x] : a.qtab[threadIdx.x];
+  if (MODE == DCTZHIP_QT && threadIdx.x < 64) qt[threadIdx.x] = qtab_src[threadIdx.x];
   // ---- the flags of the tile (dctz-decomp-lib.c:400 / :446) -------------------------------------------------------------
   one_stamp(a.b, 0);
-  unsigned w[16];
+  u32x4 bw[4] = {u32x4{0u, 0u, 0u, 0u}, u32x4{0u, 0u, 0u, 0u}, u32x4{0u, 0u, 0u, 0u}, u32x4{0u, 0u, 0u, 0u}};
   float dc_t = 0.f;
   unsigned tot = 0, ptr = 0;
   unsigned rbin = 0, rrank = 0;
   bool rexc = false;
   if (tile_wave) {
     const __amdgpu_buffer_rsrc_t r_bin = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(p.bin + first_el), 0, range_el, 0x00020000);
-    u32x4 bw[4];
 #pragma unroll
     for (int i = 0; i < 4; i++) bw[i] = __builtin_amdgcn_raw_buffer_load_b128(r_bin, lane * 64 + i * 16, 0, 0);
     dc_t = active ? p.dc[(size_t)tile * TILE_BLKS + lane] : 0.f;
-#pragma unroll
-    for (int i = 0; i < 4; i++) { w[4 * i] = bw[i].x; w[4 * i + 1] = bw[i].y; w[4 * i + 2] = bw[i].z; w[4 * i + 3] = bw[i].w; }
+    const unsigned w[16] = {bw[0].x, bw[0].y, bw[0].z, bw[0].w, bw[1].x, bw[1].y, bw[1].z, bw[1].w,
+                            bw[2].x, bw[2].y, bw[2].z, bw[2].w, bw[3].x, bw[3].y, bw[3].z, bw[3].w};
     unsigned n = 0;
 #pragma unroll
     for (int i = 0; i < 16; i++) {
@@ -832,6 +865,8 @@ __device__ __forceinline__ void decompress_one_body(const OneInv<T>& a, const un
     }
     const float* const stage = reinterpret_cast<const float*>(io);
     constexpr unsigned stage_last = (unsigned)(G::TILEB / 4) - 1u;
+    const unsigned w[16] = {bw[0].x, bw[0].y, bw[0].z, bw[0].w, bw[1].x, bw[1].y, bw[1].z, bw[1].w,
+                            bw[2].x, bw[2].y, bw[2].z, bw[2].w, bw[3].x, bw[3].y, bw[3].z, bw[3].w};
     T x[64];
     if constexpr (sizeof(T) == 8) {
       // four coefficients = one dword of bin ids at a time (dctz_kernels.hip: decompress_body)
@@ -949,11 +984,11 @@ __device__ __forceinline__ void decompress_one_body(const OneInv<T>& a, const un
 }
 
 template <typename T, int MODE>
-__global__ __launch_bounds__(OTW * 64) void k_decompress_one(const OneInv<T> a) {
-  decompress_one_body<T, MODE>(a, blockIdx.x);
+__global__ __launch_bounds__(OTW * 64) __attribute__((amdgpu_waves_per_eu(one_waves<T>(), one_waves<T>()))) void k_decompress_one(const OneInv<T> a) {
+  decompress_one_body<T, MODE>(a, blockIdx.x, a.qtab);
 }
 template <typename T, int MODE>
-__global__ __launch_bounds__(OTW * 64) void k_decompress_one_batch(const OneBatchD<T> cm) {
+__global__ __launch_bounds__(OTW * 64) __attribute__((amdgpu_waves_per_eu(one_waves<T>(), one_waves<T>()))) void k_decompress_one_batch(const OneBatchD<T> cm) {
   const OneRecD r = one_load_rec(&cm.recs[blockIdx.x]);
   OneInv<T> a;
   InvParams<T>& p = a.p;
@@ -964,8 +999,7 @@ __global__ __launch_bounds__(OTW * 64) void k_decompress_one_batch(const OneBatc
   a.b.ga = nullptr; a.b.gb = cm.b.gb + r.board_base; a.b.rec = nullptr; a.b.epoch = cm.b.epoch; a.b.nwg = r.nwg; a.b.dbg = cm.b.dbg;
   a.box = nullptr; a.seq = 0; a.rem = r.rem; a.tag = cm.tag;
   a.bres = cm.res + r.item;
-  a.qtab_ptr = (const T*)r.qtab;
-  decompress_one_body<T, MODE>(a, r.wg_local);
+  decompress_one_body<T, MODE>(a, r.wg_local, (const T*)r.qtab);
 }
 
 // ================================================================= launchers ==

@@ -126,6 +126,8 @@ struct dctzhip_ctx {
   double* one_rec = nullptr;
   Ctl* one_ctl = nullptr;           // three blocks: compress calls alternate between [0] and [1] (a call's hand-off zeroes the other one); [2]: decode's error word
   unsigned one_cslot = 0;
+  unsigned long long* one_qt = nullptr;    // QT: two tables of per-position maxima (this call's, the next call's), ONE_QT_WORDS each
+  unsigned long long* one_bqt = nullptr;   // ... of a batch: two halves of one_bctl_cap x 64 words
   int one_bad_guess = 0;            // DCTZHIP_ONE_BADGUESS (tests): 1 = the replay path of k_compress_one on every call, 3 = it guesses whatever the grid
   unsigned long long* one_dbg = nullptr;   // DCTZHIP_ONE_STAMPS=1: 16 time stamps per workgroup of the last one-launch kernel
   unsigned one_epoch = 0;
@@ -152,6 +154,8 @@ static constexpr int PART_SLOTS = 256 * 16 + 64;       // >= largest k_compress 
 static constexpr int SPEC_COOLDOWN = 8;
 static constexpr int ONE_BOARD = 256 * 8 + 64;         // granules of the one-launch path: workgroups of ONE_TW waves, at most 8 per CU
 static constexpr int ONE_COOLDOWN = 64;
+static constexpr unsigned ONE_QT_SHARDS = 4, ONE_QT_STRIDE = 32;      // single arrays: a word per 256 bytes, four shards (dctz_device.h: OneFwd::qt)
+static constexpr size_t ONE_QT_WORDS = (size_t)ONE_QT_SHARDS * 64 * ONE_QT_STRIDE;
 static constexpr int WG_PER_CU_MAX = 12;               // single-wave workgroups per CU: three per SIMD (k_compress<float>: 160 VGPRs, 12 KiB of LDS)
 static constexpr size_t PIN_STATS = 0, PIN_CTL = 64, PIN_TAB = 64 + sizeof(Ctl);
 static constexpr size_t PIN_BYTES = PIN_TAB + sizeof(double) * RTAB_SIZE + sizeof(double) * 64;
@@ -250,6 +254,8 @@ extern "C" int dctzhip_ctx_create(dctzhip_ctx** out, int device) {
   HIPCHK(nullptr, hipMemset(c->one_ga, 0, sizeof(unsigned long long) * ONE_BOARD));
   HIPCHK(nullptr, hipMemset(c->one_gb, 0, sizeof(unsigned long long) * ONE_BOARD));
   HIPCHK(nullptr, hipMemset(c->one_ctl, 0, sizeof(Ctl) * 3));
+  HIPCHK(nullptr, hipMalloc(&c->one_qt, sizeof(unsigned long long) * 2 * ONE_QT_WORDS));
+  HIPCHK(nullptr, hipMemset(c->one_qt, 0, sizeof(unsigned long long) * 2 * ONE_QT_WORDS));
   if (const char* e = getenv("DCTZHIP_ONE_STAMPS")) if (atoi(e)) { HIPCHK(nullptr, hipMalloc(&c->one_dbg, sizeof(unsigned long long) * 16 * ONE_BOARD)); HIPCHK(nullptr, hipMemset(c->one_dbg, 0, sizeof(unsigned long long) * 16 * ONE_BOARD)); }
   *out = c;
   return DCTZHIP_OK;
@@ -262,7 +268,7 @@ extern "C" void dctzhip_ctx_destroy(dctzhip_ctx* c) {
   (void)dctzhip_comm_destroy(c);
   (void)hipStreamSynchronize(c->stream);
   if (c->side_stream) { (void)hipStreamSynchronize(c->side_stream); (void)hipStreamDestroy(c->side_stream); }
-  void* bufs[] = {c->one_bctl, c->one_dbg, c->one_ga, c->one_gb, c->one_rec, c->one_ctl, c->qcnt, c->ttot, c->ac_tmp, c->tile_cnt, c->wg_cnt, c->serial_out, c->tab_f64, c->tab_f32, c->rtab, c->qtab, c->ctl, c->part, c->stats_out, c->qt_item, c->qt_j, c->nd_buf, c->dfl_buf, c->sf_thr[0], c->sf_thr[1], c->sf_pw[0], c->sf_pw[1], c->sf_guess};
+  void* bufs[] = {c->one_qt, c->one_bqt, c->one_bctl, c->one_dbg, c->one_ga, c->one_gb, c->one_rec, c->one_ctl, c->qcnt, c->ttot, c->ac_tmp, c->tile_cnt, c->wg_cnt, c->serial_out, c->tab_f64, c->tab_f32, c->rtab, c->qtab, c->ctl, c->part, c->stats_out, c->qt_item, c->qt_j, c->nd_buf, c->dfl_buf, c->sf_thr[0], c->sf_thr[1], c->sf_pw[0], c->sf_pw[1], c->sf_guess};
   for (void* b : bufs) if (b) (void)hipFree(b);
   if (c->h_pin) (void)hipHostFree(c->h_pin);
   if (c->box) (void)hipHostFree(c->box);
@@ -765,6 +771,7 @@ static unsigned one_capacity(dctzhip_ctx* c, bool decode, int mode, bool scaled)
   if (slot == 0) {
     const int v = decode ? decompress_one_occupancy<T>(mode) : compress_one_occupancy<T>(mode, scaled);
     slot = v < 1 ? -1 : (v > 8 ? 8 : v);
+    if (getenv("DCTZHIP_ONE_DEBUG")) fprintf(stderr, "[dctzhip] one-launch occupancy f64=%d decode=%d qt=%d scaled=%d: %d workgroups per CU\n", (int)(sizeof(T) == 8), (int)decode, (int)(mode == DCTZHIP_QT), (int)scaled, v);
   }
   return slot > 0 ? (unsigned)(slot * c->num_cu) : 0u;
 }
@@ -777,6 +784,7 @@ static int one_gave_up(dctzhip_ctx* c) {
   c->one_fallbacks++;
   c->one_cooldown = ONE_COOLDOWN;
   HIPCHK(c, hipMemsetAsync(c->one_ctl, 0, sizeof(Ctl) * 3, c->stream));
+  HIPCHK(c, hipMemsetAsync(c->one_qt, 0, sizeof(unsigned long long) * 2 * ONE_QT_WORDS, c->stream));
   return DCTZHIP_OK;
 }
 
@@ -799,9 +807,9 @@ static int compress_one(dctzhip_ctx* c, const T* d_in, size_t n, double eb, int 
   FwdParams<T>& p = a.p;
   p.x = d_in; p.bin = d_bin; p.dc = d_dc; p.ac = d_ac; p.coef = d_coef; p.scaled = d_scaled;
   p.tab = tab_of<T>(c); p.rtab = reinterpret_cast<const T*>(c->rtab);
-  const unsigned slot = c->one_cslot;
-  c->one_cslot ^= 1u;
-  p.ctl = c->one_ctl + slot;
+  const unsigned slot = c->one_cslot;                // (the tables of maxima alternate between QT calls: a call's hand-off zeroes the other one)
+  if (mode == DCTZHIP_QT) c->one_cslot ^= 1u;
+  p.ctl = c->one_ctl;
   p.nfull = nfull; p.ntiles = ntiles; p.last_is_full = rem ? 0u : 1u;
   // bin ranges, dctz-comp-lib.c:271-281 (computed in double, stored in T)
   const int half = DCTZHIP_NBINS / 2;
@@ -820,7 +828,7 @@ static int compress_one(dctzhip_ctx* c, const T* d_in, size_t n, double eb, int 
   a.box = c->box_dev;
   const unsigned long long seq = ++c->seq;
   a.seq = seq;
-  a.ctl_next = c->one_ctl + (slot ^ 1u);
+  a.qt = c->one_qt + slot * ONE_QT_WORDS; a.qt_next = c->one_qt + (slot ^ 1u) * ONE_QT_WORDS; a.qt_stride = ONE_QT_STRIDE; a.qt_shards = ONE_QT_SHARDS;
   a.eb = eb; a.rem = (unsigned)rem; a.bad_guess = (unsigned)c->one_bad_guess;
   if (c->profiling) { HIPCHK(c, hipEventRecord(c->ev[0], s)); HIPCHK(c, hipEventRecord(c->ev[1], s)); HIPCHK(c, hipEventRecord(c->ev[2], s)); }
   launch_compress_one<T>(a, mode, d_scaled != nullptr, s);
@@ -1835,6 +1843,10 @@ static int ensure_one_bctl(dctzhip_ctx* c, size_t K) {
   c->one_bctl = nullptr; c->one_bctl_cap = 0;
   HIPCHK(c, hipMalloc(&c->one_bctl, 2 * cap * sizeof(Ctl)));
   HIPCHK(c, hipMemset(c->one_bctl, 0, 2 * cap * sizeof(Ctl)));
+  if (c->one_bqt) HIPCHK(c, hipFree(c->one_bqt));
+  c->one_bqt = nullptr;
+  HIPCHK(c, hipMalloc(&c->one_bqt, 2 * cap * 64 * sizeof(unsigned long long)));
+  HIPCHK(c, hipMemset(c->one_bqt, 0, 2 * cap * 64 * sizeof(unsigned long long)));
   c->one_bctl_cap = cap; c->one_bdirty[0] = c->one_bdirty[1] = 0;
   return DCTZHIP_OK;
 }
@@ -1896,9 +1908,9 @@ static int batch_one_compress(dctzhip_ctx* c, int k, const dctzhip_batch_citem* 
   if (rc) return rc;
   hipStream_t s = c->stream;
   const unsigned h = c->one_bslot;
-  c->one_bslot ^= 1u;
+  if (mode == DCTZHIP_QT) c->one_bslot ^= 1u;
   if (c->one_bdirty[h] > 0) {                        // (entries a call with more arrays than its successor left behind)
-    HIPCHK(c, hipMemsetAsync(c->one_bctl + h * c->one_bctl_cap, 0, c->one_bctl_cap * sizeof(Ctl), s));
+    HIPCHK(c, hipMemsetAsync(c->one_bqt + (size_t)h * c->one_bctl_cap * 64, 0, c->one_bctl_cap * 64 * sizeof(unsigned long long), s));
     c->one_bdirty[h] = 0;
   }
   const unsigned tag = (unsigned)(++c->seq) | 0x80000000u;
@@ -1925,13 +1937,14 @@ static int batch_one_compress(dctzhip_ctx* c, int k, const dctzhip_batch_citem* 
     BatchResC* res_d = reinterpret_cast<BatchResC*>(c->b_res_hdev);
     BatchResQ* resq_d = mode == DCTZHIP_QT ? reinterpret_cast<BatchResQ*>(c->b_res_hdev + c->b_cap * sizeof(BatchResC)) : nullptr;
     const OneRecC* recs_d = reinterpret_cast<const OneRecC*>(c->b_blob_hdev) + q.rec_off;
-    Ctl* ctl = c->one_bctl + h * c->one_bctl_cap;
-    Ctl* ctl_next = c->one_bctl + (h ^ 1u) * c->one_bctl_cap;
+    Ctl* ctl = c->one_bctl;
+    unsigned long long* qt = c->one_bqt + (size_t)h * c->one_bctl_cap * 64;
+    unsigned long long* qt_next = c->one_bqt + (size_t)(h ^ 1u) * c->one_bctl_cap * 64;
     if (dt == DCTZHIP_F64) {
-      OneBatchC<double> cm = {recs_d, c->tab_f64, ctl, ctl_next, b, sft, res_d, resq_d, tag, (unsigned)c->one_bad_guess};
+      OneBatchC<double> cm = {recs_d, c->tab_f64, ctl, qt, qt_next, b, sft, res_d, resq_d, tag, (unsigned)c->one_bad_guess};
       launch_compress_one_batch<double>(cm, q.grid, mode, q.scaled, s);
     } else {
-      OneBatchC<float> cm = {recs_d, c->tab_f32, ctl, ctl_next, b, sft, res_d, resq_d, tag, (unsigned)c->one_bad_guess};
+      OneBatchC<float> cm = {recs_d, c->tab_f32, ctl, qt, qt_next, b, sft, res_d, resq_d, tag, (unsigned)c->one_bad_guess};
       launch_compress_one_batch<float>(cm, q.grid, mode, q.scaled, s);
     }
     if (prof) { HIPCHK(c, hipEventRecord(ev[2], s)); HIPCHK(c, hipEventRecord(ev[3], s)); HIPCHK(c, hipEventRecord(ev[4], s)); }
@@ -1941,7 +1954,7 @@ static int batch_one_compress(dctzhip_ctx* c, int k, const dctzhip_batch_citem* 
   }
   // this call's half: dirty where QT maxima were merged (EC leaves it clean); the other half: its first K entries are zeroed
   if (mode == DCTZHIP_QT) c->one_bdirty[h] = (unsigned)K;
-  if (c->one_bdirty[h ^ 1u] <= K) c->one_bdirty[h ^ 1u] = 0;
+  if (mode == DCTZHIP_QT && c->one_bdirty[h ^ 1u] <= K) c->one_bdirty[h ^ 1u] = 0;
   rc = wait_tags(c, &res[0].pad, sizeof(BatchResC), K, tag, "compress batch (one launch)");
   if (rc) { (void)one_gave_up(c); c->one_bdirty[0] = c->one_bdirty[1] = (unsigned)c->one_bctl_cap; return rc; }
   if (c->profiling) {
