@@ -47,6 +47,37 @@ if ROOT not in sys.path:
 HBM_PEAK_GBPS = 8000.0      # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 
 
+def kernel_source_hash(root=ROOT):
+    """sha256 over the sources every kernel of the library is built from (dctz_amd/csrc/*.hip|*.h, include/*.h, the build
+    flags in dctz_amd/Makefile): what ties a committed PMC traffic record to the code it was measured on.  (The GPU box
+    has no .git, and a rebuilt .so differs in more than its kernels.)"""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    files = sorted(glob.glob(os.path.join(root, "dctz_amd", "csrc", "*.hip")) + glob.glob(os.path.join(root, "dctz_amd", "csrc", "*.h"))
+                   + glob.glob(os.path.join(root, "include", "*.h")) + [os.path.join(root, "dctz_amd", "Makefile")])
+    for f in files:
+        h.update(os.path.relpath(f, root).encode())
+        with open(f, "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
+def lookup_traffic(record_path, kernel, key, source_hash):
+    """(traffic, source) from a committed PMC record, or (None, reason): a record taken on other sources is never quoted."""
+    try:
+        rec = json.load(open(record_path))
+    except (OSError, ValueError):
+        return None, None
+    name = os.path.relpath(record_path, ROOT)
+    if rec.get("source_hash") != source_hash:
+        return None, f"{name} was measured on sources {rec.get('source_hash')}, this build is {source_hash}: not quoted"
+    ent = rec.get("kernels", {}).get(kernel, {}).get(key)
+    if ent is None:
+        return None, None
+    return ent["hbm_bytes_per_launch"], name + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command on these sources, gfx950 correction applied)"
+
+
 def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -111,6 +142,23 @@ def workload(a, rank):
             [W.c3(a.n, seed=512 + rank, dtype=np_dtype)], [a.eb])
 
 
+# exit codes of a rank whose LAST phase (the gather of an N-rank run) failed or timed out: rank 0 has printed its line
+RC_GATHER_PEER, RC_GATHER_RANK0 = 3, 4
+
+
+def _complete_line(raw):
+    """rank 0's stdout if it holds one complete JSON result line, else None"""
+    txt = (raw or b"").decode(errors="replace")
+    for ln in reversed(txt.strip().splitlines()):
+        try:
+            d = json.loads(ln)
+        except ValueError:
+            continue
+        if isinstance(d, dict) and ("metric" in d or "plumbing_only" in d):
+            return ln + "\n"
+    return None
+
+
 # ------------------------------------------------------------------ launcher --
 def launch(a):
     """Parent of an N-rank run.  Makes NO GPU call (imports neither the array framework nor the library): it only
@@ -146,7 +194,14 @@ def launch(a):
         rcs = [p.poll() for p in procs]
         if all(rc is not None for rc in rcs):
             break
-        bad = [i for i, rc in enumerate(rcs) if rc not in (None, 0)]
+        bad = [i for i, rc in enumerate(rcs) if rc not in (None, 0, RC_GATHER_PEER, RC_GATHER_RANK0)]
+        left = [i for i, rc in enumerate(rcs) if rc in (RC_GATHER_PEER, RC_GATHER_RANK0)]
+        if left and not bad:
+            # a rank has left from the gather phase (the last one): rank 0's line is out or about to be -- give the others a
+            # few seconds to follow instead of ending them at once
+            deadline = min(deadline, time.monotonic() + 10.0)
+            if time.monotonic() > deadline - 0.01 and why is None:
+                why = f"rank {left[0]} left the gather phase with code {rcs[left[0]]}"
         if bad:
             why = f"rank {bad[0]} exited with code {rcs[bad[0]]}"
         elif time.monotonic() > deadline:
@@ -169,7 +224,15 @@ def launch(a):
         sys.stdout.write((out0[0] if out0 else b"").decode())
         sys.stdout.flush()
         return 0
+    # A run whose LAST phase failed has measured everything its line reports: a complete line of rank 0 is forwarded
+    # whatever happened afterwards (the line's with_gather says what), the failing ranks go to stderr, and the exit code is
+    # 0 only if rank 0 itself ended in one of the two ways that follow a printed line.
+    line = _complete_line(out0[0] if out0 else b"")
     print(f"bench.py: {why or 'a rank failed'}; rank exit codes {rcs}", file=sys.stderr)
+    if line is not None and rcs[0] in (0, RC_GATHER_RANK0):
+        sys.stdout.write(line)
+        sys.stdout.flush()
+        return 0
     return 1
 
 
@@ -282,11 +345,28 @@ def run_rank(a, rank, local_rank, world):
             ctx.decompress_batch(None, None, None, None, None, None, mode, prepared=state["dp"])
         return infos
 
-    # Settling, in front of the W warm-up steps the caller asked for: the first call allocates (5 ms), and the part's power
-    # management answers sustained load with a dip -- steps 4 to 12 of a fresh process run 12 % slower than steps 1 to 3 and
-    # than everything from step 15 on (tools/warm_probe.py: 0.51 / 0.60 / 0.52 ms; host time follows the GPU's, it is not
-    # the library).  A 20-step window behind 5 warm-up steps would measure that dip.  --settle-ms 0 switches this off.
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    red_dev = "cpu" if a.rehearse_one_gpu else ctx.device   # (gloo reduces host tensors)
+    # ---- first the form exactly as asked, nothing in front of it: W warm-up steps of a fresh process, then K timed steps.
+    # This is what a caller who makes W + K calls sees (`unsettled_ms_per_step`); the settled figure follows in the same run.
     infos = None
+    for _ in range(a.warmup):
+        infos = step()
+    barrier()
+    u0 = time.perf_counter()
+    for _ in range(a.steps):
+        infos = step()
+    barrier()
+    unsettled_ms = shard.max_over_ranks(time.perf_counter() - u0, red_dev) * 1e3 / a.steps
+    # Settling, in front of a second set of W warm-up steps: the part's power management answers sustained load with a dip
+    # -- steps 4 to 12 of a fresh process run 12 % slower than steps 1 to 3 and than everything from step 15 on
+    # (tools/warm_probe.py: 0.51 / 0.60 / 0.52 ms; host time follows the GPU's, it is not the library).  The 20-step window
+    # behind 5 warm-up steps above measures that dip; the window below measures the steady state.  --settle-ms 0: off.
     settle_steps = 0
     if a.settle_ms > 0:
         torch.cuda.synchronize()
@@ -300,27 +380,21 @@ def run_rank(a, rank, local_rank, world):
     if infos is None:
         infos = step()
 
-    def barrier():
-        torch.cuda.synchronize()
-        if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize()
-
     # ---- timed region: exactly K steps, profiling off (no event overhead) ------
     barrier()
     t0 = time.perf_counter()
     for _ in range(a.steps):
         infos = step()
     barrier()
-    red_dev = "cpu" if a.rehearse_one_gpu else ctx.device   # (gloo reduces host tensors)
-    elapsed = shard.max_over_ranks(time.perf_counter() - t0, red_dev)
+    local_elapsed = time.perf_counter() - t0
+    elapsed = shard.max_over_ranks(local_elapsed, red_dev)
     ms_per_step = elapsed * 1e3 / a.steps
     info = infos[0]
 
     # ---- the step with the reference's in-place scaling made visible: dctz_compress divides the CALLER's array by sf
-    # (dctz-comp-lib.c:193-216); the device entry point does that on request into d_scaled (a 2 s bytes / element pass of
-    # its own, after the codec kernels, with the verified sf).  `value` is quoted without it ("add s"); this is
-    # the same K steps with it ----
+    # (dctz-comp-lib.c:193-216); the device entry point does that on request into d_scaled -- written by the compress kernel
+    # itself (the SC variant of k_compress / k_compress_one: the scaled tile goes registers -> LDS image -> rows while it is
+    # in registers anyway).  `value` is quoted without it ("add s"); this is the same K steps with it ----
     with_scaled = None
     if not many:
         sc = torch.empty_like(x)
@@ -336,7 +410,7 @@ def run_rank(a, rank, local_rank, world):
         barrier()
         w_ms = shard.max_over_ranks(time.perf_counter() - w0, red_dev) * 1e3 / a.steps
         with_scaled = {"ms_per_step": w_ms, "value": in_bytes * world / (w_ms * 1e-3) / 1e9,
-                       "note": "compress writes x / sf into a second buffer as well (the reference's in-place scaling of the caller's array)"}
+                       "note": "compress writes x / sf into a second buffer as well (the reference's in-place scaling of the caller's array), by the SC variant of the compress kernel"}
         del sc
 
     # ---- a list of arrays: the same list with one call per array (what the batch entry points replace) ----
@@ -434,6 +508,10 @@ def run_rank(a, rank, local_rank, world):
         return sum(ns[j] * (xs_host[j].itemsize + 1.0 + 4.0 / 64.0 + 4.0 * infos_all[j].cnt / ns[j]) for j in js)
     infos_all = infos if many else [info]
     kern_name = {"c": "k_compress", "d": "k_decompress"}
+    one_launch = bool(infos_all[0].flags & dctz_amd.hip.INFO_ONE_LAUNCH)   # the whole call was ONE kernel (dctz_kernels_one.hip)
+    if one_launch and not many:
+        tn = "double" if es == 8 else "float"
+        kern_name = {"c": f"k_compress_one<{tn}>", "d": f"k_decompress_one<{tn}>"}
     if many:
         by = {"f64": [j for j in range(len(xs)) if xs_host[j].itemsize == 8], "f32": [j for j in range(len(xs)) if xs_host[j].itemsize == 4]}
         dom_seq = max(by, key=lambda nm: sum(ns[j] * xs_host[j].itemsize for j in by[nm]))
@@ -464,16 +542,9 @@ def run_rank(a, rank, local_rank, world):
 
     # HBM traffic of the dominant kernel: NOT measured in this run (PMC counters need rocprofv3 passes of their own);
     # the committed record of the same command on the same build is quoted with its source, or null
-    traffic, traffic_source = None, None
-    try:
-        src = os.path.join("profiles", "r03_pmc_traffic.json")
-        rec_t = json.load(open(os.path.join(ROOT, src)))
-        key = f"{a.config}_{a.dtype}_{a.n}_{a.mode}_{a.eb:g}"
-        if key in rec_t.get(kern_name[dominant], {}):
-            traffic = rec_t[kern_name[dominant]][key]["hbm_bytes_per_launch"]
-            traffic_source = src + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, gfx950 correction applied)"
-    except (OSError, ValueError):
-        pass
+    src_hash = kernel_source_hash()
+    tkey = f"{a.config}_{a.dtype}_{a.n}_{a.mode}_{a.eb:g}"
+    traffic, traffic_source = lookup_traffic(os.path.join(ROOT, "profiles", "pmc_traffic.json"), kern_name[dominant], tkey, src_hash)
 
     # ---- the entropy stage on the device, rank 0, outside the timed region: what
     # it costs to turn the streams of the last compress call into the container's three zlib sections in HBM ----
@@ -551,6 +622,15 @@ def run_rank(a, rank, local_rank, world):
                              "note": "same port, one pass: " + ("whole arrays dealt to the threads" if many else
                                      "the sample cut into one slice per available core (each slice its own sf)")}}
 
+    # every rank's own figures (an N-GPU run: the curve's points come with the spread behind them)
+    mine_rank = {"rank": rank, "device": f"cuda:{dev}", "ms_per_step_local": local_elapsed * 1e3 / a.steps,
+                 "k_compress_ms": acc["c_main"], "k_decompress_ms": acc["d_main"], "compress_tail_ms": acc["c_tail"],
+                 "decompress_count_ms": acc["d_pre"], "exception_fraction": p}
+    per_rank = [None] * world
+    if dist is not None:
+        dist.all_gather_object(per_rank, mine_rank)
+    else:
+        per_rank = [mine_rank]
     if rank == 0:
         value = in_bytes * world / (ms_per_step * 1e-3) / 1e9
         kern_sum = kern_all
@@ -564,11 +644,15 @@ def run_rank(a, rank, local_rank, world):
             "settle": {"ms": a.settle_ms, "steps": settle_steps, "note": "untimed, in front of the warm-up steps: first-call allocations and the "
                        "power management's dip under fresh load (steps 4-12 of a process run 12 % slow, tools/warm_probe.py)"},
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            # the same K steps timed FIRST in this run, behind nothing but the W warm-up steps of a fresh process: what a
+            # caller who makes W + K calls sees (value = the settled figure, both are of this build and this box)
+            "unsettled_ms_per_step": unsettled_ms, "unsettled_value": in_bytes * world / (unsettled_ms * 1e-3) / 1e9,
+            "kernel_source_hash": src_hash,
             "dtype": a.dtype if not many else "f64+f32", "data": "synthetic",
             "config": {"workload": wl_name + ("; step = dctzhip_compress + dctzhip_decompress" if not many else "") + ", inputs resident in HBM",
                        "config": a.config, "arrays_per_gpu": len(xs), "elements_per_gpu": int(sum(ns)), "bytes_per_gpu": int(in_bytes),
                        "exception_fraction": p, "parallelism": f"shard-per-gpu x{world}"},
-            "ranks_seen": len({d["rank"] for d in devices}), "devices": devices,
+            "ranks_seen": len({d["rank"] for d in devices}), "devices": devices, "per_rank": per_rank,
             "pct_hbm_peak_input": 100.0 * (in_bytes / (ms_per_step * 1e-3) / 1e9) / HBM_PEAK_GBPS,
             "roofline": {"bound": "hbm", "kernel": kern_name[dominant] + " (the longer of the two big kernels in THIS run"
                                                    + (f", launch sequence of the {dom_seq} arrays: they carry most of the list's bytes)" if many else ")"),
@@ -576,8 +660,11 @@ def run_rank(a, rank, local_rank, world):
                          "traffic": traffic, "traffic_source": traffic_source,
                          "algorithmic_bytes_per_launch": bytes_main, "avg_launch_ms": dom[0],
                          "k_compress_frac": ach_c / HBM_PEAK_GBPS, "k_decompress_frac": ach_d / HBM_PEAK_GBPS},
-            "statistics": ("fused into k_compress behind a sampled guess of sf, verified every step "
+            "statistics": ("inside the one kernel of the call: every workgroup posts the decade of its maximum, the scaling factor follows "
+                           "from a sweep of those (dctz_kernels_one.hip)") if one_launch else
+                          ("fused into k_compress behind a sampled guess of sf, verified every step "
                            "(k_stats below = the 1/64 sample + final reduction)") if fused else "separate k_stats pass",
+            "one_launch_per_call": one_launch,
             "kernels": {"k_stats": ({"ms": acc["c_stats"], "sampled_fraction": 1.0 / 64.0} if fused else
                                     {"ms": acc["c_stats"], "GBps": ach_s, "frac": ach_s / HBM_PEAK_GBPS}),
                         "k_compress": {"ms": acc["c_main"], "GBps": ach_c, "frac": ach_c / HBM_PEAK_GBPS},
@@ -614,11 +701,22 @@ def run_rank(a, rank, local_rank, world):
         import threading
         barrier()                                             # (rank 0 comes from its CPU baseline: the timers below start together)
 
+        out_lock = threading.Lock()                           # the line goes out ONCE: by the watchdog or by the main thread
+        emitted = [False]
+
+        def emit(with_gather):
+            with out_lock:
+                if rank == 0 and not emitted[0]:
+                    line["with_gather"] = with_gather
+                    print(json.dumps(line), flush=True)
+                    emitted[0] = True
+
         def bail():
-            if rank == 0:
-                line["with_gather"] = {"error": f"the gather phase did not finish within {a.gather_timeout:.0f} s"}
-                print(json.dumps(line), flush=True)
-            os._exit(0)
+            # a hung gather is NOT a clean run: the line (everything it reports was measured before this phase) goes out with
+            # the reason, and the exit codes say what happened (the launcher forwards a complete line of rank 0 whatever
+            # the codes are)
+            emit({"error": f"the gather phase did not finish within {a.gather_timeout:.0f} s"})
+            os._exit(RC_GATHER_RANK0 if rank == 0 else RC_GATHER_PEER)
         watchdog = threading.Timer(a.gather_timeout, bail)
         watchdog.daemon = True
         watchdog.start()
@@ -650,8 +748,22 @@ def run_rank(a, rank, local_rank, world):
                     ctx.comm_gather(out, info.cnt, n, root=0)
                 barrier()
                 g_ms = shard.max_over_ranks(time.perf_counter() - g0, red_dev) * 1e3 / a.steps
+                # ... and the gather by itself (the streams of the last step, K times): what the exchange costs and what rank 0
+                # takes in per second over its inbound links
+                cnts = [None] * world
+                dist.all_gather_object(cnts, int(info.cnt))
+                barrier()
+                h0 = time.perf_counter()
+                for _ in range(a.steps):
+                    ctx.comm_gather(out, info.cnt, n, root=0)
+                barrier()
+                h_ms = shard.max_over_ranks(time.perf_counter() - h0, red_dev) * 1e3 / a.steps
+                inbound = sum(n + 4 * ((n + 63) // 64) + 4 * c for r_, c in enumerate(cnts) if r_ != 0)
                 with_gather = {"ms_per_step": g_ms, "value": n * es * world / (g_ms * 1e-3) / 1e9,
-                               "note": "compress + decompress + RCCL gather of bin_index / DC / AC_exact of every shard to rank 0 per step"}
+                               "gather_only_ms": h_ms, "inbound_bytes_per_step": int(inbound),
+                               "root_ingest_GBps": inbound / (h_ms * 1e-3) / 1e9 if h_ms > 0 else None,
+                               "note": "compress + decompress + RCCL gather of bin_index / DC / AC_exact of every shard to rank 0 per step; "
+                                       "gather_only_ms: the gather alone, same streams"}
             else:
                 if mine_ok:
                     ctx.lib.dctzhip_comm_destroy(ctx.h)
@@ -659,9 +771,14 @@ def run_rank(a, rank, local_rank, world):
         except Exception as e:
             with_gather = {"error": f"rank {rank}: {e}"}
         watchdog.cancel()
-        if rank == 0:
-            line["with_gather"] = with_gather
-    if rank == 0:
+        emit(with_gather)
+        if isinstance(with_gather, dict) and "error" in with_gather:
+            # after an error in this phase the ranks are no longer in step: no further collective (a final barrier would
+            # hang or fail on the ranks whose peers have left), no clean tear-down of the process group
+            if rank != 0:
+                print(f"bench.py: rank {rank}: gather phase failed: {with_gather['error']}", file=sys.stderr, flush=True)
+            os._exit(RC_GATHER_RANK0 if rank == 0 else RC_GATHER_PEER)
+    elif rank == 0:
         print(json.dumps(line), flush=True)
     if dist is not None:
         dist.barrier()

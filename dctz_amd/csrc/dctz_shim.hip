@@ -22,6 +22,22 @@
 #include "dctz_device.h"
 #include "dctz_tables.h"
 
+// RCCL is loaded with dlopen (single-GPU users need none), so its header is not needed -- but where it is installed at build
+// time, the things this file restates from it are checked against it by the compiler (the header declares, it defines
+// nothing: no link dependency); at load time the library's major version is checked (rccl_load).
+#define DCTZ_NCCL_UINT8 1
+#define DCTZ_NCCL_UINT64 5
+#define DCTZ_NCCL_FLOAT32 7
+#if defined(__has_include)
+#if __has_include(<rccl/rccl.h>)
+#include <rccl/rccl.h>
+static_assert(sizeof(ncclUniqueId) == DCTZHIP_COMM_ID_BYTES, "DCTZHIP_COMM_ID_BYTES must be sizeof(ncclUniqueId) of the installed RCCL");
+static_assert((int)ncclUint8 == DCTZ_NCCL_UINT8 && (int)ncclUint64 == DCTZ_NCCL_UINT64 && (int)ncclFloat32 == DCTZ_NCCL_FLOAT32,
+              "ncclDataType_t values differ from the installed rccl.h");
+static_assert(NCCL_MAJOR == 2, "this file was written against the NCCL 2 API");
+#endif
+#endif
+
 using namespace dctz;
 
 struct dctzhip_ctx {
@@ -2172,19 +2188,22 @@ extern "C" int dctzhip_compress_batch(dctzhip_ctx* c, int k, const dctzhip_batch
     if (rc) return rc;
     const unsigned long long seq = ++c->seq;
     bool seen[2] = {false, false};
+    // (from here on every exit joins the second stream first: its kernels share this context's scratch with whatever the
+    // next call queues on the first one)
+    auto bail = [&](int code) { (void)chains_join(c, two); c->ctl_dirty = 1; c->b_ctl_dirty = 1; return code; };
     for (size_t qi = 0; qi < seqs.size(); qi++) {
       const SeqC& q = seqs[qi];
       const bool last = ch[q.chain].last == (int)qi;
       rc = (q.dtype == DCTZHIP_F64) ? launch_compress_seq<double>(c, items, mode, q, ch[q.chain], last, seq, !seen[q.dtype])
                                     : launch_compress_seq<float>(c, items, mode, q, ch[q.chain], last, seq, !seen[q.dtype]);
-      if (rc) return rc;
+      if (rc) return bail(rc);
       seen[q.dtype] = true;
     }
     rc = chains_join(c, two);
     if (rc) return rc;
     rc = wait_seq(c, ch[0].word, seq, "compress batch");
-    if (rc) return rc;
-    if (two) { rc = wait_seq(c, ch[1].word, seq, "compress batch (second chain)"); if (rc) return rc; }
+    if (rc) { c->b_ctl_dirty = 1; return rc; }
+    if (two) { rc = wait_seq(c, ch[1].word, seq, "compress batch (second chain)"); if (rc) { c->b_ctl_dirty = 1; return rc; } }
     if (c->profiling) {
       for (int dt = 0; dt < 2; dt++) if (!c->b_one_seen[dt]) c->b_last[dt] = dctzhip_timings{0, 0, 0, 0};
       for (int dt = 0; dt < 2; dt++) if (seen[dt]) { rc = batch_timings(c, dt); if (rc) return rc; }
@@ -2201,7 +2220,13 @@ extern "C" int dctzhip_compress_batch(dctzhip_ctx* c, int k, const dctzhip_batch
         const double true_sf = scaling_factor(dtype, r.stats[0]);
         const bool same = dtype == DCTZHIP_F64 ? true_sf == r.sf_used : (float)true_sf == (float)r.sf_used;
         const bool window_ok = r.fast_used != 2 || (value_in_window(dtype, r.stats[1]) && value_in_window(dtype, r.stats[0]));
-        if (!same || !window_ok) { single.push_back(i); continue; }     // (a table bug: never seen; the array is done again on its own)
+        if (!same || !window_ok) {                    // (a table bug: never seen; the array is done again on its own)
+          // ... unless k_scale_batch has already divided the input in place by the wrong factor: nothing to run it on again
+          if (items[i].d_scaled && items[i].d_scaled == items[i].d_in)
+            return fail(c, DCTZHIP_E_INTERNAL, "array %d: scaling factor %g chosen on the device differs from the host's %g after an in-place pass", i, r.sf_used, true_sf);
+          single.push_back(i);
+          continue;
+        }
         if (!infos) continue;
         dctzhip_cinfo* info = &infos[i];
         memset(info, 0, sizeof(*info));
@@ -2391,19 +2416,20 @@ extern "C" int dctzhip_decompress_batch(dctzhip_ctx* c, int k, const dctzhip_bat
     if (rc) return rc;
     const unsigned long long seq = ++c->seq;
     bool seen[2] = {false, false};
+    auto bail = [&](int code) { (void)chains_join(c, two); c->ctl_dirty = 1; c->b_ctl_dirty = 1; return code; };   // (as in dctzhip_compress_batch)
     for (size_t qi = 0; qi < seqs.size(); qi++) {
       const SeqD& q = seqs[qi];
       const bool last = ch[q.chain].last == (int)qi;
       rc = (q.dtype == DCTZHIP_F64) ? launch_decompress_seq<double>(c, items, mode, q, ch[q.chain], last, seq, !seen[q.dtype])
                                     : launch_decompress_seq<float>(c, items, mode, q, ch[q.chain], last, seq, !seen[q.dtype]);
-      if (rc) return rc;
+      if (rc) return bail(rc);
       seen[q.dtype] = true;
     }
     rc = chains_join(c, two);
     if (rc) return rc;
     rc = wait_seq(c, ch[0].word, seq, "decompress batch");
-    if (rc) return rc;
-    if (two) { rc = wait_seq(c, ch[1].word, seq, "decompress batch (second chain)"); if (rc) return rc; }
+    if (rc) { c->b_ctl_dirty = 1; return rc; }
+    if (two) { rc = wait_seq(c, ch[1].word, seq, "decompress batch (second chain)"); if (rc) { c->b_ctl_dirty = 1; return rc; } }
     if (c->profiling) {
       for (int dt = 0; dt < 2; dt++) if (!c->b_one_seen[dt]) c->b_last[dt] = dctzhip_timings{0, 0, 0, 0};
       for (int dt = 0; dt < 2; dt++) if (seen[dt]) { rc = batch_timings(c, dt); if (rc) return rc; }
@@ -2451,7 +2477,8 @@ Rccl g_rccl;
 // ncclDataType_t as /opt/rocm/include/rccl/rccl.h spells it: ncclInt8 = 0, ncclUint8 = 1, ncclInt32 = 2, ncclUint32 = 3,
 // ncclInt64 = 4, ncclUint64 = 5, ncclFloat16 = 6, ncclFloat32 = 7, ncclFloat64 = 8 (the library is loaded with dlopen, so
 // the header is not included; tests/test_abi_cpu.py compares these three with the header's text when it is installed)
-constexpr int NCCL_UINT8 = 1, NCCL_UINT64 = 5, NCCL_FLOAT32 = 7;
+constexpr int NCCL_UINT8 = DCTZ_NCCL_UINT8, NCCL_UINT64 = DCTZ_NCCL_UINT64, NCCL_FLOAT32 = DCTZ_NCCL_FLOAT32;
+constexpr int RCCL_MAJOR_KNOWN = 2;                  // ncclGetVersion() / 10000 this file's call signatures were read from
 
 bool rccl_load(dctzhip_ctx* c) {
   if (g_rccl.ok) return true;
@@ -2468,6 +2495,16 @@ bool rccl_load(dctzhip_ctx* c) {
   SYM(AllGather, "ncclAllGather") SYM(Send, "ncclSend") SYM(Recv, "ncclRecv") SYM(GroupStart, "ncclGroupStart")
   SYM(GroupEnd, "ncclGroupEnd") SYM(GetErrorString, "ncclGetErrorString")
 #undef SYM
+  // the by-value 128-byte id, the enum values and the argument lists above are those of NCCL 2.x: a library of another
+  // major version is refused here, before the first call through a pointer of the wrong shape
+  {
+    int (*get_version)(int*) = nullptr;
+    *(void**)(&get_version) = dlsym(g_rccl.h, "ncclGetVersion");
+    int v = 0;
+    if (!get_version || get_version(&v) != 0) { fail(c, DCTZHIP_E_HIP, "RCCL: ncclGetVersion is missing or failed"); return false; }
+    const int major = v >= 10000 ? v / 10000 : v / 1000;        // (NCCL_VERSION: X * 10000 + Y * 100 + Z from 2.9 on, X * 1000 + ... before)
+    if (major != RCCL_MAJOR_KNOWN) { fail(c, DCTZHIP_E_HIP, "RCCL version code %d (major %d): this library speaks the NCCL %d API only", v, major, RCCL_MAJOR_KNOWN); return false; }
+  }
   g_rccl.ok = true;
   return true;
 }

@@ -142,7 +142,9 @@ int dctzhip_host_unregister(dctzhip_ctx *ctx, void *ptr);
  *               j ascending -- byte-identical to the reference's AC_exact[]
  *   d_scaled    optional: receives x/sf (the reference's in-place scaling of the
  *               caller's buffer, :193-216); may be NULL, may alias d_in (then the
- *               call runs on verified statistics: see dctzhip_set_speculation)
+ *               call runs on verified statistics: see dctzhip_set_speculation).
+ *               Like every output it is complete in STREAM order, not at return
+ *               (single arrays and batches alike), unless dctzhip_set_blocking is on
  *   d_coef      optional debug tap: the DCT coefficients a_x after pass 1
  *               (= dct_result.bin under -DDCT_FILE_DEBUG, :422-428); may be NULL
  * On return *info is filled (the host has waited for it); the last kernels of the
@@ -198,7 +200,7 @@ int dctzhip_decompress(dctzhip_ctx *ctx, const void *d_bin_index, const float *d
  * single-array path inside the call (their kernels dwarf the launch cost, and that path saves the statistics pass).
  * Fields have the meaning of the same-named arguments of dctzhip_compress / dctzhip_decompress. */
 typedef struct {
-  const void *d_in;          /* n elements of dtype, device, 16-byte aligned; not modified */
+  const void *d_in;          /* n elements of dtype, device, 16-byte aligned; not modified unless d_scaled aliases it */
   size_t n;
   int dtype;                 /* DCTZHIP_F32 | DCTZHIP_F64, per array */
   double error_bound;        /* per array */

@@ -5,6 +5,7 @@ import ctypes as C
 import os
 import re
 import subprocess
+import sys
 
 import pytest
 
@@ -102,8 +103,31 @@ def test_rccl_datatype_values_match_the_header():
         pytest.skip("rccl.h not installed")
     txt = open(hdr).read()
     src = open(os.path.join(ROOT, "dctz_amd", "csrc", "dctz_shim.hip")).read()
-    m = re.search(r"constexpr int NCCL_UINT8 = (\d+), NCCL_UINT64 = (\d+), NCCL_FLOAT32 = (\d+);", src)
-    assert m, "the shim's ncclDataType_t constants moved"
-    for name, val in zip(("ncclUint8", "ncclUint64", "ncclFloat32"), m.groups()):
+    vals = [re.search(r"#define DCTZ_NCCL_%s (\d+)" % k, src) for k in ("UINT8", "UINT64", "FLOAT32")]
+    assert all(vals), "the shim's ncclDataType_t constants moved"
+    assert "static_assert((int)ncclUint8 == DCTZ_NCCL_UINT8" in src     # (and the compiler checks them where the header is installed)
+    for name, val in zip(("ncclUint8", "ncclUint64", "ncclFloat32"), [v.group(1) for v in vals]):
         h = re.search(name + r"\s*=\s*(\d+)", txt)
         assert h and h.group(1) == val, (name, val, h and h.group(1))
+
+
+def test_an_rccl_of_another_major_version_is_refused():
+    """The gather calls RCCL through dlsym'd pointers whose shapes (the by-value 128-byte id, the enum values) were read from
+    the NCCL 2 header: a library that reports another major version is refused at load, with a message.
+    The test double stands in for the library; no GPU is touched (the id call needs none)."""
+    import subprocess
+    double = os.path.join(ROOT, "tests", "c", "librccl_double.so")
+    if not os.path.exists(double):
+        pytest.skip("test double not built")
+    code = ("import ctypes, sys; sys.path.insert(0, %r); from dctz_amd import hip as H; L = H.load_library(); "
+            "b = ctypes.create_string_buffer(128); rc = L.dctzhip_comm_unique_id(b); "
+            "print(rc, L.dctzhip_last_error(None).decode())" % ROOT)
+    for ver, ok in (("22707", True), ("30100", False), ("1900", False)):
+        env = dict(os.environ, DCTZHIP_RCCL_LIBRARY=double, RCCL_DOUBLE_VERSION=ver)
+        r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=120)
+        assert r.returncode == 0, r.stderr[-1500:]
+        rc, _, msg = r.stdout.strip().partition(" ")
+        if ok:
+            assert rc == "0", r.stdout
+        else:
+            assert rc != "0" and "NCCL 2 API" in msg, r.stdout
