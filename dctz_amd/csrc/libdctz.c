@@ -1070,12 +1070,21 @@ void dctz_dct_blocks_f(float *a, float *b, size_t n, int inverse) { blocks(a, b,
 /* one block of length dn per call, like the reference (dct.c:55, :115).  The reference transforms ANY length with one
  * length-dn plan; the codec only ever uses dn <= BLK_SZ = 64 (dctz.h:28), which is what the GPU tables cover: a longer
  * block is refused loudly instead of being cut into 64-element blocks (a different transform). */
+/* ... on the HOST (dct_host.cpp): the caller's block is in host memory and is read back at once; the product's own lane
+ * flow (dct64_block.h, the code one GPU lane runs) compiled for the CPU gives bit for bit what dctz_dct_blocks() returns
+ * from the device, without an H2D copy, a launch and a D2H copy per 512 bytes.  (DCTZ_BLOCK_ON_GPU=1: through the GPU.) */
+void dctz_host_block_f64(const double *a, double *b, int dn, int inverse);
+void dctz_host_block_f32(const float *a, float *b, int dn, int inverse);
 static void one_block(void *a, void *b, int dn, int is_d, int inverse) {
+  static int on_gpu = -1;
   if (dn < 1 || dn > BLK_SZ) {
     fprintf(stderr, "libdctz: %s with dn = %d: only block lengths 1..%d are supported\n", inverse ? "ifft_idct" : "dct_fftw", dn, BLK_SZ);
     exit(1);
   }
-  blocks(a, b, (size_t)dn, is_d, inverse);
+  if (on_gpu < 0) { const char *e = getenv("DCTZ_BLOCK_ON_GPU"); on_gpu = e && atoi(e) ? 1 : 0; }
+  if (on_gpu) { blocks(a, b, (size_t)dn, is_d, inverse); return; }
+  if (is_d) dctz_host_block_f64((const double *)a, (double *)b, dn, inverse);
+  else dctz_host_block_f32((const float *)a, (float *)b, dn, inverse);
 }
 void dct_fftw(double *a, double *b, int dn, int nblk) { (void)nblk; one_block(a, b, dn, 1, 0); }
 void dct_fftw_f(float *a, float *b, int dn, int nblk) { (void)nblk; one_block(a, b, dn, 0, 0); }

@@ -101,3 +101,30 @@ def test_packed_fp32_transform_bit_identical_to_oracle(emu):
         assert np.array_equal(b.view(np.uint32), O.dct_fwd(a, O.FAST).view(np.uint32))
         emu.emu_pk_f32(a.ctypes.data_as(C.c_void_p), b.ctypes.data_as(C.c_void_p), 1)
         assert np.array_equal(b.view(np.uint32), O.dct_inv(a, O.FAST).view(np.uint32))
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_host_per_block_entry_points_follow_the_pinned_flow(dtype):
+    """dct_fftw / ifft_idct of the drop-in run on the host (dctz_amd/csrc/dct_host.cpp: the product's lane flow compiled for
+    the CPU).  The exported block routine against the oracle's pinned flow, every length 1 .. 64, both directions -- no GPU
+    involved (the library loads without one; only its GPU entry points need one)."""
+    import ctypes as C
+    from oracle import oracle as O
+    so = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "dctz_amd", "lib", "libdctz-ec.so")
+    if not os.path.exists(so):
+        pytest.skip("drop-in library not built")
+    lib = C.CDLL(so)
+    fn = lib.dctz_host_block_f64 if dtype == np.float64 else lib.dctz_host_block_f32
+    fn.restype = None
+    fn.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int]
+    rng = np.random.default_rng(5)
+    for l in range(1, 65):
+        x = (rng.standard_normal(l) * 3.0).astype(dtype)
+        a, b = np.zeros_like(x), np.zeros_like(x)
+        fn(x.ctypes.data, a.ctypes.data, l, 0)
+        assert np.array_equal(a.view(np.uint8), O.dct_fwd(x, O.FAST).view(np.uint8)), l
+        fn(a.ctypes.data, b.ctypes.data, l, 1)
+        assert np.array_equal(b.view(np.uint8), O.dct_inv(a, O.FAST).view(np.uint8)), l
+        y = x.copy()
+        fn(y.ctypes.data, y.ctypes.data, l, 0)                 # in place
+        assert np.array_equal(y.view(np.uint8), a.view(np.uint8))

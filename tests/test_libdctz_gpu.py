@@ -195,6 +195,43 @@ def test_dct_h_per_block_api():
     assert np.abs(back - x).max() < 1e-13
 
 
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_per_block_calls_are_the_batched_kernels_bit_for_bit(dtype):
+    """dct_fftw / ifft_idct run the product's lane flow on the HOST (dct_host.cpp: no PCIe round trip per 64 elements);
+    the same blocks through dctz_dct_blocks -- the GPU kernels k_dct_blocks / k_dct_rem -- must be the same bytes, for
+    every block length the codec can meet (1 .. 64), forward and inverse."""
+    lib = _lib("ec")
+    f = "" if dtype == np.float64 else "_f"
+    fwd, inv, batched = getattr(lib, "dct_fftw" + f), getattr(lib, "ifft_idct" + f), getattr(lib, "dctz_dct_blocks" + f)
+    getattr(lib, "dct_init" + f)(64)
+    for l in range(1, 65):
+        x = W.ragged(64 * 2 + l, dtype, scale=11.0)[-l:].copy()
+        a, b, g = np.zeros_like(x), np.zeros_like(x), np.zeros_like(x)
+        fwd(x.ctypes.data_as(C.c_void_p), a.ctypes.data_as(C.c_void_p), l, 1)
+        batched(x.ctypes.data_as(C.c_void_p), g.ctypes.data_as(C.c_void_p), C.c_size_t(l), 0)
+        assert np.array_equal(a.view(np.uint8), g.view(np.uint8)), f"forward, l={l}"
+        inv(l, a.ctypes.data_as(C.c_void_p), b.ctypes.data_as(C.c_void_p))
+        batched(a.ctypes.data_as(C.c_void_p), g.ctypes.data_as(C.c_void_p), C.c_size_t(l), 1)
+        assert np.array_equal(b.view(np.uint8), g.view(np.uint8)), f"inverse, l={l}"
+    getattr(lib, "dct_finish" + f)()
+
+
+def test_dct_test_style_loop_is_not_a_pcie_round_trip_per_block():
+    """dct-test.c:81-152's loop -- one call per 64-element block -- built in C against the drop-in: round 3 paid an H2D copy,
+    a launch and a D2H copy per call (about 50 us per block); the reference's own FFTW path takes about 1 us."""
+    import subprocess
+    root = os.path.dirname(LIBDIR.rstrip("/")).rsplit("/dctz_amd", 1)[0]
+    exe = os.path.join(root, "tests", "c", "dct_loop")
+    lib_dir = LIBDIR
+    subprocess.check_call(["gcc", "-O2", "-o", exe, os.path.join(root, "tests", "c", "dct_loop.c"), "-L" + lib_dir, "-ldctz-ec",
+                           "-Wl,-rpath," + lib_dir, "-lm"])
+    out = subprocess.run([exe, "16384"], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-800:]
+    f_ns, i_ns, worst = (float(v) for v in out.stdout.split()[-3:])
+    assert f_ns < 4000 and i_ns < 4000, out.stdout            # (measured: well under a microsecond each; the reference: about 1 us)
+    assert worst < 1e-12
+
+
 def test_calc_data_stat_and_gen_bins():
     lib = _lib("ec")
 
