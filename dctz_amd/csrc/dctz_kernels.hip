@@ -43,6 +43,10 @@
 // reference Makefile:2) is unfused here too; the transform's fused operations are explicit.
 #include "dctz_kernel_common.h"
 
+#ifndef DCTZ_PART
+#define DCTZ_PART 0          /* n > 0: this translation unit is the n-th hot kernel alone (see the end of the file) */
+#endif
+
 namespace dctz {
 
 // Hand-off of a call's results to the host, by ONE workgroup: final reduction of the fused statistics (nparts > 0),
@@ -78,12 +82,14 @@ __device__ __forceinline__ void finish_body(const FinBody& f) {
   if (t == 0) box_publish(&box->seq_done, f.seq);
 }
 
+#if DCTZ_PART == 0
 __global__ __launch_bounds__(SWG) void k_finish(FinArgs a) {
   FinBody f;
   f.ctl = a.ctl; f.part = a.part; f.nparts = a.nparts; f.box = a.box; f.seq = a.seq; f.guess = a.guess;
   f.cnt_known = false; f.err_known = false; f.cnt_total = 0; f.error = 0;
   finish_body<true>(f);
 }
+#endif
 
 // ================================================================= compress ==
 // Fused: [calc_data_stat util.c:12-44 ->] scale (dctz-comp-lib.c:193-216) -> DCT-II per block (:337-340,
@@ -870,10 +876,12 @@ __device__ __forceinline__ void count_tiles_body(const uint8_t* __restrict__ bin
     wg_cnt[wg] = sum;
   }
 }
+#if DCTZ_PART == 0
 __global__ __launch_bounds__(SWG) void k_count_tiles(const uint8_t* __restrict__ bin, unsigned nfull, unsigned ntiles, unsigned nwg,
                                                      unsigned* __restrict__ tile_cnt, unsigned* __restrict__ wg_cnt) {
   count_tiles_body(bin, nfull, ntiles, nwg, tile_cnt, wg_cnt, blockIdx.x);
 }
+#endif
 
 // Fused: gen_bins (binning.c:12-50) + de-quantise (dctz-decomp-lib.c:389-417 / :438-463) -> DCT-III per block
 // (:428, dct.c:115-205) -> de-scale (:494-511).  Lane b rebuilds block b of the tile in registers; the tile's
@@ -1196,10 +1204,12 @@ template <typename T, int MODE, bool SCALE>
 __global__ __launch_bounds__(64) void k_decompress_rem(InvParams<T> p, int l) { decompress_rem_body<T, MODE>(p, l, SCALE); }
 
 // ================================================================= launchers ==
+#if DCTZ_PART == 0
 void launch_finish(Ctl* ctl, const double* part, int nparts, HostBox* box, unsigned long long seq, hipStream_t s) {
   const FinArgs f = {ctl, part, nparts, box, seq, nullptr};
   hipLaunchKernelGGL(k_finish, dim3(1), dim3(SWG), 0, s, f);
 }
+#endif
 
 template <typename T>
 void launch_compress(const FwdParams<T>& p, int mode, bool stats, int grid, int geom, hipStream_t s) {
@@ -1272,9 +1282,11 @@ void launch_compress_rem(const FwdParams<T>& p, int mode, int l, hipStream_t s) 
   else hipLaunchKernelGGL((k_compress_rem<T, DCTZHIP_QT>), dim3(1), dim3(64), 0, s, p, l);
 }
 
+#if DCTZ_PART == 0
 void launch_count_tiles(const uint8_t* bin, unsigned nfull, unsigned ntiles, unsigned nwg, unsigned* tile_cnt, unsigned* wg_cnt, hipStream_t s) {
   hipLaunchKernelGGL(k_count_tiles, dim3(nwg), dim3(SWG), 0, s, bin, nfull, ntiles, nwg, tile_cnt, wg_cnt);
 }
+#endif
 
 template <typename T>
 void launch_compact_ac(const FwdParams<T>& p, int mode, double eb, unsigned nlists, int grid, const FinArgs& fin, hipStream_t s) {
@@ -1510,8 +1522,119 @@ void launch_decompress_rem_batch(const BatchInv<T>* items, const unsigned* rem_i
 // explicit instantiations used by dctz_shim.hip
 // (development: tools/dev_one.sh compiles ONE kernel instantiation alone -- seconds instead of a minute -- for
 // register-allocation experiments)
+// ---- one hot kernel per translation unit -----------------------------------------------------------------------------
+// The register allocation of a k_compress instantiation depends on what ELSE is compiled beside it: alone in its module,
+// k_compress<double, QT, STATS> gets 256 registers and no scratch; with a second k_compress instantiation in the same module
+// it spills ten (round 3's QT kernel: 20 bytes of scratch inside the tile loop, 5-8 % behind its EC twin), and the headline
+// EC kernel two (tools/dev_one.sh shows the 'alone' numbers; the inliner and scheduler see another module).  So the flat
+// k_compress instantiations and the batch forms are each built as a translation unit of their own: -DDCTZ_PART=n compiles
+// this file down to the n-th kernel of the list below, the main build (DCTZ_PART = 0) declares them `extern template` and
+// keeps everything else, launchers included (the host side needs only the kernel's handle, a link-time symbol).
+#define DCTZ_PARTS 20
+#if DCTZ_PART == 1
+template __global__ void k_compress<double, DCTZHIP_EC, true, Phases<double>::C, GEOM_1D, false>(FwdParams<double>);
+#elif DCTZ_PART == 0
+extern template __global__ void k_compress<double, DCTZHIP_EC, true, Phases<double>::C, GEOM_1D, false>(FwdParams<double>);
+#endif
+#if DCTZ_PART == 2
+template __global__ void k_compress<double, DCTZHIP_EC, true, Phases<double>::C, GEOM_1D, true>(FwdParams<double>);
+#elif DCTZ_PART == 0
+extern template __global__ void k_compress<double, DCTZHIP_EC, true, Phases<double>::C, GEOM_1D, true>(FwdParams<double>);
+#endif
+#if DCTZ_PART == 3
+template __global__ void k_compress<double, DCTZHIP_EC, false, Phases<double>::C, GEOM_1D, false>(FwdParams<double>);
+#elif DCTZ_PART == 0
+extern template __global__ void k_compress<double, DCTZHIP_EC, false, Phases<double>::C, GEOM_1D, false>(FwdParams<double>);
+#endif
+#if DCTZ_PART == 4
+template __global__ void k_compress<double, DCTZHIP_EC, false, Phases<double>::C, GEOM_1D, true>(FwdParams<double>);
+#elif DCTZ_PART == 0
+extern template __global__ void k_compress<double, DCTZHIP_EC, false, Phases<double>::C, GEOM_1D, true>(FwdParams<double>);
+#endif
+#if DCTZ_PART == 5
+template __global__ void k_compress<double, DCTZHIP_QT, true, Phases<double>::C, GEOM_1D, false>(FwdParams<double>);
+#elif DCTZ_PART == 0
+extern template __global__ void k_compress<double, DCTZHIP_QT, true, Phases<double>::C, GEOM_1D, false>(FwdParams<double>);
+#endif
+#if DCTZ_PART == 6
+template __global__ void k_compress<double, DCTZHIP_QT, true, Phases<double>::C, GEOM_1D, true>(FwdParams<double>);
+#elif DCTZ_PART == 0
+extern template __global__ void k_compress<double, DCTZHIP_QT, true, Phases<double>::C, GEOM_1D, true>(FwdParams<double>);
+#endif
+#if DCTZ_PART == 7
+template __global__ void k_compress<double, DCTZHIP_QT, false, Phases<double>::C, GEOM_1D, false>(FwdParams<double>);
+#elif DCTZ_PART == 0
+extern template __global__ void k_compress<double, DCTZHIP_QT, false, Phases<double>::C, GEOM_1D, false>(FwdParams<double>);
+#endif
+#if DCTZ_PART == 8
+template __global__ void k_compress<double, DCTZHIP_QT, false, Phases<double>::C, GEOM_1D, true>(FwdParams<double>);
+#elif DCTZ_PART == 0
+extern template __global__ void k_compress<double, DCTZHIP_QT, false, Phases<double>::C, GEOM_1D, true>(FwdParams<double>);
+#endif
+#if DCTZ_PART == 9
+template __global__ void k_compress<float, DCTZHIP_EC, true, Phases<float>::C, GEOM_1D, false>(FwdParams<float>);
+#elif DCTZ_PART == 0
+extern template __global__ void k_compress<float, DCTZHIP_EC, true, Phases<float>::C, GEOM_1D, false>(FwdParams<float>);
+#endif
+#if DCTZ_PART == 10
+template __global__ void k_compress<float, DCTZHIP_EC, true, Phases<float>::C, GEOM_1D, true>(FwdParams<float>);
+#elif DCTZ_PART == 0
+extern template __global__ void k_compress<float, DCTZHIP_EC, true, Phases<float>::C, GEOM_1D, true>(FwdParams<float>);
+#endif
+#if DCTZ_PART == 11
+template __global__ void k_compress<float, DCTZHIP_EC, false, Phases<float>::C, GEOM_1D, false>(FwdParams<float>);
+#elif DCTZ_PART == 0
+extern template __global__ void k_compress<float, DCTZHIP_EC, false, Phases<float>::C, GEOM_1D, false>(FwdParams<float>);
+#endif
+#if DCTZ_PART == 12
+template __global__ void k_compress<float, DCTZHIP_EC, false, Phases<float>::C, GEOM_1D, true>(FwdParams<float>);
+#elif DCTZ_PART == 0
+extern template __global__ void k_compress<float, DCTZHIP_EC, false, Phases<float>::C, GEOM_1D, true>(FwdParams<float>);
+#endif
+#if DCTZ_PART == 13
+template __global__ void k_compress<float, DCTZHIP_QT, true, Phases<float>::C, GEOM_1D, false>(FwdParams<float>);
+#elif DCTZ_PART == 0
+extern template __global__ void k_compress<float, DCTZHIP_QT, true, Phases<float>::C, GEOM_1D, false>(FwdParams<float>);
+#endif
+#if DCTZ_PART == 14
+template __global__ void k_compress<float, DCTZHIP_QT, true, Phases<float>::C, GEOM_1D, true>(FwdParams<float>);
+#elif DCTZ_PART == 0
+extern template __global__ void k_compress<float, DCTZHIP_QT, true, Phases<float>::C, GEOM_1D, true>(FwdParams<float>);
+#endif
+#if DCTZ_PART == 15
+template __global__ void k_compress<float, DCTZHIP_QT, false, Phases<float>::C, GEOM_1D, false>(FwdParams<float>);
+#elif DCTZ_PART == 0
+extern template __global__ void k_compress<float, DCTZHIP_QT, false, Phases<float>::C, GEOM_1D, false>(FwdParams<float>);
+#endif
+#if DCTZ_PART == 16
+template __global__ void k_compress<float, DCTZHIP_QT, false, Phases<float>::C, GEOM_1D, true>(FwdParams<float>);
+#elif DCTZ_PART == 0
+extern template __global__ void k_compress<float, DCTZHIP_QT, false, Phases<float>::C, GEOM_1D, true>(FwdParams<float>);
+#endif
+#if DCTZ_PART == 17
+template __global__ void k_compress_batch<double, DCTZHIP_EC>(const BatchFwd<double>*, const unsigned*, unsigned);
+#elif DCTZ_PART == 0
+extern template __global__ void k_compress_batch<double, DCTZHIP_EC>(const BatchFwd<double>*, const unsigned*, unsigned);
+#endif
+#if DCTZ_PART == 18
+template __global__ void k_compress_batch<double, DCTZHIP_QT>(const BatchFwd<double>*, const unsigned*, unsigned);
+#elif DCTZ_PART == 0
+extern template __global__ void k_compress_batch<double, DCTZHIP_QT>(const BatchFwd<double>*, const unsigned*, unsigned);
+#endif
+#if DCTZ_PART == 19
+template __global__ void k_compress_batch<float, DCTZHIP_EC>(const BatchFwd<float>*, const unsigned*, unsigned);
+#elif DCTZ_PART == 0
+extern template __global__ void k_compress_batch<float, DCTZHIP_EC>(const BatchFwd<float>*, const unsigned*, unsigned);
+#endif
+#if DCTZ_PART == 20
+template __global__ void k_compress_batch<float, DCTZHIP_QT>(const BatchFwd<float>*, const unsigned*, unsigned);
+#elif DCTZ_PART == 0
+extern template __global__ void k_compress_batch<float, DCTZHIP_QT>(const BatchFwd<float>*, const unsigned*, unsigned);
+#endif
 #ifdef DCTZ_DEV_ONE
 template __global__ void DCTZ_DEV_ONE(DCTZ_DEV_ARGS);
+#elif DCTZ_PART > 0
+// (this translation unit is one kernel: see above)
 #else
 
 #define INST(T)                                                                                         \
