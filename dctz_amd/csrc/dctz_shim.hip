@@ -17,6 +17,8 @@
 #include <cstdlib>
 #include <cstring>
 #include <thread>
+#include <atomic>
+#include <thread>
 #include <vector>
 
 #include "dctz_device.h"
@@ -389,7 +391,15 @@ static int staged_d2h(dctzhip_ctx* c, void* dst, const void* src, size_t bytes) 
     if (!c->stage_stream[i]) HIPCHK(c, hipStreamCreateWithFlags(&c->stage_stream[i], hipStreamNonBlocking));
   }
   HIPCHK(c, hipStreamSynchronize(c->stream));            // what the copy reads has been produced on the context's stream
-  const size_t pieces = (bytes + SLOT - 1) / SLOT;
+  // (pieces of a slot's size, or smaller ones when that keeps every worker busy: a 64 MiB copy -- one group of the pipelined
+  // dctz_decompress -- is thirty-two pieces of 2 MiB, not four of 16)
+  size_t PIECE = SLOT;
+  if (bytes < (size_t)4 * W * SLOT) {                  // (four pieces per worker: one worker's host copy runs under another's transfer)
+    PIECE = ((bytes + 4 * W - 1) / (4 * W) + 4095) & ~(size_t)4095;
+    if (PIECE < ((size_t)1 << 20)) PIECE = (size_t)1 << 20;
+    if (PIECE > SLOT) PIECE = SLOT;
+  }
+  const size_t pieces = (bytes + PIECE - 1) / PIECE;
   hipError_t err[W];
   std::vector<std::thread> th;
   for (int w = 0; w < W; w++) {
@@ -397,7 +407,7 @@ static int staged_d2h(dctzhip_ctx* c, void* dst, const void* src, size_t bytes) 
     th.emplace_back([=, &err]() {
       if (hipSetDevice(c->device) != hipSuccess) { err[w] = hipErrorInvalidDevice; return; }
       for (size_t k = (size_t)w; k < pieces; k += W) {
-        const size_t off = k * SLOT, len = bytes - off < SLOT ? bytes - off : SLOT;
+        const size_t off = k * PIECE, len = bytes - off < PIECE ? bytes - off : PIECE;
         hipError_t e = hipMemcpyAsync(c->stage[w], (const char*)src + off, len, hipMemcpyDeviceToHost, c->stage_stream[w]);
         if (e == hipSuccess) e = hipStreamSynchronize(c->stage_stream[w]);
         if (e != hipSuccess) { err[w] = e; return; }
@@ -410,9 +420,92 @@ static int staged_d2h(dctzhip_ctx* c, void* dst, const void* src, size_t bytes) 
   return DCTZHIP_OK;
 }
 
+// ---- a D2H copy that FOLLOWS its producer ------------------------------------------------------------------------------
+// dctz_decompress rebuilds a large array group by group (libdctz.c: decompress_pipelined); the copy of the reconstruction
+// into the caller's (pageable) array is one continuous stream of pieces through the pinned slots above, started before the
+// first group exists: a piece is moved as soon as the producer has announced its range (dctzhip_d2h_pipe_advance: an event
+// on the context's stream behind the kernels that write it -- the workers' streams wait for it on the GPU, no host sync).
+//   begin(dst, src, bytes)   starts the workers          advance(upto)   bytes [0, upto) of src are complete in stream order
+//   end()                    waits for the last piece
+namespace {
+struct D2hPipe {
+  std::vector<std::thread> th;
+  std::atomic<size_t> upto{0};
+  std::atomic<int> nev{0};
+  struct Mark { size_t upto; hipEvent_t ev; };
+  Mark marks[256];
+  std::atomic<int> failed{0};
+  std::atomic<int> stop{0};
+  bool active = false;
+};
+D2hPipe g_pipe;
+}
+extern "C" int dctzhip_d2h_pipe_begin(dctzhip_ctx* c, void* dst, const void* src, size_t bytes) {
+  if (!c || !dst || !src || !bytes) return DCTZHIP_E_ARG;
+  if (g_pipe.active) return fail(c, DCTZHIP_E_ARG, "a D2H pipe is already open");
+  constexpr int W = dctzhip_ctx::STAGE_WORKERS;
+  constexpr size_t SLOT = dctzhip_ctx::STAGE_SLOT;
+  HIPCHK(c, hipSetDevice(c->device));
+  for (int i = 0; i < W; i++) {
+    if (!c->stage[i]) HIPCHK(c, hipHostMalloc(&c->stage[i], SLOT, hipHostMallocDefault));
+    if (!c->stage_stream[i]) HIPCHK(c, hipStreamCreateWithFlags(&c->stage_stream[i], hipStreamNonBlocking));
+  }
+  g_pipe.upto = 0; g_pipe.nev = 0; g_pipe.failed = 0; g_pipe.stop = 0; g_pipe.active = true;
+  const size_t PIECE = (size_t)4 << 20;
+  const size_t pieces = (bytes + PIECE - 1) / PIECE;
+  for (int w = 0; w < W; w++) {
+    g_pipe.th.emplace_back([=]() {
+      if (hipSetDevice(c->device) != hipSuccess) { g_pipe.failed = 1; return; }
+      int seen = 0;                                   // marks this worker has made its stream wait for
+      for (size_t k = (size_t)w; k < pieces; k += W) {
+        const size_t off = k * PIECE, len = bytes - off < PIECE ? bytes - off : PIECE;
+        while (g_pipe.upto.load(std::memory_order_acquire) < off + len) {
+          if (g_pipe.stop.load() || g_pipe.failed.load()) return;
+          std::this_thread::yield();
+        }
+        // the youngest mark that covers the piece: the stream waits for its event (older marks are implied: one stream)
+        const int n = g_pipe.nev.load(std::memory_order_acquire);
+        int need = seen;
+        while (need < n && g_pipe.marks[need].upto < off + len) need++;
+        if (need < n && need >= seen) {
+          if (hipStreamWaitEvent(c->stage_stream[w], g_pipe.marks[need].ev, 0) != hipSuccess) { g_pipe.failed = 1; return; }
+          seen = need + 1;
+        }
+        hipError_t e = hipMemcpyAsync(c->stage[w], (const char*)src + off, len, hipMemcpyDeviceToHost, c->stage_stream[w]);
+        if (e == hipSuccess) e = hipStreamSynchronize(c->stage_stream[w]);
+        if (e != hipSuccess) { g_pipe.failed = 1; return; }
+        memcpy((char*)dst + off, c->stage[w], len);
+      }
+    });
+  }
+  return DCTZHIP_OK;
+}
+extern "C" int dctzhip_d2h_pipe_advance(dctzhip_ctx* c, size_t upto) {
+  if (!c || !g_pipe.active) return DCTZHIP_E_ARG;
+  const int n = g_pipe.nev.load();
+  if (n >= 256) return fail(c, DCTZHIP_E_ARG, "too many marks in one D2H pipe");
+  hipEvent_t ev;
+  HIPCHK(c, hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+  HIPCHK(c, hipEventRecord(ev, c->stream));
+  g_pipe.marks[n].upto = upto; g_pipe.marks[n].ev = ev;
+  g_pipe.nev.store(n + 1, std::memory_order_release);
+  g_pipe.upto.store(upto, std::memory_order_release);
+  return DCTZHIP_OK;
+}
+extern "C" int dctzhip_d2h_pipe_end(dctzhip_ctx* c, int abandon) {
+  if (!c || !g_pipe.active) return DCTZHIP_E_ARG;
+  if (abandon) g_pipe.stop = 1;
+  for (auto& t : g_pipe.th) t.join();
+  g_pipe.th.clear();
+  for (int i = 0; i < g_pipe.nev.load(); i++) (void)hipEventDestroy(g_pipe.marks[i].ev);
+  g_pipe.active = false;
+  if (g_pipe.failed.load()) return fail(c, DCTZHIP_E_HIP, "pipelined D2H copy failed");
+  return DCTZHIP_OK;
+}
+
 extern "C" int dctzhip_memcpy_d2h(dctzhip_ctx* c, void* dst, const void* src, size_t bytes) {
   if (!c) return DCTZHIP_E_ARG;
-  if (c->staged_d2h && bytes >= ((size_t)64 << 20)) {
+  if (c->staged_d2h && bytes >= ((size_t)16 << 20)) {
     hipPointerAttribute_t at;
     const bool pageable = hipPointerGetAttributes(&at, dst) != hipSuccess || at.type == hipMemoryTypeUnregistered;
     (void)hipGetLastError();

@@ -826,6 +826,182 @@ int dctz_check_container(const void *z, size_t zbytes, int max_elements, int dee
 }
 
 /* ------------------------------------------------------------ decompress --- */
+/* ---- dctz_decompress, pipelined (round 4) ------------------------------------------------------------------------------
+ * A container whose sections are independent chunks ("DZIX") is rebuilt GROUP by group of DCTZ_PIPE_GROUP elements
+ * (default 8 Mi): while the host threads inflate the chunks of the groups ahead, the streams of the groups that are
+ * complete go to the device, their blocks are rebuilt there (dctzhip_decompress on the group's slices: a group is a
+ * range of whole blocks, and its first "stored exactly" coefficient is the number of flags in front of it -- the running
+ * `pos` of dctz-decomp-lib.c:402-412 -- which the inflating threads count on the way), and a copier thread brings finished
+ * groups back into the caller's array.  Round 3 ran inflate (17 ms per GiB), H2D (3), kernels (0.3) and D2H (21) one after
+ * the other; the stages now overlap and the call takes about as long as its longest one.  The reconstruction is the same
+ * bytes: the same kernels on the same inputs.  DCTZ_PIPELINE=0: the serial path. */
+static int pipeline_on(void) { const char *e = getenv("DCTZ_PIPELINE"); return e ? atoi(e) != 0 : 1; }
+static size_t pipe_group(void) {
+  const char *e = getenv("DCTZ_PIPE_GROUP");
+  long long v = e ? atoll(e) : 0;
+  return v >= (1 << 18) ? ((size_t)v & ~(size_t)((1 << 18) - 1)) : ((size_t)1 << 23);   /* a multiple of 256 Ki elements */
+}
+typedef struct {
+  const unsigned char *src;
+  unsigned int zlen, len;
+  unsigned char *dst;
+  uLong adler;
+  unsigned int n255;          /* bytes == 255 in the chunk (bin_index chunks: flags + block heads) */
+  int count255;
+  volatile int done;          /* 1: inflated, 2: does not inflate */
+} pp_chunk;
+typedef struct {
+  pp_chunk *chunks;
+  size_t nchunks;
+  size_t next;
+} pp_queue;
+static void pp_do(pp_chunk *c) {
+  z_stream zs;
+  int bad = 0;
+  memset(&zs, 0, sizeof(zs));
+  if (inflateInit2(&zs, -15) != Z_OK) bad = 1;
+  else {
+    zs.next_in = (Bytef *)c->src; zs.avail_in = c->zlen;
+    zs.next_out = c->dst; zs.avail_out = c->len;
+    const int rc = inflate(&zs, Z_SYNC_FLUSH);
+    if ((rc != Z_OK && rc != Z_BUF_ERROR) || zs.avail_in != 0 || zs.avail_out != 0) bad = 1;
+    inflateEnd(&zs);
+  }
+  if (!bad) {
+    c->adler = adler32(adler32(0L, Z_NULL, 0), c->dst, c->len);
+    if (c->count255) {
+      unsigned int k = 0;
+      for (unsigned int i = 0; i < c->len; i++) k += (c->dst[i] == 255);
+      c->n255 = k;
+    }
+  }
+  __atomic_store_n(&c->done, bad ? 2 : 1, __ATOMIC_RELEASE);
+}
+static int pp_step(pp_queue *q) {                       /* one chunk, if any is left; 0: the list is exhausted */
+  const size_t i = __atomic_fetch_add(&q->next, 1, __ATOMIC_RELAXED);
+  if (i >= q->nchunks) return 0;
+  pp_do(&q->chunks[i]);
+  return 1;
+}
+static void *pp_worker(void *arg) {
+  while (pp_step((pp_queue *)arg)) {}
+  return NULL;
+}
+/* returns 1: done; 0: not applicable / something does not inflate -- the caller takes the serial path (and its way of
+ * reporting damage) */
+static int decompress_pipelined(dctzhip_ctx *c, const struct header *h, const unsigned char *const sec[3], const unsigned int zl[3],
+                                size_t chunk, uint32_t *const sizes[3], const void *qtable, t_var *var_r, size_t *got_out) {
+  const int is_d = ((h->datatype & 0xff) == DOUBLE);
+  const size_t ts = is_d ? sizeof(double) : sizeof(float);
+  const int dtype = is_d ? DCTZHIP_F64 : DCTZHIP_F32;
+  const size_t n = h->num_elements, nblk = CEIL(n, BLK_SZ), cnt = h->tot_AC_exact_count;
+  const size_t gel = pipe_group();
+  if (gel % (16 * chunk) != 0 || n < 2 * gel) return 0;
+  const size_t G = (n + gel - 1) / gel;
+  const size_t raw[3] = {n, nblk * sizeof(float), cnt * sizeof(float)};
+  size_t nch[3], total = 0;
+  for (int i = 0; i < 3; i++) { nch[i] = (raw[i] + chunk - 1) / chunk; total += nch[i]; }
+  unsigned char *const dst[3] = {(unsigned char *)host_buf(0, raw[0]), (unsigned char *)host_buf(1, raw[1]), (unsigned char *)host_buf(2, raw[2])};
+  pp_chunk *chunks = (pp_chunk *)calloc(total ? total : 1, sizeof(pp_chunk));
+  size_t *first[3];                                     /* position of a section's chunk j in the (priority-ordered) list */
+  for (int i = 0; i < 3; i++) first[i] = (size_t *)malloc((nch[i] ? nch[i] : 1) * sizeof(size_t));
+  size_t *goff = (size_t *)malloc(G * sizeof(size_t)), *gbytes = (size_t *)malloc(G * sizeof(size_t));
+  if (!chunks || !first[0] || !first[1] || !first[2] || !goff || !gbytes) { fprintf(stderr, "Out of memory: chunk list\n"); exit(1); }
+  /* the list in the order the groups need it: group g's bin_index and DC chunks, and the g-th share of AC_exact's */
+  size_t zoff[3] = {2, 2, 2}, nextc[3] = {0, 0, 0}, k = 0;
+  const size_t bpg = gel / chunk, dpg = gel / 16 / chunk;
+  for (size_t g = 0; g < G; g++) {
+    const size_t upto[3] = {(g + 1) * bpg < nch[0] ? (g + 1) * bpg : nch[0], (g + 1) * dpg < nch[1] ? (g + 1) * dpg : nch[1],
+                            g + 1 == G ? nch[2] : nch[2] * (g + 1) / G};
+    for (int i = 0; i < 3; i++)
+      for (; nextc[i] < upto[i]; nextc[i]++, k++) {
+        const size_t j = nextc[i];
+        chunks[k].src = sec[i] + zoff[i]; chunks[k].zlen = sizes[i][j];
+        chunks[k].dst = dst[i] + j * chunk;
+        chunks[k].len = (unsigned int)(raw[i] - j * chunk < chunk ? raw[i] - j * chunk : chunk);
+        chunks[k].count255 = (i == 0);
+        zoff[i] += sizes[i][j];
+        first[i][j] = k;
+      }
+  }
+  pp_queue q = {chunks, total, 0};
+  int threads = host_threads();
+  if ((size_t)threads > total) threads = total ? (int)total : 1;
+  pthread_t *th = (pthread_t *)malloc(sizeof(pthread_t) * (size_t)threads);
+  int started = 0;
+  if (th) for (int t = 0; t < threads; t++) { if (pthread_create(&th[started], NULL, pp_worker, &q)) break; started++; }
+
+  grow(&g_dev.out, &g_dev.out_cap, n * ts);
+  unsigned char *host_out = is_d ? (unsigned char *)var_r->buf.d : (unsigned char *)var_r->buf.f;
+  if (dctzhip_d2h_pipe_begin(c, host_out, g_dev.out, n * ts) != DCTZHIP_OK) die("D2H pipe");
+  const double sf = is_d ? h->scaling_factor.d : (double)h->scaling_factor.f;
+  int ok = 1;
+  size_t S = 0, ac_up = 0;                               /* exact coefficients consumed so far; bytes of AC_exact on the device */
+  const int dbg = getenv("DCTZ_PIPE_DEBUG") != NULL;
+  const double tp0 = now_s();
+  for (size_t g = 0; g < G && ok; g++) {
+    const double tg0 = now_s();
+    const size_t e0 = g * gel, ne = n - e0 < gel ? n - e0 : gel;
+    const size_t b0 = e0 / BLK_SZ, nb = CEIL(ne, BLK_SZ);
+    /* wait for the group's bin_index and DC chunks (helping with whatever chunk is next meanwhile) */
+    size_t flags = 0;
+    const size_t c_lo[2] = {e0 / chunk, b0 * sizeof(float) / chunk};
+    const size_t c_hi[2] = {(e0 + ne + chunk - 1) / chunk, ((b0 + nb) * sizeof(float) + chunk - 1) / chunk};
+    for (int i = 0; i < 2 && ok; i++)
+      for (size_t j = c_lo[i]; j < c_hi[i] && ok; j++) {
+        pp_chunk *pc = &chunks[first[i][j]];
+        int d;
+        while ((d = __atomic_load_n(&pc->done, __ATOMIC_ACQUIRE)) == 0) { if (!pp_step(&q)) sched_yield(); }
+        if (d != 1) ok = 0;
+        if (i == 0) flags += pc->n255;
+      }
+    if (!ok) break;
+    flags -= nb;                                           /* every block's first byte is the 255 of dctz-comp-lib.c:361, not a flag */
+    size_t S1 = S + flags;
+    if (S1 > cnt) S1 = cnt;                                /* (a stream that flags more than it brings: the kernels report it) */
+    for (size_t j = ac_up / chunk; j < (S1 * sizeof(float) + chunk - 1) / chunk && ok; j++) {
+      pp_chunk *pc = &chunks[first[2][j]];
+      int d;
+      while ((d = __atomic_load_n(&pc->done, __ATOMIC_ACQUIRE)) == 0) { if (!pp_step(&q)) sched_yield(); }
+      if (d != 1) ok = 0;
+    }
+    if (!ok) break;
+    const double tg1 = now_s();
+    /* the group's streams -> device */
+    if (dctzhip_memcpy_h2d(c, (unsigned char *)g_dev.bin + e0, dst[0] + e0, ne) != DCTZHIP_OK) die("H2D bin_index");
+    if (dctzhip_memcpy_h2d(c, (unsigned char *)g_dev.dc + b0 * sizeof(float), dst[1] + b0 * sizeof(float), nb * sizeof(float)) != DCTZHIP_OK) die("H2D DC");
+    const size_t ac_to = S1 * sizeof(float);
+    if (ac_to > ac_up) {
+      if (dctzhip_memcpy_h2d(c, (unsigned char *)g_dev.ac + ac_up, dst[2] + ac_up, ac_to - ac_up) != DCTZHIP_OK) die("H2D AC_exact");
+      ac_up = ac_to;
+    }
+    const double tg2 = now_s();
+    if (dctzhip_decompress(c, (unsigned char *)g_dev.bin + e0, (const float *)g_dev.dc + b0, (const float *)g_dev.ac + S, (uint32_t)(cnt - S), qtable, ne, dtype,
+                           h->error_bound, sf, DCTZ_MODE, (unsigned char *)g_dev.out + e0 * ts) != DCTZHIP_OK) die("dctzhip_decompress");
+    if (dbg) fprintf(stderr, "[pipe] group %zu: start %.2f ms, waited %.2f for its chunks, H2D %.2f, call %.2f\n", g, (tg0 - tp0) * 1e3, (tg1 - tg0) * 1e3, (tg2 - tg1) * 1e3, (now_s() - tg2) * 1e3);
+    S = S1;
+    if (dctzhip_d2h_pipe_advance(c, (e0 + ne) * ts) != DCTZHIP_OK) die("D2H pipe");     /* the group's bytes: complete behind its kernels */
+  }
+  while (pp_step(&q)) {}                                   /* (what is left of the list: chunks no group waited for) */
+  for (int t = 0; t < started; t++) pthread_join(th[t], NULL);
+  if (dbg) fprintf(stderr, "[pipe] all groups queued at %.2f ms\n", (now_s() - tp0) * 1e3);
+  if (dctzhip_d2h_pipe_end(c, !ok) != DCTZHIP_OK) die("D2H output");
+  if (dbg) fprintf(stderr, "[pipe] copies done at %.2f ms\n", (now_s() - tp0) * 1e3);
+  /* what inflate() checks at the end of a stream: the adler32 of the content */
+  for (int i = 0; i < 3 && ok; i++) {
+    uLong a = adler32(0L, Z_NULL, 0);
+    for (size_t j = 0; j < nch[i]; j++) { const pp_chunk *pc = &chunks[first[i][j]]; if (pc->done != 1) ok = 0; a = adler32_combine(a, pc->adler, (z_off_t)pc->len); }
+    const unsigned char *t = sec[i] + zl[i] - 4;
+    const uLong want = ((uLong)t[0] << 24) | ((uLong)t[1] << 16) | ((uLong)t[2] << 8) | (uLong)t[3];
+    if (a != want) ok = 0;
+  }
+  free(th); free(chunks); free(goff); free(gbytes);
+  for (int i = 0; i < 3; i++) free(first[i]);
+  if (!ok) fprintf(stderr, "libdctz: a chunk of an indexed section does not inflate; falling back to the one-stream inflate\n");
+  *got_out = n;
+  return ok;
+}
+
 int dctz_decompress(t_var *var_z, t_var *var_r) {
   const double t_begin = now_s();
   const int is_d = (var_z->datatype == DOUBLE);
@@ -877,6 +1053,23 @@ int dctz_decompress(t_var *var_z, t_var *var_r) {
   grow(&g_dev.bin, &g_dev.bin_cap, npos);
   grow(&g_dev.dc, &g_dev.dc_cap, nblk * sizeof(float));
   grow(&g_dev.ac, &g_dev.ac_cap, (cnt ? cnt : 4) * sizeof(float));
+  if (indexed && !nd && !inflate_gpu() && pipeline_on()) {
+    const void *qt_p = NULL;
+#ifdef USE_QTABLE
+    double qd_p[BLK_SZ];
+    float qf_p[BLK_SZ];
+    if (is_d) { memcpy(qd_p, cur + zl[0] + zl[1] + zl[2], sizeof(qd_p)); qt_p = qd_p; } /* :193-199 */
+    else { memcpy(qf_p, cur + zl[0] + zl[1] + zl[2], sizeof(qf_p)); qt_p = qf_p; }
+#endif
+    size_t got_p = 0;
+    if (decompress_pipelined(c, &h, secp, zl, ix_chunk_bytes, ix_sizes, qt_p, var_r, &got_p)) {
+      for (int i = 0; i < 3; i++) free(ix_sizes[i]);
+      if (!quiet()) printf("uncompressed bin_index size is: %lu\n", (unsigned long)got_p); /* :260-262 */
+      g_times.zlib_s = 0.0; g_times.h2d_s = 0.0; g_times.gpu_s = 0.0; g_times.d2h_s = 0.0;   /* (the stages overlap: only the total means something) */
+      g_times.total_s = now_s() - t_begin;
+      return 1;
+    }
+  }
   if (indexed && inflate_gpu() && ix_chunk_bytes == dctzhip_deflate_chunk_bytes()) {
     size_t zlen[3];
     for (int i = 0; i < 3; i++) {

@@ -125,6 +125,14 @@ int dctzhip_free(dctzhip_ctx *ctx, void *dptr);
 int dctzhip_memcpy_h2d(dctzhip_ctx *ctx, void *dst, const void *src, size_t bytes);
 int dctzhip_memcpy_d2h(dctzhip_ctx *ctx, void *dst, const void *src, size_t bytes);
 int dctzhip_sync(dctzhip_ctx *ctx);
+/* A D2H copy into pageable host memory that FOLLOWS its producer (dctz_decompress rebuilds a large array group by group
+ * and brings finished groups back while the next ones are built): begin() starts the copy of bytes [0, bytes) of d_src to
+ * dst through pinned slots, piece by piece, each piece as soon as advance() has announced it -- "bytes [0, upto) are
+ * complete in the order of the context's stream" (an event behind the kernels queued so far; no host synchronisation) --,
+ * end() waits for the last piece (abandon != 0: stops after the pieces under way).  One pipe at a time per process. */
+int dctzhip_d2h_pipe_begin(dctzhip_ctx *ctx, void *dst, const void *d_src, size_t bytes);
+int dctzhip_d2h_pipe_advance(dctzhip_ctx *ctx, size_t upto);
+int dctzhip_d2h_pipe_end(dctzhip_ctx *ctx, int abandon);
 /* Page-lock a caller-owned host buffer for the copies above (hipHostRegister): pageable copies run at about 24 GB/s,
  * pinned ones at PCIe speed.  Pinning itself costs about as much as one pageable copy of the buffer, so it pays for
  * buffers that are reused across calls; the buffer must be unregistered before it is freed. */

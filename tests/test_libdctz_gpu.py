@@ -232,6 +232,53 @@ def test_dct_test_style_loop_is_not_a_pcie_round_trip_per_block():
     assert worst < 1e-12
 
 
+@pytest.mark.parametrize("mode", ["ec", "qt"])
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_pipelined_decompress_is_the_serial_one(mode, dtype, monkeypatch):
+    """dctz_decompress of an indexed container works group by group (inflate of the groups ahead, H2D, kernels and D2H of
+    finished groups overlapping): the reconstruction must be the bytes of the serial path and of the oracle -- here with
+    a small group (DCTZ_PIPE_GROUP) so that an array of a few MB is six groups, a remainder block in the last one, and
+    exceptions spread unevenly over the groups."""
+    lib = _lib(mode)
+    qt = mode == "qt"
+    n = (1 << 18) * 5 + 64 * 1000 + 37
+    x = W.ragged(n, dtype, scale=37.0)
+    x[: 1 << 18] += (np.random.default_rng(3).standard_normal(1 << 18) * 3.0).astype(dtype)   # a noisy first group: most of AC_exact
+    orig = x.copy()
+    eb = 1e-3
+    monkeypatch.setenv("DCTZ_ZLIB_GPU", "1")
+    zbuf = np.zeros(n * x.itemsize + 4096, np.uint8)
+    var, var_z = _tvar(x), TVar()
+    var_z.datatype = var.datatype
+    var_z.buf.d = zbuf.ctypes.data_as(C.POINTER(C.c_double))
+    out_size = C.c_size_t(0)
+    assert lib.dctz_compress(C.byref(var), n, C.byref(out_size), C.byref(var_z), eb) == 1
+    ref = O.decompress(O.compress(orig, eb, O.QT if qt else O.EC, O.FAST), O.FAST)
+    recs = {}
+    for name, env in (("pipelined", {"DCTZ_PIPE_GROUP": str(1 << 18)}), ("serial", {"DCTZ_PIPELINE": "0"})):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        rec = np.zeros(n, dtype)
+        var_r = _tvar(rec)
+        assert lib.dctz_decompress(C.byref(var_z), C.byref(var_r)) == 1
+        recs[name] = rec
+        for k in env:
+            monkeypatch.delenv(k)
+    assert np.array_equal(recs["pipelined"].view(np.uint8), recs["serial"].view(np.uint8))
+    assert np.array_equal(recs["pipelined"].view(np.uint8), ref.view(np.uint8))
+    # a damaged chunk in the middle: the pipelined reader notices and hands the container to the one-stream inflate,
+    # which treats damage the way the reference's reader does (no crash, the call returns)
+    monkeypatch.setenv("DCTZ_PIPE_GROUP", str(1 << 18))
+    bad = zbuf.copy()
+    bad[56 + 5000] ^= 0x40
+    var_b = TVar()
+    var_b.datatype = var.datatype
+    var_b.buf.d = bad.ctypes.data_as(C.POINTER(C.c_double))
+    rec = np.zeros(n, dtype)
+    var_r = _tvar(rec)
+    assert lib.dctz_decompress(C.byref(var_b), C.byref(var_r)) == 1
+
+
 def test_calc_data_stat_and_gen_bins():
     lib = _lib("ec")
 

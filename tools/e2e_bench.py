@@ -70,10 +70,13 @@ def main():
         os.environ.pop("DCTZ_ZLIB_GPU", None)
         os.environ.pop("DCTZ_ZLIB_THREADS", None)
         os.environ.pop("DCTZ_FAST_MEAN", None)
-        if threads in ("gpu", "gpu_fast_mean"):
+        os.environ.pop("DCTZ_PIPELINE", None)
+        if threads in ("gpu", "gpu_fast_mean", "gpu_fast_mean_serial"):
             os.environ["DCTZ_ZLIB_GPU"] = "1"
-            if threads == "gpu_fast_mean":
+            if threads != "gpu":
                 os.environ["DCTZ_FAST_MEAN"] = "1"
+            if threads == "gpu_fast_mean_serial":              # round 3's calls: every stage after the other
+                os.environ["DCTZ_PIPELINE"] = "0"
         elif threads:
             os.environ["DCTZ_ZLIB_THREADS"] = str(threads)
         res = {}
@@ -111,11 +114,13 @@ def main():
     par, s_par = one(a.threads)
     gpu, s_gpu = one("gpu")
     gpu_fm, s_gpu_fm = one("gpu_fast_mean")
-    assert (s_ref is None or s_ref == s_par) and s_par == s_gpu == s_gpu_fm, "all tails must inflate to the same three streams"
+    gpu_ser, s_gpu_ser = one("gpu_fast_mean_serial")
+    assert (s_ref is None or s_ref == s_par) and s_par == s_gpu == s_gpu_fm == s_gpu_ser, "all tails must inflate to the same three streams"
     print(json.dumps({"what": "drop-in dctz_compress/dctz_decompress, host buffers, zlib included",
                       "workload": f"{a.dtype} {a.n}^3 C3 formula, {a.mode.upper()} eb={a.eb:g}", "input_bytes": x0.nbytes,
                       "host_cores": os.cpu_count(), "zlib": zlib.ZLIB_VERSION,
                       "reference_tail_3_threads": ref, f"chunked_tail_{a.threads}_threads": par, "deflate_on_gpu": gpu, "deflate_on_gpu_tree_order_mean": gpu_fm,
+                      "deflate_on_gpu_tree_order_mean_stages_not_overlapped": gpu_ser,
                       "streams_identical": True}))
 
 
