@@ -732,6 +732,248 @@ int dctz_compress(t_var *var, int N, size_t *outSize, t_var *var_z, double error
   return 1;
 }
 
+/* ---- lists of arrays in host memory (round 4; ADDITIONS to the reference's API, include/dctz.h) ---------------------------
+ * The reference's own workloads are lists of small arrays, one dctz_compress() call -- one process -- per array
+ * (tests/test-dctz.sh:13-56 over tests/list-msst19.txt:1-6).  Through this drop-in one such call is an H2D copy, one kernel,
+ * a D2H copy and three zlib threads around a few microseconds of GPU work; k of them in a loop are k times that.
+ * dctz_compress_batch() takes the k arrays at once: ONE staged H2D copy, ONE batch launch (dctzhip_compress_batch: every
+ * array with its own statistics, scaling factor, bin ranges and tot_AC_exact_count, as in its own call), ONE copy back, and
+ * the 3 k single-shot deflates of the reference's tail (dctz-comp-lib.c:620-732, same parameters) dealt to a pool of host
+ * threads together with the k in-place scalings (:193-216) and serial-order means (util.c:18-28).  Every container is byte
+ * for byte the one dctz_compress() writes for that array (reference tail), every caller's array ends up divided by its sf. */
+typedef struct {
+  int kind;                     /* 0: deflate one section, 1: scale + mean of one array, 2: inflate one section */
+  int arr, sec;
+  const void *src; size_t n;    /* deflate / inflate input */
+  Bytef *dst; uLong cap, out;   /* ... output */
+  void *x; size_t nx; int is_d; double sf, mean;
+  int rc;
+} bjob;
+typedef struct { bjob *jobs; size_t njobs, next; } bpool;
+static void bjob_run(bjob *j) {
+  if (j->kind == 0) {
+    z_stream zs;
+    memset(&zs, 0, sizeof(zs));
+    /* dctz-comp-lib.c:642-643: default level, 32K window, memLevel 8, default strategy; one deflate(Z_FINISH) (:75-88) */
+    if (deflateInit2(&zs, Z_DEFAULT_COMPRESSION, Z_DEFLATED, 15, DEF_MEM_LEVEL, Z_DEFAULT_STRATEGY) != Z_OK) { j->rc = 1; return; }
+    zs.data_type = Z_UNKNOWN;
+    zs.next_in = (Bytef *)j->src; zs.avail_in = (uInt)j->n;
+    zs.next_out = j->dst; zs.avail_out = (uInt)j->cap;
+    if (deflate(&zs, Z_FINISH) != Z_STREAM_END) j->rc = 1;
+    j->out = zs.total_out;
+    deflateEnd(&zs);
+  } else if (j->kind == 2) {
+    j->out = inflate_into((const Bytef *)j->src, (uLong)j->n, j->dst, (size_t)j->cap);
+  } else {
+    /* the header's mean in the reference's order (util.c:18-28 / :31-41), then the in-place x /= sf (:193-216) */
+    if (j->is_d) {
+      double *x = (double *)j->x, sum = 0.0;
+      for (size_t i = 1; i < j->nx; i++) sum += x[i];
+      j->mean = sum / (double)(int)j->nx;
+      if (j->sf != 1.0) for (size_t i = 0; i < j->nx; i++) x[i] /= j->sf;
+    } else {
+      float *x = (float *)j->x, sum = 0.0f;
+      const float sf = (float)j->sf;
+      for (size_t i = 1; i < j->nx; i++) sum += x[i];
+      j->mean = (double)(sum / (float)(int)j->nx);
+      if (sf != 1.0f) for (size_t i = 0; i < j->nx; i++) x[i] /= sf;
+    }
+  }
+}
+static void *bpool_worker(void *arg) {
+  bpool *p = (bpool *)arg;
+  for (;;) {
+    const size_t i = __atomic_fetch_add(&p->next, 1, __ATOMIC_RELAXED);
+    if (i >= p->njobs) break;
+    bjob_run(&p->jobs[i]);
+  }
+  return NULL;
+}
+static void bpool_run(bjob *jobs, size_t njobs) {
+  bpool p = {jobs, njobs, 0};
+  int T = host_threads();
+  if ((size_t)T > njobs) T = (int)njobs;
+  pthread_t th[64];
+  if (T > 64) T = 64;
+  int started = 0;
+  for (int t = 1; t < T; t++) { if (pthread_create(&th[started], NULL, bpool_worker, &p) == 0) started++; }
+  bpool_worker(&p);
+  for (int t = 0; t < started; t++) pthread_join(th[t], NULL);
+}
+static size_t up256(size_t v) { return (v + 255) & ~(size_t)255; }
+static struct { void *pin; size_t pin_cap; void *dev; size_t dev_cap; } g_batch;
+static void batch_buffers(dctzhip_ctx *c, size_t host_bytes, size_t dev_bytes) {
+  if (host_bytes > g_batch.pin_cap) {
+    if (g_batch.pin) dctzhip_host_unregister(c, g_batch.pin), free(g_batch.pin);
+    g_batch.pin = NULL; g_batch.pin_cap = 0;
+    if (posix_memalign(&g_batch.pin, 4096, host_bytes)) { fprintf(stderr, "Out of memory: batch staging\n"); exit(1); }
+    memset(g_batch.pin, 0, host_bytes);
+    (void)dctzhip_host_register(c, g_batch.pin, host_bytes);      /* (pinned: one fast copy each way; unpinned it still works) */
+    g_batch.pin_cap = host_bytes;
+  }
+  grow(&g_batch.dev, &g_batch.dev_cap, dev_bytes);
+}
+
+int dctz_compress_batch(int k, t_var *const *vars, const int *N, size_t *outSizes, t_var *const *vars_z, const double *error_bounds) {
+  if (k <= 0) return 1;
+  dctzhip_ctx *c = ctx();
+  /* layout of the staging area (host, pinned) and of its device twin: inputs | bin_index | DC | AC_exact, array after array */
+  size_t *off_in = (size_t *)malloc(4 * (size_t)k * sizeof(size_t));
+  dctzhip_batch_citem *items = (dctzhip_batch_citem *)calloc((size_t)k, sizeof(*items));
+  dctzhip_cinfo *infos = (dctzhip_cinfo *)calloc((size_t)k, sizeof(*infos));
+  if (!off_in || !items || !infos) { fprintf(stderr, "Out of memory: batch\n"); exit(1); }
+  size_t *off_bin = off_in + k, *off_dc = off_in + 2 * k, *off_ac = off_in + 3 * k;
+  size_t in_bytes = 0, total = 0;
+  for (int i = 0; i < k; i++) {
+    if (error_bounds[i] < 1E-6) { printf("ERROR BOUND is not acceptable"); exit(1); }     /* dctz-comp-lib.c:135-138 */
+    if (N[i] <= 0) { fprintf(stderr, "libdctz: N must be positive\n"); exit(1); }
+    const size_t ts = vars[i]->datatype == DOUBLE ? 8 : 4;
+    off_in[i] = in_bytes; in_bytes += up256((size_t)N[i] * ts);
+  }
+  total = in_bytes;
+  for (int i = 0; i < k; i++) { off_bin[i] = total; total += up256((size_t)N[i]); }
+  for (int i = 0; i < k; i++) { off_dc[i] = total; total += up256(CEIL((size_t)N[i], BLK_SZ) * sizeof(float)); }
+  for (int i = 0; i < k; i++) { off_ac[i] = total; total += up256((size_t)N[i] * sizeof(float)); }
+  batch_buffers(c, total, total);
+  unsigned char *hp = (unsigned char *)g_batch.pin, *dp = (unsigned char *)g_batch.dev;
+  for (int i = 0; i < k; i++) {
+    const int is_d = vars[i]->datatype == DOUBLE;
+    const size_t ts = is_d ? 8 : 4;
+    memcpy(hp + off_in[i], is_d ? (void *)vars[i]->buf.d : (void *)vars[i]->buf.f, (size_t)N[i] * ts);
+    items[i].d_in = dp + off_in[i]; items[i].n = (size_t)N[i]; items[i].dtype = is_d ? DCTZHIP_F64 : DCTZHIP_F32;
+    items[i].error_bound = error_bounds[i];
+    items[i].d_bin_index = dp + off_bin[i]; items[i].d_dc = (float *)(dp + off_dc[i]); items[i].d_ac_exact = (float *)(dp + off_ac[i]);
+    items[i].d_scaled = NULL;
+  }
+  if (dctzhip_memcpy_h2d(c, dp, hp, in_bytes) != DCTZHIP_OK) die("H2D (batch)");
+  if (dctzhip_compress_batch(c, k, items, DCTZ_MODE, infos) != DCTZHIP_OK) die("dctzhip_compress_batch");
+  if (dctzhip_memcpy_d2h(c, hp + in_bytes, dp + in_bytes, total - in_bytes) != DCTZHIP_OK) die("D2H (batch)");   /* (waits for the kernels first) */
+  /* the tails: 3 k deflates + k (mean, scaling) jobs on the pool, the longest first */
+  bjob *jobs = (bjob *)calloc(4 * (size_t)k, sizeof(bjob));
+  if (!jobs) { fprintf(stderr, "Out of memory: batch\n"); exit(1); }
+  size_t nj = 0;
+  for (int pass = 0; pass < 4; pass++)                /* AC_exact sections first (bytes of floats: the slow ones), then bin_index, DC, scalings */
+    for (int i = 0; i < k; i++) {
+      const size_t n = (size_t)N[i], nblk = CEIL(n, BLK_SZ);
+      bjob *j = &jobs[nj];
+      j->arr = i;
+      if (pass == 3) {
+        const int is_d = vars[i]->datatype == DOUBLE;
+        j->kind = 1; j->x = is_d ? (void *)vars[i]->buf.d : (void *)vars[i]->buf.f; j->nx = n; j->is_d = is_d; j->sf = infos[i].sf;
+      } else {
+        const int sec = pass == 0 ? 2 : pass - 1;
+        const size_t bytes = sec == 0 ? n : (sec == 1 ? nblk * sizeof(float) : (size_t)infos[i].cnt * sizeof(float));
+        j->kind = 0; j->sec = sec; j->n = bytes;
+        j->src = hp + (sec == 0 ? off_bin[i] : (sec == 1 ? off_dc[i] : off_ac[i]));
+        j->cap = compressBound((uLong)bytes);
+        j->dst = (Bytef *)malloc(j->cap ? j->cap : 1);
+        if (!j->dst) { fprintf(stderr, "Out of memory: zlib buffer\n"); exit(1); }
+      }
+      nj++;
+    }
+  if (getenv("DCTZ_DUMP_STREAMS")) fprintf(stderr, "libdctz: DCTZ_DUMP_STREAMS is a tap of single calls; dctz_compress_batch writes no dump files\n");
+  bpool_run(jobs, nj);
+  /* containers: header | bin_indexz | DCz | AC_exactz | [qtable]  (:775-820) */
+  for (int i = 0; i < k; i++) {
+    const int is_d = vars[i]->datatype == DOUBLE;
+    const size_t ts = is_d ? 8 : 4;
+    const bjob *jz[3] = {NULL, NULL, NULL}, *js = NULL;
+    for (size_t q = 0; q < nj; q++) if (jobs[q].arr == i) { if (jobs[q].kind == 1) js = &jobs[q]; else jz[jobs[q].sec] = &jobs[q]; }
+    for (int s3 = 0; s3 < 3; s3++) if (jz[s3]->rc) { fprintf(stderr, "libdctz: deflate failed\n"); exit(1); }
+    struct header h;
+    memset(&h, 0, sizeof(h));
+    h.datatype = vars[i]->datatype;
+    h.num_elements = (unsigned int)N[i];
+    h.error_bound = error_bounds[i];
+    h.tot_AC_exact_count = infos[i].cnt;
+    if (is_d) { h.scaling_factor.d = infos[i].sf; h.mean.d = js->mean; }
+    else { h.scaling_factor.f = (float)infos[i].sf; h.mean.f = (float)js->mean; }
+    h.bindex_sz_compressed = (unsigned int)jz[0]->out;
+    h.DC_sz_compressed = (unsigned int)jz[1]->out;
+    h.AC_exact_sz_compressed = (unsigned int)jz[2]->out;
+#ifdef USE_QTABLE
+    h.bindex_count = (unsigned int)N[i];
+#endif
+    unsigned char *cur = is_d ? (unsigned char *)vars_z[i]->buf.d : (unsigned char *)vars_z[i]->buf.f;
+    size_t out = sizeof(h) + jz[0]->out + jz[1]->out + jz[2]->out;
+    memcpy(cur, &h, sizeof(h)); cur += sizeof(h);
+    for (int s3 = 0; s3 < 3; s3++) { memcpy(cur, jz[s3]->dst, jz[s3]->out); cur += jz[s3]->out; }
+#ifdef USE_QTABLE
+    if (is_d) memcpy(cur, infos[i].qtable, BLK_SZ * sizeof(double));
+    else { float qf[BLK_SZ]; for (int j = 0; j < BLK_SZ; j++) qf[j] = (float)infos[i].qtable[j]; memcpy(cur, qf, sizeof(qf)); }
+    out += BLK_SZ * ts;
+#endif
+    (void)ts;
+    outSizes[i] = out;
+    if (!quiet()) printf("outSize = %zu\n", out); /* :841-843 */
+  }
+  for (size_t q = 0; q < nj; q++) free(jobs[q].dst);
+  free(jobs); free(off_in); free(items); free(infos);
+  return 1;
+}
+
+int dctz_decompress_batch(int k, t_var *const *vars_z, t_var *const *vars_r) {
+  if (k <= 0) return 1;
+  dctzhip_ctx *c = ctx();
+  struct header *hs = (struct header *)malloc((size_t)k * sizeof(struct header));
+  size_t *off_bin = (size_t *)malloc(4 * (size_t)k * sizeof(size_t));
+  dctzhip_batch_ditem *items = (dctzhip_batch_ditem *)calloc((size_t)k, sizeof(*items));
+  bjob *jobs = (bjob *)calloc(3 * (size_t)k, sizeof(bjob));
+  double *qtabs = (double *)malloc((size_t)k * BLK_SZ * sizeof(double));
+  if (!hs || !off_bin || !items || !jobs || !qtabs) { fprintf(stderr, "Out of memory: batch\n"); exit(1); }
+  size_t *off_dc = off_bin + k, *off_ac = off_bin + 2 * k, *off_out = off_bin + 3 * k;
+  size_t total = 0, in_bytes;
+  for (int i = 0; i < k; i++) {
+    const unsigned char *cur = vars_z[i]->datatype == DOUBLE ? (const unsigned char *)vars_z[i]->buf.d : (const unsigned char *)vars_z[i]->buf.f;
+    memcpy(&hs[i], cur, sizeof(struct header));                       /* dctz-decomp-lib.c:84-94 */
+    if (hs[i].num_elements == 0) { fprintf(stderr, "libdctz: empty stream\n"); exit(1); }
+    if (DCTZ_GEOM_OF(hs[i].datatype)) { fprintf(stderr, "libdctz: dctz_decompress_batch takes flat containers\n"); exit(1); }
+  }
+  for (int i = 0; i < k; i++) { off_bin[i] = total; total += up256(hs[i].num_elements); }
+  for (int i = 0; i < k; i++) { off_dc[i] = total; total += up256(CEIL((size_t)hs[i].num_elements, BLK_SZ) * sizeof(float)); }
+  for (int i = 0; i < k; i++) { off_ac[i] = total; total += up256(((size_t)hs[i].tot_AC_exact_count + 4) * sizeof(float)); }
+  in_bytes = total;
+  for (int i = 0; i < k; i++) { off_out[i] = total; total += up256((size_t)hs[i].num_elements * (vars_z[i]->datatype == DOUBLE ? 8 : 4)); }
+  batch_buffers(c, total, total);
+  unsigned char *hp = (unsigned char *)g_batch.pin, *dp = (unsigned char *)g_batch.dev;
+  size_t nj = 0;
+  for (int i = 0; i < k; i++) {
+    const int is_d = vars_z[i]->datatype == DOUBLE;
+    const size_t ts = is_d ? 8 : 4, n = hs[i].num_elements, nblk = CEIL(n, BLK_SZ);
+    const unsigned char *cur = (is_d ? (const unsigned char *)vars_z[i]->buf.d : (const unsigned char *)vars_z[i]->buf.f) + sizeof(struct header);
+    const unsigned int zl[3] = {hs[i].bindex_sz_compressed, hs[i].DC_sz_compressed, hs[i].AC_exact_sz_compressed};
+    const size_t raw[3] = {n, nblk * sizeof(float), (size_t)hs[i].tot_AC_exact_count * sizeof(float)};
+    const size_t offs[3] = {off_bin[i], off_dc[i], off_ac[i]};
+    for (int s3 = 0; s3 < 3; s3++) {                                   /* three inflates per array (dctz-decomp-lib.c:244-322) */
+      bjob *j = &jobs[nj++];
+      j->kind = 2; j->arr = i; j->sec = s3; j->src = cur; j->n = zl[s3]; j->dst = hp + offs[s3]; j->cap = (uLong)raw[s3];
+      cur += zl[s3];
+    }
+    const void *qt = NULL;
+#ifdef USE_QTABLE
+    memcpy(qtabs + (size_t)i * BLK_SZ, cur, BLK_SZ * ts);              /* :193-199 */
+    qt = qtabs + (size_t)i * BLK_SZ;
+#endif
+    (void)ts;
+    items[i].d_bin_index = dp + off_bin[i]; items[i].d_dc = (const float *)(dp + off_dc[i]); items[i].d_ac_exact = (const float *)(dp + off_ac[i]);
+    items[i].ac_count = hs[i].tot_AC_exact_count; items[i].qtable_host = qt;
+    items[i].n = n; items[i].dtype = is_d ? DCTZHIP_F64 : DCTZHIP_F32; items[i].error_bound = hs[i].error_bound;
+    items[i].sf = is_d ? hs[i].scaling_factor.d : (double)hs[i].scaling_factor.f;
+    items[i].d_out = dp + off_out[i];
+  }
+  bpool_run(jobs, nj);
+  if (!quiet()) for (int i = 0; i < k; i++) printf("uncompressed bin_index size is: %lu\n", (unsigned long)jobs[3 * (size_t)i].out); /* :260-262 */
+  if (dctzhip_memcpy_h2d(c, dp, hp, in_bytes) != DCTZHIP_OK) die("H2D (batch)");
+  if (dctzhip_decompress_batch(c, k, items, DCTZ_MODE, NULL) != DCTZHIP_OK) die("dctzhip_decompress_batch");
+  if (dctzhip_memcpy_d2h(c, hp + in_bytes, dp + in_bytes, total - in_bytes) != DCTZHIP_OK) die("D2H (batch)");
+  for (int i = 0; i < k; i++) {
+    const int is_d = vars_z[i]->datatype == DOUBLE;
+    memcpy(is_d ? (void *)vars_r[i]->buf.d : (void *)vars_r[i]->buf.f, hp + off_out[i], (size_t)hs[i].num_elements * (is_d ? 8 : 4));
+  }
+  free(hs); free(off_bin); free(items); free(jobs); free(qtabs);
+  return 1;
+}
+
 /* ------------------------------------------------------- container check --- */
 /* dctz_decompress() trusts the header the way the reference does (dctz-decomp-lib.c:84-100:
  * no size is checked against the buffer, a corrupt file reads out of bounds).  A caller that

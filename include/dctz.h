@@ -122,6 +122,16 @@ void idct_finish_f(void);
  * compute with a loop. */
 void dctz_dct_blocks(double *a, double *b, size_t n, int inverse);
 void dctz_dct_blocks_f(float *a, float *b, size_t n, int inverse);
+/* Lists of arrays (ADDITIONS, round 4).  The reference's own workloads are lists of small arrays, one dctz_compress()
+ * call -- one process -- per array (tests/test-dctz.sh:13-56 over tests/list-msst19.txt:1-6).  These take k arrays at once:
+ * one copy in, ONE batch launch (every array with its own calc_data_stat, scaling factor, bin ranges, tot_AC_exact_count
+ * and QT table: dctz-comp-lib.c:186 onwards couples nothing across arrays), one copy back, and the reference's tail -- one
+ * single-shot deflate per section, dctz-comp-lib.c:620-732 -- for all 3 k sections on a pool of host threads.  Arguments
+ * as dctz_compress()'s, per array: vars[i] (N[i] elements, scaled in place by its sf on return), vars_z[i] (>= N[i] *
+ * type_size bytes), outSizes[i], error_bounds[i].  Container i is byte for byte what dctz_compress(vars[i], ...) writes
+ * with the default tail.  Flat blocks only.  dctz_decompress_batch() is the mirror image (any flat containers). */
+int dctz_compress_batch(int k, t_var *const *vars, const int *N, size_t *outSizes, t_var *const *vars_z, const double *error_bounds);
+int dctz_decompress_batch(int k, t_var *const *vars_z, t_var *const *vars_r);
 /* Multi-dimensional blocks (optional; SURVEY section 8 f4 -- NOT in the reference, whose library flattens every
  * array, dctz-test.c:77-91; the hint is its FFTW r2r experiment dct-fftw-test.c:74-97).  The NEXT dctz_compress call
  * treats var->buf as a row-major ndims-dimensional array (ndims = 2: 8 x 8 tiles, ndims = 3: 4 x 4 x 4 tiles, last
