@@ -188,27 +188,44 @@ __host__ __device__ __forceinline__ TileRange tile_range(unsigned b, unsigned G,
 
 // ---------------------------------------------------------- the tile in LDS --
 // A tile's image in LDS is made of 1 KiB ROWS; row (jg, s) holds segment s (128 bytes) of the 8 blocks
-// 8 jg .. 8 jg + 7, and inside a block's 128 bytes the 16-byte chunks are XOR-swizzled with
-// f(block) = (block >> 1) & 7.  A row is what ONE LDS-DMA instruction writes (lane l -> bytes
-// [16 l, 16 l + 16) of the row) and what one 16-byte-per-lane store instruction reads back, and lane l's
-// share of a row is a piece of a whole 128-byte line in HBM.  Lane b = block b reads chunk ch of its block
-// with ds_read_b128 at lds_a[ch & 7] + (ch >> 3) * 1024: inside each group of 16 lanes that the LDS
-// services together, the 16 addresses fall into 16 different 16-byte bank groups (conflict-free; the
-// same for the ds_write_b128 of the inverse direction).
+// 8 jg .. 8 jg + 7, and inside a block's 128 bytes the 16-byte chunks are XOR-swizzled with f(block).  A row is what ONE
+// LDS-DMA instruction writes (lane l -> bytes [16 l, 16 l + 16) of the row) and what one 16-byte-per-lane store
+// instruction reads back, and lane l's share of a row is a piece of a whole 128-byte line in HBM.  Lane b = block b
+// moves chunk ch of its block with ds_read_b128 / ds_write_b128 at lds_a[ch & 7] + (ch >> 3) * 1024.
+// The two directions bank differently on gfx950 (MI355X guide, LDS table):
+//   * ds_read_b128: groups of 16 lanes {0-3,12-15,20-27}, {4-11,16-19,28-31}, ... ; bank = (a / 4) mod 64.  Lane b's
+//     address mod 256 is (b & 1) * 128 + (g ^ f) * 16, so f has to differ between the lanes of equal parity of a group;
+//   * ds_write_b128: groups of 8 CONTIGUOUS lanes; bank = (a / 4) mod 32, i.e. only (g ^ f) * 16 counts: f has to take
+//     8 different values over b & 7.
+// f = (b & 7) ^ ((b >> 4) & 1) does both.  Rounds 1-3 used f = (b >> 1) & 7 (DCTZ_SWZ = 0), which is right for the reads
+// and 2-way conflicted for every write of the image: k_decompress's 32 writes per tile made 9.07 M of its 22.05 M
+// LDS-array cycles conflict cycles (41 %, profiles/r03_pmc.txt).
+#ifndef DCTZ_SWZ
+#define DCTZ_SWZ 1
+#endif
 template <typename T, int PH>
 struct TileMap {
   using G = Geo<T, PH>;
   int lds_a[8];        // LDS byte offset of chunk class g = ch & 7 of this lane's block (row part of segment 0)
-  int g_even, g_odd;   // HBM byte offset (inside a tile) of this lane's 16 bytes of row (jg, 0), jg even / odd
+  int g_even, g_odd;   // HBM byte offset (inside a tile) of this lane's 16 bytes of row (jg, 0), for odd_row(jg) false / true
+  // which of the two a row takes: the part of f that comes from the row's number
+  static __host__ __device__ constexpr bool odd_row(int jg) { return DCTZ_SWZ ? (jg & 2) != 0 : (jg & 1) != 0; }
+  __device__ __forceinline__ int g_of(int jg) const { return odd_row(jg) ? g_odd : g_even; }
   __device__ __forceinline__ void init(int lane) {
-    const int f = (lane >> 1) & 7;
+    const int f = DCTZ_SWZ ? ((lane & 7) ^ ((lane >> 4) & 1)) : ((lane >> 1) & 7);
 #pragma unroll
     for (int g = 0; g < 8; g++) lds_a[g] = (lane >> 3) * G::SEGP * 1024 + (lane & 7) * 128 + ((g ^ f) * 16);
+    // as lane l of a ROW instruction: slot l of the row = chunk class (l & 7) ^ f(block) of block 8 jg + (l >> 3)
     const int beta = lane >> 3, gam = lane & 7;
-    g_even = beta * G::BLKB + ((gam ^ (beta >> 1)) * 16);
-    g_odd = g_even ^ 64;
+    g_even = beta * G::BLKB + ((gam ^ (DCTZ_SWZ ? beta : (beta >> 1))) * 16);
+    g_odd = g_even ^ (DCTZ_SWZ ? 16 : 64);
   }
 };
+// (the same for the multi-dimensional forms, which compute their chunk per row: chunk class of row-instruction lane
+// (beta, gam) in row jg)
+__device__ __forceinline__ int swz_row_chunk(int beta, int gam, int jg) {
+  return DCTZ_SWZ ? (gam ^ beta ^ ((jg >> 1) & 1)) : (gam ^ (beta >> 1) ^ ((jg & 1) << 2));
+}
 
 // HBM -> LDS, one phase of a tile, no registers.  rsrc covers the workgroup's input range; the range check
 // zero-fills whatever lies beyond the last whole block.
@@ -221,7 +238,7 @@ __device__ __forceinline__ void issue_phase_dma(__amdgpu_buffer_rsrc_t rsrc, uns
   for (int jg = JG0; jg < JG1; jg++)
 #pragma unroll
     for (int s = 0; s < G::SEGP; s++)
-      DMA16(rsrc, tilebuf + (jg * G::SEGP + s) * 1024, (jg & 1) ? tm.g_odd : tm.g_even, base + jg * 8 * G::BLKB + s * 128, 2 /* nt */);
+      DMA16(rsrc, tilebuf + (jg * G::SEGP + s) * 1024, tm.g_of(jg), base + jg * 8 * G::BLKB + s * 128, 2 /* nt */);
 }
 
 // ---- multi-dimensional blocks straight from / to the array (NdDirect) ----
@@ -263,7 +280,7 @@ __device__ __forceinline__ void issue_phase_dma_nd(__amdgpu_buffer_rsrc_t rsrc, 
 #pragma unroll
   for (int jg = 0; jg < 8; jg++) {
     const unsigned org = nd_block_origin<T>(nd, tile * (unsigned)TILE_BLKS + (unsigned)(8 * jg + beta));
-    const int cg = gam ^ (beta >> 1) ^ ((jg & 1) << 2);                // chunk of the segment this lane moves (TileMap's swizzle)
+    const int cg = swz_row_chunk(beta, gam, jg);                       // chunk of the segment this lane moves (TileMap's swizzle)
 #pragma unroll
     for (int s = 0; s < G::SEGP; s++) {
       const unsigned off = org + nd_chunk_offset<T>(nd, 8 * (phase * G::SEGP + s) + cg);

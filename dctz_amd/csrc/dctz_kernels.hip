@@ -199,7 +199,7 @@ __device__ __forceinline__ void compress_body(const FwdParams<T>& p, const unsig
     const int vbase = (int)(rel_s * (unsigned)G::TILEB);
 #pragma unroll
     for (int jg = 0; jg < 8; jg++) {
-      const int vo = vbase + jg * 8 * G::BLKB + ((jg & 1) ? tmx.g_odd : tmx.g_even);
+      const int vo = vbase + jg * 8 * G::BLKB + tmx.g_of(jg);
 #pragma unroll
       for (int sg = 0; sg < G::SEGP; sg++) {
         const u32x4 r = *reinterpret_cast<const u32x4*>(tilebuf + (jg * G::SEGP + sg) * 1024 + lane * 16);
@@ -1000,9 +1000,9 @@ __device__ __forceinline__ void decompress_body(const InvParams<T>& p, const uns
       if (GEOM != GEOM_1D && nd_direct) {              // this lane's piece of row (jg, s): a chunk of block 8 jg + beta of the tile
         const int beta = lane >> 3, gam = lane & 7;
         org = nd_block_origin<T>(p.nd, tile_s * (unsigned)TILE_BLKS + (unsigned)(8 * jg + beta));
-        cg = gam ^ (beta >> 1) ^ ((jg & 1) << 2);
+        cg = swz_row_chunk(beta, gam, jg);
       }
-      const int vo = vbase + jg * 8 * G::BLKB + ((jg & 1) ? tm.g_odd : tm.g_even);
+      const int vo = vbase + jg * 8 * G::BLKB + tm.g_of(jg);
 #pragma unroll
       for (int s = 0; s < G::SEGP; s++) {
         const u32x4 v = *reinterpret_cast<const u32x4*>(outbuf + (jg * G::SEGP + s) * 1024 + lane * 16);

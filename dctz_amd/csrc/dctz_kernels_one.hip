@@ -455,7 +455,7 @@ __device__ __forceinline__ void compress_one_body(const OneFwd<T>& a, const unsi
         write_phase<T, 1, 0>(x, tilebuf, tm);
   #pragma unroll
         for (int jg = 0; jg < 8; jg++) {
-          const int vo = jg * 8 * G::BLKB + ((jg & 1) ? tm.g_odd : tm.g_even);
+          const int vo = jg * 8 * G::BLKB + tm.g_of(jg);
   #pragma unroll
           for (int sg = 0; sg < G::SEGP; sg++) {
             const u32x4 r = *reinterpret_cast<const u32x4*>(tilebuf + (jg * G::SEGP + sg) * 1024 + lane * 16);
@@ -928,7 +928,7 @@ __device__ __forceinline__ void decompress_one_body(const OneInv<T>& a, const un
     write_phase<T, 1, 0>(x, io, tm);
 #pragma unroll
     for (int jg = 0; jg < 8; jg++) {
-      const int vo = jg * 8 * G::BLKB + ((jg & 1) ? tm.g_odd : tm.g_even);
+      const int vo = jg * 8 * G::BLKB + tm.g_of(jg);
 #pragma unroll
       for (int s = 0; s < G::SEGP; s++) {
         const u32x4 v = *reinterpret_cast<const u32x4*>(io + (jg * G::SEGP + s) * 1024 + lane * 16);
