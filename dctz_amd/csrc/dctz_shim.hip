@@ -503,6 +503,99 @@ extern "C" int dctzhip_d2h_pipe_end(dctzhip_ctx* c, int abandon) {
   return DCTZHIP_OK;
 }
 
+// ---- an H2D copy its CONSUMER follows ----------------------------------------------------------------------------------
+// dctz_compress of a large array (libdctz.c: compress_pipelined) starts the kernels of a group of elements as soon as that
+// group is on the device, while the rest of the caller's (pageable) array is still crossing PCIe.  One thread issues the
+// groups in order on a stream of its own and records an event behind each.
+//   begin(dst, src, bytes, group)   starts the thread
+//   wait(upto)     the context's stream waits (on the GPU) for the group that ends at or behind `upto`; the host only
+//                  waits until that copy has been ISSUED
+//   landed(upto)   the host waits until bytes [0, upto) are on the device -- the source is no longer read (the in-place
+//                  x /= sf of the caller's array follows the copy at this distance)
+//   end(abandon)
+namespace {
+struct H2dPipe {
+  std::thread th;
+  std::atomic<int> issued{0};
+  std::atomic<int> failed{0};
+  std::atomic<int> stop{0};
+  std::vector<hipEvent_t> ev;
+  size_t group = 0, bytes = 0;
+  hipStream_t st = nullptr;
+  int device = -1;
+  int waited = 0;                                     // events the context's stream already waits for
+  bool active = false;
+};
+H2dPipe g_h2d;
+}
+extern "C" int dctzhip_h2d_pipe_begin(dctzhip_ctx* c, void* d_dst, const void* src, size_t bytes, size_t group_bytes) {
+  if (!c || !d_dst || !src || !bytes || !group_bytes) return DCTZHIP_E_ARG;
+  if (g_h2d.active) return fail(c, DCTZHIP_E_ARG, "an H2D pipe is already open");
+  HIPCHK(c, hipSetDevice(c->device));
+  if (g_h2d.st && g_h2d.device != c->device) { (void)hipStreamDestroy(g_h2d.st); g_h2d.st = nullptr; }
+  if (!g_h2d.st) { HIPCHK(c, hipStreamCreateWithFlags(&g_h2d.st, hipStreamNonBlocking)); g_h2d.device = c->device; }
+  const size_t ngroups = (bytes + group_bytes - 1) / group_bytes;
+  if (ngroups > 4096) return fail(c, DCTZHIP_E_ARG, "too many groups in one H2D pipe");
+  g_h2d.ev.resize(ngroups);
+  for (size_t i = 0; i < ngroups; i++) HIPCHK(c, hipEventCreateWithFlags(&g_h2d.ev[i], hipEventDisableTiming));
+  g_h2d.issued = 0; g_h2d.failed = 0; g_h2d.stop = 0; g_h2d.waited = 0;
+  g_h2d.group = group_bytes; g_h2d.bytes = bytes; g_h2d.active = true;
+  const int device = c->device;
+  g_h2d.th = std::thread([=]() {
+    if (hipSetDevice(device) != hipSuccess) { g_h2d.failed = 1; return; }
+    for (size_t g = 0; g < ngroups; g++) {
+      if (g_h2d.stop.load()) return;
+      const size_t off = g * group_bytes, len = bytes - off < group_bytes ? bytes - off : group_bytes;
+      hipError_t e = hipMemcpyAsync((char*)d_dst + off, (const char*)src + off, len, hipMemcpyHostToDevice, g_h2d.st);
+      if (e == hipSuccess) e = hipEventRecord(g_h2d.ev[g], g_h2d.st);
+      if (e != hipSuccess) { g_h2d.failed = 1; return; }
+      g_h2d.issued.store((int)g + 1, std::memory_order_release);
+    }
+  });
+  return DCTZHIP_OK;
+}
+static int h2d_group_of(size_t upto) {                // index of the group that holds byte upto - 1
+  if (upto > g_h2d.bytes) upto = g_h2d.bytes;
+  return upto ? (int)((upto - 1) / g_h2d.group) : -1;
+}
+static int h2d_issued(dctzhip_ctx* c, int g) {
+  while (g_h2d.issued.load(std::memory_order_acquire) <= g) {
+    if (g_h2d.failed.load()) return fail(c, DCTZHIP_E_HIP, "pipelined H2D copy failed");
+    std::this_thread::yield();
+  }
+  return DCTZHIP_OK;
+}
+extern "C" int dctzhip_h2d_pipe_wait(dctzhip_ctx* c, size_t upto) {
+  if (!c || !g_h2d.active) return DCTZHIP_E_ARG;
+  const int g = h2d_group_of(upto);
+  if (g < 0 || g < g_h2d.waited) return DCTZHIP_OK;
+  int rc = h2d_issued(c, g);
+  if (rc) return rc;
+  HIPCHK(c, hipStreamWaitEvent(c->stream, g_h2d.ev[g], 0));
+  g_h2d.waited = g + 1;
+  return DCTZHIP_OK;
+}
+extern "C" int dctzhip_h2d_pipe_landed(dctzhip_ctx* c, size_t upto) {
+  if (!c || !g_h2d.active) return DCTZHIP_E_ARG;
+  const int g = h2d_group_of(upto);
+  if (g < 0) return DCTZHIP_OK;
+  int rc = h2d_issued(c, g);
+  if (rc) return rc;
+  HIPCHK(c, hipEventSynchronize(g_h2d.ev[g]));
+  return DCTZHIP_OK;
+}
+extern "C" int dctzhip_h2d_pipe_end(dctzhip_ctx* c, int abandon) {
+  if (!c || !g_h2d.active) return DCTZHIP_E_ARG;
+  if (abandon) g_h2d.stop = 1;
+  if (g_h2d.th.joinable()) g_h2d.th.join();
+  hipError_t e = hipStreamSynchronize(g_h2d.st);
+  for (auto& ev : g_h2d.ev) (void)hipEventDestroy(ev);
+  g_h2d.ev.clear();
+  g_h2d.active = false;
+  if (g_h2d.failed.load() || e != hipSuccess) return fail(c, DCTZHIP_E_HIP, "pipelined H2D copy failed");
+  return DCTZHIP_OK;
+}
+
 extern "C" int dctzhip_memcpy_d2h(dctzhip_ctx* c, void* dst, const void* src, size_t bytes) {
   if (!c) return DCTZHIP_E_ARG;
   if (c->staged_d2h && bytes >= ((size_t)16 << 20)) {
@@ -513,6 +606,16 @@ extern "C" int dctzhip_memcpy_d2h(dctzhip_ctx* c, void* dst, const void* src, si
   }
   HIPCHK(c, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
+  return DCTZHIP_OK;
+}
+// A D2H copy beside the context's stream (the pipelined dctz_compress brings the compressed pieces of finished groups back on
+// a thread of its own while the calling thread queues the next group's kernels): the caller vouches that the source is
+// complete -- it has synchronised with its producer -- and that at most one thread makes such copies at a time.
+extern "C" int dctzhip_memcpy_d2h_side(dctzhip_ctx* c, void* dst, const void* src, size_t bytes) {
+  if (!c || (bytes && (!dst || !src))) return DCTZHIP_E_ARG;
+  if (!bytes) return DCTZHIP_OK;
+  if (hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, c->side_stream) != hipSuccess) return DCTZHIP_E_HIP;
+  if (hipStreamSynchronize(c->side_stream) != hipSuccess) return DCTZHIP_E_HIP;
   return DCTZHIP_OK;
 }
 extern "C" int dctzhip_host_register(dctzhip_ctx* c, void* ptr, size_t bytes) {
@@ -1359,6 +1462,74 @@ extern "C" int dctzhip_compress(dctzhip_ctx* c, const void* d_in, size_t n, int 
   rc = (dtype == DCTZHIP_F64)
            ? compress_impl<double>(c, (const double*)d_in, n, eb, mode, (uint8_t*)d_bin, d_dc, d_ac, (double*)d_scaled, (double*)d_coef, info)
            : compress_impl<float>(c, (const float*)d_in, n, eb, mode, (uint8_t*)d_bin, d_dc, d_ac, (float*)d_scaled, (float*)d_coef, info);
+  if (rc == DCTZHIP_OK && c->blocking) HIPCHK(c, hipStreamSynchronize(c->stream));
+  return rc;
+}
+
+// ---- a PART of an array whose statistics the caller already has ---------------------------------------------------------
+// The streams of elements [lo, lo + n) of an array are the same whether the array is compressed in one call or part by
+// part (blocks are independent, AC_exact is block-major), provided every part is scaled by the ARRAY's scaling factor
+// (util.c:29) -- which is all that couples them.  dctz_compress of a large host array (libdctz.c: compress_pipelined) takes
+// max|x| / min|x| of the whole array on host threads while the first parts cross PCIe and then runs the parts one by one,
+// each as soon as it has landed.  EC only (QT's table is a property of the whole array, dctz-comp-lib.c:435-476).
+// part_stats: max|x|, min|x| of the part and the sum of its elements FROM THE SECOND ON (util.c:22 starts at i = 1: the
+// caller adds the first one where the part is not the array's first).
+template <typename T>
+static int compress_part_impl(dctzhip_ctx* c, const T* d_in, size_t n, double eb, const HostStats& st, uint8_t* d_bin, float* d_dc,
+                              float* d_ac, uint32_t* cnt, double* part_stats, double* sf_out) {
+  hipStream_t s = c->stream;
+  double* hs = reinterpret_cast<double*>(c->h_pin + PIN_STATS);
+  Ctl* hc = reinterpret_cast<Ctl*>(c->h_pin + PIN_CTL);
+  const bool box = c->handoff != 0;
+  HostBox* hb = c->box;
+  HIPCHK(c, hipMemsetAsync(c->ctl, 0, sizeof(Ctl), s));      // (no statistics kernel in front that would do it)
+  c->ctl_dirty = 1;
+  const unsigned long long seq = box ? ++c->seq : 0ull;
+  if (c->profiling) { HIPCHK(c, hipEventRecord(c->ev[0], s)); HIPCHK(c, hipEventRecord(c->ev[1], s)); }
+  double sf = 1.0;
+  T sf_t = T(1);
+  unsigned fast_sf = 0;
+  int rc = compress_pass<T>(c, d_in, n, eb, DCTZHIP_EC, d_bin, d_dc, d_ac, (T*)nullptr, st, true, &sf, &sf_t, &fast_sf, seq, GEOM_1D);
+  if (rc) return rc;
+  if (box) {
+    rc = wait_seq(c, &hb->seq_done, seq, "compress (part)");
+    if (rc) return rc;
+    c->ctl_dirty = 0;
+    hc->cnt_total = hb->cnt_total; hc->error = hb->error;
+    hs[4] = hb->fstats[0]; hs[5] = hb->fstats[1]; hs[6] = hb->fstats[2];
+    if (c->profiling) HIPCHK(c, hipEventSynchronize(c->ev[4]));
+  } else {
+    HIPCHK(c, hipMemcpyAsync(hs + 4, c->stats_out, 3 * sizeof(double), hipMemcpyDeviceToHost, s));
+    HIPCHK(c, hipMemcpyAsync(hc, c->ctl, sizeof(Ctl), hipMemcpyDeviceToHost, s));
+    HIPCHK(c, hipStreamSynchronize(s));
+  }
+  if (hc->error) return fail(c, DCTZHIP_E_INTERNAL, "in-kernel error flag set (code %u)", hc->error);
+  if (c->profiling) { rc = read_timings(c, 2); if (rc) return rc; }
+  // the part's own extremes must lie inside the array's (else the caller's statistics are not this array's)
+  if (hs[4] > st.max_abs || hs[5] < st.min_abs)
+    return fail(c, DCTZHIP_E_ARG, "dctzhip_compress_part: the part's max|x| %g / min|x| %g lie outside the statistics given (%g / %g)", hs[4], hs[5], st.max_abs, st.min_abs);
+  *cnt = hc->cnt_total;
+  if (part_stats) { part_stats[0] = hs[4]; part_stats[1] = hs[5]; part_stats[2] = hs[6]; }
+  if (sf_out) *sf_out = sf;
+  return DCTZHIP_OK;
+}
+extern "C" int dctzhip_compress_part(dctzhip_ctx* c, const void* d_in, size_t n, int dtype, double eb, double max_abs, double min_abs,
+                                     void* d_bin, float* d_dc, float* d_ac, uint32_t* cnt, double* part_stats, double* sf) {
+  int rc = check_common(c, n, dtype, DCTZHIP_EC);
+  if (rc) return rc;
+  if (!d_in || !d_bin || !d_dc || !d_ac || !cnt) return fail(c, DCTZHIP_E_ARG, "null buffer");
+  // (a part that starts at block b has its DC at d_dc + b: dword stores through a descriptor, like AC_exact's)
+  if (!aligned16(d_in) || !aligned16(d_bin) || ((uintptr_t)d_dc & 3u) || ((uintptr_t)d_ac & 3u))
+    return fail(c, DCTZHIP_E_ARG, "device buffers must be 16-byte aligned (DC, AC_exact: 4)");
+  if (eb < 1E-6) return fail(c, DCTZHIP_E_BOUND, "ERROR BOUND is not acceptable");   // dctz-comp-lib.c:135-138
+  if (!(max_abs >= min_abs) || !(min_abs >= 0.0)) return fail(c, DCTZHIP_E_ARG, "dctzhip_compress_part: statistics are not a max|x| >= min|x| >= 0 pair");
+  HIPCHK(c, hipSetDevice(c->device));
+  rc = ensure_scratch(c, n, dtype, DCTZHIP_EC);
+  if (rc) return rc;
+  const HostStats st = {max_abs, min_abs, 0.0};
+  rc = (dtype == DCTZHIP_F64)
+           ? compress_part_impl<double>(c, (const double*)d_in, n, eb, st, (uint8_t*)d_bin, d_dc, d_ac, cnt, part_stats, sf)
+           : compress_part_impl<float>(c, (const float*)d_in, n, eb, st, (uint8_t*)d_bin, d_dc, d_ac, cnt, part_stats, sf);
   if (rc == DCTZHIP_OK && c->blocking) HIPCHK(c, hipStreamSynchronize(c->stream));
   return rc;
 }

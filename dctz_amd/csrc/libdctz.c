@@ -514,6 +514,395 @@ static int take_block_dims(size_t n, size_t dims[3]) {
   return nd;
 }
 
+/* ---- dctz_compress of a large array, pipelined (round 4) --------------------------------------------------------------
+ * With the entropy stage on the device a 1 GiB call was H2D 19.4 ms -> kernels 0.3 -> deflate 2.6 -> D2H of the
+ * compressed sections 4.5, one after the other, the host cores scaling the caller's array meanwhile: 27 ms, of which the
+ * GPU worked for three.  The blocks of an array are independent once its scaling factor is known (util.c:29: a function of
+ * max|x| alone), so:
+ *   * the array crosses PCIe in GROUPS of DCTZ_PIPE_GROUP elements (default 8 Mi; dctzhip_h2d_pipe_*);
+ *   * host threads take max|x| / min|x| of the caller's array while the first groups are under way (3 ms);
+ *   * every group that has landed is compressed with the ARRAY's statistics (dctzhip_compress_part: same streams as the
+ *     one call, AC_exact appended behind the groups in front), its bin_index and DC are deflated on the device -- the
+ *     entropy stage codes 16 KiB chunks that reference nothing outside themselves, and a group is a whole number of chunks
+ *     of both sections, so the groups' pieces concatenate to exactly the stream of the one call (adler32_combine for the
+ *     check value) -- and the compressed bytes go back while the next groups are still arriving;
+ *   * the in-place x /= sf of the caller's array (dctz-comp-lib.c:193-216) follows the copy: a block is divided once the
+ *     group it lies in is on the device;
+ *   * behind the last group only AC_exact (known in full only then) is left to deflate and bring back.
+ * Same container as the serial path of this mode except for the header's `mean` (a tree-order sum either way; this path
+ * adds the groups' sums).  DCTZ_PIPELINE=0: the serial path. */
+static int pipeline_on(void) { const char *e = getenv("DCTZ_PIPELINE"); return e ? atoi(e) != 0 : 1; }
+static size_t pipe_group(void) {
+  const char *e = getenv("DCTZ_PIPE_GROUP");
+  long long v = e ? atoll(e) : 0;
+  return v >= (1 << 18) ? ((size_t)v & ~(size_t)((1 << 18) - 1)) : ((size_t)1 << 23);   /* a multiple of 256 Ki elements */
+}
+typedef struct { const void *x; size_t lo, hi; int is_d; double mx, mn; } mm_job;
+/* util.c:18-25: max|x| and min|x|.  A NaN never wins a comparison there; vmaxpd / vminpd return their SECOND operand when
+ * the comparison is unordered, so with the running value second a NaN element is passed over the same way. */
+__attribute__((target("avx2"))) static void mm_range_avx2(mm_job *j) {
+  if (j->is_d) {
+    typedef double v4 __attribute__((vector_size(32), aligned(8)));
+    typedef long long m4 __attribute__((vector_size(32)));
+    const double *x = (const double *)j->x;
+    const m4 absm = {0x7fffffffffffffffLL, 0x7fffffffffffffffLL, 0x7fffffffffffffffLL, 0x7fffffffffffffffLL};
+    v4 mx[4], mn[4];
+    for (int u = 0; u < 4; u++) { mx[u] = (v4){-1.0, -1.0, -1.0, -1.0}; mn[u] = (v4){INFINITY, INFINITY, INFINITY, INFINITY}; }
+    size_t i = j->lo;
+    for (; i + 16 <= j->hi; i += 16)
+      for (int u = 0; u < 4; u++) {
+        const v4 a = (v4)((m4)(*(const v4 *)(x + i + 4 * u)) & absm);
+        mx[u] = __builtin_ia32_maxpd256(a, mx[u]);
+        mn[u] = __builtin_ia32_minpd256(a, mn[u]);
+      }
+    double m = -1.0, l = INFINITY;
+    for (int u = 0; u < 4; u++) for (int k = 0; k < 4; k++) { if (mx[u][k] > m) m = mx[u][k]; if (mn[u][k] < l) l = mn[u][k]; }
+    for (; i < j->hi; i++) { const double a = fabs(x[i]); if (a > m) m = a; if (a < l) l = a; }
+    j->mx = m; j->mn = l;
+  } else {
+    typedef float v8 __attribute__((vector_size(32), aligned(4)));
+    typedef int m8 __attribute__((vector_size(32)));
+    const float *x = (const float *)j->x;
+    const m8 absm = {0x7fffffff, 0x7fffffff, 0x7fffffff, 0x7fffffff, 0x7fffffff, 0x7fffffff, 0x7fffffff, 0x7fffffff};
+    v8 mx[4], mn[4];
+    for (int u = 0; u < 4; u++) for (int k = 0; k < 8; k++) { mx[u][k] = -1.0f; mn[u][k] = INFINITY; }
+    size_t i = j->lo;
+    for (; i + 32 <= j->hi; i += 32)
+      for (int u = 0; u < 4; u++) {
+        const v8 a = (v8)((m8)(*(const v8 *)(x + i + 8 * u)) & absm);
+        mx[u] = __builtin_ia32_maxps256(a, mx[u]);
+        mn[u] = __builtin_ia32_minps256(a, mn[u]);
+      }
+    float m = -1.0f, l = INFINITY;
+    for (int u = 0; u < 4; u++) for (int k = 0; k < 8; k++) { if (mx[u][k] > m) m = mx[u][k]; if (mn[u][k] < l) l = mn[u][k]; }
+    for (; i < j->hi; i++) { const float a = fabsf(x[i]); if (a > m) m = a; if (a < l) l = a; }
+    j->mx = (double)m; j->mn = (double)l;
+  }
+}
+static void *mm_main(void *arg) {
+  mm_job *j = (mm_job *)arg;
+  if (__builtin_cpu_supports("avx2")) { mm_range_avx2(j); return NULL; }
+  enum { U = 8 };                               /* independent chains: a single running maximum is one element per 4 cycles */
+  if (j->is_d) {
+    const double *x = (const double *)j->x;
+    double mx[U], mn[U];
+    for (int u = 0; u < U; u++) { mx[u] = -1.0; mn[u] = INFINITY; }
+    size_t i = j->lo;
+    for (; i + U <= j->hi; i += U)
+      for (int u = 0; u < U; u++) { const double a = fabs(x[i + u]); if (a > mx[u]) mx[u] = a; if (a < mn[u]) mn[u] = a; }
+    for (; i < j->hi; i++) { const double a = fabs(x[i]); if (a > mx[0]) mx[0] = a; if (a < mn[0]) mn[0] = a; }
+    for (int u = 1; u < U; u++) { if (mx[u] > mx[0]) mx[0] = mx[u]; if (mn[u] < mn[0]) mn[0] = mn[u]; }
+    j->mx = mx[0]; j->mn = mn[0];
+  } else {
+    const float *x = (const float *)j->x;
+    float mx[U], mn[U];
+    for (int u = 0; u < U; u++) { mx[u] = -1.0f; mn[u] = INFINITY; }
+    size_t i = j->lo;
+    for (; i + U <= j->hi; i += U)
+      for (int u = 0; u < U; u++) { const float a = fabsf(x[i + u]); if (a > mx[u]) mx[u] = a; if (a < mn[u]) mn[u] = a; }
+    for (; i < j->hi; i++) { const float a = fabsf(x[i]); if (a > mx[0]) mx[0] = a; if (a < mn[0]) mn[0] = a; }
+    for (int u = 1; u < U; u++) { if (mx[u] > mx[0]) mx[0] = mx[u]; if (mn[u] < mn[0]) mn[0] = mn[u]; }
+    j->mx = (double)mx[0]; j->mn = (double)mn[0];
+  }
+  return NULL;
+}
+/* x[lo, hi) /= sf, the reference's loop (IEEE division in the data type); four / eight lanes at a time where the CPU has
+ * AVX2 (vdivpd / vdivps round like divsd / divss) */
+__attribute__((target("avx2"))) static void scale_range_avx2(void *xv, size_t lo, size_t hi, int is_d, double sf) {
+  if (is_d) {
+    double *x = (double *)xv;
+    typedef double v4 __attribute__((vector_size(32), aligned(8)));
+    const v4 d = {sf, sf, sf, sf};
+    size_t i = lo;
+    for (; i + 4 <= hi; i += 4) { v4 v = *(v4 *)(x + i); v = v / d; *(v4 *)(x + i) = v; }
+    for (; i < hi; i++) x[i] /= sf;
+  } else {
+    float *x = (float *)xv;
+    const float f = (float)sf;
+    typedef float v8 __attribute__((vector_size(32), aligned(4)));
+    const v8 d = {f, f, f, f, f, f, f, f};
+    size_t i = lo;
+    for (; i + 8 <= hi; i += 8) { v8 v = *(v8 *)(x + i); v = v / d; *(v8 *)(x + i) = v; }
+    for (; i < hi; i++) x[i] /= f;
+  }
+}
+static void scale_range(void *xv, size_t lo, size_t hi, int is_d, double sf) {
+  if (__builtin_cpu_supports("avx2")) { scale_range_avx2(xv, lo, hi, is_d, sf); return; }
+  if (is_d) { double *x = (double *)xv; for (size_t i = lo; i < hi; i++) x[i] /= sf; }
+  else { float *x = (float *)xv; const float f = (float)sf; for (size_t i = lo; i < hi; i++) x[i] /= f; }
+}
+#define FOLLOW_BLOCK ((size_t)1 << 17)        /* elements a worker of the follower divides at a time */
+typedef struct {
+  void *x; size_t n; int is_d; double sf;
+  size_t landed;                /* elements of the caller's array the copy has finished with (released group by group) */
+  size_t next;
+  int failed;
+} follow_job;
+static void *follow_worker(void *arg) {
+  follow_job *f = (follow_job *)arg;
+  for (;;) {
+    const size_t lo = __atomic_fetch_add(&f->next, FOLLOW_BLOCK, __ATOMIC_RELAXED);
+    if (lo >= f->n) break;
+    const size_t hi = lo + FOLLOW_BLOCK < f->n ? lo + FOLLOW_BLOCK : f->n;
+    while (__atomic_load_n(&f->landed, __ATOMIC_ACQUIRE) < hi) {
+      if (__atomic_load_n(&f->failed, __ATOMIC_ACQUIRE)) return NULL;
+      usleep(20);
+    }
+    scale_range(f->x, lo, hi, f->is_d, f->sf);
+  }
+  return NULL;
+}
+typedef struct { dctzhip_ctx *c; follow_job *f; size_t gel, ts; } track_job;
+static void *track_main(void *arg) {            /* releases the groups to the follower as their copies complete */
+  track_job *t = (track_job *)arg;
+  for (size_t e = 0; e < t->f->n;) {
+    e = e + t->gel < t->f->n ? e + t->gel : t->f->n;
+    if (dctzhip_h2d_pipe_landed(t->c, e * t->ts) != DCTZHIP_OK) { __atomic_store_n(&t->f->failed, 1, __ATOMIC_RELEASE); return NULL; }
+    __atomic_store_n(&t->f->landed, e, __ATOMIC_RELEASE);
+  }
+  return NULL;
+}
+static void put_be32(unsigned char *p, uLong v) { p[0] = (unsigned char)(v >> 24); p[1] = (unsigned char)(v >> 16); p[2] = (unsigned char)(v >> 8); p[3] = (unsigned char)v; }
+static uLong get_be32(const unsigned char *p) { return ((uLong)p[0] << 24) | ((uLong)p[1] << 16) | ((uLong)p[2] << 8) | (uLong)p[3]; }
+/* the drainer: compressed pieces of finished groups, device -> host, in order, beside the calling thread */
+typedef struct {
+  const unsigned char *src;     /* device: a piece's stream (78 5E | chunks | 03 00 | adler32) */
+  size_t len, raw;              /* its length; the bytes it inflates to */
+  int sec;
+} drain_piece;
+typedef struct {
+  dctzhip_ctx *c;
+  drain_piece *q;
+  size_t posted, cap;           /* pieces posted so far (released by the calling thread) */
+  int closed, failed;
+  unsigned char *base[3];       /* where a section's stream is assembled on the host */
+  size_t off[3];                /* its bytes so far, trailer excluded */
+  uLong adler[3];
+  int started[3];
+} drain_job;
+static void *drain_main(void *arg) {
+  drain_job *d = (drain_job *)arg;
+  for (size_t k = 0;; k++) {
+    while (__atomic_load_n(&d->posted, __ATOMIC_ACQUIRE) <= k) {
+      if (__atomic_load_n(&d->closed, __ATOMIC_ACQUIRE) && __atomic_load_n(&d->posted, __ATOMIC_ACQUIRE) <= k) return NULL;
+      usleep(10);
+    }
+    const drain_piece *p = &d->q[k];
+    /* the first piece of a section keeps its two header bytes; every piece's trailer is overwritten by the next piece's chunks */
+    const size_t skip = d->started[p->sec] ? 2 : 0;
+    unsigned char *at = d->base[p->sec] + d->off[p->sec];
+    if (p->len < 8 || dctzhip_memcpy_d2h_side(d->c, at, p->src + skip, p->len - skip) != DCTZHIP_OK) { __atomic_store_n(&d->failed, 1, __ATOMIC_RELEASE); return NULL; }
+    d->off[p->sec] += p->len - skip - 6;
+    const uLong a = get_be32(d->base[p->sec] + d->off[p->sec] + 2);
+    d->adler[p->sec] = d->started[p->sec] ? adler32_combine(d->adler[p->sec], a, (z_off_t)p->raw) : a;
+    d->started[p->sec] = 1;
+  }
+}
+typedef struct { unsigned char *dst; const unsigned char *src; size_t n; } pcopy_job;
+static void *pcopy_main(void *arg) { pcopy_job *j = (pcopy_job *)arg; memcpy(j->dst, j->src, j->n); return NULL; }
+static void par_memcpy(void *dst, const void *src, size_t n, int T) {
+  if (T > 16) T = 16;
+  if (n < ((size_t)1 << 20) || T < 2) { memcpy(dst, src, n); return; }
+  pcopy_job j[16];
+  pthread_t th[16];
+  int started = 0;
+  const size_t per = (n / (size_t)T + 4095) & ~(size_t)4095;
+  for (int t = 0; t < T; t++) {
+    const size_t lo = per * (size_t)t;
+    if (lo >= n) break;
+    j[t].dst = (unsigned char *)dst + lo; j[t].src = (const unsigned char *)src + lo; j[t].n = n - lo < per ? n - lo : per;
+    if (t && pthread_create(&th[started], NULL, pcopy_main, &j[t]) == 0) started++; else pcopy_main(&j[t]);
+  }
+  for (int t = 0; t < started; t++) pthread_join(th[t], NULL);
+}
+/* returns 1: the container is written; 0: not applicable, the caller takes the serial path */
+static int compress_pipelined(dctzhip_ctx *c, t_var *var, void *host_in, size_t n, int is_d, double error_bound, t_var *var_z, size_t *outSize,
+                              double t_begin) {
+  if (DCTZ_MODE != DCTZHIP_EC) return 0;          /* QT: the table is a property of the whole array (dctz-comp-lib.c:435-476) */
+  const size_t ts = is_d ? sizeof(double) : sizeof(float);
+  const int dtype = is_d ? DCTZHIP_F64 : DCTZHIP_F32;
+  const size_t chunk = dctzhip_deflate_chunk_bytes();
+  /* groups of 16 Mi elements unless DCTZ_PIPE_GROUP says otherwise: a group's entropy stage is a millisecond whatever the
+   * group's size (four latency-bound kernels per section), a 128 MiB group takes 2.4 ms to arrive */
+  const size_t gel = getenv("DCTZ_PIPE_GROUP") ? pipe_group() : ((size_t)1 << 24);
+  if (gel % (16 * chunk) != 0 || n < 4 * gel) return 0;
+  if (is_d ? isnan(((const double *)host_in)[0]) : isnan(((const float *)host_in)[0])) return 0;   /* util.c:18-19: max = NaN from the start */
+  const size_t G = (n + gel - 1) / gel, nblk = CEIL(n, BLK_SZ);
+  const int dbg = getenv("DCTZ_PIPE_DEBUG") != NULL;
+  /* the first element of every group, as the caller gave it (the follower divides the array while the groups' sums come in) */
+  double *firsts = (double *)malloc(G * sizeof(double));
+  if (!firsts) { fprintf(stderr, "Out of memory\n"); exit(1); }
+  for (size_t g = 0; g < G; g++) firsts[g] = is_d ? ((const double *)host_in)[g * gel] : (double)((const float *)host_in)[g * gel];
+
+  grow(&g_dev.in, &g_dev.in_cap, n * ts);
+  grow(&g_dev.bin, &g_dev.bin_cap, n);
+  grow(&g_dev.dc, &g_dev.dc_cap, nblk * sizeof(float));
+  grow(&g_dev.ac, &g_dev.ac_cap, n * sizeof(float));
+  /* every group's pieces have slots of their own in the device buffers of the compressed sections (the drainer is still
+   * reading a group's while the next group's are written); AC_exact: what a group can add, plus the chunk carried over */
+  const size_t bound[3] = {(dctzhip_deflate_bound(gel) + 255) & ~(size_t)255, (dctzhip_deflate_bound(gel / 16) + 255) & ~(size_t)255,
+                           (dctzhip_deflate_bound(gel * sizeof(float) + chunk) + 255) & ~(size_t)255};
+  for (int i = 0; i < 3; i++) grow(&g_dev.z[i], &g_dev.z_cap[i], G * bound[i]);
+  const size_t bpg = gel / chunk, dpg = gel / 16 / chunk;       /* chunks of bin_index / DC per group */
+  size_t ix_n[3] = {(n + chunk - 1) / chunk, (nblk * sizeof(float) + chunk - 1) / chunk, 0};
+  uint32_t *ix[3] = {(uint32_t *)malloc((ix_n[0] + 1) * sizeof(uint32_t)), (uint32_t *)malloc((ix_n[1] + 1) * sizeof(uint32_t)),
+                     (uint32_t *)malloc((n * sizeof(float) / chunk + G + 2) * sizeof(uint32_t))};
+  /* DC's and AC_exact's compressed pieces wait on the host until bin_index's length is known */
+  unsigned char *dcz = (unsigned char *)host_buf(1, G * bound[1]), *acz = (unsigned char *)host_buf(2, G * bound[2]);
+  drain_piece *pieces = (drain_piece *)malloc((3 * G + 3) * sizeof(drain_piece));
+  if (!ix[0] || !ix[1] || !ix[2] || !pieces) { fprintf(stderr, "Out of memory: chunk index\n"); exit(1); }
+  unsigned char *zc = (is_d ? (unsigned char *)var_z->buf.d : (unsigned char *)var_z->buf.f) + sizeof(struct header);
+
+  const double t0 = now_s();
+  if (dctzhip_h2d_pipe_begin(c, g_dev.in, host_in, n * ts, gel * ts) != DCTZHIP_OK) die("H2D pipe");
+  /* max|x|, min|x| of the whole array (util.c:18-25) */
+  int T = host_threads();
+  if (T > 64) T = 64;
+  /* threads of the max|x| pass / of the follower: the call is bound by the HOST's memory traffic (the copy's staging, the
+   * max|x| pass and the division together move six times the array: 250 GB/s on the measured host), more threads only take
+   * bandwidth from the copy (tools/cpipe_sweep.py) */
+  int TM = T < 16 ? T : 16, TF = T < 12 ? T : 12;
+  { const char *e = getenv("DCTZ_PIPE_MM_THREADS"); if (e && atoi(e) > 0) TM = atoi(e) > 64 ? 64 : atoi(e); }
+  { const char *e = getenv("DCTZ_PIPE_FOLLOW_THREADS"); if (e && atoi(e) > 0) TF = atoi(e) > 64 ? 64 : atoi(e); }
+  mm_job mj[64];
+  pthread_t mth[64];
+  int mstarted = 0;
+  for (int t = 0; t < TM; t++) {
+    mj[t].x = host_in; mj[t].is_d = is_d; mj[t].lo = n / (size_t)TM * (size_t)t; mj[t].hi = t + 1 == TM ? n : n / (size_t)TM * (size_t)(t + 1);
+    mj[t].mx = -1.0; mj[t].mn = INFINITY;
+    if (t + 1 < TM && pthread_create(&mth[mstarted], NULL, mm_main, &mj[t]) == 0) mstarted++; else mm_main(&mj[t]);
+  }
+  for (int t = 0; t < mstarted; t++) pthread_join(mth[t], NULL);
+  double mx = -1.0, mn = INFINITY;
+  for (int t = 0; t < TM; t++) { if (mj[t].mx > mx) mx = mj[t].mx; if (mj[t].mn < mn) mn = mj[t].mn; }
+  if (!(mx >= 0.0)) { mx = 0.0; mn = 0.0; }             /* (nothing but NaNs behind a finite first element: as the serial loop, max = |x[0]|) */
+  { const double a0 = fabs(firsts[0]); if (a0 > mx) mx = a0; if (a0 < mn) mn = a0; }
+  const double t_mm = now_s();
+
+  drain_job dj;
+  memset(&dj, 0, sizeof(dj));
+  dj.c = c; dj.q = pieces; dj.cap = 3 * G + 3;
+  dj.base[0] = zc; dj.base[1] = dcz; dj.base[2] = acz;
+  pthread_t dth;
+  if (pthread_create(&dth, NULL, drain_main, &dj)) { fprintf(stderr, "Error creating thread\n"); exit(0); }
+  size_t npieces = 0, S = 0, ac_done = 0;                 /* pieces posted; exact coefficients so far; bytes of AC_exact deflated so far */
+  double sum = 0.0, sf = 1.0, t_gpu = 0.0, t_tail = 0.0;
+  follow_job fj = {host_in, n, is_d, 1.0, 0, 0, 0};
+  track_job tj = {c, &fj, gel, ts};
+  pthread_t fth[64], tth;
+  int fstarted = 0, tracking = 0;
+  for (size_t g = 0; g < G; g++) {
+    const size_t e0 = g * gel, ne = n - e0 < gel ? n - e0 : gel, b0 = e0 / BLK_SZ, nb = CEIL(ne, BLK_SZ);
+    const double tg0 = now_s();
+    if (dctzhip_h2d_pipe_wait(c, (e0 + ne) * ts) != DCTZHIP_OK) die("H2D pipe");
+    uint32_t cnt_g = 0;
+    double pst[3];
+    if (dctzhip_compress_part(c, (const char *)g_dev.in + e0 * ts, ne, dtype, error_bound, mx, mn, (unsigned char *)g_dev.bin + e0,
+                              (float *)g_dev.dc + b0, (float *)g_dev.ac + S, &cnt_g, pst, &sf) != DCTZHIP_OK) die("dctzhip_compress_part");
+    sum += pst[2] + (g ? firsts[g] : 0.0);
+    S += cnt_g;
+    const double tg1 = now_s();
+    if (g == 0 && sf != 1.0 && scale_on_host(1)) {        /* the in-place x /= sf follows the copy from here on */
+      fj.sf = sf;
+      if (pthread_create(&tth, NULL, track_main, &tj) == 0) tracking = 1;
+      for (int t = 0; tracking && t < TF; t++) if (pthread_create(&fth[fstarted], NULL, follow_worker, &fj) == 0) fstarted++;
+    }
+    /* the group's bin_index and DC, and the chunks of AC_exact that are complete by now (all of the rest behind the last group) */
+    size_t ac_upto = S * sizeof(float);
+    if (g + 1 < G) ac_upto -= ac_upto % chunk;
+    const int nsec = ac_upto > ac_done ? 3 : 2;
+    const void *gsrc[3] = {(const unsigned char *)g_dev.bin + e0, (const float *)g_dev.dc + b0, (const unsigned char *)g_dev.ac + ac_done};
+    const size_t gn[3] = {ne, nb * sizeof(float), ac_upto - ac_done};
+    void *gdst[3] = {(unsigned char *)g_dev.z[0] + g * bound[0], (unsigned char *)g_dev.z[1] + g * bound[1], (unsigned char *)g_dev.z[2] + g * bound[2]};
+    uint32_t *gix[3] = {ix[0] + g * bpg, ix[1] + g * dpg, ix[2] + ac_done / chunk};
+    const unsigned gflags[3] = {0u, DCTZHIP_DEFLATE_LITERALS, DCTZHIP_DEFLATE_LITERALS};   /* DC and AC_exact are bytes of floats */
+    size_t glen[3] = {0, 0, 0};
+    if (dctzhip_deflate_ex(c, nsec, gsrc, gn, gdst, bound, glen, gix, gflags) != DCTZHIP_OK) die("dctzhip_deflate");
+    for (int i = 0; i < nsec; i++) {
+      pieces[npieces].src = (const unsigned char *)gdst[i]; pieces[npieces].len = glen[i]; pieces[npieces].raw = gn[i]; pieces[npieces].sec = i;
+      npieces++;
+    }
+    __atomic_store_n(&dj.posted, npieces, __ATOMIC_RELEASE);
+    ac_done = ac_upto;
+    const double tg2 = now_s();
+    t_gpu += tg1 - tg0; t_tail += tg2 - tg1;
+    if (dbg) fprintf(stderr, "[cpipe] group %zu: start %.2f ms, wait + kernels %.2f, deflate %.2f (cnt %u), landed %zu\n", g, (tg0 - t0) * 1e3, (tg1 - tg0) * 1e3, (tg2 - tg1) * 1e3, cnt_g,
+                     __atomic_load_n(&fj.landed, __ATOMIC_RELAXED) / gel);
+  }
+  ix_n[2] = (S * sizeof(float) + chunk - 1) / chunk;
+  if (S == 0) {                                            /* no exact coefficient at all: the empty stream, as the one call writes it */
+    const size_t zero = 0;
+    const void *asrc[1] = {g_dev.ac};
+    void *adst[1] = {g_dev.z[2]};
+    uint32_t *aix[1] = {ix[2]};
+    size_t alen = 0;
+    if (dctzhip_deflate_ex(c, 1, asrc, &zero, adst, &bound[2], &alen, aix, NULL) != DCTZHIP_OK) die("dctzhip_deflate");
+    pieces[npieces].src = (const unsigned char *)g_dev.z[2]; pieces[npieces].len = alen; pieces[npieces].raw = 0; pieces[npieces].sec = 2;
+    npieces++;
+    __atomic_store_n(&dj.posted, npieces, __ATOMIC_RELEASE);
+  }
+  const double t_loop = now_s();
+  __atomic_store_n(&dj.closed, 1, __ATOMIC_RELEASE);
+  pthread_join(dth, NULL);
+  if (dj.failed) die("D2H compressed pieces");
+  if (dctzhip_h2d_pipe_end(c, 0) != DCTZHIP_OK) die("H2D pipe");
+  const double t_drain = now_s();
+  /* close the three streams (03 00 | adler32 of the whole section) and put DC's and AC_exact's behind bin_index's */
+  size_t zlen[3];
+  for (int i = 0; i < 3; i++) {
+    unsigned char *t = dj.base[i] + dj.off[i];
+    t[0] = 0x03; t[1] = 0x00; put_be32(t + 2, dj.adler[i]);
+    zlen[i] = dj.off[i] + 6;
+  }
+  const size_t z0 = zlen[0], z1 = zlen[1], z2 = zlen[2];
+  if (z0 > 0xffffffffu || z1 > 0xffffffffu || z2 > 0xffffffffu) { fprintf(stderr, "libdctz: a compressed section exceeds the header's 32-bit sizes (dctz.h:104-113): shard the array\n"); exit(1); }
+  par_memcpy(zc + z0, dcz, z1, 4);
+  par_memcpy(zc + z0 + z1, acz, z2, 8);
+  const double t_asm = now_s();
+  for (int t = 0; t < fstarted; t++) pthread_join(fth[t], NULL);
+  if (tracking) pthread_join(tth, NULL);
+  if (fj.failed) die("H2D pipe (follower)");
+  if (sf != 1.0 && !fstarted) {                            /* (no follower thread could be started, or DCTZ_SCALE_HOST=0: the device's copy) */
+    if (dctzhip_scale_inplace(c, g_dev.in, n, dtype, sf) != DCTZHIP_OK) die("scale");
+    if (dctzhip_memcpy_d2h(c, host_in, g_dev.in, n * ts) != DCTZHIP_OK) die("D2H scaled input");
+  }
+
+  /* container: header | bin_indexz | DCz | AC_exactz | "DZIX"  (:775-820) */
+  struct header h;
+  memset(&h, 0, sizeof(h));
+  h.datatype = var->datatype;
+  h.num_elements = (unsigned int)n;
+  h.error_bound = error_bound;
+  h.tot_AC_exact_count = (unsigned int)S;
+  if (is_d) { h.scaling_factor.d = sf; h.mean.d = sum / (double)(int)n; }           /* util.c:28 / :41, on a tree-order sum (DCTZ_FAST_MEAN) */
+  else { h.scaling_factor.f = (float)sf; h.mean.f = (float)sum / (float)(int)n; }
+  h.bindex_sz_compressed = (unsigned int)z0;
+  h.DC_sz_compressed = (unsigned int)z1;
+  h.AC_exact_sz_compressed = (unsigned int)z2;
+  memcpy(zc - sizeof(h), &h, sizeof(h));
+  const size_t ix_bytes = (20 + 2 * (ix_n[0] + ix_n[1] + ix_n[2]) + 3) & ~(size_t)3;
+  unsigned char *cur = zc + z0 + z1 + z2;
+  const unsigned int hd[5] = {DCTZ_IX_MAGIC, (unsigned int)chunk, (unsigned int)ix_n[0], (unsigned int)ix_n[1], (unsigned int)ix_n[2]};
+  memset(cur, 0, ix_bytes);
+  memcpy(cur, hd, sizeof(hd));
+  unsigned short *e = (unsigned short *)(cur + sizeof(hd));
+  for (int i = 0; i < 3; i++) {
+    for (size_t k = 0; k < ix_n[i]; k++) *e++ = (unsigned short)ix[i][k];
+    free(ix[i]);
+  }
+  free(firsts); free(pieces);
+  *outSize = sizeof(struct header) + z0 + z1 + z2 + ix_bytes;
+  const double t_end = now_s();
+  /* the stages overlap: h2d_s is the span up to the last group's kernels, gpu_s / zlib_s what the calling thread spent in the
+   * groups' kernels / entropy stage, d2h_s what was left behind the last group (drain, assembly, the follower) */
+  g_times.h2d_s = t_loop - t0; g_times.gpu_s = t_gpu; g_times.zlib_s = t_tail; g_times.d2h_s = t_end - t_loop;
+  g_times.total_s = t_end - t_begin;
+  if (dbg) fprintf(stderr, "[cpipe] max|x| at %.2f ms, last group queued %.2f, pieces drained %.2f, assembled %.2f, follower joined %.2f\n", (t_mm - t0) * 1e3, (t_loop - t0) * 1e3,
+                   (t_drain - t0) * 1e3, (t_asm - t0) * 1e3, (t_end - t0) * 1e3);
+  if (!quiet()) printf("outSize = %zu\n", *outSize); /* :841-843 */
+  return 1;
+}
+
 /* -------------------------------------------------------------- compress --- */
 int dctz_compress(t_var *var, int N, size_t *outSize, t_var *var_z, double error_bound) {
   const double t_begin = now_s();
@@ -538,6 +927,8 @@ int dctz_compress(t_var *var, int N, size_t *outSize, t_var *var_z, double error
   const size_t npos = nd ? nblk * BLK_SZ : n;   /* positions the streams cover (edge tiles are padded) */
 
   dctzhip_ctx *c = ctx();
+  if (!nd && zlib_gpu() && fast_mean() && pipeline_on() && !getenv("DCTZ_DUMP_STREAMS") &&
+      compress_pipelined(c, var, host_in, n, is_d, error_bound, var_z, outSize, t_begin)) return 1;
   grow(&g_dev.in, &g_dev.in_cap, n * ts);
   grow(&g_dev.bin, &g_dev.bin_cap, npos);
   grow(&g_dev.dc, &g_dev.dc_cap, nblk * sizeof(float));
@@ -1077,12 +1468,6 @@ int dctz_check_container(const void *z, size_t zbytes, int max_elements, int dee
  * groups back into the caller's array.  Round 3 ran inflate (17 ms per GiB), H2D (3), kernels (0.3) and D2H (21) one after
  * the other; the stages now overlap and the call takes about as long as its longest one.  The reconstruction is the same
  * bytes: the same kernels on the same inputs.  DCTZ_PIPELINE=0: the serial path. */
-static int pipeline_on(void) { const char *e = getenv("DCTZ_PIPELINE"); return e ? atoi(e) != 0 : 1; }
-static size_t pipe_group(void) {
-  const char *e = getenv("DCTZ_PIPE_GROUP");
-  long long v = e ? atoll(e) : 0;
-  return v >= (1 << 18) ? ((size_t)v & ~(size_t)((1 << 18) - 1)) : ((size_t)1 << 23);   /* a multiple of 256 Ki elements */
-}
 typedef struct {
   const unsigned char *src;
   unsigned int zlen, len;

@@ -109,6 +109,12 @@ _PROTOS = {
     "dctzhip_comm_sizes": (C.c_int, [C.c_void_p, C.c_uint64, C.c_uint64, C.POINTER(C.c_uint64)]),
     "dctzhip_comm_gather": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_uint64),
                                       C.c_void_p, C.c_void_p, C.c_void_p]),
+    "dctzhip_compress_part": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_double, C.c_double, C.c_double, C.c_void_p,
+                                        C.c_void_p, C.c_void_p, C.POINTER(C.c_uint32), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
+    "dctzhip_h2d_pipe_begin": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t]),
+    "dctzhip_h2d_pipe_wait": (C.c_int, [C.c_void_p, C.c_size_t]),
+    "dctzhip_h2d_pipe_landed": (C.c_int, [C.c_void_p, C.c_size_t]),
+    "dctzhip_h2d_pipe_end": (C.c_int, [C.c_void_p, C.c_int]),
     "dctzhip_version": (C.c_char_p, []),
 }
 
@@ -234,6 +240,20 @@ class Context:
             coef.data_ptr() if coef is not None else None, C.byref(info))
         self._check(rc, "dctzhip_compress")
         return out, info
+
+    def compress_part(self, x, eb, max_abs, min_abs, out, lo, ac_at):
+        """Elements of one part of an array (x: the part, a 1-D CUDA tensor that starts on a block boundary `lo` of the
+        array) with the ARRAY's max|x| / min|x|: its streams go to their places in `out` (the array's outputs), the exact
+        coefficients at ac_at.  Returns (cnt, (max|x|, min|x|, sum from the second element on), sf)."""
+        assert x.is_cuda and x.is_contiguous() and x.dim() == 1 and lo % 64 == 0
+        self._bind_stream()
+        cnt, st, sf = C.c_uint32(0), (C.c_double * 3)(), C.c_double(0.0)
+        rc = self.lib.dctzhip_compress_part(
+            self.h, x.data_ptr(), x.numel(), _dt(x.dtype), float(eb), float(max_abs), float(min_abs),
+            out["bin_index"].data_ptr() + lo, out["dc"].data_ptr() + 4 * (lo // 64), out["ac_exact"].data_ptr() + 4 * int(ac_at),
+            C.byref(cnt), st, C.byref(sf))
+        self._check(rc, "dctzhip_compress_part")
+        return cnt.value, (st[0], st[1], st[2]), sf.value
 
     def decompress(self, out, cnt, n, dtype, eb, sf, mode=EC, qtable=None, dst=None):
         t = self.torch

@@ -125,6 +125,10 @@ int dctzhip_free(dctzhip_ctx *ctx, void *dptr);
 int dctzhip_memcpy_h2d(dctzhip_ctx *ctx, void *dst, const void *src, size_t bytes);
 int dctzhip_memcpy_d2h(dctzhip_ctx *ctx, void *dst, const void *src, size_t bytes);
 int dctzhip_sync(dctzhip_ctx *ctx);
+/* A D2H copy on a stream BESIDE the context's, for a second host thread (the pipelined dctz_compress brings finished pieces
+ * back while the calling thread queues the next kernels): the caller has synchronised with whatever produced d_src, and
+ * makes such copies from one thread at a time. */
+int dctzhip_memcpy_d2h_side(dctzhip_ctx *ctx, void *dst, const void *d_src, size_t bytes);
 /* A D2H copy into pageable host memory that FOLLOWS its producer (dctz_decompress rebuilds a large array group by group
  * and brings finished groups back while the next ones are built): begin() starts the copy of bytes [0, bytes) of d_src to
  * dst through pinned slots, piece by piece, each piece as soon as advance() has announced it -- "bytes [0, upto) are
@@ -133,6 +137,16 @@ int dctzhip_sync(dctzhip_ctx *ctx);
 int dctzhip_d2h_pipe_begin(dctzhip_ctx *ctx, void *dst, const void *d_src, size_t bytes);
 int dctzhip_d2h_pipe_advance(dctzhip_ctx *ctx, size_t upto);
 int dctzhip_d2h_pipe_end(dctzhip_ctx *ctx, int abandon);
+/* An H2D copy from pageable host memory whose CONSUMER follows it (dctz_compress of a large array starts the kernels of a
+ * group of elements as soon as that group is on the device): begin() starts the copy of src[0, bytes) to d_dst in groups
+ * of group_bytes, in order, on a stream of its own; wait(upto) makes the context's stream wait -- on the GPU -- for the
+ * group that holds byte upto - 1 (the host waits only until that group's copy has been issued); landed(upto) blocks the
+ * host until bytes [0, upto) are on the device, i.e. until the source range is no longer read; end() joins (abandon != 0:
+ * no further group is issued).  One pipe at a time per process. */
+int dctzhip_h2d_pipe_begin(dctzhip_ctx *ctx, void *d_dst, const void *src, size_t bytes, size_t group_bytes);
+int dctzhip_h2d_pipe_wait(dctzhip_ctx *ctx, size_t upto);
+int dctzhip_h2d_pipe_landed(dctzhip_ctx *ctx, size_t upto);
+int dctzhip_h2d_pipe_end(dctzhip_ctx *ctx, int abandon);
 /* Page-lock a caller-owned host buffer for the copies above (hipHostRegister): pageable copies run at about 24 GB/s,
  * pinned ones at PCIe speed.  Pinning itself costs about as much as one pageable copy of the buffer, so it pays for
  * buffers that are reused across calls; the buffer must be unregistered before it is freed. */
@@ -162,6 +176,19 @@ int dctzhip_compress(dctzhip_ctx *ctx, const void *d_in, size_t n, int dtype,
                      double error_bound, int mode, void *d_bin_index, float *d_dc,
                      float *d_ac_exact, void *d_scaled, void *d_coef,
                      dctzhip_cinfo *info);
+
+/* A PART of an array whose statistics the caller already has (EC mode).  The streams of elements [lo, lo + n) of an array
+ * are the same whether the array is compressed in one call or part by part -- blocks are independent
+ * (dctz-comp-lib.c:323-416), AC_exact is block-major (:478-544) -- provided every part is scaled by the ARRAY's scaling
+ * factor (util.c:29), the one thing that couples them: max_abs / min_abs are max|x| and min|x| of the WHOLE array
+ * (calc_data_stat, util.c:18-25).  Parts start on block boundaries (lo % 64 == 0); only the array's last part may end in
+ * a short block.  d_bin / d_dc: the part's own positions (bin_index + lo, DC + lo / 64); d_ac: where the part's exact
+ * coefficients go -- AC_exact + the counts of the parts in front; *cnt: the part's count; part_stats (or NULL): max|x|,
+ * min|x| of the part and the sum of its elements from the SECOND on (util.c:22 starts at i = 1: the caller adds a part's
+ * first element unless the part is the array's first); *sf (or NULL): the scaling factor used.  A part whose own extremes
+ * lie outside [min_abs, max_abs] is refused (DCTZHIP_E_ARG: the statistics are not this array's). */
+int dctzhip_compress_part(dctzhip_ctx *ctx, const void *d_in, size_t n, int dtype, double error_bound, double max_abs,
+                          double min_abs, void *d_bin, float *d_dc, float *d_ac, uint32_t *cnt, double *part_stats, double *sf);
 
 /* calc_data_stat alone (util.c:12-44): fills sf, mean (device order), max_abs,
  * min_abs and nblk of *info. */

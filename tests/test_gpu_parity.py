@@ -504,3 +504,40 @@ def test_fuzz_against_oracle(ctx, seed, n, log_amp, noise, eb, mode, dtype, zero
     tdt = torch.float64 if dtype == np.float64 else torch.float32
     r = ctx.decompress(out, info.cnt, n, tdt, eb, info.sf, mode, qtable=np.array(info.qtable[:])).cpu().numpy()
     assert _same(r, O.decompress(c, O.FAST))
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+@pytest.mark.parametrize("part", [64 * 64 * 3, 64 * 1000, 64 * 64 * 40 + 64 * 5])
+def test_parts_with_the_arrays_statistics_are_the_one_call(ctx, dtype, part):
+    """dctzhip_compress_part: an array compressed part by part -- parts of whole blocks, every part scaled by the ARRAY's
+    scaling factor (max|x| / min|x| given by the caller), AC_exact appended behind the parts in front -- gives the bytes of
+    the one call and of the oracle; the parts' sums add up to the array's (util.c:22: from the second element on).  The
+    array's largest value sits in the LAST part: a part scaled by its own statistics would differ."""
+    import torch
+    n = part * 3 + 64 * 17 + 29
+    x = W.ragged(n, dtype, scale=3.0)
+    x[n - 50] = -4321.0
+    eb = 1e-3
+    c = O.compress(x, eb, O.EC, O.FAST)
+    xd = _dev(ctx, x)
+    out = ctx.alloc_outputs(n, xd.dtype)
+    for k in out:
+        out[k].zero_()
+    mx, mn = float(np.abs(x).max()), float(np.abs(x).min())
+    S, total, lo = 0, 0.0, 0
+    while lo < n:
+        ne = min(part, n - lo)
+        cnt, st, sf = ctx.compress_part(xd[lo:lo + ne], eb, mx, mn, out, lo, S)
+        assert sf == c.sf
+        assert st[0] == float(np.abs(x[lo:lo + ne]).max()) and st[1] == float(np.abs(x[lo:lo + ne]).min())
+        total += st[2] + (float(x[lo]) if lo else 0.0)
+        S += cnt
+        lo += ne
+    assert S == c.cnt
+    assert np.array_equal(out["bin_index"].cpu().numpy(), c.bin_index)
+    assert _same(out["dc"].cpu().numpy(), c.dc)
+    assert _same(out["ac_exact"][:S].cpu().numpy(), c.ac_exact)
+    assert abs(total / n - c.mean) <= 1e-5 * max(1.0, abs(c.mean))
+    # statistics that are not the array's are refused
+    with pytest.raises(H.DctzHipError):
+        ctx.compress_part(xd[n - 64 * 17 - 29:], eb, 10.0, mn, out, n - 64 * 17 - 29, 0)

@@ -279,6 +279,57 @@ def test_pipelined_decompress_is_the_serial_one(mode, dtype, monkeypatch):
     assert lib.dctz_decompress(C.byref(var_b), C.byref(var_r)) == 1
 
 
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_pipelined_compress_is_the_serial_one(dtype, monkeypatch):
+    """dctz_compress of a large array with the entropy stage on the device works group by group (H2D of the groups ahead,
+    max|x| on host threads, kernels + deflate + D2H of the groups that have landed, the in-place x /= sf following the
+    copy): the container must be the serial path's byte for byte -- but for the header's tree-order `mean` -- and the
+    caller's array the same x / sf.  A small group (DCTZ_PIPE_GROUP) makes an array of a few MB six groups with a
+    remainder block in the last; the array's largest value sits in the last group (the scaling factor is the ARRAY's)."""
+    lib = _lib("ec")
+    n = (1 << 18) * 5 + 64 * 1000 + 37
+    x = W.ragged(n, dtype, scale=37.0)
+    x[: 1 << 18] += (np.random.default_rng(3).standard_normal(1 << 18) * 3.0).astype(dtype)
+    x[n - 70] = 5432.0
+    orig = x.copy()
+    eb = 1e-3
+    monkeypatch.setenv("DCTZ_ZLIB_GPU", "1")
+    monkeypatch.setenv("DCTZ_FAST_MEAN", "1")
+    got = {}
+    for name, env in (("pipelined", {"DCTZ_PIPE_GROUP": str(1 << 18)}), ("serial", {"DCTZ_PIPELINE": "0"})):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        xin = orig.copy()
+        zbuf = np.zeros(n * x.itemsize + 4096, np.uint8)
+        var, var_z = _tvar(xin), TVar()
+        var_z.datatype = var.datatype
+        var_z.buf.d = zbuf.ctypes.data_as(C.POINTER(C.c_double))
+        out_size = C.c_size_t(0)
+        assert lib.dctz_compress(C.byref(var), n, C.byref(out_size), C.byref(var_z), eb) == 1
+        got[name] = (zbuf[: out_size.value].copy(), xin, None)
+        for k in env:
+            monkeypatch.delenv(k)
+    (zp, xp, _), (zs, xs, _) = got["pipelined"], got["serial"]
+    assert zp.size == zs.size
+    MEAN = slice(32, 40)                                   # struct header: mean at offset 32 (tests/test_abi_cpu.py)
+    assert np.array_equal(np.delete(zp, np.r_[MEAN]), np.delete(zs, np.r_[MEAN]))
+    mp = zp[MEAN].view(np.float64)[0] if dtype == np.float64 else zp[32:36].view(np.float32)[0]
+    ms = zs[MEAN].view(np.float64)[0] if dtype == np.float64 else zs[32:36].view(np.float32)[0]
+    assert abs(mp - ms) <= 1e-6 * max(1.0, abs(ms))
+    assert np.array_equal(xp.view(np.uint8), xs.view(np.uint8))
+    sf = 10.0 ** (np.ceil(np.log10(np.abs(orig).max())) - 1)
+    assert np.array_equal(xp, orig / dtype(sf))
+    # ... and it decodes to the oracle's reconstruction
+    ref = O.decompress(O.compress(orig, eb, O.EC, O.FAST), O.FAST)
+    var_z = TVar()
+    var_z.datatype = _tvar(orig).datatype
+    var_z.buf.d = zp.ctypes.data_as(C.POINTER(C.c_double))
+    rec = np.zeros(n, dtype)
+    var_r = _tvar(rec)
+    assert lib.dctz_decompress(C.byref(var_z), C.byref(var_r)) == 1
+    assert np.array_equal(rec.view(np.uint8), ref.view(np.uint8))
+
+
 @pytest.mark.parametrize("mode", ["ec", "qt"])
 def test_host_buffer_batch_is_the_looped_calls(mode):
     """dctz_compress_batch / dctz_decompress_batch (additions to dctz.h): the list tests/test-dctz.sh loops over -- the six
