@@ -674,6 +674,7 @@ typedef struct {
   dctzhip_ctx *c;
   drain_piece *q;
   size_t posted, cap;           /* pieces posted so far (released by the calling thread) */
+  size_t done;                  /* pieces brought back so far (released by the drainer) */
   int closed, failed;
   unsigned char *base[3];       /* where a section's stream is assembled on the host */
   size_t off[3];                /* its bytes so far, trailer excluded */
@@ -696,6 +697,7 @@ static void *drain_main(void *arg) {
     const uLong a = get_be32(d->base[p->sec] + d->off[p->sec] + 2);
     d->adler[p->sec] = d->started[p->sec] ? adler32_combine(d->adler[p->sec], a, (z_off_t)p->raw) : a;
     d->started[p->sec] = 1;
+    __atomic_store_n(&d->done, k + 1, __ATOMIC_RELEASE);
   }
 }
 typedef struct { unsigned char *dst; const unsigned char *src; size_t n; } pcopy_job;
@@ -818,11 +820,41 @@ static int compress_pipelined(dctzhip_ctx *c, t_var *var, void *host_in, size_t 
     const unsigned gflags[3] = {0u, DCTZHIP_DEFLATE_LITERALS, DCTZHIP_DEFLATE_LITERALS};   /* DC and AC_exact are bytes of floats */
     size_t glen[3] = {0, 0, 0};
     if (dctzhip_deflate_ex(c, nsec, gsrc, gn, gdst, bound, glen, gix, gflags) != DCTZHIP_OK) die("dctzhip_deflate");
+    const size_t first_new = npieces;
     for (int i = 0; i < nsec; i++) {
       pieces[npieces].src = (const unsigned char *)gdst[i]; pieces[npieces].len = glen[i]; pieces[npieces].raw = gn[i]; pieces[npieces].sec = i;
       npieces++;
     }
-    __atomic_store_n(&dj.posted, npieces, __ATOMIC_RELEASE);
+    if (g + 1 == G && S == 0) {                            /* no exact coefficient at all: the empty stream, as the one call writes it */
+      const size_t zero = 0;
+      const void *asrc[1] = {g_dev.ac};
+      void *adst[1] = {g_dev.z[2]};
+      uint32_t *aix[1] = {ix[2]};
+      size_t alen = 0;
+      if (dctzhip_deflate_ex(c, 1, asrc, &zero, adst, &bound[2], &alen, aix, NULL) != DCTZHIP_OK) die("dctzhip_deflate");
+      pieces[npieces].src = (const unsigned char *)g_dev.z[2]; pieces[npieces].len = alen; pieces[npieces].raw = 0; pieces[npieces].sec = 2;
+      npieces++;
+    }
+    if (g + 1 == G) {
+      /* The lengths of all three streams are known now -- what the drainer has brought back plus these last pieces --, so
+       * DC's and AC_exact's last pieces go straight to their final places behind bin_index, and what is staged of them is
+       * moved there by this thread while the drainer is busy with the last group. */
+      while (__atomic_load_n(&dj.done, __ATOMIC_ACQUIRE) < first_new) { if (__atomic_load_n(&dj.failed, __ATOMIC_ACQUIRE)) die("D2H compressed pieces"); usleep(10); }
+      size_t fin[3] = {dj.off[0], dj.off[1], dj.off[2]};
+      int st[3] = {dj.started[0], dj.started[1], dj.started[2]};
+      for (size_t k = first_new; k < npieces; k++) {
+        if (pieces[k].len < 8) die("deflate: short stream");
+        fin[pieces[k].sec] += pieces[k].len - (st[pieces[k].sec] ? 2 : 0) - 6;
+        st[pieces[k].sec] = 1;
+      }
+      const size_t staged1 = dj.off[1], staged2 = dj.off[2];
+      dj.base[1] = zc + fin[0] + 6;
+      dj.base[2] = zc + fin[0] + 6 + fin[1] + 6;
+      __atomic_store_n(&dj.posted, npieces, __ATOMIC_RELEASE);
+      par_memcpy(dj.base[1], dcz, staged1, 4);
+      par_memcpy(dj.base[2], acz, staged2, 8);
+    } else
+      __atomic_store_n(&dj.posted, npieces, __ATOMIC_RELEASE);
     ac_done = ac_upto;
     const double tg2 = now_s();
     t_gpu += tg1 - tg0; t_tail += tg2 - tg1;
@@ -830,17 +862,6 @@ static int compress_pipelined(dctzhip_ctx *c, t_var *var, void *host_in, size_t 
                      __atomic_load_n(&fj.landed, __ATOMIC_RELAXED) / gel);
   }
   ix_n[2] = (S * sizeof(float) + chunk - 1) / chunk;
-  if (S == 0) {                                            /* no exact coefficient at all: the empty stream, as the one call writes it */
-    const size_t zero = 0;
-    const void *asrc[1] = {g_dev.ac};
-    void *adst[1] = {g_dev.z[2]};
-    uint32_t *aix[1] = {ix[2]};
-    size_t alen = 0;
-    if (dctzhip_deflate_ex(c, 1, asrc, &zero, adst, &bound[2], &alen, aix, NULL) != DCTZHIP_OK) die("dctzhip_deflate");
-    pieces[npieces].src = (const unsigned char *)g_dev.z[2]; pieces[npieces].len = alen; pieces[npieces].raw = 0; pieces[npieces].sec = 2;
-    npieces++;
-    __atomic_store_n(&dj.posted, npieces, __ATOMIC_RELEASE);
-  }
   const double t_loop = now_s();
   __atomic_store_n(&dj.closed, 1, __ATOMIC_RELEASE);
   pthread_join(dth, NULL);
@@ -856,8 +877,7 @@ static int compress_pipelined(dctzhip_ctx *c, t_var *var, void *host_in, size_t 
   }
   const size_t z0 = zlen[0], z1 = zlen[1], z2 = zlen[2];
   if (z0 > 0xffffffffu || z1 > 0xffffffffu || z2 > 0xffffffffu) { fprintf(stderr, "libdctz: a compressed section exceeds the header's 32-bit sizes (dctz.h:104-113): shard the array\n"); exit(1); }
-  par_memcpy(zc + z0, dcz, z1, 4);
-  par_memcpy(zc + z0 + z1, acz, z2, 8);
+  if (dj.base[1] != zc + z0 || dj.base[2] != zc + z0 + z1) die("pipelined compress: section lengths do not add up");
   const double t_asm = now_s();
   for (int t = 0; t < fstarted; t++) pthread_join(fth[t], NULL);
   if (tracking) pthread_join(tth, NULL);

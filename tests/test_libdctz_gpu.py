@@ -279,8 +279,9 @@ def test_pipelined_decompress_is_the_serial_one(mode, dtype, monkeypatch):
     assert lib.dctz_decompress(C.byref(var_b), C.byref(var_r)) == 1
 
 
+@pytest.mark.parametrize("kind", ["ragged", "flat"])
 @pytest.mark.parametrize("dtype", [np.float64, np.float32])
-def test_pipelined_compress_is_the_serial_one(dtype, monkeypatch):
+def test_pipelined_compress_is_the_serial_one(dtype, kind, monkeypatch):
     """dctz_compress of a large array with the entropy stage on the device works group by group (H2D of the groups ahead,
     max|x| on host threads, kernels + deflate + D2H of the groups that have landed, the in-place x /= sf following the
     copy): the container must be the serial path's byte for byte -- but for the header's tree-order `mean` -- and the
@@ -288,9 +289,12 @@ def test_pipelined_compress_is_the_serial_one(dtype, monkeypatch):
     remainder block in the last; the array's largest value sits in the last group (the scaling factor is the ARRAY's)."""
     lib = _lib("ec")
     n = (1 << 18) * 5 + 64 * 1000 + 37
-    x = W.ragged(n, dtype, scale=37.0)
-    x[: 1 << 18] += (np.random.default_rng(3).standard_normal(1 << 18) * 3.0).astype(dtype)
-    x[n - 70] = 5432.0
+    if kind == "flat":                                    # nothing stored exactly anywhere: AC_exact is the empty stream
+        x = np.full(n, 42.5, dtype)
+    else:
+        x = W.ragged(n, dtype, scale=37.0)
+        x[: 1 << 18] += (np.random.default_rng(3).standard_normal(1 << 18) * 3.0).astype(dtype)
+        x[n - 70] = 5432.0
     orig = x.copy()
     eb = 1e-3
     monkeypatch.setenv("DCTZ_ZLIB_GPU", "1")
