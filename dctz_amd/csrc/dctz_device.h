@@ -321,7 +321,10 @@ template <typename T> void launch_decompress_rem_batch(const BatchInv<T>* items,
 // loads by the first wave of every workgroup (every workgroup of the launch is resident: the grid is at most what the
 // chip holds at once).  Several tiles per workgroup because a sweep reads a granule per WORKGROUP: with single-wave
 // workgroups the sweeps of a 2000-tile array would move 2000 x 2000 x 8 bytes past the caches.
-constexpr int ONE_TW = 4;
+#ifndef DCTZ_ONE_TW
+#define DCTZ_ONE_TW 4
+#endif
+constexpr int ONE_TW = DCTZ_ONE_TW;
 struct OneBoard {
   unsigned long long* ga;          // per workgroup: decade index of its max|x| (+ "outside FastDiv's window"), compress only
   unsigned long long* gb;          // per workgroup: its "stored exactly" coefficients (tot_AC_exact_count of the tile)
@@ -431,7 +434,9 @@ template <typename T> void launch_gather_nd(const T* x, T* lin, const NdShape& s
 template <typename T> void launch_scatter_nd(const T* lin, T* out, const NdShape& sh, int grid, hipStream_t s);
 template <typename T> void launch_compress_rem(const FwdParams<T>& p, int mode, int l, hipStream_t s);
 template <typename T> void launch_compact_ac(const FwdParams<T>& p, int mode, double eb, unsigned nlists, int grid, const FinArgs& fin, hipStream_t s);
-void launch_count_tiles(const uint8_t* bin, unsigned nfull, unsigned ntiles, unsigned nwg, unsigned* tile_cnt, unsigned* wg_cnt, hipStream_t s);
+struct QtabArg { unsigned long long w[64]; };       // a QT table (64 values of either element type) as a kernel argument
+void launch_count_tiles(const uint8_t* bin, unsigned nfull, unsigned ntiles, unsigned nwg, unsigned* tile_cnt, unsigned* wg_cnt, hipStream_t s,
+                        const void* qtab_host = nullptr, size_t qtab_bytes = 0, void* qtab_dev = nullptr);
 template <typename T> void launch_decompress(const InvParams<T>& p, int mode, int grid, const FinArgs& fin, int geom, hipStream_t s);
 template <typename T> void launch_decompress_rem(const InvParams<T>& p, int mode, bool scale, int l, hipStream_t s);
 template <typename T> void launch_dct_blocks(const T* x, T* out, const T* gtab, const T* rtab, size_t n,

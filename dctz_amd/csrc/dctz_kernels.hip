@@ -41,6 +41,7 @@
 // Reference code replaced: see include/dctz_hip.h (per entry point) and the comment on each kernel.
 // Built with -ffp-contract=off: the arithmetic that the reference does unfused (gcc, baseline x86-64,
 // reference Makefile:2) is unfused here too; the transform's fused operations are explicit.
+#include <cstring>
 #include "dctz_kernel_common.h"
 
 #ifndef DCTZ_PART
@@ -877,8 +878,12 @@ __device__ __forceinline__ void count_tiles_body(const uint8_t* __restrict__ bin
   }
 }
 #if DCTZ_PART == 0
+// (QT: the call's quantisation table rides in this kernel's arguments and is put where k_decompress -- the next kernel of
+// the stream -- reads it: a 512-byte copy of its own in front of the call was a dispatch of 4 us)
 __global__ __launch_bounds__(SWG) void k_count_tiles(const uint8_t* __restrict__ bin, unsigned nfull, unsigned ntiles, unsigned nwg,
-                                                     unsigned* __restrict__ tile_cnt, unsigned* __restrict__ wg_cnt) {
+                                                     unsigned* __restrict__ tile_cnt, unsigned* __restrict__ wg_cnt, QtabArg qt,
+                                                     unsigned qwords, unsigned long long* __restrict__ qdst) {
+  if (blockIdx.x == 0 && threadIdx.x < qwords) qdst[threadIdx.x] = qt.w[threadIdx.x];
   count_tiles_body(bin, nfull, ntiles, nwg, tile_cnt, wg_cnt, blockIdx.x);
 }
 #endif
@@ -1283,8 +1288,13 @@ void launch_compress_rem(const FwdParams<T>& p, int mode, int l, hipStream_t s) 
 }
 
 #if DCTZ_PART == 0
-void launch_count_tiles(const uint8_t* bin, unsigned nfull, unsigned ntiles, unsigned nwg, unsigned* tile_cnt, unsigned* wg_cnt, hipStream_t s) {
-  hipLaunchKernelGGL(k_count_tiles, dim3(nwg), dim3(SWG), 0, s, bin, nfull, ntiles, nwg, tile_cnt, wg_cnt);
+void launch_count_tiles(const uint8_t* bin, unsigned nfull, unsigned ntiles, unsigned nwg, unsigned* tile_cnt, unsigned* wg_cnt, hipStream_t s,
+                        const void* qtab_host, size_t qtab_bytes, void* qtab_dev) {
+  QtabArg q;
+  std::memset(&q, 0, sizeof(q));
+  if (qtab_host && qtab_bytes <= sizeof(q)) std::memcpy(&q, qtab_host, qtab_bytes); else qtab_bytes = 0;
+  hipLaunchKernelGGL(k_count_tiles, dim3(nwg), dim3(SWG), 0, s, bin, nfull, ntiles, nwg, tile_cnt, wg_cnt, q, (unsigned)(qtab_bytes / 8),
+                     reinterpret_cast<unsigned long long*>(qtab_dev));
 }
 #endif
 

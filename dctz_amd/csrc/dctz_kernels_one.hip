@@ -51,7 +51,7 @@ constexpr unsigned ONE_GAVE_UP = 0xFFFFFFFFu;                // what a sweep tha
 constexpr int OTW = ONE_TW;
 // waves per SIMD the register allocation aims at: fp32 two (two workgroups of 64 KiB of LDS per CU), fp64 one (128 KiB)
 template <typename T> constexpr int one_waves() { return sizeof(T) == 4 ? 2 : 1; }
-constexpr int ONE_SPEC_MIN_WG = 128;                         // workgroups from which k_compress_one scales on a guess (see there)
+constexpr int ONE_SPEC_MIN_WG = 128 * 4 / ONE_TW;                         // workgroups from which k_compress_one scales on a guess (see there)
 
 // Development aid: time stamps of the first wave of every workgroup at the phases of the kernels (OneBoard::dbg != NULL)
 __device__ __forceinline__ void one_stamp(const OneBoard& b, int k) {

@@ -1549,7 +1549,7 @@ static int decompress_impl(dctzhip_ctx* c, const uint8_t* d_bin, const float* d_
   }
   if (!box || c->ctl_dirty) HIPCHK(c, hipMemsetAsync(c->ctl, 0, sizeof(Ctl), s));      // (a good call leaves `error` at zero)
   c->ctl_dirty = 1;
-  if (mode == DCTZHIP_QT) {
+  if (mode == DCTZHIP_QT && !ntiles) {              // (with tiles the table rides in k_count_tiles' arguments, below)
     // staged through pinned memory that the NEXT call may rewrite: safe because every call ends with a host
     // wait on this stream (mailbox or stream sync) before it returns
     T* hq = reinterpret_cast<T*>(c->h_pin + PIN_TAB + sizeof(double) * RTAB_SIZE);
@@ -1579,7 +1579,7 @@ static int decompress_impl(dctzhip_ctx* c, const uint8_t* d_bin, const float* d_
   p.nwg = (unsigned)grid;
   if (c->profiling) HIPCHK(c, hipEventRecord(c->ev[0], s));
   // counts of "stored exactly" flags per tile and per workgroup of k_decompress: where every piece of AC_exact starts
-  if (ntiles) launch_count_tiles(d_bin, nfull, ntiles, p.nwg, c->tile_cnt, c->wg_cnt, s);
+  if (ntiles) launch_count_tiles(d_bin, nfull, ntiles, p.nwg, c->tile_cnt, c->wg_cnt, s, mode == DCTZHIP_QT ? qtable_host : nullptr, sizeof(T) * 64, c->qtab);
   if (c->profiling) { HIPCHK(c, hipEventRecord(c->ev[1], s)); HIPCHK(c, hipEventRecord(c->ev[2], s)); }
   const unsigned long long seq = box ? ++c->seq : 0ull;
   // With the mailbox and no remainder block, the first workgroup of k_decompress tells the host at once whether the
