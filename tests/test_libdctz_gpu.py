@@ -279,7 +279,7 @@ def test_pipelined_decompress_is_the_serial_one(mode, dtype, monkeypatch):
     assert lib.dctz_decompress(C.byref(var_b), C.byref(var_r)) == 1
 
 
-@pytest.mark.parametrize("kind", ["ragged", "flat"])
+@pytest.mark.parametrize("kind", ["ragged", "flat", "short_last_group"])
 @pytest.mark.parametrize("dtype", [np.float64, np.float32])
 def test_pipelined_compress_is_the_serial_one(dtype, kind, monkeypatch):
     """dctz_compress of a large array with the entropy stage on the device works group by group (H2D of the groups ahead,
@@ -289,6 +289,8 @@ def test_pipelined_compress_is_the_serial_one(dtype, kind, monkeypatch):
     remainder block in the last; the array's largest value sits in the last group (the scaling factor is the ARRAY's)."""
     lib = _lib("ec")
     n = (1 << 18) * 5 + 64 * 1000 + 37
+    if kind == "short_last_group":                        # the last group is nothing but the array's short last block
+        n = (1 << 18) * 4 + 37
     if kind == "flat":                                    # nothing stored exactly anywhere: AC_exact is the empty stream
         x = np.full(n, 42.5, dtype)
     else:
