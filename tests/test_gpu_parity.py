@@ -541,3 +541,24 @@ def test_parts_with_the_arrays_statistics_are_the_one_call(ctx, dtype, part):
     # statistics that are not the array's are refused
     with pytest.raises(H.DctzHipError):
         ctx.compress_part(xd[n - 64 * 17 - 29:], eb, 10.0, mn, out, n - 64 * 17 - 29, 0)
+
+
+@pytest.mark.parametrize("key,dtype,tol", [("f64", np.float64, 4e-15), ("f32", np.float32, 1e-6)])
+def test_block_transform_on_the_gpu_against_fftw_generated_values(ctx, key, dtype, tol):
+    """dctzhip_dct_blocks against results of FFTW itself (tests/golden/fftw_r2r_ref.json: FFTW's REDFT10 / REDFT01 on
+    0, 1, ..., n-1, from scipy's fftpack test data; tests/test_oracle.py has the scaling): the HIP path, not only the
+    oracle, agrees with the library the reference links to rounding, for the full block and for short last blocks."""
+    import json
+    ref = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "fftw_r2r_ref.json")))
+    for n in (2, 3, 4, 8, 12, 15, 16, 17, 32, 64):
+        x = np.arange(n).astype(dtype)
+        y2 = np.array([float(v) for v in ref[key]["dct_2_%d" % n]])
+        c = np.ones(n)
+        c[0] = 1.0 / np.sqrt(2.0)
+        want = y2 / 2.0 * np.sqrt(2.0 / n) * c
+        got = ctx.dct_blocks(_dev(ctx, x), inverse=False).cpu().numpy().astype(np.float64)
+        assert np.abs(got - want).max() <= tol * np.abs(want).max(), (n, "forward")
+        y3 = np.array([float(v) for v in ref[key]["dct_3_%d" % n]])
+        want = y3 / 2.0 * np.sqrt(2.0 / n)
+        got = ctx.dct_blocks(_dev(ctx, x), inverse=True).cpu().numpy().astype(np.float64)
+        assert np.abs(got - want).max() <= tol * np.abs(want).max(), (n, "inverse")

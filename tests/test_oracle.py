@@ -168,3 +168,32 @@ def test_psnr_restatement():
     p = O.psnr(x, r)
     assert p["range"] == 4.0 and abs(p["maxdiff"] - 0.2) < 1e-15
     assert abs(p["psnr"] - 20 * np.log10(4.0 / np.sqrt((0.01 + 0.01 + 0.04) / 4))) < 1e-12
+
+
+FFTW = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "fftw_r2r_ref.json")))
+
+
+@pytest.mark.parametrize("impl", [O.FAST, O.NAIVE])
+@pytest.mark.parametrize("key,dtype,tol", [("f64", np.float64, 4e-15), ("f32", np.float32, 1e-6)])
+def test_block_transform_against_fftw_generated_values(impl, key, dtype, tol):
+    """The oracle's block transform against results of FFTW ITSELF: scipy's fftpack test-suite ships the outputs of FFTW's
+    r2r transforms REDFT10 (DCT-II) and REDFT01 (DCT-III) on x = 0, 1, ..., n-1 (tests/golden/fftw_r2r_ref.json, made by
+    tests/golden/scripts/make_fftw_r2r_fixture.py from scipy's data files; lengths 2 ... 64 -- all of them block lengths
+    the codec can meet: 64, and the short last block).  Not the reference's own fixture -- it has none -- and not the
+    complex-DFT route dct.c takes through FFTW, but values computed by the library the reference links, where scipy's own
+    transform (pocketfft, the other independent check of this file) is not.
+       REDFT10:  Y_k = 2 sum_j x_j cos(pi (j + 1/2) k / n)            -> orthonormal DCT-II  = sqrt(2/n) c_k Y_k / 2
+       REDFT01:  Y_k = X_0 + 2 sum_{j>=1} X_j cos(pi j (k + 1/2) / n)  -> orthonormal DCT-III of (0, 1, ..., n-1)
+                                                                         = sqrt(2/n) Y_k / 2   (X_0 = 0)"""
+    for n in (2, 3, 4, 8, 12, 15, 16, 17, 32, 64):
+        x = np.arange(n).astype(dtype)
+        y2 = np.array([float(v) for v in FFTW[key]["dct_2_%d" % n]])
+        c = np.ones(n)
+        c[0] = 1.0 / np.sqrt(2.0)
+        ref = y2 / 2.0 * np.sqrt(2.0 / n) * c
+        got = O.dct_fwd(x, impl).astype(np.float64)
+        assert np.abs(got - ref).max() <= tol * np.abs(ref).max(), (n, "forward")
+        y3 = np.array([float(v) for v in FFTW[key]["dct_3_%d" % n]])
+        ref = y3 / 2.0 * np.sqrt(2.0 / n)
+        got = O.dct_inv(x, impl).astype(np.float64)
+        assert np.abs(got - ref).max() <= tol * np.abs(ref).max(), (n, "inverse")
