@@ -250,6 +250,7 @@ struct InvParams {
   const T* qtab;                   // QT: clamped table (device)
   const unsigned* tile_cnt;        // per-TILE counts of "stored exactly" flags (k_count_tiles)
   const unsigned* wg_cnt;          // the same summed over the tile range of every workgroup of k_decompress (nwg entries)
+  const unsigned* tile_pre;        // tile-interleaved k_decompress: counts of the tiles of the same RANGE in front of a tile (k_count_tiles)
   Ctl* ctl;
   unsigned nfull, ntiles, ac_count;
   unsigned nwg;                    // grid of k_decompress
@@ -436,7 +437,7 @@ template <typename T> void launch_compress_rem(const FwdParams<T>& p, int mode, 
 template <typename T> void launch_compact_ac(const FwdParams<T>& p, int mode, double eb, unsigned nlists, int grid, const FinArgs& fin, hipStream_t s);
 struct QtabArg { unsigned long long w[64]; };       // a QT table (64 values of either element type) as a kernel argument
 void launch_count_tiles(const uint8_t* bin, unsigned nfull, unsigned ntiles, unsigned nwg, unsigned* tile_cnt, unsigned* wg_cnt, hipStream_t s,
-                        const void* qtab_host = nullptr, size_t qtab_bytes = 0, void* qtab_dev = nullptr);
+                        const void* qtab_host = nullptr, size_t qtab_bytes = 0, void* qtab_dev = nullptr, unsigned* tile_pre = nullptr);
 template <typename T> void launch_decompress(const InvParams<T>& p, int mode, int grid, const FinArgs& fin, int geom, hipStream_t s);
 template <typename T> void launch_decompress_rem(const InvParams<T>& p, int mode, bool scale, int l, hipStream_t s);
 template <typename T> void launch_dct_blocks(const T* x, T* out, const T* gtab, const T* rtab, size_t n,

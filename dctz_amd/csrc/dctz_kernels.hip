@@ -837,8 +837,11 @@ __global__ __launch_bounds__(SWG) void k_compact_ac(FwdParams<T> p, double eb, u
 // A wave takes whole tiles (4 x 1 KiB coalesced rows, plain loads: k_decompress re-reads these lines from the
 // Infinity Cache); no workgroup barrier per tile.
 __device__ __forceinline__ void count_tiles_body(const uint8_t* __restrict__ bin, unsigned nfull, unsigned ntiles, unsigned nwg,
-                                                 unsigned* __restrict__ tile_cnt, unsigned* __restrict__ wg_cnt, const unsigned wg) {
+                                                 unsigned* __restrict__ tile_cnt, unsigned* __restrict__ wg_cnt, const unsigned wg,
+                                                 unsigned* __restrict__ tile_pre = nullptr) {
   __shared__ unsigned part[SWG / 64];
+  constexpr unsigned PRE_MAX = 256;                                    // tiles of a range whose prefix is kept in LDS (tile_pre; the host checks the range)
+  __shared__ unsigned tcs[PRE_MAX];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const TileRange tr = tile_range(wg, nwg, ntiles);
   const size_t end = (size_t)nfull * 64;
@@ -865,7 +868,7 @@ __device__ __forceinline__ void count_tiles_body(const uint8_t* __restrict__ bin
       }
     }
     const unsigned tot = (unsigned)__builtin_amdgcn_readlane((int)wave_incl_scan(c), 63);
-    if (lane == 0) tile_cnt[tile] = tot;
+    if (lane == 0) { tile_cnt[tile] = tot; if (tile_pre != nullptr && tile - tr.lo < PRE_MAX) tcs[tile - tr.lo] = tot; }
     acc += tot;
   }
   if (lane == 0) part[wave] = acc;
@@ -876,15 +879,28 @@ __device__ __forceinline__ void count_tiles_body(const uint8_t* __restrict__ bin
     for (int w = 0; w < SWG / 64; w++) sum += part[w];
     wg_cnt[wg] = sum;
   }
+  // tile_pre[t]: the counts of the tiles of THIS range in front of t (k_decompress with tile-interleaved workgroups adds the
+  // ranges in front: the running pos of dctz-decomp-lib.c:402-412 at any tile without a scan kernel)
+  if (tile_pre != nullptr && wave == 0) {
+    const unsigned nt = min(tr.hi - tr.lo, PRE_MAX);
+    unsigned run = 0;
+    for (unsigned i0 = 0; i0 < nt; i0 += 64u) {
+      const unsigned i = i0 + (unsigned)lane;
+      const unsigned v = i < nt ? tcs[i] : 0u;
+      const unsigned incl = wave_incl_scan(v);
+      if (i < nt) tile_pre[tr.lo + i] = run + incl - v;
+      run += (unsigned)__builtin_amdgcn_readlane((int)incl, 63);
+    }
+  }
 }
 #if DCTZ_PART == 0
 // (QT: the call's quantisation table rides in this kernel's arguments and is put where k_decompress -- the next kernel of
 // the stream -- reads it: a 512-byte copy of its own in front of the call was a dispatch of 4 us)
 __global__ __launch_bounds__(SWG) void k_count_tiles(const uint8_t* __restrict__ bin, unsigned nfull, unsigned ntiles, unsigned nwg,
                                                      unsigned* __restrict__ tile_cnt, unsigned* __restrict__ wg_cnt, QtabArg qt,
-                                                     unsigned qwords, unsigned long long* __restrict__ qdst) {
+                                                     unsigned qwords, unsigned long long* __restrict__ qdst, unsigned* __restrict__ tile_pre) {
   if (blockIdx.x == 0 && threadIdx.x < qwords) qdst[threadIdx.x] = qt.w[threadIdx.x];
-  count_tiles_body(bin, nfull, ntiles, nwg, tile_cnt, wg_cnt, blockIdx.x);
+  count_tiles_body(bin, nfull, ntiles, nwg, tile_cnt, wg_cnt, blockIdx.x, tile_pre);
 }
 #endif
 
@@ -902,6 +918,9 @@ size_t decompress_lds_bytes() { return (size_t)Geo<T, Phases<T>::D>::PHB + 256 *
 // hands the call's result to the host)
 #ifndef DCTZ_BC_ARITH
 #define DCTZ_BC_ARITH 1
+#endif
+#ifndef DCTZ_DEC_STORE_AUX
+#define DCTZ_DEC_STORE_AUX 2     /* cache policy of k_decompress's row stores: 2 = nt */
 #endif
 // (bin_centre: dctz_kernel_common.h)
 template <typename T, int MODE, int PH, int GEOM, typename Handoff>
@@ -1013,7 +1032,7 @@ __device__ __forceinline__ void decompress_body(const InvParams<T>& p, const uns
         const u32x4 v = *reinterpret_cast<const u32x4*>(outbuf + (jg * G::SEGP + s) * 1024 + lane * 16);
         int at = vo + (PHASE * G::SEGP + s) * 128;
         if (GEOM != GEOM_1D && nd_direct) at = (int)(org >= 0xFFFFFFF0u ? org : org + nd_chunk_offset<T>(p.nd, 8 * (PHASE * G::SEGP + s) + cg));
-        __builtin_amdgcn_raw_buffer_store_b128(v, r_out, at, 0, 2 /* nt */);
+        __builtin_amdgcn_raw_buffer_store_b128(v, r_out, at, 0, DCTZ_DEC_STORE_AUX);
       }
     }
   };
@@ -1137,6 +1156,224 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu((sizeof(T) =
     if (fin.box != nullptr && blockIdx.x == 0) {
       // the one thing the host waits for on decode: does the stream promise more exact coefficients than the caller
       // provides (all counts are in: k_count_tiles)?  Known before the first block is rebuilt -> hand it over now.
+      const int lane = threadIdx.x;
+      unsigned all = 0;
+      for (unsigned i = (unsigned)lane; i < p.nwg; i += WG) all += p.wg_cnt[i];
+      all = (unsigned)__builtin_amdgcn_readlane((int)wave_incl_scan(all), 63);
+      FinBody f;
+      f.ctl = fin.ctl; f.part = nullptr; f.nparts = 0; f.box = fin.box; f.seq = fin.seq; f.guess = nullptr;
+      f.cnt_known = true; f.cnt_total = all;
+      f.err_known = true; f.error = all > p.ac_count ? 2u : 0u;
+      finish_body<false>(f);
+    }
+  });
+}
+
+// ---- the same kernel with TILE-INTERLEAVED workgroups (flat blocks, one array) -------------------------------------------
+// Workgroup b of G takes tiles b, b + G, b + 2 G, ...: at any moment the grid writes ONE contiguous window of the output
+// instead of G ranges side by side.  A 1 GiB stream of 1 KiB row stores from 1024 single-wave workgroups runs at 5.0 TB/s
+// in the range-per-workgroup shape and at 5.4 in this one (tools/ubench/store_shapes.hip), and the reconstruction is
+// seven eighths of what k_decompress moves.  The running pos of dctz-decomp-lib.c:402-412 at a tile = the counts of the
+// k_count_tiles RANGES in front of the tile's range (their exclusive prefix: built once per workgroup in the LDS array that
+// is still free then) + the counts of the range's tiles in front of it (tile_pre, left by k_count_tiles); a workgroup keeps
+// the start and the count of its next 64 tiles in a register pair, lane r = its r-th tile.
+template <typename T, int MODE, int PH, typename Handoff>
+__device__ __forceinline__ void decompress_il_body(const InvParams<T>& p, const unsigned wg, const unsigned nwg, Handoff&& handoff) {
+  using G = Geo<T, PH>;
+  constexpr int DEC_CAP = DecStage<T>::CAP;
+  __shared__ __attribute__((aligned(1024))) unsigned char io[G::PHB + DEC_CAP * 4];
+  unsigned char* const outbuf = io;
+  float* const excbuf = reinterpret_cast<float*>(io + G::PHB);
+  static_assert(G::PHB + DEC_CAP * 4 >= TILE_ELEMS * 4, "a dense tile's coefficients fit the array");
+  static_assert(G::PHB + DEC_CAP * 4 >= 4096 * 4, "the ranges' prefix (at most 4096 of them) fits the array before the first tile");
+  constexpr bool BC_ARITH = DCTZ_BC_ARITH != 0 && sizeof(T) == 8;
+  __shared__ __attribute__((aligned(16))) T bctab[BC_ARITH ? 1 : 256]; // bin_center[] of gen_bins
+  __shared__ T qt[64];
+  const int lane = threadIdx.x;
+  // the ranges' exclusive prefix -> LDS (p.nwg ranges, the partition k_count_tiles counted in)
+  // (every workgroup does this before its first tile: the counts come in with eight independent loads per lane and trip --
+  // one load per trip was sixteen to twenty-eight dependent round trips, 8-14 us --, are summed per lane over a contiguous
+  // stretch out of LDS and scanned across the lanes once)
+  unsigned* const rpre = reinterpret_cast<unsigned*>(io);
+  {
+    const unsigned K = (p.nwg + 63u) / 64u;           // entries per lane (<= 64: the host keeps the grid <= 4096)
+    for (unsigned i0 = 0; i0 < p.nwg; i0 += 512u) {
+      unsigned v[8];
+#pragma unroll
+      for (int u = 0; u < 8; u++) { const unsigned i = i0 + (unsigned)u * 64u + (unsigned)lane; v[u] = i < p.nwg ? p.wg_cnt[i] : 0u; }
+#pragma unroll
+      for (int u = 0; u < 8; u++) { const unsigned i = i0 + (unsigned)u * 64u + (unsigned)lane; if (i < K * 64u) rpre[i] = v[u]; }
+    }
+    for (unsigned i = p.nwg + (unsigned)lane; i < K * 64u; i += 64u) rpre[i] = 0u;       // (the stretch of the last lanes)
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    unsigned mine = 0;
+    for (unsigned j = 0; j < K; j++) mine += rpre[(unsigned)lane * K + j];
+    unsigned run = wave_incl_scan(mine) - mine;
+    for (unsigned j = 0; j < K; j++) { const unsigned v = rpre[(unsigned)lane * K + j]; rpre[(unsigned)lane * K + j] = run; run += v; }
+  }
+  handoff();
+  // the inverse of tile_range(): which range a tile lies in
+  const unsigned rq = p.ntiles / p.nwg, rr = p.ntiles % p.nwg;
+  auto range_of = [&](unsigned t) -> unsigned { return t < rr * (rq + 1u) ? t / (rq + 1u) : rr + (t - rr * (rq + 1u)) / rq; };
+  const unsigned my_tiles = wg < p.ntiles ? (p.ntiles - wg + nwg - 1u) / nwg : 0u;      // <= 64 (the host checks)
+  unsigned starts = 0, cnts = 0;                     // lane r: first exact coefficient / count of this workgroup's r-th tile
+  if ((unsigned)lane < my_tiles) {
+    const unsigned t = wg + (unsigned)lane * nwg;
+    starts = rpre[range_of(t)] + p.tile_pre[t];
+    cnts = p.tile_cnt[t];
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // (rpre is read: the array may be written now)
+  TileMap<T, PH> tm;
+  tm.init(lane);
+  const CTab<T> tab = as_ctab<T>(p.tab);
+  if (!BC_ARITH)
+    for (int b = lane; b < 256; b += WG) {
+      const int ti = (b & 1) ? (b >> 1) + 1 : -(b >> 1);
+      bctab[b] = (T)ti * p.bin_width;
+    }
+  if (MODE == DCTZHIP_QT) qt[lane] = p.qtab[lane];
+  const bool scale = (p.sf != T(1));                 // dctz-decomp-lib.c:496 / :505
+  bool underrun = false;
+
+  // a tile's buffers behind descriptors based at the tile (32-bit offsets stay small for any N)
+  auto blocks_of = [&](unsigned tile) { return min((unsigned)TILE_BLKS, p.nfull - tile * (unsigned)TILE_BLKS); };
+  u32x4 bw[4];
+  float dcv = 0.f;
+  unsigned S = 0, total = 0;                          // first exact coefficient of the prefetched tile / how many (uniform)
+  auto prefetch = [&](unsigned tile, unsigned r) {
+    S = (unsigned)__builtin_amdgcn_readlane((int)starts, (int)r);
+    total = (unsigned)__builtin_amdgcn_readlane((int)cnts, (int)r);
+    const unsigned nb = blocks_of(tile);
+    const size_t ac_left = S < p.ac_count ? (size_t)(p.ac_count - S) * 4 : 0;
+    const __amdgpu_buffer_rsrc_t r_ac = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.ac + (ac_left ? S : 0u)), 0, (int)min(ac_left, (size_t)0x7ffffffc), 0x00020000);
+    if (total <= (unsigned)DEC_CAP) {
+#pragma unroll
+      for (int i = 0; i < DEC_CAP / 256; i++)
+        if ((unsigned)(i * 256) < total) DMA16(r_ac, excbuf + i * 256, lane * 16, i * 1024, 0);
+    }
+    const __amdgpu_buffer_rsrc_t r_bin = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(p.bin + (size_t)tile * TILE_ELEMS), 0, (int)(nb * 64u), 0x00020000);
+    const __amdgpu_buffer_rsrc_t r_dc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.dc + (size_t)tile * TILE_BLKS), 0, (int)(nb * 4u), 0x00020000);
+#pragma unroll
+    for (int i = 0; i < 4; i++) bw[i] = __builtin_amdgcn_raw_buffer_load_b128(r_bin, lane * 64 + i * 16, 0, 0);
+    dcv = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r_dc, lane * 4, 0, 0));
+  };
+  auto landed = [&]() {
+    if constexpr (sizeof(T) == 8) asm volatile("" :: "v"(dcv));
+  };
+  if (my_tiles) { prefetch(wg, 0u); landed(); }
+  for (unsigned r = 0; r < my_tiles; r++) {
+    const unsigned tile = wg + r * nwg;
+    const unsigned blks_here = blocks_of(tile);
+    const bool active = (unsigned)lane < blks_here;
+    const unsigned S_t = S, total_t = total;
+    const __amdgpu_buffer_rsrc_t r_out = __builtin_amdgcn_make_buffer_rsrc(p.out + (size_t)tile * TILE_ELEMS, 0, (int)(blks_here * 64u * (unsigned)sizeof(T)), 0x00020000);
+    const bool staged = total_t <= (unsigned)DEC_CAP;
+    const float* const stage = reinterpret_cast<const float*>(io) + (staged ? (unsigned)(G::PHB / 4) : 0u);
+    const unsigned stage_last = staged ? (unsigned)DEC_CAP - 1u : (unsigned)TILE_ELEMS - 1u;
+    if (!staged) {
+      const size_t ac_left = S_t < p.ac_count ? (size_t)(p.ac_count - S_t) * 4 : 0;
+      const __amdgpu_buffer_rsrc_t r_ac = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.ac + (ac_left ? S_t : 0u)), 0, (int)min(ac_left, (size_t)0x7ffffffc), 0x00020000);
+      for (unsigned i = 0; i * 256u < total_t; i++) DMA16(r_ac, io + i * 1024u, lane * 16, (int)(i * 1024u), 0);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    unsigned w[16] = {bw[0].x, bw[0].y, bw[0].z, bw[0].w, bw[1].x, bw[1].y, bw[1].z, bw[1].w,
+                      bw[2].x, bw[2].y, bw[2].z, bw[2].w, bw[3].x, bw[3].y, bw[3].z, bw[3].w};
+    const float dc_t = dcv;
+    unsigned n = 0;
+#pragma unroll
+    for (int i = 0; i < 16; i++) {
+      const unsigned v = ~w[i];                                        // a zero byte of v <=> bin id 255
+      const unsigned z = ((v & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | v;        // bit 7 of a byte set <=> that byte of v is non-zero
+      unsigned m = ~z & 0x80808080u;
+      if (i == 0) m &= ~0x80u;                                         // j = 0 is the DC slot (:392 / :438)
+      n += (unsigned)__popc(m);
+    }
+    if (!active) n = 0;
+    unsigned ptr = wave_incl_scan(n) - n;                              // index inside the tile's piece of AC_exact
+    if (S_t + total_t > p.ac_count) underrun = true;                  // the stream promises more than the caller provides
+    T x[64];
+    if constexpr (sizeof(T) == 8) {
+#pragma unroll
+    for (int g = 0; g < 16; g++) {
+      const unsigned wgd = w[g];
+      const unsigned nv = ~wgd;                                        // a zero byte of nv <=> bin id 255
+      unsigned m = ~(((nv & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | nv) & 0x80808080u;
+      if (g == 0) m &= ~0x80u;                                         // j = 0 is the DC slot (:392 / :438)
+      const unsigned w1 = ((wgd >> 1) & 0x7F7F7F7Fu) + (wgd & 0x01010101u);   // four magnitudes (b + 1) >> 1
+      float e[4] = {0.f, 0.f, 0.f, 0.f};
+      if (__builtin_amdgcn_ballot_w64(m != 0u)) {                      // :400 / :446 somewhere in the wave
+        unsigned at[4];
+        at[0] = ptr;
+        at[1] = at[0] + ((m >> 7) & 1u);
+        at[2] = at[1] + ((m >> 15) & 1u);
+        at[3] = at[2] + ((m >> 23) & 1u);
+        ptr = at[3] + (m >> 31);
+#pragma unroll
+        for (int i = 0; i < 4; i++) e[i] = stage[min(at[i], stage_last)];
+      }
+#pragma unroll
+      for (int i = 0; i < 4; i++) {
+        const int j = 4 * g + i;
+        if (j == 0) { x[0] = (T)dc_t; continue; }                      // :392 / :438
+        T v;
+        if constexpr (BC_ARITH) v = bin_centre<T>(w1, nv, i, p.bin_width);
+        else v = bctab[(wgd >> (8 * i)) & 255u];                       // :416 / :462
+        if ((m >> (8 * i + 7)) & 1u) {
+          v = (T)e[i];
+          if (MODE == DCTZHIP_QT) v = qt_restore(v, qt[j], p.eb, T(10), p.range_min, p.range_max);
+        }
+        x[j] = v;
+      }
+    }
+    } else {
+    x[0] = (T)dc_t;                                                    // :392 / :438
+#pragma unroll
+    for (int j = 1; j < 64; j++) {
+      const unsigned b = (w[j >> 2] >> (8 * (j & 3))) & 255u;
+      T v;
+      if constexpr (BC_ARITH) {
+        const unsigned wj = w[j >> 2];
+        v = bin_centre<T>(((wj >> 1) & 0x7F7F7F7Fu) + (wj & 0x01010101u), ~wj, j & 3, p.bin_width);
+      } else v = bctab[b];                                             // :416 / :462
+      if (b == 255u) {                                                 // :400 / :446
+        const float e = stage[min(ptr, stage_last)];
+        ptr++;
+        v = (T)e;
+        if (MODE == DCTZHIP_QT) v = qt_restore(v, qt[j], p.eb, T(10), p.range_min, p.range_max);
+      }
+      x[j] = v;
+    }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                  // the staged coefficients are consumed: the strip is free
+    if (r + 1 < my_tiles) prefetch(tile + nwg, r + 1);
+    block_inv<T, CTab<T>, GEOM_1D, (PH > 1)>(x, tab);
+    if (scale) {
+#pragma unroll
+      for (int j = 0; j < 64; j++) x[j] = x[j] * p.sf;                 // dctz-decomp-lib.c:494-511
+    }
+    if (r + 1 < my_tiles) landed();
+    auto store_phase = [&](auto phase) {
+      constexpr int PHASE = decltype(phase)::value;
+      write_phase<T, PH, PHASE>(x, outbuf, tm);
+#pragma unroll
+      for (int jg = 0; jg < 8; jg++) {
+        const int vo = jg * 8 * G::BLKB + tm.g_of(jg);
+#pragma unroll
+        for (int sg = 0; sg < G::SEGP; sg++) {
+          const u32x4 v = *reinterpret_cast<const u32x4*>(outbuf + (jg * G::SEGP + sg) * 1024 + lane * 16);
+          __builtin_amdgcn_raw_buffer_store_b128(v, r_out, vo + (PHASE * G::SEGP + sg) * 128, 0, DCTZ_DEC_STORE_AUX);
+        }
+      }
+    };
+    store_phase(std::integral_constant<int, 0>{});
+    if (PH == 2) store_phase(std::integral_constant<int, PH - 1>{});
+  }
+  if (underrun) atomicExch(&p.ctl->error, 2u);
+}
+template <typename T, int MODE, int PH>
+__global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu((sizeof(T) == 4 && DCTZ_WPED32) ? DCTZ_WPED32 : PH, (sizeof(T) == 4 && DCTZ_WPED32) ? DCTZ_WPED32 : PH))) void k_decompress_il(InvParams<T> p, FinArgs fin) {
+  decompress_il_body<T, MODE, PH>(p, blockIdx.x, gridDim.x, [&]() {
+    if (fin.box != nullptr && blockIdx.x == 0) {
       const int lane = threadIdx.x;
       unsigned all = 0;
       for (unsigned i = (unsigned)lane; i < p.nwg; i += WG) all += p.wg_cnt[i];
@@ -1289,12 +1526,12 @@ void launch_compress_rem(const FwdParams<T>& p, int mode, int l, hipStream_t s) 
 
 #if DCTZ_PART == 0
 void launch_count_tiles(const uint8_t* bin, unsigned nfull, unsigned ntiles, unsigned nwg, unsigned* tile_cnt, unsigned* wg_cnt, hipStream_t s,
-                        const void* qtab_host, size_t qtab_bytes, void* qtab_dev) {
+                        const void* qtab_host, size_t qtab_bytes, void* qtab_dev, unsigned* tile_pre) {
   QtabArg q;
   std::memset(&q, 0, sizeof(q));
   if (qtab_host && qtab_bytes <= sizeof(q)) std::memcpy(&q, qtab_host, qtab_bytes); else qtab_bytes = 0;
   hipLaunchKernelGGL(k_count_tiles, dim3(nwg), dim3(SWG), 0, s, bin, nfull, ntiles, nwg, tile_cnt, wg_cnt, q, (unsigned)(qtab_bytes / 8),
-                     reinterpret_cast<unsigned long long*>(qtab_dev));
+                     reinterpret_cast<unsigned long long*>(qtab_dev), tile_pre);
 }
 #endif
 
@@ -1309,7 +1546,13 @@ void launch_compact_ac(const FwdParams<T>& p, int mode, double eb, unsigned nlis
 
 template <typename T>
 void launch_decompress(const InvParams<T>& p, int mode, int grid, const FinArgs& fin, int geom, hipStream_t s) {
-  if (geom == GEOM_1D) {
+  // tile-interleaved workgroups: fp64 EC only (the shim sets tile_pre for one array of flat blocks with <= 64 tiles per
+  // workgroup).  Measured on one box, builds alternating (tools/r04_il.sh): fp64 EC 220 -> 200-206 us, fp64 EC at p = 0.69
+  // 316-335 -> 313-314; fp64 QT 243 -> 257 and fp32 117 -> 130-140 the OTHER way (half the bytes per tile behind the same
+  // per-tile jump to another page of every stream), so those keep a contiguous range per workgroup.
+  if (geom == GEOM_1D && p.tile_pre != nullptr && sizeof(T) == 8 && mode == DCTZHIP_EC) {
+    if constexpr (sizeof(T) == 8) hipLaunchKernelGGL((k_decompress_il<T, DCTZHIP_EC, Phases<T>::D>), dim3(grid), dim3(WG), 0, s, p, fin);
+  } else if (geom == GEOM_1D) {
     if (mode == DCTZHIP_EC) hipLaunchKernelGGL((k_decompress<T, DCTZHIP_EC, Phases<T>::D, GEOM_1D>), dim3(grid), dim3(WG), 0, s, p, fin);
     else hipLaunchKernelGGL((k_decompress<T, DCTZHIP_QT, Phases<T>::D, GEOM_1D>), dim3(grid), dim3(WG), 0, s, p, fin);
   } else if (geom == GEOM_2D) {

@@ -68,6 +68,8 @@ struct dctzhip_ctx {
   size_t tile_cap = 0;              // entries
   unsigned* qcnt = nullptr;         // k_compress -> k_compact_ac: per block, the counts of its tile's sub-lists (dctz_device.h: Sub)
   unsigned* ttot = nullptr;         // ... per tile, its "stored exactly" coefficients
+  unsigned* tile_pre = nullptr;     // decode, tile-interleaved k_decompress: per tile, the counts of its range's tiles in front of it
+  int dec_il = 1;                   // 0: k_decompress with a contiguous tile range per workgroup (DCTZHIP_DEC_IL)
   size_t qcnt_cap = 0;              // tiles the two hold
   void* qt_item = nullptr;
   uint8_t* qt_j = nullptr;
@@ -261,6 +263,7 @@ extern "C" int dctzhip_ctx_create(dctzhip_ctx** out, int device) {
   if (const char* e = getenv("DCTZHIP_GRID_C")) c->grid_c = atoi(e);
   if (const char* e = getenv("DCTZHIP_BLOCKING")) c->blocking = atoi(e) != 0;
   if (const char* e = getenv("DCTZHIP_STAGED_D2H")) c->staged_d2h = atoi(e) != 0;
+  if (const char* e = getenv("DCTZHIP_DEC_IL")) c->dec_il = atoi(e) != 0;
   if (const char* e = getenv("DCTZHIP_DEFLATE_SIDE")) c->dfl_side = atoi(e) != 0;
   if (int rc = build_sf_tables(c)) return rc;
   if (const char* e = getenv("DCTZHIP_ONE")) c->one = atoi(e) != 0;
@@ -286,7 +289,7 @@ extern "C" void dctzhip_ctx_destroy(dctzhip_ctx* c) {
   (void)dctzhip_comm_destroy(c);
   (void)hipStreamSynchronize(c->stream);
   if (c->side_stream) { (void)hipStreamSynchronize(c->side_stream); (void)hipStreamDestroy(c->side_stream); }
-  void* bufs[] = {c->one_qt, c->one_bqt, c->one_bctl, c->one_dbg, c->one_ga, c->one_gb, c->one_rec, c->one_ctl, c->qcnt, c->ttot, c->ac_tmp, c->tile_cnt, c->wg_cnt, c->serial_out, c->tab_f64, c->tab_f32, c->rtab, c->qtab, c->ctl, c->part, c->stats_out, c->qt_item, c->qt_j, c->nd_buf, c->dfl_buf, c->sf_thr[0], c->sf_thr[1], c->sf_pw[0], c->sf_pw[1], c->sf_guess};
+  void* bufs[] = {c->tile_pre, c->one_qt, c->one_bqt, c->one_bctl, c->one_dbg, c->one_ga, c->one_gb, c->one_rec, c->one_ctl, c->qcnt, c->ttot, c->ac_tmp, c->tile_cnt, c->wg_cnt, c->serial_out, c->tab_f64, c->tab_f32, c->rtab, c->qtab, c->ctl, c->part, c->stats_out, c->qt_item, c->qt_j, c->nd_buf, c->dfl_buf, c->sf_thr[0], c->sf_thr[1], c->sf_pw[0], c->sf_pw[1], c->sf_guess};
   for (void* b : bufs) if (b) (void)hipFree(b);
   if (c->h_pin) (void)hipHostFree(c->h_pin);
   if (c->box) (void)hipHostFree(c->box);
@@ -797,8 +800,9 @@ static int ensure_scratch(dctzhip_ctx* c, size_t n, int dtype, int mode, bool co
   if (entries < min_entries) entries = min_entries;
   int rc;
   {
-    size_t cap = c->tile_cap;
+    size_t cap = c->tile_cap, cap2 = c->tile_cap;
     if ((rc = regrow(c, &c->tile_cnt, &cap, entries, sizeof(unsigned)))) return rc;
+    if ((rc = regrow(c, &c->tile_pre, &cap2, entries, sizeof(unsigned)))) return rc;
     if ((rc = regrow(c, &c->wg_cnt, &c->tile_cap, entries, sizeof(unsigned)))) return rc;
   }
   if (!compress) return DCTZHIP_OK;
@@ -1562,7 +1566,7 @@ static int decompress_impl(dctzhip_ctx* c, const uint8_t* d_bin, const float* d_
   p.bin = d_bin; p.dc = d_dc; p.ac = d_ac; p.out = d_out;
   p.tab = tab_of<T>(c); p.rtab = reinterpret_cast<const T*>(c->rtab); p.qtab = reinterpret_cast<const T*>(c->qtab);
   p.ctl = c->ctl;
-  p.tile_cnt = c->tile_cnt; p.wg_cnt = c->wg_cnt;
+  p.tile_cnt = c->tile_cnt; p.wg_cnt = c->wg_cnt; p.tile_pre = nullptr;
   if (nd) p.nd = *nd; else memset(&p.nd, 0, sizeof(p.nd));
   p.nfull = nfull; p.ntiles = ntiles; p.ac_count = ac_count;
   p.sf = (T)sf;
@@ -1577,9 +1581,14 @@ static int decompress_impl(dctzhip_ctx* c, const uint8_t* d_bin, const float* d_
   const unsigned cap = (unsigned)(c->num_cu * wg_per_cu<T>(c, true, mode, false, geom));
   const int grid = (int)(cap < ntiles ? cap : ntiles);
   p.nwg = (unsigned)grid;
+  // tile-interleaved workgroups (k_decompress_il: the grid writes one contiguous window of the output at a time) for one
+  // array of flat blocks whose workgroups take at most 64 tiles each
+  if (c->dec_il && sizeof(T) == 8 && mode == DCTZHIP_EC && geom == GEOM_1D && !nd && ntiles && (size_t)ntiles <= (size_t)64 * (size_t)grid && grid <= 4096)
+    p.tile_pre = c->tile_pre;                       // (fp64 EC: the one combination it measured faster for, launch_decompress)
   if (c->profiling) HIPCHK(c, hipEventRecord(c->ev[0], s));
   // counts of "stored exactly" flags per tile and per workgroup of k_decompress: where every piece of AC_exact starts
-  if (ntiles) launch_count_tiles(d_bin, nfull, ntiles, p.nwg, c->tile_cnt, c->wg_cnt, s, mode == DCTZHIP_QT ? qtable_host : nullptr, sizeof(T) * 64, c->qtab);
+  if (ntiles) launch_count_tiles(d_bin, nfull, ntiles, p.nwg, c->tile_cnt, c->wg_cnt, s, mode == DCTZHIP_QT ? qtable_host : nullptr, sizeof(T) * 64, c->qtab,
+                                 const_cast<unsigned*>(p.tile_pre));
   if (c->profiling) { HIPCHK(c, hipEventRecord(c->ev[1], s)); HIPCHK(c, hipEventRecord(c->ev[2], s)); }
   const unsigned long long seq = box ? ++c->seq : 0ull;
   // With the mailbox and no remainder block, the first workgroup of k_decompress tells the host at once whether the
@@ -2575,7 +2584,7 @@ static int launch_decompress_seq(dctzhip_ctx* c, const dctzhip_batch_ditem* item
     if (q.rem[j]) { int rc = rtab_for<T>(c, (int)q.rem[j], &p.rtab); if (rc) return rc; }
     p.qtab = reinterpret_cast<const T*>(db + j * sizeof(BatchInv<T>) + offsetof(BatchInv<T>, qtab));
     if (mode == DCTZHIP_QT) memcpy(b.qtab, it.qtable_host, sizeof(T) * 64);
-    p.tile_cnt = c->tile_cnt + ch.tile_off + q.tile_base[j]; p.wg_cnt = c->wg_cnt + ch.list_off + q.wg_base[j];
+    p.tile_cnt = c->tile_cnt + ch.tile_off + q.tile_base[j]; p.wg_cnt = c->wg_cnt + ch.list_off + q.wg_base[j]; p.tile_pre = nullptr;
     p.ctl = c->b_ctl + q.item_off + j;
     p.nfull = q.nfull[j]; p.ntiles = q.ntiles[j]; p.ac_count = it.ac_count; p.nwg = q.nwg[j];
     p.sf = (T)it.sf;
