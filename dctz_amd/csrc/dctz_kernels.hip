@@ -1192,24 +1192,25 @@ __device__ __forceinline__ void decompress_il_body(const InvParams<T>& p, const 
   const int lane = threadIdx.x;
   // the ranges' exclusive prefix -> LDS (p.nwg ranges, the partition k_count_tiles counted in)
   // (every workgroup does this before its first tile: the counts come in with eight independent loads per lane and trip --
-  // one load per trip was sixteen to twenty-eight dependent round trips, 8-14 us --, are summed per lane over a contiguous
-  // stretch out of LDS and scanned across the lanes once)
+  // one load per trip was sixteen to twenty-eight dependent round trips, 8-14 us -- and are scanned out of LDS, 64 entries
+  // = one conflict-free row per wave scan)
   unsigned* const rpre = reinterpret_cast<unsigned*>(io);
   {
-    const unsigned K = (p.nwg + 63u) / 64u;           // entries per lane (<= 64: the host keeps the grid <= 4096)
     for (unsigned i0 = 0; i0 < p.nwg; i0 += 512u) {
       unsigned v[8];
 #pragma unroll
       for (int u = 0; u < 8; u++) { const unsigned i = i0 + (unsigned)u * 64u + (unsigned)lane; v[u] = i < p.nwg ? p.wg_cnt[i] : 0u; }
 #pragma unroll
-      for (int u = 0; u < 8; u++) { const unsigned i = i0 + (unsigned)u * 64u + (unsigned)lane; if (i < K * 64u) rpre[i] = v[u]; }
+      for (int u = 0; u < 8; u++) { const unsigned i = i0 + (unsigned)u * 64u + (unsigned)lane; if (i < 4096u) rpre[i] = v[u]; }
     }
-    for (unsigned i = p.nwg + (unsigned)lane; i < K * 64u; i += 64u) rpre[i] = 0u;       // (the stretch of the last lanes)
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    unsigned mine = 0;
-    for (unsigned j = 0; j < K; j++) mine += rpre[(unsigned)lane * K + j];
-    unsigned run = wave_incl_scan(mine) - mine;
-    for (unsigned j = 0; j < K; j++) { const unsigned v = rpre[(unsigned)lane * K + j]; rpre[(unsigned)lane * K + j] = run; run += v; }
+    unsigned run = 0;
+    for (unsigned i0 = 0; i0 < p.nwg; i0 += 64u) {
+      const unsigned v = rpre[i0 + (unsigned)lane];
+      const unsigned incl = wave_incl_scan(v);
+      rpre[i0 + (unsigned)lane] = run + incl - v;
+      run += (unsigned)__builtin_amdgcn_readlane((int)incl, 63);
+    }
   }
   handoff();
   // the inverse of tile_range(): which range a tile lies in

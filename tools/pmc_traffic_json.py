@@ -29,6 +29,8 @@ for line in open(txt):
         # this purpose: 8 bytes per element more)
         if name == "k_compress" and m.group(2) and m.group(2).rstrip(">").split(",")[-1].strip() == "true" and m.group(2).count(",") == 5:
             name = "k_compress_scaled"
+        if name == "k_decompress_il":                # (the tile-interleaved form IS the build's k_decompress for fp64 EC: bench.py's name for both)
+            name = "k_decompress"
         vals.setdefault(name, {})[m.group(3)] = int(m.group(4))
 out = {}
 for k, v in vals.items():
