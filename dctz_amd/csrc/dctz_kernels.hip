@@ -1547,12 +1547,13 @@ void launch_compact_ac(const FwdParams<T>& p, int mode, double eb, unsigned nlis
 
 template <typename T>
 void launch_decompress(const InvParams<T>& p, int mode, int grid, const FinArgs& fin, int geom, hipStream_t s) {
-  // tile-interleaved workgroups: fp64 EC only (the shim sets tile_pre for one array of flat blocks with <= 64 tiles per
-  // workgroup).  Measured on one box, builds alternating (tools/r04_il.sh): fp64 EC 220 -> 200-206 us, fp64 EC at p = 0.69
-  // 316-335 -> 313-314; fp64 QT 243 -> 257 and fp32 117 -> 130-140 the OTHER way (half the bytes per tile behind the same
-  // per-tile jump to another page of every stream), so those keep a contiguous range per workgroup.
-  if (geom == GEOM_1D && p.tile_pre != nullptr && sizeof(T) == 8 && mode == DCTZHIP_EC) {
-    if constexpr (sizeof(T) == 8) hipLaunchKernelGGL((k_decompress_il<T, DCTZHIP_EC, Phases<T>::D>), dim3(grid), dim3(WG), 0, s, p, fin);
+  // tile-interleaved workgroups where the shim sets tile_pre: by default fp64 EC only.  Measured on one box, builds
+  // alternating (tools/r04_il.sh, r04_il2.sh): fp64 EC 220 -> 200-206 us, fp64 EC at p = 0.69 316-335 -> 313-320; fp64 QT
+  // 245 -> 257 and fp32 119 -> 125 the OTHER way (kernels their arithmetic holds, not their store stream: they only pay for
+  // the scattered reads and the per-tile descriptors), so those keep a contiguous range per workgroup.
+  if (geom == GEOM_1D && p.tile_pre != nullptr) {     // (the shim chooses: fp64 EC by default, everything with DCTZHIP_DEC_IL=2)
+    if (mode == DCTZHIP_EC) hipLaunchKernelGGL((k_decompress_il<T, DCTZHIP_EC, Phases<T>::D>), dim3(grid), dim3(WG), 0, s, p, fin);
+    else hipLaunchKernelGGL((k_decompress_il<T, DCTZHIP_QT, Phases<T>::D>), dim3(grid), dim3(WG), 0, s, p, fin);
   } else if (geom == GEOM_1D) {
     if (mode == DCTZHIP_EC) hipLaunchKernelGGL((k_decompress<T, DCTZHIP_EC, Phases<T>::D, GEOM_1D>), dim3(grid), dim3(WG), 0, s, p, fin);
     else hipLaunchKernelGGL((k_decompress<T, DCTZHIP_QT, Phases<T>::D, GEOM_1D>), dim3(grid), dim3(WG), 0, s, p, fin);

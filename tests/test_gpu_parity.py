@@ -562,3 +562,26 @@ def test_block_transform_on_the_gpu_against_fftw_generated_values(ctx, key, dtyp
         want = y3 / 2.0 * np.sqrt(2.0 / n)
         got = ctx.dct_blocks(_dev(ctx, x), inverse=True).cpu().numpy().astype(np.float64)
         assert np.abs(got - want).max() <= tol * np.abs(want).max(), (n, "inverse")
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_under_run_is_refused_on_the_large_array_path(ctx, dtype):
+    """A header that promises fewer exact coefficients than bin_index flags (a damaged or truncated container) through the
+    persistent decode kernels -- for fp64 EC the tile-interleaved k_decompress_il, whose workgroups address AC_exact through a
+    descriptor per tile: the call is refused, nothing is read beyond ac_count (the descriptors end there), and the context
+    decodes the intact stream bit for bit afterwards."""
+    import dctz_amd, torch
+    n = (1 << 23) + 64 * 5 + 3
+    x = W.ragged(n, dtype, scale=37.0)
+    xd = _dev(ctx, x)
+    out, info = ctx.compress(xd, 1e-3, O.EC)
+    assert not (info.flags & H.INFO_ONE_LAUNCH)
+    tdt = torch.float64 if dtype == np.float64 else torch.float32
+    good = ctx.decompress(out, info.cnt, n, tdt, 1e-3, info.sf, O.EC).cpu().numpy()
+    for short in (1, 5000, info.cnt):
+        with pytest.raises(dctz_amd.DctzHipError):
+            ctx.decompress(out, info.cnt - short, n, tdt, 1e-3, info.sf, O.EC)
+    again = ctx.decompress(out, info.cnt, n, tdt, 1e-3, info.sf, O.EC).cpu().numpy()
+    assert _same(good, again)
+    ref = O.decompress(O.compress(x, 1e-3, O.EC, O.FAST), O.FAST)
+    assert _same(good, ref)
