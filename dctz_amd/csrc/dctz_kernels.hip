@@ -124,6 +124,9 @@ size_t compress_lds_bytes(int mode) {              // tile image + sub-list stag
 #ifndef DCTZ_DMA_SPREAD
 #define DCTZ_DMA_SPREAD 1
 #endif
+#ifndef DCTZ_BIN_STORE_AUX
+#define DCTZ_BIN_STORE_AUX 0     /* cache policy of k_compress's bin_index rows: plain (k_count_tiles / the entropy stage read them next) */
+#endif
 template <int I> using IC = std::integral_constant<int, I>;
 template <typename T, int MODE, int PH> constexpr int compress_waves() { return (sizeof(T) == 4 && MODE == DCTZHIP_EC && DCTZ_WPE32) ? DCTZ_WPE32 : PH; }
 // The body is shared by two launch shapes: k_compress (one array per launch: workgroup wg = blockIdx.x of nwg = gridDim.x)
@@ -249,7 +252,11 @@ __device__ __forceinline__ void compress_body(const FwdParams<T>& p, const unsig
 #pragma unroll
     for (int i = 0; i < 4; i++) {
       const u32x4 v = *reinterpret_cast<const u32x4*>(excbuf + i * 1024 + lo * 16);
-      __builtin_amdgcn_raw_buffer_store_b128(v, r_bin, voff + i * 1024, 0, 0);
+#ifndef DCTZ_DBG_NO_BINS                              /* (timing experiment only: what the bin_index stream costs the kernel) */
+      __builtin_amdgcn_raw_buffer_store_b128(v, r_bin, voff + i * 1024, 0, DCTZ_BIN_STORE_AUX);
+#else
+      asm volatile("" :: "v"(v));
+#endif
     }
     __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, p_dc), r_dc, (int)(p_rel * 64u + (unsigned)lo) * 4, 0, 0);   // :350-351 USE_TRUNCATE
     __builtin_amdgcn_raw_buffer_store_b32(p_qc, r_qc, (int)(p_rel * 64u + (unsigned)lo) * 4, 0, 0);
