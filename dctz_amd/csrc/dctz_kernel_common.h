@@ -378,6 +378,22 @@ __device__ __forceinline__ float qt_restore(float v, float q, double eb, float q
                  : (float)(((double)(v - rmin) / (eb * (double)qf)) * (double)q);
 }
 
+// The QT table on decode: lane j of a register (pair) holds qtable[j]; entry j -- j a compile-time constant at every use --
+// comes out with v_readlane into scalar registers.  (Rounds 2-3 kept the table in LDS: every flagged position of a tile
+// then was an LDS round trip inside its branch, with one wave per SIMD nothing to hide it behind -- the QT decoder waited
+// 76 % longer than its EC twin for 4 % FEWER vector instructions, profiles/r04_pmc_qt.txt.)
+template <typename T> struct QtLanes;
+template <> struct QtLanes<double> {
+  int lo, hi;
+  __device__ __forceinline__ void load(const double* qtab, int lane) { const double v = qtab[lane]; lo = __double2loint(v); hi = __double2hiint(v); }
+  __device__ __forceinline__ double at(int j) const { return __hiloint2double(__builtin_amdgcn_readlane(hi, j), __builtin_amdgcn_readlane(lo, j)); }
+};
+template <> struct QtLanes<float> {
+  int w;
+  __device__ __forceinline__ void load(const float* qtab, int lane) { w = __float_as_int(qtab[lane]); }
+  __device__ __forceinline__ float at(int j) const { return __int_as_float(__builtin_amdgcn_readlane(w, j)); }
+};
+
 // ------------------------------------------------------------- host hand-off --
 // System-scope release of a sequence number into the HostBox (fine-grained pinned host
 // memory): everything this thread (and, after a barrier, its workgroup) wrote to the

@@ -945,7 +945,6 @@ __device__ __forceinline__ void decompress_body(const InvParams<T>& p, const uns
   // p = 17 %; fp32 (VALU-bound, two waves per SIMD hide the reads): the table, computing measured 6 % slower
   constexpr bool BC_ARITH = DCTZ_BC_ARITH != 0 && sizeof(T) == 8;
   __shared__ __attribute__((aligned(16))) T bctab[BC_ARITH ? 1 : 256]; // bin_center[] of gen_bins
-  __shared__ T qt[64];
   const int lane = threadIdx.x;
   const TileRange tr = tile_range(wg, nwg, p.ntiles);
   const size_t first_el = (size_t)tr.lo * TILE_ELEMS;
@@ -974,7 +973,8 @@ __device__ __forceinline__ void decompress_body(const InvParams<T>& p, const uns
       const int ti = (b & 1) ? (b >> 1) + 1 : -(b >> 1);
       bctab[b] = (T)ti * p.bin_width;
     }
-  if (MODE == DCTZHIP_QT) qt[lane] = p.qtab[lane];
+  QtLanes<T> qtl{};
+  if (MODE == DCTZHIP_QT) qtl.load(p.qtab, lane);
   const bool scale = (p.sf != T(1));                 // dctz-decomp-lib.c:496 / :505
   bool underrun = false;
 
@@ -1108,11 +1108,27 @@ __device__ __forceinline__ void decompress_body(const InvParams<T>& p, const uns
         T v;
         if constexpr (BC_ARITH) v = bin_centre<T>(w1, nv, i, p.bin_width);
         else v = bctab[(wg >> (8 * i)) & 255u];                        // :416 / :462
-        if ((m >> (8 * i + 7)) & 1u) {
-          v = (T)e[i];
-          if (MODE == DCTZHIP_QT) v = qt_restore(v, qt[j], p.eb, T(10), p.range_min, p.range_max);
-        }
+        if ((m >> (8 * i + 7)) & 1u) v = (T)e[i];
         x[j] = v;
+      }
+    }
+    if constexpr (MODE == DCTZHIP_QT) {
+      // dctz-decomp-lib.c:404-409 in a pass of its own over the flagged positions: inside the loop above every division sat
+      // right behind the LDS read of its coefficient, one exposed round trip per flagged group (with one wave per SIMD the
+      // QT decoder spent 76 % more cycles waiting than its EC twin for FEWER vector instructions, profiles/r04_pmc_qt.txt);
+      // here the coefficients are in registers already and the reads of all sixteen groups overlap as they do in EC mode
+#pragma unroll
+      for (int g = 0; g < 16; g++) {
+        const unsigned nv = ~w[g];
+        unsigned m = ~(((nv & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | nv) & 0x80808080u;
+        if (g == 0) m &= ~0x80u;
+        if (__builtin_amdgcn_ballot_w64(m != 0u)) {
+#pragma unroll
+          for (int i = 0; i < 4; i++) {
+            const int j = 4 * g + i;
+            if (j != 0 && ((m >> (8 * i + 7)) & 1u)) x[j] = qt_restore(x[j], qtl.at(j), p.eb, T(10), p.range_min, p.range_max);
+          }
+        }
       }
     }
     } else {
@@ -1130,7 +1146,7 @@ __device__ __forceinline__ void decompress_body(const InvParams<T>& p, const uns
         const float e = stage[min(ptr, stage_last)];
         ptr++;
         v = (T)e;
-        if (MODE == DCTZHIP_QT) v = qt_restore(v, qt[j], p.eb, T(10), p.range_min, p.range_max);
+        if (MODE == DCTZHIP_QT) v = qt_restore(v, qtl.at(j), p.eb, T(10), p.range_min, p.range_max);
       }
       x[j] = v;
     }
@@ -1195,7 +1211,6 @@ __device__ __forceinline__ void decompress_il_body(const InvParams<T>& p, const 
   static_assert(G::PHB + DEC_CAP * 4 >= 4096 * 4, "the ranges' prefix (at most 4096 of them) fits the array before the first tile");
   constexpr bool BC_ARITH = DCTZ_BC_ARITH != 0 && sizeof(T) == 8;
   __shared__ __attribute__((aligned(16))) T bctab[BC_ARITH ? 1 : 256]; // bin_center[] of gen_bins
-  __shared__ T qt[64];
   const int lane = threadIdx.x;
   // the ranges' exclusive prefix -> LDS (p.nwg ranges, the partition k_count_tiles counted in)
   // (every workgroup does this before its first tile: the counts come in with eight independent loads per lane and trip --
@@ -1239,7 +1254,8 @@ __device__ __forceinline__ void decompress_il_body(const InvParams<T>& p, const 
       const int ti = (b & 1) ? (b >> 1) + 1 : -(b >> 1);
       bctab[b] = (T)ti * p.bin_width;
     }
-  if (MODE == DCTZHIP_QT) qt[lane] = p.qtab[lane];
+  QtLanes<T> qtl{};
+  if (MODE == DCTZHIP_QT) qtl.load(p.qtab, lane);
   const bool scale = (p.sf != T(1));                 // dctz-decomp-lib.c:496 / :505
   bool underrun = false;
 
@@ -1326,11 +1342,27 @@ __device__ __forceinline__ void decompress_il_body(const InvParams<T>& p, const 
         T v;
         if constexpr (BC_ARITH) v = bin_centre<T>(w1, nv, i, p.bin_width);
         else v = bctab[(wgd >> (8 * i)) & 255u];                       // :416 / :462
-        if ((m >> (8 * i + 7)) & 1u) {
-          v = (T)e[i];
-          if (MODE == DCTZHIP_QT) v = qt_restore(v, qt[j], p.eb, T(10), p.range_min, p.range_max);
-        }
+        if ((m >> (8 * i + 7)) & 1u) v = (T)e[i];
         x[j] = v;
+      }
+    }
+    if constexpr (MODE == DCTZHIP_QT) {
+      // dctz-decomp-lib.c:404-409 in a pass of its own over the flagged positions: inside the loop above every division sat
+      // right behind the LDS read of its coefficient, one exposed round trip per flagged group (with one wave per SIMD the
+      // QT decoder spent 76 % more cycles waiting than its EC twin for FEWER vector instructions, profiles/r04_pmc_qt.txt);
+      // here the coefficients are in registers already and the reads of all sixteen groups overlap as they do in EC mode
+#pragma unroll
+      for (int g = 0; g < 16; g++) {
+        const unsigned nv = ~w[g];
+        unsigned m = ~(((nv & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | nv) & 0x80808080u;
+        if (g == 0) m &= ~0x80u;
+        if (__builtin_amdgcn_ballot_w64(m != 0u)) {
+#pragma unroll
+          for (int i = 0; i < 4; i++) {
+            const int j = 4 * g + i;
+            if (j != 0 && ((m >> (8 * i + 7)) & 1u)) x[j] = qt_restore(x[j], qtl.at(j), p.eb, T(10), p.range_min, p.range_max);
+          }
+        }
       }
     }
     } else {
@@ -1347,7 +1379,7 @@ __device__ __forceinline__ void decompress_il_body(const InvParams<T>& p, const 
         const float e = stage[min(ptr, stage_last)];
         ptr++;
         v = (T)e;
-        if (MODE == DCTZHIP_QT) v = qt_restore(v, qt[j], p.eb, T(10), p.range_min, p.range_max);
+        if (MODE == DCTZHIP_QT) v = qt_restore(v, qtl.at(j), p.eb, T(10), p.range_min, p.range_max);
       }
       x[j] = v;
     }
