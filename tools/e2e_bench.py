@@ -81,7 +81,9 @@ def main():
             os.environ["DCTZ_ZLIB_THREADS"] = str(threads)
         res = {}
         streams = None
-        for rep in range(2):                      # first repetition warms the context / page tables
+        ctimes, dtimes = [], []
+        for rep in range(5):                      # first repetition warms the context / page tables; the box is shared: the best of
+                                                  # the others is reported, all of them are listed
             x = x0.copy()
             zbuf = np.zeros(n * x.itemsize + 4096, np.uint8)
             rec = np.zeros(n, dt)
@@ -100,10 +102,19 @@ def main():
             t3 = time.perf_counter()
             lib.dctz_last_stage_times(C.byref(st))
             dec = {k: getattr(st, k) for k, _ in StageTimes._fields_}
-            res = {"compress_s": t1 - t0, "decompress_s": t3 - t2, "out_bytes": out.value,
-                   "compress_GBps_input": x.nbytes / (t1 - t0) / 1e9, "decompress_GBps_input": x.nbytes / (t3 - t2) / 1e9,
-                   "compress_stages_s": comp, "decompress_stages_s": dec,
-                   "max_abs_err_vs_scaled_input": float(np.abs(rec - x0).max())}
+            if rep:
+                ctimes.append(t1 - t0)
+                dtimes.append(t3 - t2)
+            if rep and (not res or t1 - t0 <= min(ctimes)):
+                res = {"compress_s": t1 - t0, "decompress_s": min(dtimes), "out_bytes": out.value,
+                       "compress_stages_s": comp, "decompress_stages_s": dec,
+                       "max_abs_err_vs_scaled_input": float(np.abs(rec - x0).max())}
+            if rep == 4:
+                res["decompress_s"] = min(dtimes)
+                res["compress_GBps_input"] = x.nbytes / res["compress_s"] / 1e9
+                res["decompress_GBps_input"] = x.nbytes / res["decompress_s"] / 1e9
+                res["all_compress_ms"] = [round(t * 1e3, 2) for t in ctimes]
+                res["all_decompress_ms"] = [round(t * 1e3, 2) for t in dtimes]
             z = zbuf[:out.value].tobytes()
             s0, s1, s2 = struct.unpack_from("<III", z, 40)
             streams = (zlib.decompress(z[56:56 + s0]), zlib.decompress(z[56 + s0:56 + s0 + s1]),
