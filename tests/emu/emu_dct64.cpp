@@ -4,6 +4,7 @@
 // Build: g++ -O1 -ffp-contract=off -mfma -shared -fPIC (tests/test_lane_emulation.py).
 #include "../../dctz_amd/csrc/dct64_block.h"
 #include "../../dctz_amd/csrc/dct_nd_block.h"
+#include "../../dctz_amd/csrc/dct64_block_eo.h"
 #include "../../dctz_amd/csrc/dctz_tables.h"
 
 using namespace dctz;
@@ -21,7 +22,27 @@ static void emu(const T* a, T* b, bool inverse, int geom = 0) {
   for (int i = 0; i < 64; i++) b[i] = x[i];
 }
 
+
+// the forward transform as its even-coefficient and odd-coefficient halves (dct64_block_eo.h): what the two waves that
+// share a tile in k_compress_eo compute, here one after the other on the CPU
+template <typename T>
+static void emu_eo(const T* a, T* b) {
+  static T tab[TBP_TOTAL];
+  static bool ready = false;
+  if (!ready) { fill_tab_block<T>(tab); ready = true; }
+  T sr[16], si[16], dr[16], di[16], ev[32], od[32];
+  for (int m = 0; m < 16; m++) {
+    sr[m] = a[eo_lhs(m, 0)] + a[eo_rhs(m, 0)]; si[m] = a[eo_lhs(m, 1)] + a[eo_rhs(m, 1)];
+    dr[m] = a[eo_lhs(m, 0)] - a[eo_rhs(m, 0)]; di[m] = a[eo_lhs(m, 1)] - a[eo_rhs(m, 1)];
+  }
+  dct64_fwd_half<T, EO_EVEN, const T*>(sr, si, ev, tab);
+  dct64_fwd_half<T, EO_ODD, const T*>(dr, di, od, tab);
+  for (int i = 0; i < 32; i++) { b[2 * i] = ev[i]; b[2 * i + 1] = od[i]; }
+}
+
 extern "C" {
+void emu_eo_f64(const double* a, double* b) { emu_eo<double>(a, b); }
+void emu_eo_f32(const float* a, float* b) { emu_eo<float>(a, b); }
 void emu_fwd_f64(const double* a, double* b) { emu<double>(a, b, false); }
 void emu_inv_f64(const double* a, double* b) { emu<double>(a, b, true); }
 void emu_fwd_f32(const float* a, float* b) { emu<float>(a, b, false); }

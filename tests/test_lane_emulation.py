@@ -40,6 +40,33 @@ def test_lane_flow_bit_identical_to_oracle(emu, dtype, suf):
 
 
 @pytest.mark.parametrize("dtype,suf", [(np.float64, "f64"), (np.float32, "f32")])
+def test_even_odd_halves_are_the_whole_transform(emu, dtype, suf):
+    """dct64_block_eo.h: the half of dct64_fwd() behind the even-numbered coefficients and the half behind the odd-numbered
+    ones (k_compress_eo gives them to two wavefronts) share no operation and together ARE dct64_fwd(): bit for bit the
+    lane flow, hence the oracle's pinned flow.  Signed zeros, denormals and huge values included."""
+    rng = np.random.default_rng(31)
+    for i in range(3000):
+        a = (rng.standard_normal(64) * 10 ** rng.uniform(-3, 2)).astype(dtype)
+        if i == 0:
+            a[:] = 0
+        if i == 1:
+            a[:] = -0.0
+        if i == 2:
+            a[:] = 1
+        if i == 3:
+            a *= dtype(np.finfo(dtype).tiny) * dtype(4)
+        if i == 4:
+            a *= dtype(np.finfo(dtype).max) / dtype(1e4)
+        if i == 5:
+            a[::2] = 0
+        b, w = np.empty_like(a), np.empty_like(a)
+        getattr(emu, "emu_eo_" + suf)(a.ctypes.data_as(C.c_void_p), b.ctypes.data_as(C.c_void_p))
+        getattr(emu, "emu_fwd_" + suf)(a.ctypes.data_as(C.c_void_p), w.ctypes.data_as(C.c_void_p))
+        assert np.array_equal(b.view(np.uint8), w.view(np.uint8)), i
+        assert np.array_equal(b.view(np.uint8), O.dct_fwd(a, O.FAST).view(np.uint8)), i
+
+
+@pytest.mark.parametrize("dtype,suf", [(np.float64, "f64"), (np.float32, "f32")])
 def test_remainder_tables_identical_to_oracle(emu, dtype, suf):
     """Host tables of the product (explicit sincos) == the oracle's, for every length."""
     for l in range(1, 64):
