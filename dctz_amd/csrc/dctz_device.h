@@ -410,6 +410,13 @@ struct OneBatchD {
   unsigned tag;
   unsigned pad;
 };
+// A list's entry in tile_cnt[] (k_compress / k_compress_eo -> k_compact_ac): its length, and LIST_IN_ORDER when the list is in the
+// reference's order as it stands (dctz_kernels.hip).
+constexpr unsigned LIST_IN_ORDER = 0x80000000u, LIST_LEN = 0x7FFFFFFFu;
+// k_compress_eo (dctz_kernels_eo.hip): k_compress for flat fp64 blocks with every block shared by a lane of an "even" and a
+// lane of an "odd" wavefront (workgroups of two waves); same parameters, same outputs
+void launch_compress_eo(const FwdParams<double>& p, int mode, bool stats, int grid, hipStream_t s);
+int compress_eo_occupancy(int mode, bool stats);
 constexpr unsigned ONE_ERR_TIMEOUT = 3u;   // Ctl::error / HostBox::error: a sweep of the board gave up (a workgroup was not resident)
 template <typename T> void launch_compress_one(const OneFwd<T>& a, int mode, bool scaled, hipStream_t s);
 template <typename T> void launch_decompress_one(const OneInv<T>& a, int mode, hipStream_t s);

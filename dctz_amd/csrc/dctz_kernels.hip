@@ -101,7 +101,7 @@ __global__ __launch_bounds__(SWG) void k_finish(FinArgs a) {
 // A list's entry in tile_cnt[]: its length, and LIST_IN_ORDER when every tile of the workgroup had items in its first
 // sub-list only -- block-major over the first range of j is then the reference's order (a smooth field: what is stored
 // exactly are the lowest frequencies), and k_compact_ac copies the list as it is.
-constexpr unsigned LIST_IN_ORDER = 0x80000000u, LIST_LEN = 0x7FFFFFFFu;
+// (LIST_IN_ORDER, LIST_LEN: dctz_device.h)
 template <typename T>
 size_t compress_lds_bytes(int mode) {              // tile image + sub-list staging (+ positions, QT); must match k_compress's static arrays
   using G = Geo<T, Phases<T>::C>;

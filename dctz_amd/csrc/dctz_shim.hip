@@ -83,6 +83,9 @@ struct dctzhip_ctx {
   int dev_sf = 1;                   // 0: the host chooses sf between the sample and k_compress (DCTZHIP_DEVICE_SF)
   int blocking = 0;                 // 1: every compress / decompress call ends with a stream synchronisation (DCTZHIP_BLOCKING, dctzhip_set_blocking)
   int occ[2][2][2][2][3] = {};      // resident workgroups per CU per kernel instantiation [f64][decode][qt][stats][geom], 0 = not asked yet
+  int eo = 0;                       // 1: flat fp64 arrays on the chain of kernels go through k_compress_eo (a block over two lanes; DCTZHIP_EO, dctzhip_set_split)
+  int eo_occ[2][2] = {};            // its resident workgroups per CU [qt][stats]
+  unsigned long long eo_calls = 0;
   int grid_c = 0;                   // upper bound of k_compress's grid (DCTZHIP_GRID_C; 0 = what the LDS admits)
   int nd_direct = 1;                // multi-dimensional blocks read / written in place where the shape allows (DCTZHIP_ND_DIRECT)
   // large D2H copies into pageable memory: pinned staging slots, one per worker thread, each with its own stream
@@ -261,6 +264,7 @@ extern "C" int dctzhip_ctx_create(dctzhip_ctx** out, int device) {
   if (const char* e = getenv("DCTZHIP_DEVICE_SF")) c->dev_sf = atoi(e) != 0;
   if (const char* e = getenv("DCTZHIP_ND_DIRECT")) c->nd_direct = atoi(e) != 0;
   if (const char* e = getenv("DCTZHIP_GRID_C")) c->grid_c = atoi(e);
+  if (const char* e = getenv("DCTZHIP_EO")) c->eo = atoi(e) != 0;
   if (const char* e = getenv("DCTZHIP_BLOCKING")) c->blocking = atoi(e) != 0;
   if (const char* e = getenv("DCTZHIP_STAGED_D2H")) c->staged_d2h = atoi(e) != 0;
   if (const char* e = getenv("DCTZHIP_DEC_IL")) c->dec_il = atoi(e);      // 0: never, 1: where it measured faster (fp64 EC), 2: every element type and mode
@@ -343,6 +347,11 @@ extern "C" int dctzhip_set_speculation(dctzhip_ctx* c, int on, size_t min_elemen
   c->speculate = on != 0;
   c->spec_cooldown = 0;
   if (min_elements) c->spec_min = min_elements;
+  return DCTZHIP_OK;
+}
+extern "C" int dctzhip_set_split(dctzhip_ctx* c, int on) {
+  if (!c) return DCTZHIP_E_ARG;
+  c->eo = on != 0;
   return DCTZHIP_OK;
 }
 extern "C" int dctzhip_set_one_launch(dctzhip_ctx* c, int on) {
@@ -1176,7 +1185,17 @@ static int compress_pass(dctzhip_ctx* c, const T* d_in, size_t n, double eb, int
   if (rem) { int rc = upload_rtab<T>(c, rem); if (rc) return rc; }
 
   if (c->profiling) HIPCHK(c, hipEventRecord(c->ev[2], s));
-  unsigned cap = (unsigned)(c->num_cu * wg_per_cu<T>(c, false, mode, fused, geom));
+  // flat fp64 blocks, no scaled copy asked of the kernel: the form with a block over two lanes, if selected
+  bool eo = false;
+  if constexpr (sizeof(T) == 8) eo = c->eo && geom == GEOM_1D && !nd && d_scaled == nullptr && ntiles != 0;
+  unsigned cap;
+  if (eo) {
+    int& slot = c->eo_occ[mode == DCTZHIP_QT][fused ? 1 : 0];
+    if (slot == 0) { const int v = compress_eo_occupancy(mode, fused); slot = v < 1 ? 1 : (v > 8 ? 8 : v); }
+    cap = (unsigned)(c->num_cu * (c->wg_per_cu ? (c->wg_per_cu < slot ? c->wg_per_cu : slot) : slot));
+  } else {
+    cap = (unsigned)(c->num_cu * wg_per_cu<T>(c, false, mode, fused, geom));
+  }
   if (c->grid_c > 0 && (unsigned)c->grid_c < cap) cap = (unsigned)c->grid_c;       // DCTZHIP_GRID_C (experiments)
   const int grid = (int)(cap < ntiles ? cap : ntiles);
   p.nlists_main = (unsigned)grid;
@@ -1186,7 +1205,8 @@ static int compress_pass(dctzhip_ctx* c, const T* d_in, size_t n, double eb, int
   if ((size_t)grid + 2 > c->tile_cap || (fused && grid + 1 > PART_SLOTS) || (size_t)ntiles + 2 > c->qcnt_cap)
     return fail(c, DCTZHIP_E_INTERNAL, "compress grid of %d workgroups over %u tiles exceeds the scratch tables (%zu list entries, %d partials, %zu tiles)",
                 grid, ntiles, c->tile_cap, PART_SLOTS, c->qcnt_cap);
-  if (ntiles) launch_compress<T>(p, mode, fused, grid, geom, s);
+  if constexpr (sizeof(T) == 8) { if (eo) { launch_compress_eo(p, mode, fused, grid, s); c->eo_calls++; } }
+  if (ntiles && !eo) launch_compress<T>(p, mode, fused, grid, geom, s);
   if (c->profiling) HIPCHK(c, hipEventRecord(c->ev[3], s));
   if (rem) launch_compress_rem<T>(p, mode, rem, s);
   // stitch the workgroup-local lists into AC_exact[]

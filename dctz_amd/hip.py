@@ -65,6 +65,7 @@ _PROTOS = {
     "dctzhip_last_timings": (C.c_int, [C.c_void_p, C.POINTER(Timings)]),
     "dctzhip_set_speculation": (C.c_int, [C.c_void_p, C.c_int, C.c_size_t]),
     "dctzhip_set_one_launch": (C.c_int, [C.c_void_p, C.c_int]),
+    "dctzhip_set_split": (C.c_int, [C.c_void_p, C.c_int]),
     "dctzhip_malloc": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.c_size_t]),
     "dctzhip_free": (C.c_int, [C.c_void_p, C.c_void_p]),
     "dctzhip_memcpy_h2d": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
@@ -205,6 +206,10 @@ class Context:
     def set_one_launch(self, on=True):
         """One kernel per call for arrays whose tiles are all resident at once (include/dctz_hip.h); off: the chain of kernels."""
         self._check(self.lib.dctzhip_set_one_launch(self.h, int(on)), "set_one_launch")
+
+    def set_split(self, on=True):
+        """k_compress_eo (a block over two lanes) for flat fp64 arrays on the chain of kernels (include/dctz_hip.h)."""
+        self._check(self.lib.dctzhip_set_split(self.h, int(on)), "set_split")
 
     def set_blocking(self, on=True):
         """Calls return only when their outputs are complete for any observer (default: complete in stream order)."""

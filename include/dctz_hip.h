@@ -113,6 +113,13 @@ int dctzhip_last_timings(dctzhip_ctx *ctx, dctzhip_timings *t);
  * resident (another process on the GPU) gives up after 20 ms and the call is run through the chain.  Default: on (env
  * DCTZHIP_ONE=0 turns it off); on == 0 always takes the chain of kernels. */
 int dctzhip_set_one_launch(dctzhip_ctx *ctx, int on);
+/* A block over two lanes.  on != 0: the compress kernel of the chain (arrays beyond the one-launch size) for flat fp64
+ * blocks is k_compress_eo -- workgroups of two wavefronts that share a tile's blocks, one computing the even-numbered
+ * coefficients of every block, the other the odd-numbered ones (half the registers per lane, three waves per SIMD instead
+ * of two) -- with the tile's exact coefficients put into the reference's order inside the kernel.  Outputs are bit for bit
+ * those of k_compress.  Calls that ask for the scaled copy, fp32 and multi-dimensional blocks keep k_compress.
+ * Env DCTZHIP_EO=0/1 sets the default. */
+int dctzhip_set_split(dctzhip_ctx *ctx, int on);
 /* on != 0: every compress / decompress call ends with a synchronisation of the context's stream, i.e. its outputs are
  * complete for ANY observer when it returns (default off: complete in stream order, see the two calls below; env
  * DCTZHIP_BLOCKING=1 does the same).  For callers that read the buffers from another stream or from the host without
