@@ -187,6 +187,8 @@ struct FinArgs {
   HostBox* box;
   unsigned long long seq;
   const SfGuess* guess;            // device-chosen scaling factor of this call, reported with the results (NULL: the host chose it)
+  unsigned* zero_words;            // k_finish only: words to clear for the next call (the ticket counters of k_compress_eo), or NULL
+  unsigned nzero;
 };
 
 // A multi-dimensional array and its tile grid (dct_nd_block.h): nd = 2 -> 8 x 8 tiles, nd = 3 -> 4 x 4 x 4 tiles.
@@ -237,6 +239,12 @@ struct FwdParams {
   unsigned nlists_main;            // number of workgroup lists = grid of k_compress
   T sf, bin_width, range_min, range_max;
   NdDirect nd;                     // multi-dimensional blocks straight from the array (GEOM != GEOM_1D only)
+  // k_compress_eo, single-pass placement of AC_exact (direct != 0): per-tile descriptors of the look-back (dctz_kernels_eo.hip),
+  // the tag of this call's descriptors; k_compress_rem then appends behind Ctl::cnt_total instead of writing a list
+  unsigned long long* lb_desc;
+  unsigned* lb_ticket;             // eight ticket counters, 16 words apart (zero when the kernel starts: k_finish leaves them so)
+  unsigned lb_epoch;
+  unsigned direct;
 };
 
 template <typename T>
@@ -416,7 +424,7 @@ constexpr unsigned LIST_IN_ORDER = 0x80000000u, LIST_LEN = 0x7FFFFFFFu;
 // k_compress_eo (dctz_kernels_eo.hip): k_compress for flat fp64 blocks with every block shared by a lane of an "even" and a
 // lane of an "odd" wavefront (workgroups of two waves); same parameters, same outputs
 void launch_compress_eo(const FwdParams<double>& p, int mode, bool stats, int grid, hipStream_t s);
-int compress_eo_occupancy(int mode, bool stats);
+int compress_eo_occupancy(int mode, bool stats, bool direct);
 constexpr unsigned ONE_ERR_TIMEOUT = 3u;   // Ctl::error / HostBox::error: a sweep of the board gave up (a workgroup was not resident)
 template <typename T> void launch_compress_one(const OneFwd<T>& a, int mode, bool scaled, hipStream_t s);
 template <typename T> void launch_decompress_one(const OneInv<T>& a, int mode, hipStream_t s);
@@ -433,7 +441,8 @@ template <typename T> void launch_stats_sample(const T* x, size_t n, unsigned gr
                                                const SfTable* tab = nullptr, SfGuess* guess = nullptr);
 void launch_stats_final(const double* part, int nparts, double* out, hipStream_t s, HostBox* box = nullptr,
                         unsigned long long seq = 0, Ctl* zero = nullptr, const SfTable* tab = nullptr, SfGuess* guess = nullptr);
-void launch_finish(Ctl* ctl, const double* part, int nparts, HostBox* box, unsigned long long seq, hipStream_t s);
+void launch_finish(Ctl* ctl, const double* part, int nparts, HostBox* box, unsigned long long seq, hipStream_t s, const SfGuess* guess = nullptr,
+                   unsigned* zero_words = nullptr, unsigned nzero = 0);
 template <typename T> void launch_debug_divide(const T* x, size_t n, T d, int ok, T* fast, T* ref, hipStream_t s);
 template <typename T> void launch_serial_sum(const T* x, size_t n, double* out, hipStream_t s);
 template <typename T> void launch_scale(const T* x, T* out, size_t n, T sf, int grid, hipStream_t s);

@@ -85,8 +85,10 @@ __device__ __forceinline__ void finish_body(const FinBody& f) {
 
 #if DCTZ_PART == 0
 __global__ __launch_bounds__(SWG) void k_finish(FinArgs a) {
+  if (a.zero_words != nullptr) for (unsigned i = threadIdx.x; i < a.nzero; i += SWG) a.zero_words[i] = 0u;
   FinBody f;
   f.ctl = a.ctl; f.part = a.part; f.nparts = a.nparts; f.box = a.box; f.seq = a.seq; f.guess = a.guess;
+  f.zero_words = nullptr; f.nzero = 0;
   f.cnt_known = false; f.err_known = false; f.cnt_total = 0; f.error = 0;
   finish_body<true>(f);
 }
@@ -599,13 +601,16 @@ __device__ __forceinline__ void compress_rem_body(const FwdParams<T>& p, const i
   if (k >= l) exc = false;
   const unsigned long long m = __ballot(exc);
   const unsigned rank = (unsigned)__popcll(m & ((1ull << k) - 1ull));
-  const unsigned start = p.ntiles * TILE_ELEMS;                     // this block is list #nlists_main, parked behind the tiles' slots
+  // (k_compress_eo with single-pass placement, EC: there are no lists -- the block's coefficients go behind the running
+  // tot_AC_exact_count the tiles have left in the control block)
+  const bool direct = MODE == DCTZHIP_EC && p.direct != 0u;
+  const unsigned start = direct ? p.ctl->cnt_total : p.ntiles * TILE_ELEMS;   // else: this block is list #nlists_main, parked behind the tiles' slots
   if (k < l) {
     p.bin[base + k] = (uint8_t)b;
     if (p.coef != nullptr) p.coef[base + k] = coef;
     if (k == 0) { p.dc[p.nfull] = (float)coef; p.ctl->q0 = (unsigned long long)to_bits(coef); }
     if (exc) {
-      if (MODE == DCTZHIP_EC) p.ac_tmp[start + rank] = (float)coef;
+      if (MODE == DCTZHIP_EC) { if (direct) p.ac[start + rank] = (float)coef; else p.ac_tmp[start + rank] = (float)coef; }
       else {
         p.qt_item[start + rank] = coef; p.qt_j[start + rank] = (uint8_t)k;
         if (fabs(coef) > p.range_max) atomicMax(&p.ctl->qraw[k], (unsigned long long)to_bits(fabs(coef)));   // :371-372 / :396-397
@@ -613,7 +618,7 @@ __device__ __forceinline__ void compress_rem_body(const FwdParams<T>& p, const i
     }
   }
   __syncthreads();
-  if (k == 0) p.tile_cnt[p.nlists_main] = (unsigned)__popcll(m);
+  if (k == 0) { if (direct) p.ctl->cnt_total = start + (unsigned)__popcll(m); else p.tile_cnt[p.nlists_main] = (unsigned)__popcll(m); }
 }
 template <typename T, int MODE>
 __global__ __launch_bounds__(64) void k_compress_rem(FwdParams<T> p, int l) { compress_rem_body<T, MODE>(p, l); }
@@ -1487,8 +1492,9 @@ __global__ __launch_bounds__(64) void k_decompress_rem(InvParams<T> p, int l) { 
 
 // ================================================================= launchers ==
 #if DCTZ_PART == 0
-void launch_finish(Ctl* ctl, const double* part, int nparts, HostBox* box, unsigned long long seq, hipStream_t s) {
-  const FinArgs f = {ctl, part, nparts, box, seq, nullptr};
+void launch_finish(Ctl* ctl, const double* part, int nparts, HostBox* box, unsigned long long seq, hipStream_t s, const SfGuess* guess,
+                   unsigned* zero_words, unsigned nzero) {
+  const FinArgs f = {ctl, part, nparts, box, seq, guess, zero_words, nzero};
   hipLaunchKernelGGL(k_finish, dim3(1), dim3(SWG), 0, s, f);
 }
 #endif

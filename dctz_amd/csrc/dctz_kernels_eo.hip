@@ -109,29 +109,85 @@ struct EoLds {
   lds_f64* stat;                    // [2][3]
 };
 
-template <int MODE, bool STATS, int ROLE>
+// ---- single-pass placement of AC_exact (EC): decoupled look-back over the tiles' counts ------------------------------------
+// With the tile's exact coefficients in the reference's order in LDS, all that the tile still needs to write them at their
+// FINAL place is the running tot_AC_exact_count of dctz-comp-lib.c:478-544 at its first block = the counts of all tiles in
+// front of it.  Tiles are handed out in order by ticket counters (whichever workgroup is running takes the next tile, so
+// a workgroup that is not resident holds nothing anybody waits for: see the loop), every tile posts its count
+// ("aggregate", A) as soon as it is known, and later -- when its stores are due, half a tile on -- looks back over the
+// descriptors in front of it: 64 of them per load, summing counts until it meets one that already carries its prefix
+// (P), and posts its own inclusive prefix.  Descriptors are 8-byte granules {epoch of the call << 2 | state, value},
+// written by one agent-scope store and read with agent-scope loads (nothing to clear between calls: another call's tags do
+// not match).  No workgroup-local lists, no k_compact_ac: every exact coefficient is written once.
+constexpr unsigned long long EO_SPIN_TICKS = 2000000ull;   // 20 ms of the 100 MHz clock: a look-back that sees no progress gives up (Ctl::error)
+constexpr unsigned EO_ERR_LOOKBACK = 5u;
+typedef __attribute__((address_space(1))) unsigned long long eo_gu64;
+__device__ __forceinline__ unsigned long long eo_ld_agent(const unsigned long long* p) {
+  return __hip_atomic_load((eo_gu64*)(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void eo_st_agent(unsigned long long* p, unsigned long long v) {
+  __hip_atomic_store((eo_gu64*)(p), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ unsigned long long eo_desc(unsigned epoch, unsigned state, unsigned value) {
+  return ((unsigned long long)((epoch << 2) | state) << 32) | value;
+}
+// the exclusive prefix of tile t (the number of exact coefficients in front of it); every lane gets it.
+// 1: there it is; 0: (block == false only) a tile in front has not posted its count yet; -1: gave up waiting.
+__device__ __forceinline__ int eo_look_back(const unsigned long long* desc, unsigned epoch, unsigned t, unsigned& excl_out, bool block = true) {
+  const unsigned lane = threadIdx.x & 63u;
+  unsigned excl = 0;
+  unsigned pos = t;                                  // descriptors pos - 1, pos - 2, ... are looked at next
+  unsigned long long t0 = 0;
+  for (;;) {
+    if (pos == 0u) break;
+    const bool valid = lane < pos;
+    const unsigned long long v = valid ? eo_ld_agent(desc + (pos - 1u - lane)) : eo_desc(epoch, 2u, 0u);   // (in front of tile 0: prefix 0)
+    const unsigned tag = (unsigned)(v >> 32);
+    const bool ready = (tag >> 2) == (epoch & 0x3FFFFFFFu) && (tag & 3u) != 0u;
+    const unsigned long long mR = __builtin_amdgcn_ballot_w64(ready), mP = __builtin_amdgcn_ballot_w64(ready && (tag & 3u) == 2u);
+    if (mP != 0ull) {
+      const unsigned fp = (unsigned)__builtin_ctzll(mP);             // the closest tile that has its prefix
+      const unsigned long long low = fp == 0u ? 0ull : (~0ull >> (64u - fp));
+      if ((mR & low) == low) {                                       // ... and every tile between it and us has its count
+        unsigned s = lane <= fp ? (unsigned)v : 0u;
+        s = (unsigned)__builtin_amdgcn_readlane((int)wave_incl_scan(s), 63);
+        excl += s;
+        break;
+      }
+    } else if (mR == ~0ull) {                                        // 64 counts, no prefix among them: further back
+      excl += (unsigned)__builtin_amdgcn_readlane((int)wave_incl_scan((unsigned)v), 63);
+      pos -= 64u;                                                    // (valid for all 64 lanes, so pos >= 64)
+      continue;
+    }
+    if (!block) { excl_out = 0u; return 0; }
+    __builtin_amdgcn_s_sleep(2);
+    const unsigned long long now = __builtin_amdgcn_s_memrealtime();
+    if (t0 == 0ull) t0 = now;
+    else if (now - t0 > EO_SPIN_TICKS) { excl_out = 0u; return -1; }
+  }
+  excl_out = excl;
+  return 1;
+}
+
+template <int MODE, bool STATS, int ROLE, bool DIRECT>
 __device__ __forceinline__ void compress_eo_role(const FwdParams<double>& p, const unsigned wg, const unsigned nwg, const EoLds& L) {
   using T = double;
   using G = Geo<T, 2>;
   using ST = EoStage<MODE>;
   using Item = typename ST::Item;
+  static_assert(!DIRECT || MODE == DCTZHIP_EC, "QT normalises with the table of the whole array: its items go through the lists");
   constexpr unsigned CAP = (unsigned)ST::CAP;
   lds_u8* const tilebuf = L.tile;
   lds_u8* const binbuf = L.bins;
   lds_u8* const stagebuf = L.stage;
   const int lane = threadIdx.x & 63;
-  const TileRange tr = tile_range(wg, nwg, p.ntiles);
+  // lists (not DIRECT): workgroup b owns the contiguous tiles [lo, hi) and its list lives in their slots
+  const TileRange tr = DIRECT ? TileRange{0u, 0u} : tile_range(wg, nwg, p.ntiles);
   const unsigned list_base = tr.lo * TILE_ELEMS;
-  const size_t first_el = (size_t)tr.lo * TILE_ELEMS;
-  const size_t end_el = min((size_t)p.nfull * 64, (size_t)tr.hi * TILE_ELEMS);
-  const int range_el = tr.lo < tr.hi ? (int)(end_el - first_el) : 0;
-  const __amdgpu_buffer_rsrc_t r_in = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(p.x + first_el), 0, range_el * (int)sizeof(T), 0x00020000);
-  const __amdgpu_buffer_rsrc_t r_bin = __builtin_amdgcn_make_buffer_rsrc(p.bin + first_el, 0, range_el, 0x00020000);
-  const __amdgpu_buffer_rsrc_t r_dc = __builtin_amdgcn_make_buffer_rsrc(p.dc + first_el / 64, 0, range_el / 64 * 4, 0x00020000);
   const int list_slots = (int)((tr.hi - tr.lo) * (unsigned)TILE_ELEMS);
-  const __amdgpu_buffer_rsrc_t r_list = (MODE == DCTZHIP_EC)
+  const __amdgpu_buffer_rsrc_t r_list = DIRECT ? __builtin_amdgcn_make_buffer_rsrc(p.ac, 0, 0, 0x00020000) : ((MODE == DCTZHIP_EC)
       ? __builtin_amdgcn_make_buffer_rsrc(p.ac_tmp + list_base, 0, list_slots * 4, 0x00020000)
-      : __builtin_amdgcn_make_buffer_rsrc(p.qt_item + list_base, 0, list_slots * (int)sizeof(T), 0x00020000);
+      : __builtin_amdgcn_make_buffer_rsrc(p.qt_item + list_base, 0, list_slots * (int)sizeof(T), 0x00020000));
   const __amdgpu_buffer_rsrc_t r_listj = __builtin_amdgcn_make_buffer_rsrc(p.qt_j + (MODE == DCTZHIP_QT ? list_base : 0u), 0, MODE == DCTZHIP_QT ? list_slots : 0, 0x00020000);
   const T sf = p.guess ? (T)p.guess->sf : p.sf;
   const unsigned fast_sf = p.guess ? p.guess->fast_sf : p.fast_sf;
@@ -148,40 +204,42 @@ __device__ __forceinline__ void compress_eo_role(const FwdParams<double>& p, con
   const unsigned stage_at = lds_at(stagebuf), bins_at = lds_at(binbuf), xmask_at = lds_at(L.xmask);
   const unsigned qmax_at = lds_at(L.qmax);
   if (MODE == DCTZHIP_QT && ROLE == EO_EVEN) L.qmax[lane] = 0ull;
+  auto blocks_of = [&](unsigned tile) { return min((unsigned)TILE_BLKS, p.nfull - tile * (unsigned)TILE_BLKS); };
 
-  // this wave's half of a phase's rows, HBM -> LDS
-  auto issue = [&](unsigned rel, auto phase) {
+  // this wave's half of a phase's rows of a tile, HBM -> LDS (a descriptor per tile: offsets are constants, and the range
+  // check zero-fills whatever lies beyond the last whole block)
+  auto issue = [&](unsigned tile, auto phase) {
     constexpr int PHASE = decltype(phase)::value;
-    // (ONE scalar the compiler cannot see through: left alone, it keeps an induction variable per DMA instruction --
-    // sixteen of them, spilled, a v_readlane / v_writelane pair each per trip)
-    int base = (int)(rel * (unsigned)G::TILEB);
-    asm volatile("" : "+s"(base));
+    const __amdgpu_buffer_rsrc_t r_in = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(p.x + (size_t)tile * TILE_ELEMS), 0, (int)(blocks_of(tile) * (unsigned)G::BLKB), 0x00020000);
 #pragma unroll
     for (int jg = 4 * ROLE; jg < 4 * ROLE + 4; jg++)
 #pragma unroll
       for (int s = 0; s < 2; s++)
-        DMA16(r_in, tilebuf + (jg * 2 + s) * 1024, tm.g_of(jg), base + jg * 8 * G::BLKB + EoMap::seg(PHASE, s) * 128, 2 /* nt */);
+        DMA16(r_in, tilebuf + (jg * 2 + s) * 1024, tm.g_of(jg), jg * 8 * G::BLKB + EoMap::seg(PHASE, s) * 128, 2 /* nt */);
   };
 
   // the outputs of the tile before, on their way out (see the head of the file)
   bool pend = false;
-  unsigned p_rel = 0, p_run = 0, p_cnt = 0;
+  unsigned p_tile = 0, p_run = 0, p_cnt = 0, p_tot = 0;
   float p_dc = 0.f;
-  unsigned run = 0;                                  // length of the workgroup's list so far (uniform, the same in both waves)
+  unsigned run = 0;                                  // lists: length of the workgroup's list so far (uniform, the same in both waves)
+  bool gave_up = false;
 
-  // rows [0, cnt) of the staged piece -> the workgroup's list at `at0`; the two waves take every other row
   // (lane numbers through a register the compiler cannot see through wherever per-lane addresses are made of them outside
   // the arithmetic: kept alive across the loop they are spilled to scratch, and a scratch reload waits behind the DMA in flight)
   auto lane_now = [&]() { int l = lane; asm volatile("" : "+v"(l)); return l; };
-  auto store_rows = [&](unsigned at0, unsigned cnt) {
+  // rows [0, cnt) of the staged piece -> the workgroup's list (DIRECT: AC_exact[]) at `at0`; the two waves take every other row
+  auto store_rows = [&](unsigned at0, unsigned cnt, unsigned first_row = (unsigned)ROLE, unsigned row_step = 2u) {
     const int ln = lane_now();
-    for (unsigned r = (unsigned)ROLE; r * 64u < cnt; r += 2u) {
+    const __amdgpu_buffer_rsrc_t r_ac = __builtin_amdgcn_make_buffer_rsrc(p.ac + (DIRECT ? at0 : 0u), 0, DIRECT ? (int)(cnt * 4u) : 0, 0x00020000);
+    for (unsigned r = first_row; r * 64u < cnt; r += row_step) {
       const unsigned e = r * 64u + (unsigned)ln;
       const bool in = e < cnt;
       const int at = (int)(at0 + e);
       if (MODE == DCTZHIP_EC) {
         const unsigned v = *(const lds_u32*)(stagebuf + e * 4u);
-        __builtin_amdgcn_raw_buffer_store_b32(v, r_list, in ? at * 4 : 0x7FFFFFF0, 0, 0);
+        if (DIRECT) __builtin_amdgcn_raw_buffer_store_b32(v, r_ac, (int)(e * 4u), 0, 0);      // (beyond cnt: outside the descriptor)
+        else __builtin_amdgcn_raw_buffer_store_b32(v, r_list, in ? at * 4 : 0x7FFFFFF0, 0, 0);
       } else {
         const u32x2 v = *(lds_cu2*)(stagebuf + e * 8u);
         const unsigned char jj = stagebuf[ST::ITEM_BYTES + e];
@@ -194,19 +252,48 @@ __device__ __forceinline__ void compress_eo_role(const FwdParams<double>& p, con
       }
     }
   };
+  // DIRECT: where tile t's piece of AC_exact[] starts (waits for it); the even wave also posts the tile's inclusive prefix
+  auto posted = [&](unsigned t, unsigned excl, unsigned tot) {
+    if (ROLE == EO_EVEN && lane == 0) {
+      eo_st_agent(p.lb_desc + t, eo_desc(p.lb_epoch, 2u, excl + tot));
+      if (t == p.ntiles - 1u) p.ctl->cnt_total = excl + tot;       // tot_AC_exact_count of the full blocks (:478-544)
+    }
+  };
+  auto place_of = [&](unsigned t, unsigned tot) -> unsigned {
+    unsigned excl = 0;
+    if (eo_look_back(p.lb_desc, p.lb_epoch, t, excl) < 0) gave_up = true;
+    posted(t, excl, tot);
+    return excl;
+  };
+  // DIRECT, even wave: the pending piece of AC_exact[] (a tile's exact coefficients, in order, in the staging buffer) leaves as
+  // soon as every tile in front of it has posted its count; asked at several points of the next tile, waited for only at the
+  // last one -- behind the next tile's OWN count, so that no workgroup ever keeps the others waiting for a count while it
+  // waits itself (with the look-back waited for where the stores are first due, the tiles ran in convoys: 460 us)
+  bool pend_rows = false;
+  auto try_rows = [&](bool block) {
+    unsigned excl = 0;
+    const int st = eo_look_back(p.lb_desc, p.lb_epoch, p_tile, excl, block);
+    if (st == 0) return;
+    if (st < 0) gave_up = true;
+    posted(p_tile, excl, p_tot);
+    store_rows(excl, p_cnt, 0u, 1u);
+    pend_rows = false;
+  };
   auto flush_prev = [&]() {
-    store_rows(p_run, p_cnt);
+    if (!DIRECT) store_rows(p_run, p_cnt);
     if (ROLE == EO_EVEN) {
       // bin ids: (through their staging buffer) 1 KiB rows of 16 consecutive blocks; DC (:350-351 USE_TRUNCATE)
       const int lane = lane_now();
+      const unsigned nb = blocks_of(p_tile);
+      const __amdgpu_buffer_rsrc_t r_bin = __builtin_amdgcn_make_buffer_rsrc(p.bin + (size_t)p_tile * TILE_ELEMS, 0, (int)(nb * 64u), 0x00020000);
+      const __amdgpu_buffer_rsrc_t r_dc = __builtin_amdgcn_make_buffer_rsrc(p.dc + (size_t)p_tile * TILE_BLKS, 0, (int)(nb * 4u), 0x00020000);
       const int bin_goff = (lane >> 2) * 64 + (((lane & 3) ^ ((lane >> 3) & 3)) * 16);
-      const int voff = (int)(p_rel * (unsigned)TILE_ELEMS) + bin_goff;
 #pragma unroll
       for (int i = 0; i < 4; i++) {
         const u32x4 v = *(lds_cu4*)(binbuf + i * 1024 + lane * 16);
-        __builtin_amdgcn_raw_buffer_store_b128(v, r_bin, voff + i * 1024, 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b128(v, r_bin, bin_goff + i * 1024, 0, 0);
       }
-      __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, p_dc), r_dc, (int)(p_rel * 64u + (unsigned)lane) * 4, 0, 0);
+      __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, p_dc), r_dc, lane * 4, 0, 0);
     }
   };
 
@@ -260,17 +347,17 @@ __device__ __forceinline__ void compress_eo_role(const FwdParams<double>& p, con
     else phase_math(r, phase, active, first, std::integral_constant<int, 0>{});
   };
 
-  // ---- the tile loop ------------------------------------------------------------------------------------------------------
-  // One tile per trip.  (Two software-pipelined forms were built and measured in round 5 -- the binning and ordering of tile
-  // k - 1 under tile k's second DMA flight, carrying the coefficients, resp. their float images and the bin ids, across the
-  // trip: both need the previous tile's state AND a phase's 32 raw values in registers at once, spill at 168 registers,
-  // and a scratch reload waits behind the DMA in flight: 353 and 484 us against 268, EXPERIMENTS.)
-  const unsigned my_tiles = tr.hi - tr.lo;
-  unsigned pf_sink = 0;
-  if (my_tiles) issue(0u, IC2<0>{});
-  for (unsigned it = 0; it < my_tiles; it++) {
-    const unsigned tile = tr.lo + it, rel = it;
-    const unsigned blks_here = min((unsigned)TILE_BLKS, p.nfull - tile * TILE_BLKS);
+  // ---- one tile ------------------------------------------------------------------------------------------------------------
+  // Phase 0 of `tile` is in flight when this is entered; phase 0 of `next_tile` (if has_next) when it is left.
+  // (Two software-pipelined forms were built and measured in round 5 -- the binning and ordering of tile k - 1 under tile k's
+  // second DMA flight, carrying the coefficients, resp. their float images and the bin ids, across the trip: both need the
+  // previous tile's state AND a phase's 32 raw values in registers at once, spill at 168 registers, and a scratch reload
+  // waits behind the DMA in flight: 353 and 484 us against 268, EXPERIMENTS.)
+  // Hooks (the ticket draw of the DIRECT loop): after_first_issue -- behind the DMA issue of the second phase;
+  // after_second_wait -- behind the wait for that DMA, in front of the barrier; next_of(has_next, next_tile) -- behind the
+  // barrier that frees the image for the next tile's first phase.
+  auto do_tile = [&](const unsigned tile, auto&& after_first_issue, auto&& after_second_wait, auto&& next_of) {
+    const unsigned blks_here = blocks_of(tile);
     const bool active = (unsigned)lane < blks_here;
     {
       T r[32];
@@ -278,32 +365,25 @@ __device__ __forceinline__ void compress_eo_role(const FwdParams<double>& p, con
       eo_barrier();                                  // ... and the other wave's
       read32(r);
       eo_barrier();                                  // both waves have the phase in registers: the image is free
-      issue(rel, IC2<1>{});
+      issue(tile, IC2<1>{});
+      after_first_issue();
       if (pend) { flush_prev(); pend = false; }
+      if (DIRECT && ROLE == EO_EVEN && pend_rows) try_rows(false);
       phase_any(r, IC2<0>{}, active, tile == 0);
     }
     __builtin_amdgcn_sched_barrier(0);
     {
       T r[32];
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      after_second_wait();
       eo_barrier();
       read32(r);
       eo_barrier();
-      if (it + 1u < my_tiles) {
-        issue(rel + 1u, IC2<0>{});
-#if DCTZ_EO_PREFETCH
-        // ... and the lines of its SECOND phase are asked for as well, one dword of each 128-byte line into a register
-        // nothing reads: that DMA is issued with ~110 instructions in front of its wait (the image is one phase large), and
-        // finds its data in the caches instead of in HBM
-        {
-          const int ln = lane_now();
-          const int line = ROLE * 64 + ln;                                    // 128 lines = the 16 KiB of the phase: (block, slot)
-          const int off = (int)((rel + 1u) * (unsigned)G::TILEB) + (line >> 1) * G::BLKB + EoMap::seg(1, line & 1) * 128;
-          pf_sink = __builtin_amdgcn_raw_buffer_load_b32(r_in, off, 0, 0);
-          asm volatile("" :: "v"(pf_sink));
-        }
-#endif
-      }
+      bool has_next = false;
+      unsigned next_tile = 0;
+      next_of(has_next, next_tile);
+      if (has_next) issue(next_tile, IC2<0>{});
+      if (DIRECT && ROLE == EO_EVEN && pend_rows) try_rows(false);
       phase_any(r, IC2<1>{}, active, false);
     }
     __builtin_amdgcn_sched_barrier(0);
@@ -367,8 +447,10 @@ __device__ __forceinline__ void compress_eo_role(const FwdParams<double>& p, con
       lds_store_b128(bins_at + (unsigned)lane * 64u, u32x4{w[0], w[1], w[2], w[3]});
       lds_store_b128(bins_at + (unsigned)lane * 64u + 16u, u32x4{w[4], w[5], w[6], w[7]});
     }
+    if (DIRECT && ROLE == EO_EVEN && lane == 0) L.xmask[131] = pend_rows ? 1u : 0u;     // (the piece before is still in the staging buffer)
     eo_barrier();
     const unsigned mp = L.xmask[(ROLE ^ 1) * 64 + lane];
+    const bool late = DIRECT && __builtin_amdgcn_readfirstlane((int)L.xmask[131]) != 0;
     if (ROLE == EO_EVEN) {
       unsigned pw[16];
       const u32x4 o0 = *(lds_cu4*)(binbuf + lane * 64), o1 = *(lds_cu4*)(binbuf + lane * 64 + 16);
@@ -390,6 +472,18 @@ __device__ __forceinline__ void compress_eo_role(const FwdParams<double>& p, con
     const unsigned tot = (unsigned)__builtin_amdgcn_readlane((int)incl, 63);
     const unsigned base = incl - n;                  // this block's place in the tile's piece
     const bool single = tot <= CAP;
+    unsigned at_dense = 0;
+    if (DIRECT) {
+      // the tile's count goes on the board at once (tile 0 has its prefix with it); its place is looked up when its stores
+      // are due -- now, if the piece leaves in several rounds
+      if (ROLE == EO_EVEN && lane == 0) eo_st_agent(p.lb_desc + tile, eo_desc(p.lb_epoch, 1u, tot));
+      if (late) {                                    // now it is waited for (this tile's count is out); the odd wave keeps off the buffer meanwhile
+        if (ROLE == EO_EVEN) try_rows(true);
+        eo_barrier();
+      }
+      if (!single) at_dense = place_of(tile, tot);
+      if (p.direct == 2u && tile == 1u) gave_up = true;      // (tests: a look-back that gave up, DCTZHIP_EO_LB_FAIL)
+    }
     // position j = 2 i + ROLE of the block is item number popc(own & below(i)) + popc(other & below(i + ROLE)) of the block
     unsigned jv = (unsigned)ROLE;
     if (MODE == DCTZHIP_QT) asm volatile("" : "+v"(jv));
@@ -415,14 +509,70 @@ __device__ __forceinline__ void compress_eo_role(const FwdParams<double>& p, con
       }
       if (!single) {                                 // a dense tile: round by round, at once
         eo_barrier();
-        store_rows(run + lo, min(tot - lo, CAP));
+        store_rows((DIRECT ? at_dense : run) + lo, min(tot - lo, CAP));
       }
     }
-    pend = true; p_rel = rel; p_run = run; p_cnt = single ? tot : 0u; p_dc = dc_here;
+    pend = true; p_tile = tile; p_run = run; p_cnt = single ? tot : 0u; p_tot = tot; p_dc = dc_here;
+    pend_rows = DIRECT && single;                    // (a piece that left in rounds is placed already)
     run += tot;
+  };
+
+  if (!DIRECT) {
+    if (tr.lo < tr.hi) issue(tr.lo, IC2<0>{});
+    for (unsigned tile = tr.lo; tile < tr.hi; tile++)
+      do_tile(tile, []() {}, []() {}, [&](bool& has_next, unsigned& next_tile) { has_next = tile + 1u < tr.hi; next_tile = tile + 1u; });
+  } else {
+    // Tickets.  A tile is a ticket (with several tiles per ticket, a workgroup's later tiles post their counts only after its
+    // first tile's look-back -- which waits for the LAST tiles of the tickets in front: the chunks run one after the other;
+    // measured, round 5).  One counter would have to serve 130 draws per microsecond (a word saturates at ~88), so there are
+    // eight, 64 bytes apart: counter x hands out the tiles x, x + 8, x + 16, ... and a workgroup draws from the counter of the
+    // XCD it runs on (workgroups are dealt round-robin over the XCDs: eight streams of equal speed); when that one is
+    // exhausted it goes on to the others, so every tile is drawn by a workgroup that is running, whatever the placement.
+    // The even wave's first lane draws; the number crosses to the odd wave through LDS behind a barrier that is there anyway:
+    // the NEXT tile is drawn behind the DMA issue of this tile's second phase (the wait for that DMA is the wait for the
+    // number too), stored in front of the barrier that follows the wait, and read where the next tile's first DMA is issued.
+    lds_u32* const tick = L.xmask + 128;             // [0], [1]: the draw made during a tile, by parity; [2]: a draw of its own
+    unsigned shard;
+    asm volatile("s_getreg_b32 %0, hwreg(20, 0, 4)" : "=s"(shard));     // HW_REG_XCC_ID (any value will do: speed only)
+    shard &= 7u;
+    unsigned tried = 0;                              // counters found exhausted
+    auto draw_sync = [&]() -> unsigned {             // a tile of the first counter, from `shard` on, that still has one; else ~0
+      for (; tried < 8u; tried++, shard = (shard + 1u) & 7u) {
+        if (ROLE == EO_EVEN && lane == 0) tick[2] = atomicAdd(p.lb_ticket + shard * 16u, 1u);
+        eo_barrier();
+        const unsigned t = (unsigned)__builtin_amdgcn_readfirstlane((int)tick[2]) * 8u + shard;
+        eo_barrier();                                // (read by both waves before the next draw overwrites it)
+        if (t < p.ntiles) return t;
+      }
+      return ~0u;
+    };
+    unsigned tile = draw_sync();
+    if (tile != ~0u) issue(tile, IC2<0>{});
+    unsigned nd = 0;
+    while (tile != ~0u) {
+      const unsigned slot = nd & 1u;
+      nd++;
+      unsigned drawn = 0, next = ~0u;
+      do_tile(tile,
+              [&]() { if (ROLE == EO_EVEN && lane == 0) drawn = atomicAdd(p.lb_ticket + shard * 16u, 1u); },
+              [&]() { if (ROLE == EO_EVEN && lane == 0) tick[slot] = drawn; },
+              [&](bool& has_next, unsigned& next_tile) {
+                next_tile = (unsigned)__builtin_amdgcn_readfirstlane((int)tick[slot]) * 8u + shard;
+                has_next = next_tile < p.ntiles;
+                if (has_next) next = next_tile;
+              });
+      if (next == ~0u) {                             // this counter is exhausted: the others (the tail of the launch)
+        shard = (shard + 1u) & 7u; tried++;
+        next = draw_sync();
+        if (next != ~0u) issue(next, IC2<0>{});
+      }
+      tile = next;
+    }
   }
   if (pend) { eo_barrier(); flush_prev(); }
-  if (ROLE == EO_EVEN && lane == 0) p.tile_cnt[wg] = run | LIST_IN_ORDER;
+  if (DIRECT && ROLE == EO_EVEN && pend_rows) try_rows(true);
+  if (DIRECT && gave_up && lane == 0) atomicExch(&p.ctl->error, EO_ERR_LOOKBACK);
+  if (!DIRECT && ROLE == EO_EVEN && lane == 0) p.tile_cnt[wg] = run | LIST_IN_ORDER;
   if (MODE == DCTZHIP_QT) {
     eo_barrier();                                    // every ds_max of both waves is in
     if (ROLE == EO_EVEN) {
@@ -449,38 +599,43 @@ __device__ __forceinline__ void compress_eo_role(const FwdParams<double>& p, con
   }
 }
 
-template <int MODE, bool STATS>
+template <int MODE, bool STATS, bool DIRECT>
 __global__ __launch_bounds__(EO_WG) __attribute__((amdgpu_waves_per_eu(DCTZ_EO_WAVES))) void k_compress_eo(FwdParams<double> p) {
   __shared__ __attribute__((aligned(1024))) unsigned char tilebuf[EO_TILE_LDS];
   __shared__ __attribute__((aligned(16))) unsigned char binbuf[4096];
   __shared__ __attribute__((aligned(16))) unsigned char stagebuf[EoStage<MODE>::BYTES];
-  __shared__ unsigned xmask[128];
+  __shared__ unsigned xmask[128 + 4];
   __shared__ unsigned long long qmax[MODE == DCTZHIP_QT ? 64 : 1];
   __shared__ double stat[6];
   const EoLds L = {(lds_u8*)tilebuf, (lds_u8*)binbuf, (lds_u8*)stagebuf, (lds_u32*)xmask, (lds_u64*)qmax, (lds_f64*)stat};
   const int role = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-  if (role == 0) compress_eo_role<MODE, STATS, EO_EVEN>(p, blockIdx.x, gridDim.x, L);
-  else compress_eo_role<MODE, STATS, EO_ODD>(p, blockIdx.x, gridDim.x, L);
+  if (role == 0) compress_eo_role<MODE, STATS, EO_EVEN, DIRECT>(p, blockIdx.x, gridDim.x, L);
+  else compress_eo_role<MODE, STATS, EO_ODD, DIRECT>(p, blockIdx.x, gridDim.x, L);
 }
 
 void launch_compress_eo(const FwdParams<double>& p, int mode, bool stats, int grid, hipStream_t s) {
-  if (mode == DCTZHIP_EC) {
-    if (stats) hipLaunchKernelGGL((k_compress_eo<DCTZHIP_EC, true>), dim3(grid), dim3(EO_WG), 0, s, p);
-    else hipLaunchKernelGGL((k_compress_eo<DCTZHIP_EC, false>), dim3(grid), dim3(EO_WG), 0, s, p);
+  if (mode == DCTZHIP_EC && p.direct) {
+    if (stats) hipLaunchKernelGGL((k_compress_eo<DCTZHIP_EC, true, true>), dim3(grid), dim3(EO_WG), 0, s, p);
+    else hipLaunchKernelGGL((k_compress_eo<DCTZHIP_EC, false, true>), dim3(grid), dim3(EO_WG), 0, s, p);
+  } else if (mode == DCTZHIP_EC) {
+    if (stats) hipLaunchKernelGGL((k_compress_eo<DCTZHIP_EC, true, false>), dim3(grid), dim3(EO_WG), 0, s, p);
+    else hipLaunchKernelGGL((k_compress_eo<DCTZHIP_EC, false, false>), dim3(grid), dim3(EO_WG), 0, s, p);
   } else {
-    if (stats) hipLaunchKernelGGL((k_compress_eo<DCTZHIP_QT, true>), dim3(grid), dim3(EO_WG), 0, s, p);
-    else hipLaunchKernelGGL((k_compress_eo<DCTZHIP_QT, false>), dim3(grid), dim3(EO_WG), 0, s, p);
+    if (stats) hipLaunchKernelGGL((k_compress_eo<DCTZHIP_QT, true, false>), dim3(grid), dim3(EO_WG), 0, s, p);
+    else hipLaunchKernelGGL((k_compress_eo<DCTZHIP_QT, false, false>), dim3(grid), dim3(EO_WG), 0, s, p);
   }
 }
 
 // resident workgroups (of two waves) per CU: registers and LDS
-int compress_eo_occupancy(int mode, bool stats) {
+int compress_eo_occupancy(int mode, bool stats, bool direct) {
   int n = 0;
   hipError_t e;
-  if (mode == DCTZHIP_EC) e = stats ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, (const void*)k_compress_eo<DCTZHIP_EC, true>, EO_WG, 0)
-                                    : hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, (const void*)k_compress_eo<DCTZHIP_EC, false>, EO_WG, 0);
-  else e = stats ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, (const void*)k_compress_eo<DCTZHIP_QT, true>, EO_WG, 0)
-                 : hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, (const void*)k_compress_eo<DCTZHIP_QT, false>, EO_WG, 0);
+  if (mode == DCTZHIP_EC && direct) e = stats ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, (const void*)k_compress_eo<DCTZHIP_EC, true, true>, EO_WG, 0)
+                                              : hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, (const void*)k_compress_eo<DCTZHIP_EC, false, true>, EO_WG, 0);
+  else if (mode == DCTZHIP_EC) e = stats ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, (const void*)k_compress_eo<DCTZHIP_EC, true, false>, EO_WG, 0)
+                                         : hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, (const void*)k_compress_eo<DCTZHIP_EC, false, false>, EO_WG, 0);
+  else e = stats ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, (const void*)k_compress_eo<DCTZHIP_QT, true, false>, EO_WG, 0)
+                 : hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, (const void*)k_compress_eo<DCTZHIP_QT, false, false>, EO_WG, 0);
   if (e != hipSuccess || n <= 0) n = (int)((size_t)160 * 1024 / (mode == DCTZHIP_EC ? eo_lds_bytes<DCTZHIP_EC>() : eo_lds_bytes<DCTZHIP_QT>()));
   return n;
 }

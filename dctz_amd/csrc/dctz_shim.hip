@@ -84,8 +84,16 @@ struct dctzhip_ctx {
   int blocking = 0;                 // 1: every compress / decompress call ends with a stream synchronisation (DCTZHIP_BLOCKING, dctzhip_set_blocking)
   int occ[2][2][2][2][3] = {};      // resident workgroups per CU per kernel instantiation [f64][decode][qt][stats][geom], 0 = not asked yet
   int eo = 0;                       // 1: flat fp64 arrays on the chain of kernels go through k_compress_eo (a block over two lanes; DCTZHIP_EO, dctzhip_set_split)
-  int eo_occ[2][2] = {};            // its resident workgroups per CU [qt][stats]
+  int eo_occ[2][4] = {};            // its resident workgroups per CU [qt][stats + 2 * direct]
   unsigned long long eo_calls = 0;
+  int eo_direct = 0;                // with k_compress_eo in EC mode: AC_exact placed in the same pass (look-back over the tiles' counts), no k_compact_ac (DCTZHIP_EO_DIRECT, dctzhip_set_split(ctx, 3)); measured slower than the lists (round 5: 356 against 261 us at p = 5 %), hence off
+  int eo_lb_fail = 0;               // (tests) the look-back of one tile reports that it gave up (DCTZHIP_EO_LB_FAIL)
+  int eo_direct_pause = 0;          // calls left on the lists after a look-back that gave up
+  unsigned long long eo_direct_calls = 0, eo_lb_fallbacks = 0;
+  unsigned long long* lb_desc = nullptr;   // per-tile descriptors of the look-back (zeroed when allocated, tagged by lb_epoch)
+  unsigned* lb_ticket = nullptr;    // 8 ticket counters, 16 words apart; zero between calls (k_finish clears them)
+  size_t lb_cap = 0;
+  unsigned lb_epoch = 0;
   int grid_c = 0;                   // upper bound of k_compress's grid (DCTZHIP_GRID_C; 0 = what the LDS admits)
   int nd_direct = 1;                // multi-dimensional blocks read / written in place where the shape allows (DCTZHIP_ND_DIRECT)
   // large D2H copies into pageable memory: pinned staging slots, one per worker thread, each with its own stream
@@ -265,6 +273,8 @@ extern "C" int dctzhip_ctx_create(dctzhip_ctx** out, int device) {
   if (const char* e = getenv("DCTZHIP_ND_DIRECT")) c->nd_direct = atoi(e) != 0;
   if (const char* e = getenv("DCTZHIP_GRID_C")) c->grid_c = atoi(e);
   if (const char* e = getenv("DCTZHIP_EO")) c->eo = atoi(e) != 0;
+  if (const char* e = getenv("DCTZHIP_EO_DIRECT")) c->eo_direct = atoi(e) != 0;
+  if (const char* e = getenv("DCTZHIP_EO_LB_FAIL")) c->eo_lb_fail = atoi(e) != 0;
   if (const char* e = getenv("DCTZHIP_BLOCKING")) c->blocking = atoi(e) != 0;
   if (const char* e = getenv("DCTZHIP_STAGED_D2H")) c->staged_d2h = atoi(e) != 0;
   if (const char* e = getenv("DCTZHIP_DEC_IL")) c->dec_il = atoi(e);      // 0: never, 1: where it measured faster (fp64 EC), 2: every element type and mode
@@ -352,6 +362,8 @@ extern "C" int dctzhip_set_speculation(dctzhip_ctx* c, int on, size_t min_elemen
 extern "C" int dctzhip_set_split(dctzhip_ctx* c, int on) {
   if (!c) return DCTZHIP_E_ARG;
   c->eo = on != 0;
+  c->eo_direct = on == 3;
+  c->eo_direct_pause = 0;
   return DCTZHIP_OK;
 }
 extern "C" int dctzhip_set_one_launch(dctzhip_ctx* c, int on) {
@@ -1153,6 +1165,7 @@ static int compress_pass(dctzhip_ctx* c, const T* d_in, size_t n, double eb, int
   // ---- bin ranges, dctz-comp-lib.c:271-281 (computed in double, stored in T) --
   const int half = DCTZHIP_NBINS / 2;
   FwdParams<T> p;
+  memset(&p, 0, sizeof(p));
   p.x = d_in; p.bin = d_bin; p.dc = d_dc; p.ac = d_ac; p.coef = d_coef;
   p.scaled = d_scaled;                               // (k_compress writes x / sf there itself: compress_impl)
   p.qt_item = reinterpret_cast<T*>(c->qt_item); p.qt_j = c->qt_j;
@@ -1188,10 +1201,28 @@ static int compress_pass(dctzhip_ctx* c, const T* d_in, size_t n, double eb, int
   // flat fp64 blocks, no scaled copy asked of the kernel: the form with a block over two lanes, if selected
   bool eo = false;
   if constexpr (sizeof(T) == 8) eo = c->eo && geom == GEOM_1D && !nd && d_scaled == nullptr && ntiles != 0;
+  // ... and, in EC mode, with AC_exact placed by the kernel itself (look-back over the tiles' counts: no lists, no k_compact_ac)
+  bool direct = eo && mode == DCTZHIP_EC && c->eo_direct;
+  if (direct && c->eo_direct_pause > 0) { c->eo_direct_pause--; direct = false; }
+  if (direct) {
+    if ((size_t)ntiles + 64 > c->lb_cap) {
+      if (c->lb_desc) HIPCHK(c, hipFree(c->lb_desc));
+      c->lb_desc = nullptr; c->lb_cap = 0;
+      HIPCHK(c, hipMalloc(&c->lb_desc, ((size_t)ntiles + 64) * sizeof(unsigned long long)));
+      HIPCHK(c, hipMemsetAsync(c->lb_desc, 0, ((size_t)ntiles + 64) * sizeof(unsigned long long), s));
+      c->lb_cap = (size_t)ntiles + 64;
+    }
+    if (++c->lb_epoch >= (1u << 30)) {               // (tags of 2^30 calls ago would match again)
+      HIPCHK(c, hipMemsetAsync(c->lb_desc, 0, c->lb_cap * sizeof(unsigned long long), s));
+      c->lb_epoch = 1;
+    }
+    if (!c->lb_ticket) { HIPCHK(c, hipMalloc(&c->lb_ticket, 128 * sizeof(unsigned))); HIPCHK(c, hipMemsetAsync(c->lb_ticket, 0, 128 * sizeof(unsigned), s)); }
+    p.direct = c->eo_lb_fail ? 2u : 1u; p.lb_desc = c->lb_desc; p.lb_ticket = c->lb_ticket; p.lb_epoch = c->lb_epoch;
+  }
   unsigned cap;
   if (eo) {
-    int& slot = c->eo_occ[mode == DCTZHIP_QT][fused ? 1 : 0];
-    if (slot == 0) { const int v = compress_eo_occupancy(mode, fused); slot = v < 1 ? 1 : (v > 8 ? 8 : v); }
+    int& slot = c->eo_occ[mode == DCTZHIP_QT][(fused ? 1 : 0) + (direct ? 2 : 0)];
+    if (slot == 0) { const int v = compress_eo_occupancy(mode, fused, direct); slot = v < 1 ? 1 : (v > 8 ? 8 : v); }
     cap = (unsigned)(c->num_cu * (c->wg_per_cu ? (c->wg_per_cu < slot ? c->wg_per_cu : slot) : slot));
   } else {
     cap = (unsigned)(c->num_cu * wg_per_cu<T>(c, false, mode, fused, geom));
@@ -1205,7 +1236,7 @@ static int compress_pass(dctzhip_ctx* c, const T* d_in, size_t n, double eb, int
   if ((size_t)grid + 2 > c->tile_cap || (fused && grid + 1 > PART_SLOTS) || (size_t)ntiles + 2 > c->qcnt_cap)
     return fail(c, DCTZHIP_E_INTERNAL, "compress grid of %d workgroups over %u tiles exceeds the scratch tables (%zu list entries, %d partials, %zu tiles)",
                 grid, ntiles, c->tile_cap, PART_SLOTS, c->qcnt_cap);
-  if constexpr (sizeof(T) == 8) { if (eo) { launch_compress_eo(p, mode, fused, grid, s); c->eo_calls++; } }
+  if constexpr (sizeof(T) == 8) { if (eo) { launch_compress_eo(p, mode, fused, grid, s); c->eo_calls++; if (direct) c->eo_direct_calls++; } }
   if (ntiles && !eo) launch_compress<T>(p, mode, fused, grid, geom, s);
   if (c->profiling) HIPCHK(c, hipEventRecord(c->ev[3], s));
   if (rem) launch_compress_rem<T>(p, mode, rem, s);
@@ -1217,7 +1248,13 @@ static int compress_pass(dctzhip_ctx* c, const T* d_in, size_t n, double eb, int
   // the call's results to the host as soon as the kernel starts -- all of them are in by then -- so the host is back in
   // the caller, queueing the next call's launches, while the lists are still being moved
   const FinArgs fin = {c->ctl, c->part, fused ? (int)nlists : 0, seq ? c->box_dev : nullptr, seq, p.guess};
-  launch_compact_ac<T>(p, mode, eb, nlists, (int)nlists, fin, s);
+  if (direct) {
+    // every exact coefficient is at its place and Ctl::cnt_total is final: only the hand-off is left
+    if (seq) launch_finish(c->ctl, c->part, fused ? (int)nlists : 0, c->box_dev, seq, s, p.guess, c->lb_ticket, 128u);
+    else HIPCHK(c, hipMemsetAsync(c->lb_ticket, 0, 128 * sizeof(unsigned), s));
+  } else {
+    launch_compact_ac<T>(p, mode, eb, nlists, (int)nlists, fin, s);
+  }
   if (!seq && fused) launch_stats_final(c->part, (int)nlists, c->stats_out, s);
   if (c->profiling) HIPCHK(c, hipEventRecord(c->ev[4], s));
   HIPCHK(c, hipGetLastError());
@@ -1316,6 +1353,7 @@ static int compress_impl(dctzhip_ctx* c, const T* d_in, size_t n, double eb, int
   T sf_t = T(1);
   unsigned fast_sf = 0;
   unsigned flags = 0;
+  const unsigned long long eo0 = c->eo_calls, eod0 = c->eo_direct_calls, eof0 = c->eo_lb_fallbacks;
   bool respin = false;                              // second pass of a call: the host's own statistics and scaling factor
   // The scaled copy (dctz-comp-lib.c:193-216) is written by k_compress itself when it goes to a buffer of its own and the
   // blocks are flat (DCTZHIP_FUSE_SCALED=0: always the separate pass); a pass with a wrong guess of sf is run again with
@@ -1323,6 +1361,7 @@ static int compress_impl(dctzhip_ctx* c, const T* d_in, size_t n, double eb, int
   // above; for multi-dimensional blocks x / sf stays a pass of its own behind the kernels.
   T* const scaled_by_kernel = (scale_in_place || (d_scaled && (const void*)d_scaled != (const void*)d_in && geom == GEOM_1D && !nd && c->fuse_scaled)) ? d_scaled : nullptr;
   // one pass of the kernels + the hand-off of its results into *hc / hs[4..6]
+  bool lb_retry = false;
   auto run = [&](const HostStats& stats, bool fused) -> int {
     const bool dev = dsf && !respin;
     int rc = compress_pass<T>(c, d_in, n, eb, mode, d_bin, d_dc, d_ac, d_coef, stats, fused, &sf, &sf_t, &fast_sf, seq, geom, dev, nd, scaled_by_kernel);
@@ -1340,6 +1379,30 @@ static int compress_impl(dctzhip_ctx* c, const T* d_in, size_t n, double eb, int
       if (fused) HIPCHK(c, hipMemcpyAsync(hs + 4, c->stats_out, 3 * sizeof(double), hipMemcpyDeviceToHost, s));
       HIPCHK(c, hipMemcpyAsync(hc, c->ctl, sizeof(Ctl), hipMemcpyDeviceToHost, s));
       HIPCHK(c, hipStreamSynchronize(s));
+    }
+    if (hc->error == 5u && !lb_retry) {              // EO_ERR_LOOKBACK: a look-back of k_compress_eo gave up (a workgroup that held a chunk made no progress)
+      lb_retry = true;                                // -> the same pass through the lists, and the lists for the next calls
+      c->eo_lb_fallbacks++; c->eo_direct_pause = 64;
+      c->ctl_dirty = 1;
+      rc = reset();
+      if (rc) return rc;
+      if (box) seq = ++c->seq;
+      rc = compress_pass<T>(c, d_in, n, eb, mode, d_bin, d_dc, d_ac, d_coef, stats, fused, &sf, &sf_t, &fast_sf, seq, geom, dev, nd, scaled_by_kernel);
+      if (rc) return rc;
+      if (box) {
+        rc = wait_seq(c, &hb->seq_done, seq, "compress");
+        if (rc) return rc;
+        c->ctl_dirty = 0;
+        if (dev) { sf = hb->sf_used; sf_t = (T)sf; fast_sf = hb->fast_used; }
+        hc->cnt_total = hb->cnt_total; hc->error = hb->error; hc->q0 = hb->q0;
+        for (int j = 0; j < 64; j++) hc->qraw[j] = hb->qraw[j];
+        hs[4] = hb->fstats[0]; hs[5] = hb->fstats[1]; hs[6] = hb->fstats[2];
+        if (c->profiling) HIPCHK(c, hipEventSynchronize(c->ev[4]));
+      } else {
+        if (fused) HIPCHK(c, hipMemcpyAsync(hs + 4, c->stats_out, 3 * sizeof(double), hipMemcpyDeviceToHost, s));
+        HIPCHK(c, hipMemcpyAsync(hc, c->ctl, sizeof(Ctl), hipMemcpyDeviceToHost, s));
+        HIPCHK(c, hipStreamSynchronize(s));
+      }
     }
     if (hc->error) { c->ctl_dirty = 1; return fail(c, DCTZHIP_E_INTERNAL, "in-kernel error flag set (code %u)", hc->error); }
     if (c->profiling) { rc = read_timings(c, 2); if (rc) return rc; }
@@ -1379,6 +1442,9 @@ static int compress_impl(dctzhip_ctx* c, const T* d_in, size_t n, double eb, int
     HIPCHK(c, hipGetLastError());
   }
 
+  if (c->eo_calls > eo0) flags |= DCTZHIP_INFO_SPLIT;
+  if (c->eo_lb_fallbacks > eof0) flags |= DCTZHIP_INFO_LB_FALLBACK;
+  else if (c->eo_direct_calls > eod0) flags |= DCTZHIP_INFO_SINGLE_PASS;
   if (info) fill_cinfo(info, dtype, mode, sf, st, n_orig ? n_orig : n, hc->cnt_total, nblk, flags, hc->qraw, hc->q0);
   return DCTZHIP_OK;
 }

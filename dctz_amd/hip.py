@@ -31,6 +31,9 @@ class CompressInfo(C.Structure):
 
 INFO_STATS_FUSED = 1   # sampled guess of sf verified: the separate statistics pass was saved
 INFO_RESPUN = 2        # guess wrong: the compress kernels ran a second time with the true statistics
+INFO_SPLIT = 8         # the compress kernel was k_compress_eo (a block over two lanes)
+INFO_SINGLE_PASS = 16  # ... and AC_exact was placed by that kernel itself (no k_compact_ac)
+INFO_LB_FALLBACK = 32  # ... whose look-back gave up: the pass ran again through the lists
 INFO_ONE_LAUNCH = 4    # the whole call was one kernel (arrays whose tiles are all resident at once: dctz_kernels_one.hip)
 
 

@@ -65,6 +65,9 @@ typedef struct {
  * the true statistics. */
 #define DCTZHIP_INFO_STATS_FUSED 1u   /* guess verified: the separate statistics pass was saved */
 #define DCTZHIP_INFO_RESPUN 2u        /* guess wrong: compress kernels were run a second time    */
+#define DCTZHIP_INFO_SPLIT 8u         /* the compress kernel was k_compress_eo (a block over two lanes: dctzhip_set_split)          */
+#define DCTZHIP_INFO_SINGLE_PASS 16u  /* ... and AC_exact was placed by that kernel itself (look-back over the tiles' counts)       */
+#define DCTZHIP_INFO_LB_FALLBACK 32u  /* ... whose look-back gave up: the pass was run again through the workgroup-local lists      */
 #define DCTZHIP_INFO_ONE_LAUNCH 4u    /* the whole call was one kernel (arrays whose tiles are all resident at once)         */
 
 /* Per-kernel device time of the last compress / decompress call, milliseconds,
@@ -118,7 +121,12 @@ int dctzhip_set_one_launch(dctzhip_ctx *ctx, int on);
  * coefficients of every block, the other the odd-numbered ones (half the registers per lane, three waves per SIMD instead
  * of two) -- with the tile's exact coefficients put into the reference's order inside the kernel.  Outputs are bit for bit
  * those of k_compress.  Calls that ask for the scaled copy, fp32 and multi-dimensional blocks keep k_compress.
- * Env DCTZHIP_EO=0/1 sets the default. */
+ * on == 3, EC mode (experimental: measured slower than the lists): the kernel also writes every exact coefficient at its
+ * final place in AC_exact[] -- tiles are handed out in order by ticket counters, each posts its count and looks back over
+ * the counts in front of it for the running tot_AC_exact_count (dctz-comp-lib.c:478-544) -- so the call has no
+ * workgroup-local lists and no k_compact_ac pass (DCTZHIP_INFO_SINGLE_PASS); a look-back that sees no progress for 20 ms
+ * gives up and the pass is run again through the lists (DCTZHIP_INFO_LB_FALLBACK).  Env DCTZHIP_EO=0/1 and
+ * DCTZHIP_EO_DIRECT=0/1 set the defaults (off, off). */
 int dctzhip_set_split(dctzhip_ctx *ctx, int on);
 /* on != 0: every compress / decompress call ends with a synchronisation of the context's stream, i.e. its outputs are
  * complete for ANY observer when it returns (default off: complete in stream order, see the two calls below; env

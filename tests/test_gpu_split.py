@@ -33,7 +33,7 @@ def _same(a, b):
 
 
 def _run(ctx, xd, eb, mode, split, coef=None):
-    ctx.set_split(split)
+    ctx.set_split(int(split))
     try:
         out, info = ctx.compress(xd, eb, mode, coef=coef)
         import torch
@@ -47,9 +47,15 @@ def _check(ctx, x, eb, mode, want_coef=False):
     import torch
     xd = _dev(ctx, x)
     coef = torch.zeros_like(xd) if want_coef else None
-    a, ia = _run(ctx, xd, eb, mode, True, coef)
-    b, ib = _run(ctx, xd, eb, mode, False)
-    assert not (ia.flags & H.INFO_ONE_LAUNCH)
+    a, ia = _run(ctx, xd, eb, mode, 3, coef)          # split, AC_exact placed in the same pass (EC)
+    l, il = _run(ctx, xd, eb, mode, 1)                # split, workgroup-local lists + k_compact_ac
+    b, ib = _run(ctx, xd, eb, mode, 0)
+    assert not (ia.flags & H.INFO_ONE_LAUNCH) and (ia.flags & H.INFO_SPLIT) and (il.flags & H.INFO_SPLIT) and not (ib.flags & H.INFO_SPLIT)
+    if x.size >= 4096:
+        assert bool(ia.flags & H.INFO_SINGLE_PASS) == (mode == O.EC) and not (il.flags & H.INFO_SINGLE_PASS)
+    assert (il.cnt, il.sf) == (ib.cnt, ib.sf)
+    assert torch.equal(l["bin_index"], b["bin_index"]) and torch.equal(l["dc"].view(torch.int32), b["dc"].view(torch.int32))
+    assert torch.equal(l["ac_exact"][:il.cnt].view(torch.int32), b["ac_exact"][:ib.cnt].view(torch.int32))
     assert (ia.cnt, ia.sf, ia.max_abs, ia.min_abs, ia.nblk) == (ib.cnt, ib.sf, ib.max_abs, ib.min_abs, ib.nblk)
     assert torch.equal(a["bin_index"], b["bin_index"])
     assert torch.equal(a["dc"].view(torch.int32), b["dc"].view(torch.int32))
@@ -124,3 +130,33 @@ def test_split_kernel_special_values(ctx):
     x[3 * 4096 + 700] = 1e-310
     _check(ctx, x, 1e-3, O.EC)
     _check(ctx, x, 1e-3, O.QT)
+
+
+def test_look_back_that_gives_up_falls_back_to_the_lists():
+    """DCTZHIP_EO_LB_FAIL=1: one tile's look-back reports that it gave up; the call must come back with the lists' result --
+    the same bytes -- say so in its flags, and stay on the lists for a while."""
+    import os
+    import torch
+    import dctz_amd
+    os.environ["DCTZHIP_EO_LB_FAIL"] = "1"
+    try:
+        c = dctz_amd.Context(0)
+    finally:
+        del os.environ["DCTZHIP_EO_LB_FAIL"]
+    try:
+        c.set_one_launch(False)
+        x = W.ragged(4096 * 9 + 64 * 3 + 5, np.float64, scale=37.0)
+        xd = torch.from_numpy(x).to(c.device)
+        c.set_split(3)
+        out, info = c.compress(xd, 1e-3, O.EC)
+        torch.cuda.synchronize()
+        assert info.flags & H.INFO_LB_FALLBACK and not (info.flags & H.INFO_SINGLE_PASS)
+        ref = O.compress(x, 1e-3, O.EC, O.FAST)
+        assert info.cnt == ref.cnt and np.array_equal(out["bin_index"].cpu().numpy(), ref.bin_index)
+        assert _same(out["ac_exact"][:ref.cnt].cpu().numpy(), ref.ac_exact) and _same(out["dc"].cpu().numpy(), ref.dc)
+        out2, info2 = c.compress(xd, 1e-3, O.EC)      # the pause: lists, no look-back at all
+        torch.cuda.synchronize()
+        assert (info2.flags & H.INFO_SPLIT) and not (info2.flags & (H.INFO_SINGLE_PASS | H.INFO_LB_FALLBACK))
+        assert _same(out2["ac_exact"][:ref.cnt].cpu().numpy(), ref.ac_exact)
+    finally:
+        c.close()
