@@ -372,6 +372,7 @@ struct OneInv {
   unsigned long long seq;
   unsigned rem;
   unsigned tag;
+  unsigned withhold, pad_w;        // (tests) workgroup 0 withholds its granule: every sweep that needs it gives up
   struct BatchResD* bres;          // batch: the array's entry of the result table instead of the mailbox
   T qtab[64];                      // QT: the clamped table (dctz-decomp-lib.c:193-199), in the kernel's arguments
 };
@@ -416,7 +417,7 @@ struct OneBatchD {
   OneBoard b;
   struct BatchResD* res;
   unsigned tag;
-  unsigned pad;
+  unsigned pad;                    // (tests) != 0: workgroup 0 of every array withholds its granule
 };
 // A list's entry in tile_cnt[] (k_compress / k_compress_eo -> k_compact_ac): its length, and LIST_IN_ORDER when the list is in the
 // reference's order as it stands (dctz_kernels.hip).

@@ -276,7 +276,7 @@ __device__ __forceinline__ void compress_one_body(const OneFwd<T>& a, const unsi
   // Scaling on a guess of the array's decade (below) pays where the first sweep is long: many workgroups (C2: 397; with the
   // 65 of C1 the sweep ends 1.3 us after the last post, and the sample costs as much).  Never with SC: x / sf goes to the
   // caller's memory before the transform.
-  const bool speculate = !SC && (nwg >= (unsigned)ONE_SPEC_MIN_WG || a.bad_guess != 0u);
+  const bool speculate = !SC && (nwg >= (unsigned)ONE_SPEC_MIN_WG || (a.bad_guess & 15u) != 0u);
 
   // ---- phase 1: the data, and calc_data_stat over it (util.c:18-25) ---------------------------------------------------
   one_stamp(a.b, 0);
@@ -364,7 +364,8 @@ __device__ __forceinline__ void compress_one_body(const OneFwd<T>& a, const unsi
       st_agent_f64(a.b.rec + 3 * (size_t)wg, wmx);
       st_agent_f64(a.b.rec + 3 * (size_t)wg + 1, wmn);
       st_agent_f64(a.b.rec + 3 * (size_t)wg + 2, wsum);
-      st_agent(a.b.ga + wg, granule(epoch, kw | (vw << 16)));
+      // (bad_guess & 16, tests: workgroup 0 withholds its granule -- what a workgroup that is not resident does to the others)
+      if (!((a.bad_guess & 16u) && wg == 0u)) st_agent(a.b.ga + wg, granule(epoch, kw | (vw << 16)));
     }
   }
   // The largest decade of the whole array -- all that the scaling factor depends on (util.c:29) -- is what the FIRST SWEEP
@@ -390,7 +391,7 @@ __device__ __forceinline__ void compress_one_body(const OneFwd<T>& a, const unsi
   unsigned kk_use = 0;
   bool verified = false, replay = false;
   unsigned rs = 0;                                   // the sweep's answer: the array's decade word
-  if (!speculate || rem_wg) {
+  if (!speculate || rem_wg || (a.bad_guess & 16u)) {
     if (wv == 0) sweep_stats();
     one_stamp(a.b, 3);
     __syncthreads();
@@ -401,7 +402,7 @@ __device__ __forceinline__ void compress_one_body(const OneFwd<T>& a, const unsi
   } else {
 #pragma unroll
     for (int i = 0; i < OTW; i++) kk_use = max(kk_use, sh.gword[i]);
-    if (a.bad_guess == 1u) kk_use += 1u;
+    if ((a.bad_guess & 15u) == 1u) kk_use += 1u;
   }
   const bool own_inwin = (word >> 16) == 0u;         // FastDiv needs no per-element test for THIS tile (the same quotients either way)
 
@@ -678,7 +679,10 @@ __device__ __forceinline__ void compress_one_body(const OneFwd<T>& a, const unsi
   unsigned E = pre;                                  // this wave's first coefficient in AC_exact[]
 #pragma unroll
   for (int i = 0; i < OTW; i++) E += i < wv ? sh.tot[i] : 0u;
-  if (last_wg && wv == 0) one_handoff_compress<T, MODE>(a, pre + wg_tot, 0u, osf.sf, one_sf(a.sft, rs & 0xFFFFu, (rs >> 16) != 0u).fast, sh.q0);
+  // (the hand-off certifies the call: a workgroup whose sweep gave up -- it leaves its tiles unwritten -- has said so in the
+  // control block before the granule it missed can have reached this one)
+  if (last_wg && wv == 0) one_handoff_compress<T, MODE>(a, pre + wg_tot, __hip_atomic_load(&p.ctl->error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), osf.sf,
+                                                         one_sf(a.sft, rs & 0xFFFFu, (rs >> 16) != 0u).fast, sh.q0);
   if (tile_wave) {
     if (MODE == DCTZHIP_QT) {
       // the table is final: clamp (:450-461), normalise this tile's coefficients (:488-518) on their way into the image
@@ -832,11 +836,11 @@ __device__ __forceinline__ void decompress_one_body(const OneInv<T>& a, const un
   for (int i = 0; i < OTW; i++) wg_tot += sh_tot[i];
   if (wv == 0) {
     // the running pos of dctz-decomp-lib.c:402-412 at this workgroup: the counts of the workgroups in front of it
-    if (lane == 0) st_agent(a.b.gb + wg, granule(epoch, wg_tot));
+    if (lane == 0 && !(a.withhold && wg == 0u)) st_agent(a.b.gb + wg, granule(epoch, wg_tot));   // (withhold: tests, as in k_compress_one)
     unsigned before = 0;
     const bool ok = sweep_granules(a.b.gb, wg, epoch, [&](unsigned v, unsigned) { before += v; });
     before = wave_sum_u32(before);
-    if (lane == 0) sh_prefix = ok ? before : ONE_GAVE_UP;
+    if (lane == 0) sh_prefix = (ok && !(a.withhold && wg == 0u)) ? before : ONE_GAVE_UP;
   }
   one_stamp(a.b, 3);
   __syncthreads();
@@ -851,7 +855,10 @@ __device__ __forceinline__ void decompress_one_body(const OneInv<T>& a, const un
 #pragma unroll
   for (int i = 0; i < OTW; i++) S += i < wv ? sh_tot[i] : 0u;
   // does the stream promise more exact coefficients than the caller provides?  The one thing the host waits for.
-  if (last_wg && wv == 0) one_handoff_decompress<T>(a, pre + wg_tot, pre + wg_tot > p.ac_count ? 2u : 0u);
+  if (last_wg && wv == 0) {
+    const unsigned err = __hip_atomic_load(&p.ctl->error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (a workgroup that gave up: see k_compress_one)
+    one_handoff_decompress<T>(a, pre + wg_tot, err == ONE_ERR_TIMEOUT ? err : (pre + wg_tot > p.ac_count ? 2u : 0u));
+  }
   if (tile_wave) {
     const __amdgpu_buffer_rsrc_t r_out = __builtin_amdgcn_make_buffer_rsrc(p.out + first_el, 0, range_el * (int)sizeof(T), 0x00020000);
     TileMap<T, 1> tm;
@@ -997,7 +1004,7 @@ __global__ __launch_bounds__(OTW * 64) __attribute__((amdgpu_waves_per_eu(one_wa
   p.nfull = r.nfull; p.ntiles = r.ntiles; p.ac_count = r.ac_count;
   p.sf = (T)r.sf; p.bin_width = (T)r.bin_width; p.range_min = (T)r.range_min; p.range_max = (T)r.range_max; p.eb = r.eb;
   a.b.ga = nullptr; a.b.gb = cm.b.gb + r.board_base; a.b.rec = nullptr; a.b.epoch = cm.b.epoch; a.b.nwg = r.nwg; a.b.dbg = cm.b.dbg;
-  a.box = nullptr; a.seq = 0; a.rem = r.rem; a.tag = cm.tag;
+  a.box = nullptr; a.seq = 0; a.rem = r.rem; a.tag = cm.tag; a.withhold = cm.pad;
   a.bres = cm.res + r.item;
   decompress_one_body<T, MODE>(a, r.wg_local, (const T*)r.qtab);
 }

@@ -166,6 +166,7 @@ struct dctzhip_ctx {
   int one_cooldown = 0;             // calls left on the chain after a launch whose workgroups were not all resident
   int one_occ[2][2][2][2] = {};     // resident workgroups per CU [f64][decode][qt][scaled], 0 = not asked yet
   unsigned long long one_calls = 0, one_fallbacks = 0;
+  int one_withhold = 0;             // (tests: dctzhip_debug_knob) workgroup 0 of a one-launch kernel withholds its granule
   Ctl* one_bctl = nullptr;          // batches through the one-launch kernels: two halves of one_bctl_cap control blocks (this call's, the next call's)
   size_t one_bctl_cap = 0;
   unsigned one_bslot = 0, one_bdirty[2] = {0, 0};   // half of the next call; leading entries of a half that may be non-zero
@@ -357,6 +358,32 @@ extern "C" int dctzhip_set_speculation(dctzhip_ctx* c, int on, size_t min_elemen
   c->speculate = on != 0;
   c->spec_cooldown = 0;
   if (min_elements) c->spec_min = min_elements;
+  return DCTZHIP_OK;
+}
+// (tests and tools) counters of the context, and knobs that make a rare path run on purpose
+extern "C" int dctzhip_debug_counter(dctzhip_ctx* c, int which, unsigned long long* value) {
+  if (!c || !value) return DCTZHIP_E_ARG;
+  switch (which) {
+    case 0: *value = c->one_calls; break;
+    case 1: *value = c->one_fallbacks; break;
+    case 2: *value = (unsigned long long)c->one_cooldown; break;
+    case 3: *value = c->eo_calls; break;
+    case 4: *value = c->eo_direct_calls; break;
+    case 5: *value = c->eo_lb_fallbacks; break;
+    case 6: *value = c->spec_hits; break;
+    case 7: *value = c->spec_misses; break;
+    default: return fail(c, DCTZHIP_E_ARG, "dctzhip_debug_counter: no counter %d", which);
+  }
+  return DCTZHIP_OK;
+}
+extern "C" int dctzhip_debug_knob(dctzhip_ctx* c, int key, int value) {
+  if (!c) return DCTZHIP_E_ARG;
+  switch (key) {
+    case 0: c->one_withhold = value != 0; break;     // workgroup 0 of the one-launch kernels withholds its granule: a launch that gives up
+    case 1: c->eo_lb_fail = value != 0; break;       // one tile's look-back of k_compress_eo reports that it gave up
+    case 2: c->one_cooldown = value; break;
+    default: return fail(c, DCTZHIP_E_ARG, "dctzhip_debug_knob: no knob %d", key);
+  }
   return DCTZHIP_OK;
 }
 extern "C" int dctzhip_set_split(dctzhip_ctx* c, int on) {
@@ -1035,6 +1062,10 @@ static int compress_one(dctzhip_ctx* c, const T* d_in, size_t n, double eb, int 
   const unsigned ntiles = (nfull + TILE_BLKS - 1) / TILE_BLKS;
   const unsigned nwg = (ntiles + ONE_TW - 1) / ONE_TW + (rem ? 1u : 0u);
   if (nwg > (unsigned)ONE_BOARD || nwg > one_capacity<T>(c, false, mode, d_scaled != nullptr)) return ONE_DECLINED;
+  // In place (the scaled copy over the input: what the reference does to its caller's array) the chain of kernels takes the
+  // call: k_compress_one stores x / sf over a tile BEFORE the sweeps that can still give up, and a launch that gives up with
+  // half of the caller's array divided cannot be run again (the chain scales in place on verified statistics only)
+  if (d_scaled && (const void*)d_scaled == (const void*)d_in) return ONE_DECLINED;
   if (c->one_cooldown > 0) { c->one_cooldown--; return ONE_DECLINED; }
   hipStream_t s = c->stream;
   if (rem) { int rc = upload_rtab<T>(c, rem); if (rc) return rc; }
@@ -1066,7 +1097,7 @@ static int compress_one(dctzhip_ctx* c, const T* d_in, size_t n, double eb, int 
   const unsigned long long seq = ++c->seq;
   a.seq = seq;
   a.qt = c->one_qt + slot * ONE_QT_WORDS; a.qt_next = c->one_qt + (slot ^ 1u) * ONE_QT_WORDS; a.qt_stride = ONE_QT_STRIDE; a.qt_shards = ONE_QT_SHARDS;
-  a.eb = eb; a.rem = (unsigned)rem; a.bad_guess = (unsigned)c->one_bad_guess;
+  a.eb = eb; a.rem = (unsigned)rem; a.bad_guess = (unsigned)c->one_bad_guess | (c->one_withhold ? 16u : 0u);
   if (c->profiling) { HIPCHK(c, hipEventRecord(c->ev[0], s)); HIPCHK(c, hipEventRecord(c->ev[1], s)); HIPCHK(c, hipEventRecord(c->ev[2], s)); }
   launch_compress_one<T>(a, mode, d_scaled != nullptr, s);
   if (c->profiling) { HIPCHK(c, hipEventRecord(c->ev[3], s)); HIPCHK(c, hipEventRecord(c->ev[4], s)); }
@@ -1076,9 +1107,7 @@ static int compress_one(dctzhip_ctx* c, const T* d_in, size_t n, double eb, int 
   int rc = wait_seq(c, &hb->seq_done, seq, "compress (one launch)");
   if (rc) { (void)one_gave_up(c); return rc; }
   if (hb->error == ONE_ERR_TIMEOUT) {
-    // (nothing the caller owns is lost unless the scaled copy went over the input)
-    if (d_scaled && (const void*)d_scaled == (const void*)d_in)
-      return fail(c, DCTZHIP_E_INTERNAL, "one-launch compress gave up after its in-place scaling had begun (workgroups not all resident)");
+    // (nothing the caller owns is lost: a call whose scaled copy goes over its input never comes here)
     rc = one_gave_up(c);
     return rc ? rc : ONE_DECLINED;
   }
@@ -1131,6 +1160,7 @@ static int decompress_one(dctzhip_ctx* c, const uint8_t* d_bin, const float* d_d
   const unsigned long long seq = ++c->seq;
   a.seq = seq;
   a.rem = (unsigned)rem;
+  a.withhold = c->one_withhold ? 1u : 0u;
   if (c->profiling) { HIPCHK(c, hipEventRecord(c->ev[0], s)); HIPCHK(c, hipEventRecord(c->ev[1], s)); HIPCHK(c, hipEventRecord(c->ev[2], s)); }
   launch_decompress_one<T>(a, mode, s);
   if (c->profiling) { HIPCHK(c, hipEventRecord(c->ev[3], s)); HIPCHK(c, hipEventRecord(c->ev[4], s)); }
@@ -2270,6 +2300,8 @@ static int batch_one_compress(dctzhip_ctx* c, int k, const dctzhip_batch_citem* 
     if (c->sf_nk[dt] <= 0 || c->sf_nk[dt] > 64 * (dt == DCTZHIP_F64 ? 10 : 2)) continue;
     for (int i = 0; i < k; i++) {
       if (items[i].dtype != dt || items[i].n >= BATCH_BIG) continue;
+      // (an array whose scaled copy goes over its input takes the chain: compress_one says why)
+      if (items[i].d_scaled && items[i].d_scaled == items[i].d_in) continue;
       q.idx.push_back(i); q.nwg.push_back(one_wgs_of(items[i].n)); q.grid += q.nwg.back();
       q.scaled = q.scaled || items[i].d_scaled != nullptr;
     }
@@ -2320,10 +2352,10 @@ static int batch_one_compress(dctzhip_ctx* c, int k, const dctzhip_batch_citem* 
     unsigned long long* qt = c->one_bqt + (size_t)h * c->one_bctl_cap * 64;
     unsigned long long* qt_next = c->one_bqt + (size_t)(h ^ 1u) * c->one_bctl_cap * 64;
     if (dt == DCTZHIP_F64) {
-      OneBatchC<double> cm = {recs_d, c->tab_f64, ctl, qt, qt_next, b, sft, res_d, resq_d, tag, (unsigned)c->one_bad_guess};
+      OneBatchC<double> cm = {recs_d, c->tab_f64, ctl, qt, qt_next, b, sft, res_d, resq_d, tag, (unsigned)c->one_bad_guess | (c->one_withhold ? 16u : 0u)};
       launch_compress_one_batch<double>(cm, q.grid, mode, q.scaled, s);
     } else {
-      OneBatchC<float> cm = {recs_d, c->tab_f32, ctl, qt, qt_next, b, sft, res_d, resq_d, tag, (unsigned)c->one_bad_guess};
+      OneBatchC<float> cm = {recs_d, c->tab_f32, ctl, qt, qt_next, b, sft, res_d, resq_d, tag, (unsigned)c->one_bad_guess | (c->one_withhold ? 16u : 0u)};
       launch_compress_one_batch<float>(cm, q.grid, mode, q.scaled, s);
     }
     if (prof) { HIPCHK(c, hipEventRecord(ev[2], s)); HIPCHK(c, hipEventRecord(ev[3], s)); HIPCHK(c, hipEventRecord(ev[4], s)); }
@@ -2347,12 +2379,8 @@ static int batch_one_compress(dctzhip_ctx* c, int k, const dctzhip_batch_citem* 
     for (size_t j = 0; j < q.idx.size(); j++) {
       const int i = q.idx[j];
       const BatchResC& r = res[q.item_off + j];
-      const bool in_place = items[i].d_scaled && items[i].d_scaled == items[i].d_in;
-      if (r.error == ONE_ERR_TIMEOUT) {
-        gave_up = true;
-        if (in_place) return fail(c, DCTZHIP_E_INTERNAL, "array %d: one-launch batch gave up after its in-place scaling had begun", i);
-        continue;
-      }
+      const bool in_place = false;                   // (such arrays are not in this launch)
+      if (r.error == ONE_ERR_TIMEOUT) { gave_up = true; continue; }
       if (r.error) return fail(c, DCTZHIP_E_INTERNAL, "array %d: in-kernel error flag set (code %u)", i, r.error);
       const double true_sf = scaling_factor(dt, r.stats[0]);
       const bool same = dt == DCTZHIP_F64 ? true_sf == r.sf_used : (float)true_sf == (float)r.sf_used;
@@ -2452,10 +2480,10 @@ static int batch_one_decompress(dctzhip_ctx* c, int k, const dctzhip_batch_ditem
     const OneRecD* recs_d = reinterpret_cast<const OneRecD*>(c->b_blob_hdev) + q.rec_off;
     // (decode only ever sets `error` in its control block: any of this context's blocks will do)
     if (dt == DCTZHIP_F64) {
-      OneBatchD<double> cm = {recs_d, c->tab_f64, c->one_bctl, b, reinterpret_cast<BatchResD*>(c->b_res_hdev), tag, 0u};
+      OneBatchD<double> cm = {recs_d, c->tab_f64, c->one_bctl, b, reinterpret_cast<BatchResD*>(c->b_res_hdev), tag, c->one_withhold ? 1u : 0u};
       launch_decompress_one_batch<double>(cm, q.grid, mode, s);
     } else {
-      OneBatchD<float> cm = {recs_d, c->tab_f32, c->one_bctl, b, reinterpret_cast<BatchResD*>(c->b_res_hdev), tag, 0u};
+      OneBatchD<float> cm = {recs_d, c->tab_f32, c->one_bctl, b, reinterpret_cast<BatchResD*>(c->b_res_hdev), tag, c->one_withhold ? 1u : 0u};
       launch_decompress_one_batch<float>(cm, q.grid, mode, s);
     }
     if (prof) { HIPCHK(c, hipEventRecord(ev[2], s)); HIPCHK(c, hipEventRecord(ev[3], s)); HIPCHK(c, hipEventRecord(ev[4], s)); }

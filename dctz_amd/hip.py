@@ -69,6 +69,8 @@ _PROTOS = {
     "dctzhip_set_speculation": (C.c_int, [C.c_void_p, C.c_int, C.c_size_t]),
     "dctzhip_set_one_launch": (C.c_int, [C.c_void_p, C.c_int]),
     "dctzhip_set_split": (C.c_int, [C.c_void_p, C.c_int]),
+    "dctzhip_debug_counter": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_ulonglong)]),
+    "dctzhip_debug_knob": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
     "dctzhip_malloc": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.c_size_t]),
     "dctzhip_free": (C.c_int, [C.c_void_p, C.c_void_p]),
     "dctzhip_memcpy_h2d": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
@@ -213,6 +215,15 @@ class Context:
     def set_split(self, on=True):
         """k_compress_eo (a block over two lanes) for flat fp64 arrays on the chain of kernels (include/dctz_hip.h)."""
         self._check(self.lib.dctzhip_set_split(self.h, int(on)), "set_split")
+
+    def counter(self, which):
+        """dctzhip_debug_counter (include/dctz_hip.h): 0 one-launch calls, 1 launches that gave up, 2 cooldown, 3 split calls, ..."""
+        v = C.c_ulonglong(0)
+        self._check(self.lib.dctzhip_debug_counter(self.h, int(which), C.byref(v)), "debug_counter")
+        return int(v.value)
+
+    def knob(self, key, value):
+        self._check(self.lib.dctzhip_debug_knob(self.h, int(key), int(value)), "debug_knob")
 
     def set_blocking(self, on=True):
         """Calls return only when their outputs are complete for any observer (default: complete in stream order)."""

@@ -128,6 +128,13 @@ int dctzhip_set_one_launch(dctzhip_ctx *ctx, int on);
  * gives up and the pass is run again through the lists (DCTZHIP_INFO_LB_FALLBACK).  Env DCTZHIP_EO=0/1 and
  * DCTZHIP_EO_DIRECT=0/1 set the defaults (off, off). */
 int dctzhip_set_split(dctzhip_ctx *ctx, int on);
+/* (tests and tools)  Counters of the context -- which: 0 one-launch calls, 1 one-launch launches that gave up (run again
+ * through the chain), 2 calls left on the chain after such a launch, 3 calls through k_compress_eo, 4 of them with
+ * single-pass placement, 5 look-backs that gave up, 6 / 7 verified / wrong guesses of the scaling factor -- and knobs that
+ * make a rare path run on purpose -- key 0: workgroup 0 of the one-launch kernels withholds its granule (the launch gives
+ * up after 20 ms, the call is run through the chain), 1: one look-back of k_compress_eo gives up, 2: sets counter 2. */
+int dctzhip_debug_counter(dctzhip_ctx *ctx, int which, unsigned long long *value);
+int dctzhip_debug_knob(dctzhip_ctx *ctx, int key, int value);
 /* on != 0: every compress / decompress call ends with a synchronisation of the context's stream, i.e. its outputs are
  * complete for ANY observer when it returns (default off: complete in stream order, see the two calls below; env
  * DCTZHIP_BLOCKING=1 does the same).  For callers that read the buffers from another stream or from the host without

@@ -354,7 +354,9 @@ def test_in_place_scaling_every_layout(ctx, one, dtype, mode, n, sf_one):
         out, info = ctx.compress(xd, 1e-3, mode, scaled=xd)
     finally:
         ctx.set_one_launch(True)
-    assert bool(info.flags & H.INFO_ONE_LAUNCH) == one
+    # (round 5, ADVICE r4: a call whose scaled copy goes over its input always takes the chain of kernels -- the one-launch
+    # kernel stores x / sf before the sweeps that can still give up, and a half-divided input cannot be run again)
+    assert not (info.flags & H.INFO_ONE_LAUNCH)
     assert info.sf == c.sf and info.cnt == c.cnt
     assert _same(xd.cpu().numpy(), c.scaled)
     assert np.array_equal(out["bin_index"].cpu().numpy(), c.bin_index)
