@@ -388,7 +388,10 @@ def run_rank(a, rank, local_rank, world):
     barrier()
     local_elapsed = time.perf_counter() - t0
     elapsed = shard.max_over_ranks(local_elapsed, red_dev)
-    ms_per_step = elapsed * 1e3 / a.steps
+    settled_ms = elapsed * 1e3 / a.steps
+    # The line's `value` / `ms_per_step` is the form EXACTLY AS ASKED (W warm-up steps of a fresh process, K timed steps:
+    # ADVICE r4); the figure behind the settling is the secondary one (`settled_ms_per_step` / `settled_value`).
+    ms_per_step = unsettled_ms
     info = infos[0]
 
     # ---- the step with the reference's in-place scaling made visible: dctz_compress divides the CALLER's array by sf
@@ -544,7 +547,11 @@ def run_rank(a, rank, local_rank, world):
     # the committed record of the same command on the same build is quoted with its source, or null
     src_hash = kernel_source_hash()
     tkey = f"{a.config}_{a.dtype}_{a.n}_{a.mode}_{a.eb:g}"
-    traffic, traffic_source = lookup_traffic(os.path.join(ROOT, "profiles", "pmc_traffic.json"), kern_name[dominant], tkey, src_hash)
+    # (the record is keyed by the kernel's full name -- every template argument: variants of one kernel differ in traffic)
+    kern_exact = {"c": ctx.last_kernel(0) or kern_name["c"], "d": ctx.last_kernel(1) or kern_name["d"]}
+    if many:
+        kern_exact = {"c": ctx.last_kernel(2 if dom_seq == "f64" else 3) or kern_name["c"], "d": ctx.last_kernel(4 if dom_seq == "f64" else 5) or kern_name["d"]}
+    traffic, traffic_source = lookup_traffic(os.path.join(ROOT, "profiles", "pmc_traffic.json"), kern_exact[dominant], tkey, src_hash)
 
     # ---- the entropy stage on the device, rank 0, outside the timed region: what
     # it costs to turn the streams of the last compress call into the container's three zlib sections in HBM ----
@@ -641,11 +648,13 @@ def run_rank(a, rank, local_rank, world):
                       else f"compress+decompress GB/s (input bytes), config {a.config}: {a.dtype if not many else 'fp64+fp32 list'} "
                            f"{a.mode.upper()}" + ("" if many else f" eb={a.eb:g}"),
             "value": value, "unit": "GB/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
-            "settle": {"ms": a.settle_ms, "steps": settle_steps, "note": "untimed, in front of the warm-up steps: first-call allocations and the "
-                       "power management's dip under fresh load (steps 4-12 of a process run 12 % slow, tools/warm_probe.py)"},
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            # the same K steps timed FIRST in this run, behind nothing but the W warm-up steps of a fresh process: what a
-            # caller who makes W + K calls sees (value = the settled figure, both are of this build and this box)
+            # value / ms_per_step: the K steps behind nothing but the W warm-up steps of a fresh process, what a caller who makes
+            # W + K calls sees.  settled_*: the same K steps timed a second time in this run, behind `settle` (untimed steps) and
+            # another W warm-up steps -- the steady state; both are of this build and this box.
+            "settled_ms_per_step": settled_ms, "settled_value": in_bytes * world / (settled_ms * 1e-3) / 1e9,
+            "settle": {"ms": a.settle_ms, "steps": settle_steps, "note": "untimed steps between the as-asked window and the settled one: the "
+                       "power management's dip under fresh load (steps 4-12 of a process run 12 % slow, tools/warm_probe.py)"},
             "unsettled_ms_per_step": unsettled_ms, "unsettled_value": in_bytes * world / (unsettled_ms * 1e-3) / 1e9,
             "kernel_source_hash": src_hash,
             "dtype": a.dtype if not many else "f64+f32", "data": "synthetic",
@@ -654,8 +663,9 @@ def run_rank(a, rank, local_rank, world):
                        "exception_fraction": p, "parallelism": f"shard-per-gpu x{world}"},
             "ranks_seen": len({d["rank"] for d in devices}), "devices": devices, "per_rank": per_rank,
             "pct_hbm_peak_input": 100.0 * (in_bytes / (ms_per_step * 1e-3) / 1e9) / HBM_PEAK_GBPS,
-            "roofline": {"bound": "hbm", "kernel": kern_name[dominant] + " (the longer of the two big kernels in THIS run"
-                                                   + (f", launch sequence of the {dom_seq} arrays: they carry most of the list's bytes)" if many else ")"),
+            # kernel: the name rocprofv3 lists the timed kernel under (what the context says it launched last); which: how it was chosen
+            "roofline": {"bound": "hbm", "kernel": kern_exact[dominant],
+                         "which": "the longer of the two big kernels in THIS run" + (f", launch sequence of the {dom_seq} arrays: they carry most of the list's bytes" if many else ""),
                          "achieved": dom[1], "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": dom[1] / HBM_PEAK_GBPS,
                          "traffic": traffic, "traffic_source": traffic_source,
                          "algorithmic_bytes_per_launch": bytes_main, "avg_launch_ms": dom[0],

@@ -795,18 +795,21 @@ __device__ __forceinline__ void decompress_one_body(const OneInv<T>& a, const un
   if (MODE == DCTZHIP_QT && threadIdx.x < 64) qt[threadIdx.x] = qtab_src[threadIdx.x];
   // ---- the flags of the tile (dctz-decomp-lib.c:400 / :446) -------------------------------------------------------------
   one_stamp(a.b, 0);
-  u32x4 bw[4] = {u32x4{0u, 0u, 0u, 0u}, u32x4{0u, 0u, 0u, 0u}, u32x4{0u, 0u, 0u, 0u}, u32x4{0u, 0u, 0u, 0u}};
+  // (four named registers, not an array of vectors: as an array the bin ids -- and the copy below -- stayed in scratch memory
+  // in the fp32 EC kernel, 144 bytes per lane stored and read back per tile)
+  u32x4 bw0 = u32x4{0u, 0u, 0u, 0u}, bw1 = bw0, bw2 = bw0, bw3 = bw0;
   float dc_t = 0.f;
   unsigned tot = 0, ptr = 0;
   unsigned rbin = 0, rrank = 0;
   bool rexc = false;
   if (tile_wave) {
     const __amdgpu_buffer_rsrc_t r_bin = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(p.bin + first_el), 0, range_el, 0x00020000);
-#pragma unroll
-    for (int i = 0; i < 4; i++) bw[i] = __builtin_amdgcn_raw_buffer_load_b128(r_bin, lane * 64 + i * 16, 0, 0);
+    bw0 = __builtin_amdgcn_raw_buffer_load_b128(r_bin, lane * 64, 0, 0);
+    bw1 = __builtin_amdgcn_raw_buffer_load_b128(r_bin, lane * 64 + 16, 0, 0);
+    bw2 = __builtin_amdgcn_raw_buffer_load_b128(r_bin, lane * 64 + 32, 0, 0);
+    bw3 = __builtin_amdgcn_raw_buffer_load_b128(r_bin, lane * 64 + 48, 0, 0);
     dc_t = active ? p.dc[(size_t)tile * TILE_BLKS + lane] : 0.f;
-    const unsigned w[16] = {bw[0].x, bw[0].y, bw[0].z, bw[0].w, bw[1].x, bw[1].y, bw[1].z, bw[1].w,
-                            bw[2].x, bw[2].y, bw[2].z, bw[2].w, bw[3].x, bw[3].y, bw[3].z, bw[3].w};
+    const unsigned w[16] = {bw0.x, bw0.y, bw0.z, bw0.w, bw1.x, bw1.y, bw1.z, bw1.w, bw2.x, bw2.y, bw2.z, bw2.w, bw3.x, bw3.y, bw3.z, bw3.w};
     unsigned n = 0;
 #pragma unroll
     for (int i = 0; i < 16; i++) {
@@ -872,8 +875,7 @@ __device__ __forceinline__ void decompress_one_body(const OneInv<T>& a, const un
     }
     const float* const stage = reinterpret_cast<const float*>(io);
     constexpr unsigned stage_last = (unsigned)(G::TILEB / 4) - 1u;
-    const unsigned w[16] = {bw[0].x, bw[0].y, bw[0].z, bw[0].w, bw[1].x, bw[1].y, bw[1].z, bw[1].w,
-                            bw[2].x, bw[2].y, bw[2].z, bw[2].w, bw[3].x, bw[3].y, bw[3].z, bw[3].w};
+    const unsigned w[16] = {bw0.x, bw0.y, bw0.z, bw0.w, bw1.x, bw1.y, bw1.z, bw1.w, bw2.x, bw2.y, bw2.z, bw2.w, bw3.x, bw3.y, bw3.z, bw3.w};
     T x[64];
     if constexpr (sizeof(T) == 8) {
       // four coefficients = one dword of bin ids at a time (dctz_kernels.hip: decompress_body)
@@ -910,18 +912,31 @@ __device__ __forceinline__ void decompress_one_body(const OneInv<T>& a, const un
         }
       }
     } else {
-      x[0] = (T)dc_t;                                                  // :392 / :438
+      // position by position (two workgroups per CU hide the round trips; the grouped form measured slower for fp32), written
+      // as sixteen dwords of four: as ONE loop of 63 trips the compiler leaves it partly rolled, and the bin ids and the
+      // block then live in scratch memory -- 144 bytes per lane, stored and read back per tile: 15 MB of the 41 MB that
+      // k_decompress_one<float> wrote for a 26 MB array (profiles/r05_c2_raw_traffic.txt)
 #pragma unroll
-      for (int j = 1; j < 64; j++) {
-        const unsigned b = (w[j >> 2] >> (8 * (j & 3))) & 255u;
-        T v = bctab[b];                                                // :416 / :462
-        if (b == 255u) {                                               // :400 / :446
-          const float e = stage[min(ptr, stage_last)];
-          ptr++;
-          v = (T)e;
-          if (MODE == DCTZHIP_QT) v = qt_restore(v, qt[j], p.eb, T(10), p.range_min, p.range_max);
+      for (int g = 0; g < 16; g++) {
+        const unsigned wgd = w[g];
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+          const int j = 4 * g + i;
+          if (j == 0) { x[0] = (T)dc_t; continue; }                    // :392 / :438
+          const unsigned b = (wgd >> (8 * i)) & 255u;
+          T v = bctab[b];                                              // :416 / :462
+          if (b == 255u) {                                             // :400 / :446
+            const float e = stage[min(ptr, stage_last)];
+            ptr++;
+            v = (T)e;
+            if (MODE == DCTZHIP_QT) v = qt_restore(v, qt[j], p.eb, T(10), p.range_min, p.range_max);
+          }
+          // (each value through a register of its own: paired into <2 x float> stores by the vectoriser, the first 33
+          // elements of the block stayed an array in scratch memory -- 144 bytes per lane, stored and read back per tile:
+          // 15 MB of the 41 MB that k_decompress_one<float> wrote for a 26 MB array, profiles/r05_c2_raw_traffic.txt)
+          asm volatile("" : "+v"(v));
+          x[j] = v;
         }
-        x[j] = v;
       }
     }
     one_stamp(a.b, 5);

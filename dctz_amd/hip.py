@@ -71,6 +71,7 @@ _PROTOS = {
     "dctzhip_set_split": (C.c_int, [C.c_void_p, C.c_int]),
     "dctzhip_debug_counter": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_ulonglong)]),
     "dctzhip_debug_knob": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
+    "dctzhip_debug_last_kernel": (C.c_int, [C.c_void_p, C.c_int, C.c_char_p, C.c_size_t]),
     "dctzhip_malloc": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.c_size_t]),
     "dctzhip_free": (C.c_int, [C.c_void_p, C.c_void_p]),
     "dctzhip_memcpy_h2d": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
@@ -221,6 +222,12 @@ class Context:
         v = C.c_ulonglong(0)
         self._check(self.lib.dctzhip_debug_counter(self.h, int(which), C.byref(v)), "debug_counter")
         return int(v.value)
+
+    def last_kernel(self, which):
+        """The name rocprofv3 lists the big kernel of the last call under (0 compress, 1 decompress, 2-5 batches)."""
+        buf = C.create_string_buffer(128)
+        self._check(self.lib.dctzhip_debug_last_kernel(self.h, int(which), buf, 128), "debug_last_kernel")
+        return buf.value.decode()
 
     def knob(self, key, value):
         self._check(self.lib.dctzhip_debug_knob(self.h, int(key), int(value)), "debug_knob")

@@ -135,6 +135,9 @@ int dctzhip_set_split(dctzhip_ctx *ctx, int on);
  * up after 20 ms, the call is run through the chain), 1: one look-back of k_compress_eo gives up, 2: sets counter 2. */
 int dctzhip_debug_counter(dctzhip_ctx *ctx, int which, unsigned long long *value);
 int dctzhip_debug_knob(dctzhip_ctx *ctx, int key, int value);
+/* (tools) the name rocprofv3 lists the big kernel of the last call under, every template argument: which = 0 compress,
+ * 1 decompress, 2 / 3 batch compress of the fp64 / fp32 arrays, 4 / 5 batch decompress ("" if none ran yet) */
+int dctzhip_debug_last_kernel(dctzhip_ctx *ctx, int which, char *buf, size_t cap);
 /* on != 0: every compress / decompress call ends with a synchronisation of the context's stream, i.e. its outputs are
  * complete for ANY observer when it returns (default off: complete in stream order, see the two calls below; env
  * DCTZHIP_BLOCKING=1 does the same).  For callers that read the buffers from another stream or from the host without
