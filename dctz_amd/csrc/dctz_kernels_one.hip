@@ -627,8 +627,14 @@ __device__ __forceinline__ void compress_one_body(const OneFwd<T>& a, const unsi
       }
     }
   };
+  // (the lane's number through a register the compiler cannot see through, for everything behind the transform: the
+  // per-lane addresses made of it were kept alive across the transform otherwise -- in the fp32 EC kernel, at its 256
+  // registers, in scratch memory: 22 spilled registers stored in front of the transform and read back behind it)
+  const int lane_out = lane;
+  auto lane_again = [&]() { int l = lane_out; asm volatile("" : "+v"(l)); return l; };
   if (tile_wave) {
     // bin ids: 64 bytes per lane -> (the image) -> 1 KiB rows of 16 consecutive blocks; DC (:350-351 USE_TRUNCATE)
+    const int lane = lane_again();
     const int f2 = (lane >> 1) & 3;
 #pragma unroll
     for (int i = 0; i < 4; i++)
@@ -684,6 +690,7 @@ __device__ __forceinline__ void compress_one_body(const OneFwd<T>& a, const unsi
   if (last_wg && wv == 0) one_handoff_compress<T, MODE>(a, pre + wg_tot, __hip_atomic_load(&p.ctl->error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), osf.sf,
                                                          one_sf(a.sft, rs & 0xFFFFu, (rs >> 16) != 0u).fast, sh.q0);
   if (tile_wave) {
+    const int lane = lane_again();
     if (MODE == DCTZHIP_QT) {
       // the table is final: clamp (:450-461), normalise this tile's coefficients (:488-518) on their way into the image
       T qv = Traits<T>::from_bits((Bits)one_qt_read(a, (unsigned)lane));
