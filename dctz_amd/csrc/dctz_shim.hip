@@ -495,7 +495,7 @@ struct D2hPipe {
   std::atomic<size_t> upto{0};
   std::atomic<int> nev{0};
   struct Mark { size_t upto; hipEvent_t ev; };
-  Mark marks[256];
+  Mark marks[DCTZHIP_D2H_PIPE_MAX_MARKS];
   std::atomic<int> failed{0};
   std::atomic<int> stop{0};
   bool active = false;
@@ -545,7 +545,7 @@ extern "C" int dctzhip_d2h_pipe_begin(dctzhip_ctx* c, void* dst, const void* src
 extern "C" int dctzhip_d2h_pipe_advance(dctzhip_ctx* c, size_t upto) {
   if (!c || !g_pipe.active) return DCTZHIP_E_ARG;
   const int n = g_pipe.nev.load();
-  if (n >= 256) return fail(c, DCTZHIP_E_ARG, "too many marks in one D2H pipe");
+  if (n >= DCTZHIP_D2H_PIPE_MAX_MARKS) return fail(c, DCTZHIP_E_ARG, "too many marks in one D2H pipe");
   hipEvent_t ev;
   HIPCHK(c, hipEventCreateWithFlags(&ev, hipEventDisableTiming));
   HIPCHK(c, hipEventRecord(ev, c->stream));
@@ -597,7 +597,7 @@ extern "C" int dctzhip_h2d_pipe_begin(dctzhip_ctx* c, void* d_dst, const void* s
   if (g_h2d.st && g_h2d.device != c->device) { (void)hipStreamDestroy(g_h2d.st); g_h2d.st = nullptr; }
   if (!g_h2d.st) { HIPCHK(c, hipStreamCreateWithFlags(&g_h2d.st, hipStreamNonBlocking)); g_h2d.device = c->device; }
   const size_t ngroups = (bytes + group_bytes - 1) / group_bytes;
-  if (ngroups > 4096) return fail(c, DCTZHIP_E_ARG, "too many groups in one H2D pipe");
+  if (ngroups > DCTZHIP_H2D_PIPE_MAX_GROUPS) return fail(c, DCTZHIP_E_ARG, "too many groups in one H2D pipe");
   g_h2d.ev.resize(ngroups);
   for (size_t i = 0; i < ngroups; i++) HIPCHK(c, hipEventCreateWithFlags(&g_h2d.ev[i], hipEventDisableTiming));
   g_h2d.issued = 0; g_h2d.failed = 0; g_h2d.stop = 0; g_h2d.waited = 0;
@@ -676,6 +676,7 @@ extern "C" int dctzhip_memcpy_d2h(dctzhip_ctx* c, void* dst, const void* src, si
 extern "C" int dctzhip_memcpy_d2h_side(dctzhip_ctx* c, void* dst, const void* src, size_t bytes) {
   if (!c || (bytes && (!dst || !src))) return DCTZHIP_E_ARG;
   if (!bytes) return DCTZHIP_OK;
+  if (hipSetDevice(c->device) != hipSuccess) return DCTZHIP_E_HIP;     // (called from a thread of its own: libdctz's drainer)
   if (hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, c->side_stream) != hipSuccess) return DCTZHIP_E_HIP;
   if (hipStreamSynchronize(c->side_stream) != hipSuccess) return DCTZHIP_E_HIP;
   return DCTZHIP_OK;

@@ -730,6 +730,7 @@ static int compress_pipelined(dctzhip_ctx *c, t_var *var, void *host_in, size_t 
   if (gel % (16 * chunk) != 0 || n < 4 * gel) return 0;
   if (is_d ? isnan(((const double *)host_in)[0]) : isnan(((const float *)host_in)[0])) return 0;   /* util.c:18-19: max = NaN from the start */
   const size_t G = (n + gel - 1) / gel, nblk = CEIL(n, BLK_SZ);
+  if (G > DCTZHIP_H2D_PIPE_MAX_GROUPS) return 0;         /* (a small DCTZ_PIPE_GROUP on a large array: more groups than a pipe holds -> the serial path) */
   const int dbg = getenv("DCTZ_PIPE_DEBUG") != NULL;
   /* the first element of every group, as the caller gave it (the follower divides the array while the groups' sums come in) */
   double *firsts = (double *)malloc(G * sizeof(double));
@@ -1545,6 +1546,7 @@ static int decompress_pipelined(dctzhip_ctx *c, const struct header *h, const un
   const size_t gel = pipe_group();
   if (gel % (16 * chunk) != 0 || n < 2 * gel) return 0;
   const size_t G = (n + gel - 1) / gel;
+  if (G > DCTZHIP_D2H_PIPE_MAX_MARKS) return 0;           /* (more groups than the D2H pipe has marks -> the serial path) */
   const size_t raw[3] = {n, nblk * sizeof(float), cnt * sizeof(float)};
   size_t nch[3], total = 0;
   for (int i = 0; i < 3; i++) { nch[i] = (raw[i] + chunk - 1) / chunk; total += nch[i]; }
@@ -1603,7 +1605,12 @@ static int decompress_pipelined(dctzhip_ctx *c, const struct header *h, const un
         if (i == 0) flags += pc->n255;
       }
     if (!ok) break;
-    flags -= nb;                                           /* every block's first byte is the 255 of dctz-comp-lib.c:361, not a flag */
+    /* every block's first byte is the 255 of dctz-comp-lib.c:361, not a flag -- in a container this library or the reference
+     * wrote.  One whose block heads are something else (adler-valid all the same) would make the count wrap and the groups'
+     * places in AC_exact go backwards while the kernels, which never look at byte 0, rebuild something else than the serial
+     * path does: such a container takes the serial path. */
+    if (flags < nb) { ok = 0; break; }
+    flags -= nb;
     size_t S1 = S + flags;
     if (S1 > cnt) S1 = cnt;                                /* (a stream that flags more than it brings: the kernels report it) */
     for (size_t j = ac_up / chunk; j < (S1 * sizeof(float) + chunk - 1) / chunk && ok; j++) {

@@ -159,6 +159,10 @@ int dctzhip_memcpy_d2h_side(dctzhip_ctx *ctx, void *dst, const void *d_src, size
  * dst through pinned slots, piece by piece, each piece as soon as advance() has announced it -- "bytes [0, upto) are
  * complete in the order of the context's stream" (an event behind the kernels queued so far; no host synchronisation) --,
  * end() waits for the last piece (abandon != 0: stops after the pieces under way).  One pipe at a time per process. */
+/* capacities of the two pipes below: dctzhip_d2h_pipe_advance may be called this many times per pipe, a dctzhip_h2d_pipe_begin
+ * takes at most this many groups (a caller with more takes its unpipelined path instead) */
+#define DCTZHIP_D2H_PIPE_MAX_MARKS 256
+#define DCTZHIP_H2D_PIPE_MAX_GROUPS 4096
 int dctzhip_d2h_pipe_begin(dctzhip_ctx *ctx, void *dst, const void *d_src, size_t bytes);
 int dctzhip_d2h_pipe_advance(dctzhip_ctx *ctx, size_t upto);
 int dctzhip_d2h_pipe_end(dctzhip_ctx *ctx, int abandon);
