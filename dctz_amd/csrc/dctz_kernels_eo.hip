@@ -493,14 +493,19 @@ __device__ __forceinline__ void compress_eo_role(const FwdParams<double>& p, con
 #pragma unroll
       for (int g = 0; g < 8; g++) {
         if (__builtin_amdgcn_ballot_w64(((m >> (4 * g)) & 0xFu) != 0u)) {
+          // (the masks through registers the compiler cannot see through: the ranks are pure arithmetic, and left alone all 32
+          // of them are computed in front of the first group -- 130 instructions a tile whose flags sit in one or two groups
+          // never needs, and 32 registers held across the rounds)
+          unsigned mg = m, mpg = mp;
+          asm volatile("" : "+v"(mg), "+v"(mpg));
 #pragma unroll
           for (int k = 0; k < 4; k++) {
             constexpr unsigned ALL = 0xFFFFFFFFu;
             const int i = 4 * g + k;
             const unsigned own_below = i == 0 ? 0u : (ALL >> (32 - i));
             const unsigned oth_below = (i + ROLE) == 0 ? 0u : (ALL >> (32 - (i + ROLE)));
-            const bool f = ((m >> i) & 1u) != 0u;
-            const unsigned pos = b0 + (unsigned)__popc(m & own_below) + (unsigned)__popc(mp & oth_below);
+            const bool f = ((mg >> i) & 1u) != 0u;
+            const unsigned pos = b0 + (unsigned)__popc(mg & own_below) + (unsigned)__popc(mpg & oth_below);
             const unsigned at = (f && pos < CAP) ? pos : CAP + (unsigned)(ROLE * 64 + lane);
             lds_store_item(stage_at + at * (unsigned)sizeof(Item), (Item)c[i]);     // :496-497 / :535-537 USE_TRUNCATE (EC)
             if (MODE == DCTZHIP_QT) lds_store_b8(stage_at + (unsigned)ST::ITEM_BYTES + at, jv + 2u * (unsigned)i);
