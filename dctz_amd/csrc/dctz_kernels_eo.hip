@@ -487,17 +487,17 @@ __device__ __forceinline__ void compress_eo_role(const FwdParams<double>& p, con
     // position j = 2 i + ROLE of the block is item number popc(own & below(i)) + popc(other & below(i + ROLE)) of the block
     unsigned jv = (unsigned)ROLE;
     if (MODE == DCTZHIP_QT) asm volatile("" : "+v"(jv));
-    for (unsigned lo = 0; lo < tot; lo += CAP) {
-      if (lo != 0u) eo_barrier();                    // both waves have taken the rows of the round before out of the buffer
+    // (sparse tiles -- one round --: the masks go through registers the compiler cannot see through, inside each group's
+    // branch.  The ranks are pure arithmetic, and left alone all 32 of them are computed in front of the first group: 130
+    // instructions a tile whose flags sit in one or two groups never needs.  Dense tiles -- several rounds, every group
+    // entered --: left alone, so that the ranks are computed once for all rounds: 405 -> 384 us at p = 0.69.)
+    auto scatter = [&](const unsigned lo, auto sparse) {
       const unsigned b0 = base - lo;
 #pragma unroll
       for (int g = 0; g < 8; g++) {
         if (__builtin_amdgcn_ballot_w64(((m >> (4 * g)) & 0xFu) != 0u)) {
-          // (the masks through registers the compiler cannot see through: the ranks are pure arithmetic, and left alone all 32
-          // of them are computed in front of the first group -- 130 instructions a tile whose flags sit in one or two groups
-          // never needs, and 32 registers held across the rounds)
           unsigned mg = m, mpg = mp;
-          asm volatile("" : "+v"(mg), "+v"(mpg));
+          if (decltype(sparse)::value) asm volatile("" : "+v"(mg), "+v"(mpg));
 #pragma unroll
           for (int k = 0; k < 4; k++) {
             constexpr unsigned ALL = 0xFFFFFFFFu;
@@ -512,10 +512,13 @@ __device__ __forceinline__ void compress_eo_role(const FwdParams<double>& p, con
           }
         }
       }
-      if (!single) {                                 // a dense tile: round by round, at once
-        eo_barrier();
-        store_rows((DIRECT ? at_dense : run) + lo, min(tot - lo, CAP));
-      }
+    };
+    if (single) { if (tot != 0u) scatter(0u, std::true_type{}); }
+    else for (unsigned lo = 0; lo < tot; lo += CAP) {
+      if (lo != 0u) eo_barrier();                    // both waves have taken the rows of the round before out of the buffer
+      scatter(lo, std::false_type{});
+      eo_barrier();                                  // a dense tile: round by round, at once
+      store_rows((DIRECT ? at_dense : run) + lo, min(tot - lo, CAP));
     }
     pend = true; p_tile = tile; p_run = run; p_cnt = single ? tot : 0u; p_tot = tot; p_dc = dc_here;
     pend_rows = DIRECT && single;                    // (a piece that left in rounds is placed already)
