@@ -2038,7 +2038,7 @@ namespace {
 struct SeqC {                       // one launch sequence of a compress batch: arrays idx[] (all of one element type)
   std::vector<int> idx;
   int dtype = 0;
-  std::vector<unsigned> nfull, rem, ntiles, G, nparts, part_base, tile_base, list_base, scale_wgs;
+  std::vector<unsigned> nfull, rem, ntiles, G, nparts, part_base, tile_base, list_base, scale_wgs, stats_wgs;
   size_t tiles_total = 0, lists_total = 0, parts_total = 0;
   unsigned grid_main = 0, grid_list = 0, grid_scale = 0, grid_stats = 0, nrem = 0;
   size_t blob_off = 0, blob_bytes = 0, item_off = 0;    // item_off: first array of this sequence in b_ctl / b_guess / b_stats / results
@@ -2096,7 +2096,7 @@ static void plan_compress(dctzhip_ctx* c, const dctzhip_batch_citem* items, int 
   cap = cap > 2 * (unsigned)k ? cap - (unsigned)k : cap / 2 + 1;      // (every array with a tile gets at least one workgroup)
   size_t tiles = 0;
   q.nfull.resize(k); q.rem.resize(k); q.ntiles.resize(k); q.G.resize(k); q.nparts.resize(k); q.part_base.resize(k);
-  q.tile_base.resize(k); q.list_base.resize(k); q.scale_wgs.resize(k);
+  q.tile_base.resize(k); q.list_base.resize(k); q.scale_wgs.resize(k); q.stats_wgs.resize(k);
   for (size_t j = 0; j < k; j++) {
     const size_t n = items[q.idx[j]].n;
     q.nfull[j] = (unsigned)(n / 64); q.rem[j] = (unsigned)(n % 64);
@@ -2112,8 +2112,15 @@ static void plan_compress(dctzhip_ctx* c, const dctzhip_batch_citem* items, int 
     if (sg < 1) sg = 1;
     if (sg > (size_t)c->stats_grid) sg = (size_t)c->stats_grid;
     if (sg > maxp) sg = maxp;
-    q.nparts[j] = (unsigned)sg;
-    q.part_base[j] = (unsigned)q.parts_total; q.parts_total += sg;
+    // The same input under several error bounds (what the reference's own driver does: tests/test-dctz.sh:13-56 loops the
+    // bounds over each file): calc_data_stat (util.c:12-44) does not depend on the bound, so the statistics pass reads the
+    // array once -- the later items of the sequence take the first one's partials (every item still gets its own choice of
+    // sf and its own record).  In-place scaling (k_scale_batch) runs behind everything else of the sequence.
+    size_t own = j;
+    for (size_t i = 0; i < j && k <= 256; i++)
+      if (items[q.idx[i]].d_in == items[q.idx[j]].d_in && items[q.idx[i]].n == n) { own = i; break; }
+    if (own != j) { q.nparts[j] = q.nparts[own]; q.part_base[j] = q.part_base[own]; q.stats_wgs[j] = 0; }
+    else { q.nparts[j] = (unsigned)sg; q.part_base[j] = (unsigned)q.parts_total; q.parts_total += sg; q.stats_wgs[j] = (unsigned)sg; }
     q.tile_base[j] = (unsigned)q.tiles_total; q.tiles_total += q.ntiles[j] + 1;     // + the remainder block's list
     q.list_base[j] = (unsigned)q.lists_total; q.lists_total += q.G[j] + 1;
     q.grid_main += q.G[j];
@@ -2178,7 +2185,7 @@ static int launch_compress_seq(dctzhip_ctx* c, const dctzhip_batch_citem* items,
     b.eb = eb; b.scaled = (T*)it.d_scaled; b.n = (unsigned)it.n; b.rem = q.rem[j];
     b.nlists = q.G[j] + (q.rem[j] ? 1u : 0u);
     b.nparts = q.nparts[j]; b.part_base = q.part_base[j];
-    f_stats[j] = a_stats; a_stats += q.nparts[j];
+    f_stats[j] = a_stats; a_stats += q.stats_wgs[j];
     f_main[j] = a_main; a_main += q.G[j];
     f_list[j] = a_list; a_list += b.nlists;
     f_scale[j] = a_scale; a_scale += q.scale_wgs[j];

@@ -139,6 +139,30 @@ def test_batch_in_place_scaling_and_repeat(ctx):
         _check_compress(x, 1e-3, O.EC, out, info, t)
 
 
+@pytest.mark.parametrize("mode", [O.EC, O.QT])
+def test_error_bound_sweep_over_the_same_arrays(ctx, mode):
+    """What the reference's own driver does (tests/test-dctz.sh:13-56): every file under several bounds.  Items of a batch
+    that share their input share one statistics pass (calc_data_stat does not depend on the bound); every item must still
+    be its own call's result -- own sf, own streams, own record -- whatever the order of the items, with scaled copies too."""
+    import torch
+    ctx.set_one_launch(False)                                        # (the chain of batch kernels, where the pass is shared)
+    try:
+        a = W.ragged(4096 * 37 + 64 * 5 + 9, np.float64, scale=37.0)
+        b = W.ragged(4096 * 11 + 17, np.float32, scale=420.0)
+        c = W.ragged(4096 * 5, np.float64, seed=9, scale=0.5)
+        ad, bd, cd = _dev(ctx, a), _dev(ctx, b), _dev(ctx, c)
+        order = [(a, ad, 1e-3), (b, bd, 1e-2), (a, ad, 1e-5), (c, cd, 1e-3), (b, bd, 1e-4), (a, ad, 1e-4), (c, cd, 1e-6), (a.copy(), ad.clone(), 1e-3)]
+        xd = [t for _, t, _ in order]
+        ebs = [e for _, _, e in order]
+        scaled = [torch.empty_like(t) for t in xd]
+        outs, infos, _ = ctx.compress_batch(xd, ebs, mode, scaled=scaled)
+        torch.cuda.synchronize()
+        for (x, _, eb), out, info, sc in zip(order, outs, infos, scaled):
+            _check_compress(x, eb, mode, out, info, sc)
+    finally:
+        ctx.set_one_launch(True)
+
+
 def test_many_arrays_and_a_big_one(ctx):
     """More arrays of one element type than one launch sequence takes (1024; 1533 tiny fp64 ones here) and one array beyond the size from which a
     batch hands an array to the single-array path."""
