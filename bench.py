@@ -332,10 +332,15 @@ def run_rank(a, rank, local_rank, world):
     x, out, rec, n, es = xs[0], outs[0], recs[0], ns[0], xs_host[0].itemsize
     state = {}
 
+    # (the two C-ABI calls of a step with their arguments converted once: a dozen tensor-attribute look-ups and a fresh info
+    # structure per call cost the Python side several microseconds -- a tenth of a C1 / C2 step -- that a C caller's loop
+    # does not have)
+    pair = None if many else ctx.prepare_pair(x, out, rec, ebs[0], mode)
+
     def step():
         if not many:
-            _, info = ctx.compress(x, ebs[0], mode, out=out)
-            ctx.decompress(out, info.cnt, n, tdt[0], ebs[0], info.sf, mode, qtable=info.qtable if qt else None, dst=rec)
+            info = ctx.compress_prepared(pair)
+            ctx.decompress_prepared(pair)
             return [info]
         _, infos, state["cp"] = ctx.compress_batch(xs, ebs, mode, outs=outs, prepared=state.get("cp"))
         if "dp" not in state:                              # (the list is compressed again every step to the same streams)

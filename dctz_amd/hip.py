@@ -267,6 +267,37 @@ class Context:
         self._check(rc, "dctzhip_compress")
         return out, info
 
+    # ---- the same two calls on fixed buffers, their arguments converted once (timing loops: what a C caller's loop costs,
+    # without a dozen tensor-attribute look-ups and a fresh 1 KiB info structure per call on the Python side)
+    def prepare_pair(self, x, out, dst, eb, mode=EC):
+        assert x.is_cuda and x.is_contiguous() and x.dim() == 1 and dst.numel() == x.numel() and dst.dtype == x.dtype
+        self._bind_stream()
+        info = CompressInfo()
+        vp, n, dt = C.c_void_p, x.numel(), _dt(x.dtype)
+        b, d, a = vp(out["bin_index"].data_ptr()), vp(out["dc"].data_ptr()), vp(out["ac_exact"].data_ptr())
+        cargs = (self.h, vp(x.data_ptr()), C.c_size_t(n), C.c_int(dt), C.c_double(float(eb)), C.c_int(mode), b, d, a, None, None, C.byref(info))
+        qtab = None
+        if mode == QT:                                   # the call's table in the element type, refreshed from info per call
+            qtab = (C.c_double * 64)() if x.dtype == self.torch.float64 else (C.c_float * 64)()
+        dhead = (self.h, b, d, a)
+        dtail = (C.c_size_t(n), C.c_int(dt), C.c_double(float(eb)))
+        return {"info": info, "cargs": cargs, "dhead": dhead, "dtail": dtail, "qtab": qtab, "mode": C.c_int(mode), "dst": vp(dst.data_ptr()),
+                "keep": (x, out, dst)}
+
+    def compress_prepared(self, pp):
+        rc = self.lib.dctzhip_compress(*pp["cargs"])
+        if rc:
+            self._check(rc, "dctzhip_compress")
+        return pp["info"]
+
+    def decompress_prepared(self, pp):
+        info, q = pp["info"], pp["qtab"]
+        if q is not None:
+            q[:] = info.qtable[:]
+        rc = self.lib.dctzhip_decompress(*pp["dhead"], info.cnt, q, *pp["dtail"], info.sf, pp["mode"], pp["dst"])
+        if rc:
+            self._check(rc, "dctzhip_decompress")
+
     def compress_part(self, x, eb, max_abs, min_abs, out, lo, ac_at):
         """Elements of one part of an array (x: the part, a 1-D CUDA tensor that starts on a block boundary `lo` of the
         array) with the ARRAY's max|x| / min|x|: its streams go to their places in `out` (the array's outputs), the exact
