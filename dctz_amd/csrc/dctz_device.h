@@ -283,7 +283,8 @@ struct BatchFwd {
   unsigned rem;                    // n % 64 (the short last block)
   unsigned nlists;                 // workgroup lists of this array (+1 for the remainder block)
   unsigned nparts, part_base;      // statistics partials of this array: part[3 * (part_base + j)], j < nparts
-  unsigned pad;
+  unsigned sample;                 // != 0: a speculative item -- its statistics pass reads one 4 KiB chunk out of every `sample`, k_compress_batch<STATS>
+                                   // takes the true statistics into p.stat_part, the hand-off reports those (0: the pass reads everything)
 };
 template <typename T>
 struct BatchInv {
@@ -312,7 +313,7 @@ template <typename T> void launch_stats_batch(const BatchFwd<T>* items_src, cons
                                               const void* blob_src, void* blob_dst, size_t blob_bytes, double* part, hipStream_t s);
 template <typename T> void launch_sf_batch(const BatchFwd<T>* items, unsigned k, const double* part, double* bstats, SfTable tab, hipStream_t s);
 template <typename T> void launch_scale_batch(const BatchFwd<T>* items, const unsigned* first, unsigned k, unsigned grid, hipStream_t s);
-template <typename T> void launch_compress_batch(const BatchFwd<T>* items, const unsigned* first, unsigned k, unsigned grid, int mode, hipStream_t s);
+template <typename T> void launch_compress_batch(const BatchFwd<T>* items, const unsigned* first, unsigned k, unsigned grid, int mode, bool stats, hipStream_t s);
 template <typename T> void launch_compress_rem_batch(const BatchFwd<T>* items, const unsigned* rem_items, unsigned nrem, int mode, hipStream_t s);
 template <typename T> void launch_compact_batch(const BatchFwd<T>* items, const unsigned* first, unsigned k, unsigned grid, unsigned chunks, int mode,
                                                 const double* bstats, const BatchFin& fin, hipStream_t s);

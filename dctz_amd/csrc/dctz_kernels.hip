@@ -1653,12 +1653,14 @@ __device__ __forceinline__ S load_params(const S* src) {
   return v;
 }
 
-template <typename T, int MODE>
+// STATS: the sequence has speculative items (BatchFwd::sample) -- every workgroup also reduces max|x|, min|x| and the sum of
+// what it reads into p.stat_part (every item of such a sequence has one), as k_compress<..., STATS> does for a single array.
+template <typename T, int MODE, bool STATS>
 __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(compress_waves<T, MODE, Phases<T>::C>())))
 void k_compress_batch(const BatchFwd<T>* items, const unsigned* __restrict__ first, unsigned k) {
   const unsigned i = batch_item_of(first, k, blockIdx.x);
   const FwdParams<T> p = load_params(&items[i].p);
-  compress_body<T, MODE, false, Phases<T>::C, GEOM_1D>(p, blockIdx.x - first[i], p.nlists_main);
+  compress_body<T, MODE, STATS, Phases<T>::C, GEOM_1D>(p, blockIdx.x - first[i], p.nlists_main);
 }
 
 template <typename T, int MODE>
@@ -1673,6 +1675,27 @@ __global__ __launch_bounds__(64) void k_compress_rem_batch(const BatchFwd<T>* it
 template <typename T>
 __device__ __forceinline__ void batch_finish_compress(const BatchFwd<T>* items, unsigned k, const double* bstats, const BatchFin& fin, bool qt) {
   BatchResC* res = reinterpret_cast<BatchResC*>(fin.res);
+  // a speculative item's statistics: what k_compress_batch<STATS> (and the remainder block's kernel) left in its partials,
+  // one wave per item
+  {
+    const unsigned lane = threadIdx.x & 63u, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
+    for (unsigned i = wave; i < k; i += nwaves) {
+      const BatchFwd<T>& it = items[i];
+      if (!it.sample) continue;
+      const double* part = it.p.stat_part;
+      const unsigned np = it.p.nlists_main + (it.rem ? 1u : 0u);
+      double dmx = 0.0, dmn = 1.79769313486231570815e308, sum = 0.0;
+      for (unsigned j = lane; j < np; j += 64u) { dmx = fmax(dmx, part[3 * j]); dmn = fmin(dmn, part[3 * j + 1]); sum += part[3 * j + 2]; }
+#pragma unroll
+      for (int d = 32; d > 0; d >>= 1) {
+        dmx = fmax(dmx, __shfl_down(dmx, d));
+        dmn = fmin(dmn, __shfl_down(dmn, d));
+        sum += __shfl_down(sum, d);
+      }
+      if (lane == 0) { double* o = const_cast<double*>(bstats) + 3 * i; o[0] = dmx; o[1] = dmn; o[2] = sum; }
+    }
+    __syncthreads();                                 // (the records below read bstats)
+  }
   auto put = [&](unsigned i, unsigned cnt) {
     const BatchFwd<T>& it = items[i];
     BatchResC r;
@@ -1787,9 +1810,14 @@ __global__ __launch_bounds__(64) void k_decompress_rem_batch(const BatchInv<T>* 
 }
 
 template <typename T>
-void launch_compress_batch(const BatchFwd<T>* items, const unsigned* first, unsigned k, unsigned grid, int mode, hipStream_t s) {
-  if (mode == DCTZHIP_EC) hipLaunchKernelGGL((k_compress_batch<T, DCTZHIP_EC>), dim3(grid), dim3(WG), 0, s, items, first, k);
-  else hipLaunchKernelGGL((k_compress_batch<T, DCTZHIP_QT>), dim3(grid), dim3(WG), 0, s, items, first, k);
+void launch_compress_batch(const BatchFwd<T>* items, const unsigned* first, unsigned k, unsigned grid, int mode, bool stats, hipStream_t s) {
+  if (mode == DCTZHIP_EC) {
+    if (stats) hipLaunchKernelGGL((k_compress_batch<T, DCTZHIP_EC, true>), dim3(grid), dim3(WG), 0, s, items, first, k);
+    else hipLaunchKernelGGL((k_compress_batch<T, DCTZHIP_EC, false>), dim3(grid), dim3(WG), 0, s, items, first, k);
+  } else {
+    if (stats) hipLaunchKernelGGL((k_compress_batch<T, DCTZHIP_QT, true>), dim3(grid), dim3(WG), 0, s, items, first, k);
+    else hipLaunchKernelGGL((k_compress_batch<T, DCTZHIP_QT, false>), dim3(grid), dim3(WG), 0, s, items, first, k);
+  }
 }
 template <typename T>
 void launch_compress_rem_batch(const BatchFwd<T>* items, const unsigned* rem_items, unsigned nrem, int mode, hipStream_t s) {
@@ -1830,7 +1858,7 @@ void launch_decompress_rem_batch(const BatchInv<T>* items, const unsigned* rem_i
 // k_compress instantiations and the batch forms are each built as a translation unit of their own: -DDCTZ_PART=n compiles
 // this file down to the n-th kernel of the list below, the main build (DCTZ_PART = 0) declares them `extern template` and
 // keeps everything else, launchers included (the host side needs only the kernel's handle, a link-time symbol).
-#define DCTZ_PARTS 20
+#define DCTZ_PARTS 24
 #if DCTZ_PART == 1
 template __global__ void k_compress<double, DCTZHIP_EC, true, Phases<double>::C, GEOM_1D, false>(FwdParams<double>);
 #elif DCTZ_PART == 0
@@ -1912,24 +1940,44 @@ template __global__ void k_compress<float, DCTZHIP_QT, false, Phases<float>::C, 
 extern template __global__ void k_compress<float, DCTZHIP_QT, false, Phases<float>::C, GEOM_1D, true>(FwdParams<float>);
 #endif
 #if DCTZ_PART == 17
-template __global__ void k_compress_batch<double, DCTZHIP_EC>(const BatchFwd<double>*, const unsigned*, unsigned);
+template __global__ void k_compress_batch<double, DCTZHIP_EC, false>(const BatchFwd<double>*, const unsigned*, unsigned);
 #elif DCTZ_PART == 0
-extern template __global__ void k_compress_batch<double, DCTZHIP_EC>(const BatchFwd<double>*, const unsigned*, unsigned);
+extern template __global__ void k_compress_batch<double, DCTZHIP_EC, false>(const BatchFwd<double>*, const unsigned*, unsigned);
 #endif
 #if DCTZ_PART == 18
-template __global__ void k_compress_batch<double, DCTZHIP_QT>(const BatchFwd<double>*, const unsigned*, unsigned);
+template __global__ void k_compress_batch<double, DCTZHIP_QT, false>(const BatchFwd<double>*, const unsigned*, unsigned);
 #elif DCTZ_PART == 0
-extern template __global__ void k_compress_batch<double, DCTZHIP_QT>(const BatchFwd<double>*, const unsigned*, unsigned);
+extern template __global__ void k_compress_batch<double, DCTZHIP_QT, false>(const BatchFwd<double>*, const unsigned*, unsigned);
 #endif
 #if DCTZ_PART == 19
-template __global__ void k_compress_batch<float, DCTZHIP_EC>(const BatchFwd<float>*, const unsigned*, unsigned);
+template __global__ void k_compress_batch<float, DCTZHIP_EC, false>(const BatchFwd<float>*, const unsigned*, unsigned);
 #elif DCTZ_PART == 0
-extern template __global__ void k_compress_batch<float, DCTZHIP_EC>(const BatchFwd<float>*, const unsigned*, unsigned);
+extern template __global__ void k_compress_batch<float, DCTZHIP_EC, false>(const BatchFwd<float>*, const unsigned*, unsigned);
 #endif
 #if DCTZ_PART == 20
-template __global__ void k_compress_batch<float, DCTZHIP_QT>(const BatchFwd<float>*, const unsigned*, unsigned);
+template __global__ void k_compress_batch<float, DCTZHIP_QT, false>(const BatchFwd<float>*, const unsigned*, unsigned);
 #elif DCTZ_PART == 0
-extern template __global__ void k_compress_batch<float, DCTZHIP_QT>(const BatchFwd<float>*, const unsigned*, unsigned);
+extern template __global__ void k_compress_batch<float, DCTZHIP_QT, false>(const BatchFwd<float>*, const unsigned*, unsigned);
+#endif
+#if DCTZ_PART == 21
+template __global__ void k_compress_batch<double, DCTZHIP_EC, true>(const BatchFwd<double>*, const unsigned*, unsigned);
+#elif DCTZ_PART == 0
+extern template __global__ void k_compress_batch<double, DCTZHIP_EC, true>(const BatchFwd<double>*, const unsigned*, unsigned);
+#endif
+#if DCTZ_PART == 22
+template __global__ void k_compress_batch<double, DCTZHIP_QT, true>(const BatchFwd<double>*, const unsigned*, unsigned);
+#elif DCTZ_PART == 0
+extern template __global__ void k_compress_batch<double, DCTZHIP_QT, true>(const BatchFwd<double>*, const unsigned*, unsigned);
+#endif
+#if DCTZ_PART == 23
+template __global__ void k_compress_batch<float, DCTZHIP_EC, true>(const BatchFwd<float>*, const unsigned*, unsigned);
+#elif DCTZ_PART == 0
+extern template __global__ void k_compress_batch<float, DCTZHIP_EC, true>(const BatchFwd<float>*, const unsigned*, unsigned);
+#endif
+#if DCTZ_PART == 24
+template __global__ void k_compress_batch<float, DCTZHIP_QT, true>(const BatchFwd<float>*, const unsigned*, unsigned);
+#elif DCTZ_PART == 0
+extern template __global__ void k_compress_batch<float, DCTZHIP_QT, true>(const BatchFwd<float>*, const unsigned*, unsigned);
 #endif
 #ifdef DCTZ_DEV_ONE
 template __global__ void DCTZ_DEV_ONE(DCTZ_DEV_ARGS);
@@ -1943,7 +1991,7 @@ template __global__ void DCTZ_DEV_ONE(DCTZ_DEV_ARGS);
   template void launch_compact_ac<T>(const FwdParams<T>&, int, double, unsigned, int, const FinArgs&, hipStream_t); \
   template void launch_decompress<T>(const InvParams<T>&, int, int, const FinArgs&, int, hipStream_t);  \
   template void launch_decompress_rem<T>(const InvParams<T>&, int, bool, int, hipStream_t);             \
-  template void launch_compress_batch<T>(const BatchFwd<T>*, const unsigned*, unsigned, unsigned, int, hipStream_t);                        \
+  template void launch_compress_batch<T>(const BatchFwd<T>*, const unsigned*, unsigned, unsigned, int, bool, hipStream_t);                      \
   template void launch_compress_rem_batch<T>(const BatchFwd<T>*, const unsigned*, unsigned, int, hipStream_t);                              \
   template void launch_compact_batch<T>(const BatchFwd<T>*, const unsigned*, unsigned, unsigned, unsigned, int, const double*, const BatchFin&, hipStream_t); \
   template void launch_count_batch<T>(const BatchInv<T>*, const unsigned*, unsigned, unsigned, const void*, void*, size_t, hipStream_t);    \

@@ -133,6 +133,43 @@ __global__ __launch_bounds__(SWG) void k_stats_final_sf(const double* part, int 
   stats_final_sf_body(part, nparts, out, zero, tab, guess, box);
 }
 
+// Sampled statistics for the speculative path: one 4 KiB chunk out of every group of
+// `group` chunks, at a hashed position inside the group (a fixed stride would alias with
+// the row structure of power-of-two volumes).  Same partials layout as k_stats.
+template <typename T>
+__device__ __forceinline__ void stats_sample_body(const T* __restrict__ x, size_t n, unsigned group, double* __restrict__ part,
+                                                  const unsigned wg, const unsigned nwg) {
+  using Vec = typename Traits<T>::Vec;
+  constexpr int EPV = Traits<T>::EPV;
+  const size_t nchunks = n / ((size_t)SWG * EPV);                // whole chunks only; the tail is never sampled
+  const size_t ngroups = nchunks / group;
+  const Vec* src = reinterpret_cast<const Vec*>(x);
+  StatAcc<T> acc;
+  acc.init();
+  // up to four chunks of a workgroup in flight at once (the kernel is a handful of dependent round trips otherwise)
+  for (size_t g0 = wg; g0 < ngroups; g0 += (size_t)nwg * 4) {
+    Vec v[4];
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      const size_t g = g0 + (size_t)u * nwg;
+      const size_t gg = g < ngroups ? g : g0;                    // (a repeated chunk changes neither max nor min; its sum is skipped)
+      const unsigned h = ((unsigned)gg * 2654435761u) >> 8;
+      const size_t chunk = gg * group + h % group;
+      v[u] = load_stream(&src[chunk * SWG + threadIdx.x]);
+    }
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      const bool real = g0 + (size_t)u * nwg < ngroups;
+      T e[EPV];
+      Traits<T>::unpack(v[u], e);
+#pragma unroll
+      for (int k = 0; k < EPV; k++) acc.add(e[k], real);
+    }
+  }
+  __shared__ double ss[3 * (SWG / 64)];
+  acc.flush(part, wg, ss, SWG / 64);
+}
+
 // ---- batches (dctz_device.h: BatchFwd): calc_data_stat of k arrays in one launch, the scaling factor of every array
 // chosen on the device (one workgroup per array), and the scaled copies.  k_stats_batch is the FIRST kernel of a batch
 // sequence: it reads the item table from the host's pinned copy and leaves it in device memory for the kernels behind it.
@@ -154,7 +191,10 @@ __global__ __launch_bounds__(SWG) void k_stats_batch(const BatchFwd<T>* items, c
   for (unsigned v = blockIdx.x * SWG + threadIdx.x; v < blob_vecs; v += gridDim.x * SWG) blob_dst[v] = blob_src[v];
   const unsigned i = aux_item_of(first, k, blockIdx.x);
   const BatchFwd<T>& it = items[i];
-  stats_body<T>(it.p.x, (size_t)it.n, part + 3 * (size_t)it.part_base, blockIdx.x - first[i], it.nparts);
+  // (it.sample: a speculative item -- the pass reads one chunk out of every `sample`, k_compress_batch<STATS> takes the true
+  // statistics while it streams the array, the host verifies the choice of sf afterwards: DESIGN section 3.4)
+  if (it.sample) stats_sample_body<T>(it.p.x, (size_t)it.n, it.sample, part + 3 * (size_t)it.part_base, blockIdx.x - first[i], it.nparts);
+  else stats_body<T>(it.p.x, (size_t)it.n, part + 3 * (size_t)it.part_base, blockIdx.x - first[i], it.nparts);
 }
 // (k_sf_batch as the LAST workgroup of every array inside k_stats_batch -- a ticket per array -- was measured in round 3 and
 // dropped: the two agent-scope fences every statistics workgroup then needs cost more than the kernel boundary they save,
@@ -203,41 +243,10 @@ void launch_scale_batch(const BatchFwd<T>* items, const unsigned* first, unsigne
   hipLaunchKernelGGL(k_scale_batch<T>, dim3(grid), dim3(SWG), 0, s, items, first, k);
 }
 
-// Sampled statistics for the speculative path: one 4 KiB chunk out of every group of
-// `group` chunks, at a hashed position inside the group (a fixed stride would alias with
-// the row structure of power-of-two volumes).  Same partials layout as k_stats.
 template <typename T>
 __global__ __launch_bounds__(SWG) void k_stats_sample(const T* __restrict__ x, size_t n, unsigned group,
                                                        double* __restrict__ part) {
-  using Vec = typename Traits<T>::Vec;
-  constexpr int EPV = Traits<T>::EPV;
-  const size_t nchunks = n / ((size_t)SWG * EPV);                // whole chunks only; the tail is never sampled
-  const size_t ngroups = nchunks / group;
-  const Vec* src = reinterpret_cast<const Vec*>(x);
-  StatAcc<T> acc;
-  acc.init();
-  // up to four chunks of a workgroup in flight at once (the kernel is a handful of dependent round trips otherwise)
-  for (size_t g0 = blockIdx.x; g0 < ngroups; g0 += (size_t)gridDim.x * 4) {
-    Vec v[4];
-#pragma unroll
-    for (int u = 0; u < 4; u++) {
-      const size_t g = g0 + (size_t)u * gridDim.x;
-      const size_t gg = g < ngroups ? g : g0;                    // (a repeated chunk changes neither max nor min; its sum is skipped)
-      const unsigned h = ((unsigned)gg * 2654435761u) >> 8;
-      const size_t chunk = gg * group + h % group;
-      v[u] = load_stream(&src[chunk * SWG + threadIdx.x]);
-    }
-#pragma unroll
-    for (int u = 0; u < 4; u++) {
-      const bool real = g0 + (size_t)u * gridDim.x < ngroups;
-      T e[EPV];
-      Traits<T>::unpack(v[u], e);
-#pragma unroll
-      for (int k = 0; k < EPV; k++) acc.add(e[k], real);
-    }
-  }
-  __shared__ double ss[3 * (SWG / 64)];
-  acc.flush(part, blockIdx.x, ss, SWG / 64);
+  stats_sample_body<T>(x, n, group, part, blockIdx.x, gridDim.x);
 }
 
 // Serial-order sum for the header's `mean` (util.c:18-28 / :31-41): the reference

@@ -126,6 +126,9 @@ struct dctzhip_ctx {
   size_t spec_min = (size_t)1 << 22; // elements below which the plain statistics pass is kept (DCTZHIP_SPEC_MIN)
   unsigned spec_group = 64;         // one 4 KiB chunk sampled per group of this many (DCTZHIP_SPEC_GROUP)
   int spec_cooldown = 0;            // calls left without speculation after a wrong guess
+  int batch_speculate = 1;          // ... and in the batch sequences, for items from spec_min elements on (DCTZHIP_BATCH_SPECULATE)
+  int b_spec_now = 0;               // this batch call may speculate (no cooldown pending when it started)
+  unsigned long long b_spec_items = 0, b_spec_misses = 0;   // speculative batch items / those done again on their own
   unsigned long long spec_hits = 0, spec_misses = 0;
   int profiling = 0;
   hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
@@ -236,6 +239,7 @@ extern "C" int dctzhip_ctx_create(dctzhip_ctx** out, int device) {
   if (const char* e = getenv("DCTZHIP_STATS_GRID")) { int v = atoi(e); if (v >= 1 && v <= STATS_GRID_MAX) c->stats_grid = v; }
   if (const char* e = getenv("DCTZHIP_WG_PER_CU")) { int v = atoi(e); if (v >= 1 && v <= WG_PER_CU_MAX) c->wg_per_cu = v; }
   if (const char* e = getenv("DCTZHIP_SPECULATE")) c->speculate = atoi(e) != 0;
+  if (const char* e = getenv("DCTZHIP_BATCH_SPECULATE")) c->batch_speculate = atoi(e) != 0;
   if (const char* e = getenv("DCTZHIP_SPEC_MIN")) { long long v = atoll(e); if (v >= 0) c->spec_min = (size_t)v; }
   if (const char* e = getenv("DCTZHIP_SPEC_GROUP")) { int v = atoi(e); if (v >= 1 && v <= 4096) c->spec_group = (unsigned)v; }
   HIPCHK(nullptr, hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
@@ -383,6 +387,8 @@ extern "C" int dctzhip_debug_counter(dctzhip_ctx* c, int which, unsigned long lo
     case 5: *value = c->eo_lb_fallbacks; break;
     case 6: *value = c->spec_hits; break;
     case 7: *value = c->spec_misses; break;
+    case 8: *value = c->b_spec_items; break;         // batch items that took their scaling factor from a sample
+    case 9: *value = c->b_spec_misses; break;        // ... whose guess the true statistics refused (done again on their own)
     default: return fail(c, DCTZHIP_E_ARG, "dctzhip_debug_counter: no counter %d", which);
   }
   return DCTZHIP_OK;
@@ -2038,7 +2044,9 @@ namespace {
 struct SeqC {                       // one launch sequence of a compress batch: arrays idx[] (all of one element type)
   std::vector<int> idx;
   int dtype = 0;
-  std::vector<unsigned> nfull, rem, ntiles, G, nparts, part_base, tile_base, list_base, scale_wgs, stats_wgs;
+  std::vector<unsigned> nfull, rem, ntiles, G, nparts, part_base, tile_base, list_base, scale_wgs, stats_wgs, sample, main_part_base;
+  size_t parts_all = 0;            // statistics partials + (fused) the main kernels' partials
+  bool fused = false;              // the sequence has speculative items: k_compress_batch<STATS>, true statistics into main_part_base
   size_t tiles_total = 0, lists_total = 0, parts_total = 0;
   unsigned grid_main = 0, grid_list = 0, grid_scale = 0, grid_stats = 0, nrem = 0;
   size_t blob_off = 0, blob_bytes = 0, item_off = 0;    // item_off: first array of this sequence in b_ctl / b_guess / b_stats / results
@@ -2096,7 +2104,7 @@ static void plan_compress(dctzhip_ctx* c, const dctzhip_batch_citem* items, int 
   cap = cap > 2 * (unsigned)k ? cap - (unsigned)k : cap / 2 + 1;      // (every array with a tile gets at least one workgroup)
   size_t tiles = 0;
   q.nfull.resize(k); q.rem.resize(k); q.ntiles.resize(k); q.G.resize(k); q.nparts.resize(k); q.part_base.resize(k);
-  q.tile_base.resize(k); q.list_base.resize(k); q.scale_wgs.resize(k); q.stats_wgs.resize(k);
+  q.tile_base.resize(k); q.list_base.resize(k); q.scale_wgs.resize(k); q.stats_wgs.resize(k); q.sample.assign(k, 0u); q.main_part_base.assign(k, 0u);
   for (size_t j = 0; j < k; j++) {
     const size_t n = items[q.idx[j]].n;
     q.nfull[j] = (unsigned)(n / 64); q.rem[j] = (unsigned)(n % 64);
@@ -2119,8 +2127,24 @@ static void plan_compress(dctzhip_ctx* c, const dctzhip_batch_citem* items, int 
     size_t own = j;
     for (size_t i = 0; i < j && k <= 256; i++)
       if (items[q.idx[i]].d_in == items[q.idx[j]].d_in && items[q.idx[i]].n == n) { own = i; break; }
-    if (own != j) { q.nparts[j] = q.nparts[own]; q.part_base[j] = q.part_base[own]; q.stats_wgs[j] = 0; }
+    // Speculation, as on the single-array path: an item from spec_min elements on gets its scaling
+    // factor from a sample (one chunk of 4 KiB out of every spec_group), k_compress_batch<STATS> takes the true statistics
+    // while it streams the array, and the host's check of the device's choice below -- it has been there for every item since
+    // round 3 -- is then the check of the guess: an item it refuses is done again on its own.  Not for an item that is scaled
+    // in place (k_scale_batch would have divided the input by the wrong factor by then).
+    constexpr size_t chunk = (size_t)SWG * EPV;
+    const bool in_place = items[q.idx[j]].d_scaled && items[q.idx[j]].d_scaled == items[q.idx[j]].d_in;
+    if (c->speculate && c->batch_speculate && c->b_spec_now && !in_place && q.ntiles[j] && n >= c->spec_min && n >= 4 * chunk * c->spec_group) {
+      q.sample[j] = (unsigned)c->spec_group;
+      const size_t ngroups = n / chunk / c->spec_group;
+      const size_t scap = (size_t)(c->stats_grid > 1 ? c->stats_grid / 2 : 1);
+      sg = ngroups < scap ? ngroups : scap;
+      if (sg > maxp) sg = maxp;
+      if (sg < 1) sg = 1;
+    }
+    if (own != j && q.sample[own] == q.sample[j]) { q.nparts[j] = q.nparts[own]; q.part_base[j] = q.part_base[own]; q.stats_wgs[j] = 0; }
     else { q.nparts[j] = (unsigned)sg; q.part_base[j] = (unsigned)q.parts_total; q.parts_total += sg; q.stats_wgs[j] = (unsigned)sg; }
+    if (q.sample[j]) q.fused = true;
     q.tile_base[j] = (unsigned)q.tiles_total; q.tiles_total += q.ntiles[j] + 1;     // + the remainder block's list
     q.list_base[j] = (unsigned)q.lists_total; q.lists_total += q.G[j] + 1;
     q.grid_main += q.G[j];
@@ -2131,6 +2155,30 @@ static void plan_compress(dctzhip_ctx* c, const dctzhip_batch_citem* items, int 
     q.scale_wgs[j] = sw; q.grid_scale += sw;
   }
   q.grid_stats = (unsigned)q.parts_total;
+  if (q.fused) {
+    size_t at = q.parts_total;
+    for (size_t j = 0; j < k; j++) { q.main_part_base[j] = (unsigned)at; at += q.G[j] + 1; }
+    if (at > (size_t)PART_SLOTS) {                    // no room for the main kernels' partials: the sequence takes the full passes
+      q.fused = false;
+      q.parts_total = 0; q.grid_stats = 0;
+      std::fill(q.sample.begin(), q.sample.end(), 0u);
+      for (size_t j = 0; j < k; j++) {                // (as above, without the speculation)
+        const size_t n = items[q.idx[j]].n;
+        size_t sg = (n / EPV + SWG * 4 - 1) / (SWG * 4);
+        if (sg < 1) sg = 1;
+        if (sg > (size_t)c->stats_grid) sg = (size_t)c->stats_grid;
+        if (sg > maxp) sg = maxp;
+        size_t own = j;
+        for (size_t i = 0; i < j && k <= 256; i++)
+          if (items[q.idx[i]].d_in == items[q.idx[j]].d_in && items[q.idx[i]].n == n) { own = i; break; }
+        if (own != j) { q.nparts[j] = q.nparts[own]; q.part_base[j] = q.part_base[own]; q.stats_wgs[j] = 0; }
+        else { q.nparts[j] = (unsigned)sg; q.part_base[j] = (unsigned)q.parts_total; q.parts_total += sg; q.stats_wgs[j] = (unsigned)sg; }
+      }
+      q.grid_stats = (unsigned)q.parts_total;
+    } else {
+      q.parts_all = at;
+    }
+  }
   q.blob_bytes = align16(k * sizeof(BatchFwd<T>)) + align16(4 * (k + 1) * sizeof(unsigned) + (size_t)q.nrem * sizeof(unsigned));
 }
 
@@ -2141,7 +2189,7 @@ static int launch_compress_seq(dctzhip_ctx* c, const dctzhip_batch_citem* items,
   const size_t k = q.idx.size();
   hipStream_t s = ch.s;
   // launch-time checks of the plan against the buffers it indexes
-  if (q.parts_total > (size_t)PART_SLOTS || ch.list_off + q.lists_total + 2 > c->tile_cap || ch.tile_off + q.tiles_total > c->qcnt_cap)
+  if (q.parts_total > (size_t)PART_SLOTS || q.parts_all > (size_t)PART_SLOTS || ch.list_off + q.lists_total + 2 > c->tile_cap || ch.tile_off + q.tiles_total > c->qcnt_cap)
     return fail(c, DCTZHIP_E_INTERNAL, "batch: scratch plan exceeds its buffers");
   unsigned char* hb = c->b_blob + q.blob_off;
   BatchFwd<T>* hi = reinterpret_cast<BatchFwd<T>*>(hb);
@@ -2169,7 +2217,7 @@ static int launch_compress_seq(dctzhip_ctx* c, const dctzhip_batch_citem* items,
     if (q.rem[j]) { int rc = rtab_for<T>(c, (int)q.rem[j], &p.rtab); if (rc) return rc; }
     p.ctl = c->b_ctl + q.item_off + j;
     p.guess = c->b_guess + q.item_off + j;           // the scaling factor is chosen on the device (k_sf_batch), verified afterwards
-    p.stat_part = nullptr;
+    p.stat_part = q.fused ? c->part + 3 * (ch.part_off + (size_t)q.main_part_base[j]) : nullptr;
     p.nfull = q.nfull[j]; p.ntiles = q.ntiles[j]; p.last_is_full = q.rem[j] ? 0u : 1u;
     p.nlists_main = q.G[j];
     p.sf = (T)1; p.fast_sf = 0;                       // (placeholders: p.guess is set)
@@ -2184,7 +2232,7 @@ static int launch_compress_seq(dctzhip_ctx* c, const dctzhip_batch_citem* items,
     }
     b.eb = eb; b.scaled = (T*)it.d_scaled; b.n = (unsigned)it.n; b.rem = q.rem[j];
     b.nlists = q.G[j] + (q.rem[j] ? 1u : 0u);
-    b.nparts = q.nparts[j]; b.part_base = q.part_base[j];
+    b.nparts = q.nparts[j]; b.part_base = q.part_base[j]; b.sample = q.sample[j];
     f_stats[j] = a_stats; a_stats += q.stats_wgs[j];
     f_main[j] = a_main; a_main += q.G[j];
     f_list[j] = a_list; a_list += b.nlists;
@@ -2208,7 +2256,10 @@ static int launch_compress_seq(dctzhip_ctx* c, const dctzhip_batch_citem* items,
   const SfTable tab = {c->sf_thr[dtype], c->sf_pw[dtype], c->sf_nk[dtype], c->fastdiv, dtype};
   launch_sf_batch<T>(it_d, (unsigned)k, part, c->b_stats + 3 * q.item_off, tab, s);
   if (prof) HIPCHK(c, hipEventRecord(ev[1], s));
-  if (q.grid_main) { launch_compress_batch<T>(it_d, first_d + (k + 1), (unsigned)k, q.grid_main, mode, s); SET_LAST(c, sizeof(T) == 8 ? 2 : 3, "k_compress_batch<%s, %d>", tname<T>(), mode); }
+  if (q.grid_main) {
+    launch_compress_batch<T>(it_d, first_d + (k + 1), (unsigned)k, q.grid_main, mode, q.fused, s);
+    SET_LAST(c, sizeof(T) == 8 ? 2 : 3, "k_compress_batch<%s, %d, %s>", tname<T>(), mode, q.fused ? "true" : "false");
+  }
   if (prof) HIPCHK(c, hipEventRecord(ev[2], s));
   if (nrem) launch_compress_rem_batch<T>(it_d, first_d + 4 * (k + 1), nrem, mode, s);
   BatchFin fin;
@@ -2592,6 +2643,8 @@ extern "C" int dctzhip_compress_batch(dctzhip_ctx* c, int k, const dctzhip_batch
   const bool two = has[0] && has[1];                   // mixed batch: the fp32 sequences run beside the fp64 ones
   size_t tiles_max[2] = {0, 0}, lists_max[2] = {0, 0};
   Chain ch[2];
+  c->b_spec_now = c->spec_cooldown == 0;               // (a wrong guess pauses the speculation of the next calls, batches included)
+  if (!c->b_spec_now && !seqs.empty()) c->spec_cooldown--;
   for (size_t qi = 0; qi < seqs.size(); qi++) {
     SeqC& q = seqs[qi];
     q.chain = (two && q.dtype == DCTZHIP_F32) ? 1 : 0;
@@ -2648,7 +2701,9 @@ extern "C" int dctzhip_compress_batch(dctzhip_ctx* c, int k, const dctzhip_batch
         const double true_sf = scaling_factor(dtype, r.stats[0]);
         const bool same = dtype == DCTZHIP_F64 ? true_sf == r.sf_used : (float)true_sf == (float)r.sf_used;
         const bool window_ok = r.fast_used != 2 || (value_in_window(dtype, r.stats[1]) && value_in_window(dtype, r.stats[0]));
-        if (!same || !window_ok) {                    // (a table bug: never seen; the array is done again on its own)
+        if (q.sample[j]) c->b_spec_items++;
+        if (!same || !window_ok) {                    // (a speculative item whose sample missed the decade; else a table bug: never seen): done again on its own
+          if (q.sample[j]) { c->b_spec_misses++; c->spec_misses++; c->spec_cooldown = SPEC_COOLDOWN; }
           // ... unless k_scale_batch has already divided the input in place by the wrong factor: nothing to run it on again
           if (items[i].d_scaled && items[i].d_scaled == items[i].d_in)
             return fail(c, DCTZHIP_E_INTERNAL, "array %d: scaling factor %g chosen on the device differs from the host's %g after an in-place pass", i, r.sf_used, true_sf);
@@ -2663,6 +2718,7 @@ extern "C" int dctzhip_compress_batch(dctzhip_ctx* c, int k, const dctzhip_batch
         info->mean = (dtype == DCTZHIP_F64) ? r.stats[2] / (double)(int)n : (double)((float)r.stats[2] / (float)(int)n);
         info->max_abs = r.stats[0]; info->min_abs = r.stats[1];
         info->cnt = r.cnt; info->nblk = (uint32_t)((n + 63) / 64);
+        if (q.sample[j]) info->flags |= DCTZHIP_INFO_STATS_FUSED;
         if (mode == DCTZHIP_QT) {
           const BatchResQ& rq = resq[q.item_off + j];
           for (int jj = 0; jj < 64; jj++) {

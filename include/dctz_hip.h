@@ -130,7 +130,8 @@ int dctzhip_set_one_launch(dctzhip_ctx *ctx, int on);
 int dctzhip_set_split(dctzhip_ctx *ctx, int on);
 /* (tests and tools)  Counters of the context -- which: 0 one-launch calls, 1 one-launch launches that gave up (run again
  * through the chain), 2 calls left on the chain after such a launch, 3 calls through k_compress_eo, 4 of them with
- * single-pass placement, 5 look-backs that gave up, 6 / 7 verified / wrong guesses of the scaling factor -- and knobs that
+ * single-pass placement, 5 look-backs that gave up, 6 / 7 verified / wrong guesses of the scaling factor, 8 / 9 speculative
+ * items of batches / those whose guess was refused -- and knobs that
  * make a rare path run on purpose -- key 0: workgroup 0 of the one-launch kernels withholds its granule (the launch gives
  * up after 20 ms, the call is run through the chain), 1: one look-back of k_compress_eo gives up, 2: sets counter 2. */
 int dctzhip_debug_counter(dctzhip_ctx *ctx, int which, unsigned long long *value);

@@ -163,6 +163,70 @@ def test_error_bound_sweep_over_the_same_arrays(ctx, mode):
         ctx.set_one_launch(True)
 
 
+@pytest.fixture()
+def spec_ctx():
+    """The chain of batch kernels with speculation from 2^18 elements on (default: 2^22), so that arrays the oracle finishes
+    in a moment take their scaling factor from a sample."""
+    import dctz_amd
+    c = dctz_amd.Context(0)
+    c.set_speculation(True, 1 << 18)
+    c.set_one_launch(False)
+    yield c
+    c.close()
+
+
+def _unsampled_element(dtype, group_index, group=64):
+    """An element k_stats_batch's sample does not read (one 4 KiB chunk per group of 64, at a hashed position)."""
+    chunk_elems = 256 * (16 // np.dtype(dtype).itemsize)
+    g0 = group_index * group + (((group_index * 2654435761) & 0xFFFFFFFF) >> 8) % group
+    c = group_index * group + (0 if g0 != group_index * group else 1)
+    return c * chunk_elems + 17
+
+
+@pytest.mark.parametrize("mode", [O.EC, O.QT])
+def test_speculative_items_of_a_batch(spec_ctx, mode):
+    """Large items of a launch sequence take their scaling factor from a sample and their statistics from the compress
+    kernel (as the single-array path does): the same streams, the TRUE max / min in the record; small items and an item that
+    is scaled in place keep the full pass."""
+    import torch
+    import dctz_amd
+    xs = [W.ragged(1 << 20, np.float64, scale=37.0), W.ragged((1 << 20) + 64 * 7 + 40, np.float32, scale=420.0),
+          W.ragged(5000, np.float64, scale=3.0), W.ragged(300000, np.float32, seed=4, scale=0.6),
+          W.ragged((1 << 19) + 33, np.float64, seed=5, scale=37.0)]
+    ebs = [1e-3, 1e-4, 1e-3, 1e-3, 1e-5]
+    xd = [_dev(spec_ctx, x) for x in xs]
+    scaled = [torch.empty_like(xd[0]), None, None, torch.empty_like(xd[3]), xd[4]]     # the last one in place
+    n0 = spec_ctx.counter(8)
+    outs, infos, _ = spec_ctx.compress_batch(xd, ebs, mode, scaled=scaled)
+    torch.cuda.synchronize()
+    assert spec_ctx.counter(8) - n0 == 3 and spec_ctx.counter(9) == 0
+    for x, eb, out, info, sc, spec in zip(xs, ebs, outs, infos, scaled, [True, True, False, True, False]):
+        _check_compress(x, eb, mode, out, info, sc)
+        assert bool(info.flags & dctz_amd.hip.INFO_STATS_FUSED) == spec
+
+
+def test_speculative_item_with_a_wrong_guess_is_done_again(spec_ctx):
+    """A spike between the sample's chunks moves max|x| into the next decade: the true statistics refuse the guess, the item
+    is compressed again on its own -- the others are left as they are -- and the next batches do not speculate for a while."""
+    import torch
+    import dctz_amd
+    xs = [W.ragged(1 << 20, np.float64, scale=37.0), W.ragged(1 << 20, np.float32, seed=2, scale=37.0), W.ragged(300000, np.float64, seed=3, scale=37.0)]
+    xs[1][_unsampled_element(np.float32, 5)] = 4321.0
+    xd = [_dev(spec_ctx, x) for x in xs]
+    scaled = [torch.empty_like(t) for t in xd]
+    outs, infos, _ = spec_ctx.compress_batch(xd, 1e-3, O.EC, scaled=scaled)
+    torch.cuda.synchronize()
+    assert spec_ctx.counter(8) == 3 and spec_ctx.counter(9) == 1
+    cs = [_check_compress(x, 1e-3, O.EC, out, info, sc) for x, out, info, sc in zip(xs, outs, infos, scaled)]
+    assert cs[1].sf == 1000.0 and cs[0].sf == 10.0
+    outs, infos, _ = spec_ctx.compress_batch(xd, 1e-3, O.EC)          # the pause: full passes, same results
+    torch.cuda.synchronize()
+    assert spec_ctx.counter(8) == 3
+    for x, out, info in zip(xs, outs, infos):
+        _check_compress(x, 1e-3, O.EC, out, info)
+        assert not (info.flags & dctz_amd.hip.INFO_STATS_FUSED)
+
+
 def test_many_arrays_and_a_big_one(ctx):
     """More arrays of one element type than one launch sequence takes (1024; 1533 tiny fp64 ones here) and one array beyond the size from which a
     batch hands an array to the single-array path."""
