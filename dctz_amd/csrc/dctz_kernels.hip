@@ -848,6 +848,9 @@ __global__ __launch_bounds__(SWG) void k_compact_ac(FwdParams<T> p, double eb, u
 // k_decompress finds the start of its piece of AC_exact by adding up at most a thousand words -- no scan kernel.
 // A wave takes whole tiles (4 x 1 KiB coalesced rows, plain loads: k_decompress re-reads these lines from the
 // Infinity Cache); no workgroup barrier per tile.
+#ifndef DCTZ_COUNT_TF
+#define DCTZ_COUNT_TF 2
+#endif
 __device__ __forceinline__ void count_tiles_body(const uint8_t* __restrict__ bin, unsigned nfull, unsigned ntiles, unsigned nwg,
                                                  unsigned* __restrict__ tile_cnt, unsigned* __restrict__ wg_cnt, const unsigned wg,
                                                  unsigned* __restrict__ tile_pre = nullptr) {
@@ -858,30 +861,42 @@ __device__ __forceinline__ void count_tiles_body(const uint8_t* __restrict__ bin
   const TileRange tr = tile_range(wg, nwg, ntiles);
   const size_t end = (size_t)nfull * 64;
   unsigned acc = 0;                                                    // this wave's share of the workgroup's count (uniform)
-  for (unsigned tile = tr.lo + (unsigned)wave; tile < tr.hi; tile += SWG / 64) {
-    const size_t o = (size_t)tile * TILE_ELEMS + (size_t)lane * 16;
-    unsigned c = 0;
-    uint4 wv[4];
+  // (TF tiles of a wave in flight at once, 4 TF 16-byte loads per lane: the loop is a chain of round trips otherwise)
+  constexpr unsigned NW = SWG / 64;
+  constexpr int TF = DCTZ_COUNT_TF;
+  for (unsigned tile0 = tr.lo + (unsigned)wave; tile0 < tr.hi; tile0 += TF * NW) {
+    uint4 wv[TF][4];
 #pragma unroll
-    for (int i = 0; i < 4; i++) {
-      wv[i] = make_uint4(0u, 0u, 0u, 0u);                              // (a zero word has no 255 byte)
-      if (o + (size_t)i * 1024 < end) wv[i] = *reinterpret_cast<const uint4*>(bin + o + (size_t)i * 1024);
-    }
+    for (int h = 0; h < TF; h++) {
+      const unsigned tile = tile0 + (unsigned)h * NW;
+      const size_t o = (size_t)tile * TILE_ELEMS + (size_t)lane * 16;
 #pragma unroll
-    for (int i = 0; i < 4; i++) {
-      const unsigned w[4] = {wv[i].x, wv[i].y, wv[i].z, wv[i].w};
-#pragma unroll
-      for (int k = 0; k < 4; k++) {
-        const unsigned v = ~w[k];                                      // a zero byte of v <=> bin id 255
-        const unsigned z = ((v & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | v;      // bit 7 of a byte set <=> that byte of v is non-zero
-        unsigned m = ~z & 0x80808080u;
-        if (k == 0 && (lane & 3) == 0) m &= ~0x80u;                    // byte 0 of every 64: j = 0, the DC slot (:392 / :438)
-        c += (unsigned)__popc(m);
+      for (int i = 0; i < 4; i++) {
+        wv[h][i] = make_uint4(0u, 0u, 0u, 0u);                           // (a zero word has no 255 byte)
+        if (tile < tr.hi && o + (size_t)i * 1024 < end) wv[h][i] = *reinterpret_cast<const uint4*>(bin + o + (size_t)i * 1024);
       }
     }
-    const unsigned tot = (unsigned)__builtin_amdgcn_readlane((int)wave_incl_scan(c), 63);
-    if (lane == 0) { tile_cnt[tile] = tot; if (tile_pre != nullptr && tile - tr.lo < PRE_MAX) tcs[tile - tr.lo] = tot; }
-    acc += tot;
+#pragma unroll
+    for (int h = 0; h < TF; h++) {
+      const unsigned tile = tile0 + (unsigned)h * NW;
+      if (tile >= tr.hi) break;
+      unsigned c = 0;
+#pragma unroll
+      for (int i = 0; i < 4; i++) {
+        const unsigned w[4] = {wv[h][i].x, wv[h][i].y, wv[h][i].z, wv[h][i].w};
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+          const unsigned v = ~w[k];                                      // a zero byte of v <=> bin id 255
+          const unsigned z = ((v & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | v;      // bit 7 of a byte set <=> that byte of v is non-zero
+          unsigned m = ~z & 0x80808080u;
+          if (k == 0 && (lane & 3) == 0) m &= ~0x80u;                    // byte 0 of every 64: j = 0, the DC slot (:392 / :438)
+          c += (unsigned)__popc(m);
+        }
+      }
+      const unsigned tot = (unsigned)__builtin_amdgcn_readlane((int)wave_incl_scan(c), 63);
+      if (lane == 0) { tile_cnt[tile] = tot; if (tile_pre != nullptr && tile - tr.lo < PRE_MAX) tcs[tile - tr.lo] = tot; }
+      acc += tot;
+    }
   }
   if (lane == 0) part[wave] = acc;
   __syncthreads();
