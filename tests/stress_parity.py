@@ -18,6 +18,8 @@ def main():
     ap.add_argument("--max-n", type=int, default=6_000_000)
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--nd-cases", type=int, default=60, help="random 2-D / 3-D shapes through the tile mode (in place and gather paths)")
+    ap.add_argument("--split", type=int, default=0, help="1 / 3: flat fp64 arrays on the chain of kernels go through k_compress_eo (lists / single-pass "
+                    "placement); the one-launch kernels are turned off so that every array takes the chain")
     a = ap.parse_args()
     import numpy as np
     import torch
@@ -27,6 +29,9 @@ def main():
     rng = np.random.default_rng(a.seed)
     ctx = dctz_amd.Context(0)
     ctx.set_speculation(True, 1 << 18)
+    if a.split:
+        ctx.set_one_launch(False)
+        ctx.set_split(a.split)
     t0 = time.time()
     flags_seen = {}
     for k in range(a.cases):
